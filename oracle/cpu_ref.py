@@ -1,0 +1,261 @@
+"""ctypes binding of oracle/libcpu_ref.so (CPU restatement of the reference PPO path).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under deep_rl_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcpu_ref.so")
+NPARAMS = 9155
+T_DEFAULT = 128
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "cpu_ref.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libcpu_ref.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        L = _lib
+        L.ref_env_create.restype = C.c_void_p
+        L.ref_env_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64]
+        L.ref_env_destroy.argtypes = [C.c_void_p]
+        L.ref_env_state.restype = C.POINTER(C.c_double)
+        L.ref_env_state.argtypes = [C.c_void_p]
+        L.ref_env_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_env_step.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        L.ref_cartpole_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_actor.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_critic.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_categorical.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_ppo_rollout.restype = C.c_int
+        L.ref_ppo_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 11 + [C.c_int]
+        L.ref_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.ref_adv_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_ppo_minibatch.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float,
+                                                          C.c_double, C.c_void_p, C.c_void_p]
+        L.ref_clip_grad_norm.restype = C.c_float
+        L.ref_clip_grad_norm.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.ref_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_double,
+                                    C.c_double, C.c_double, C.c_double]
+        L.ref_explained_var.restype = C.c_double
+        L.ref_explained_var.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ref_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.ref_reset_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.ref_action_uniform.restype = C.c_float
+        L.ref_action_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.ref_feistel.restype = C.c_uint32
+        L.ref_feistel.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.ref_make_perm.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p]
+        L.ref_perm_key.restype = C.c_uint64
+        L.ref_perm_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.ref_ppo_ws_create.restype = C.c_void_p
+        L.ref_ppo_ws_create.argtypes = [C.c_int, C.c_int]
+        L.ref_ppo_ws_destroy.argtypes = [C.c_void_p]
+        L.ref_ppo_update.restype = C.c_int
+        L.ref_ppo_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_float, C.c_float, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.ref_num_threads.restype = C.c_int
+        L.ref_set_num_threads.argtypes = [C.c_int]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+class Episode(C.Structure):
+    _fields_ = [("env", C.c_int32), ("t", C.c_int32), ("ret", C.c_float), ("len", C.c_int32)]
+
+
+class VecCartPole:
+    """N CartPole-v1 envs with TimeLimit(500), episode statistics and ppo.py's auto-reset."""
+
+    def __init__(self, n, seed=1, env_id_base=0):
+        self.n = n
+        self.h = lib().ref_env_create(n, seed, env_id_base)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ref_env_destroy(self.h)
+            self.h = None
+
+    @property
+    def state(self):
+        return np.ctypeslib.as_array(lib().ref_env_state(self.h), shape=(self.n, 4))
+
+    def reset(self, forced_state=None):
+        obs = np.empty((self.n, 4), np.float32)
+        fs = _c(forced_state, np.float64)
+        lib().ref_env_reset(self.h, _p(obs), _p(fs))
+        return obs
+
+    def step(self, actions, forced_reset=None):
+        n = self.n
+        a = _c(actions, np.int64)
+        fr = _c(forced_reset, np.float64)
+        obs = np.empty((n, 4), np.float32); rew = np.empty(n, np.float32)
+        done = np.empty(n, np.uint8); trunc = np.empty(n, np.uint8)
+        fret = np.empty(n, np.float32); flen = np.empty(n, np.int32)
+        lib().ref_env_step(self.h, _p(a), _p(fr), _p(obs), _p(rew), _p(done), _p(trunc), _p(fret), _p(flen))
+        return obs, rew, done, trunc, fret, flen
+
+
+def cartpole_step(state, action):
+    s = _c(state, np.float64); out = np.empty(4, np.float64); term = C.c_int(0)
+    lib().ref_cartpole_step(_p(s), int(action), _p(out), C.byref(term))
+    return out, bool(term.value)
+
+
+def actor(params, obs):
+    p = _c(params, np.float32); o = _c(obs, np.float32).reshape(-1, 4)
+    out = np.empty((o.shape[0], 2), np.float32)
+    lib().ref_actor(_p(p), _p(o), o.shape[0], _p(out))
+    return out
+
+
+def critic(params, obs):
+    p = _c(params, np.float32); o = _c(obs, np.float32).reshape(-1, 4)
+    out = np.empty(o.shape[0], np.float32)
+    lib().ref_critic(_p(p), _p(o), o.shape[0], _p(out))
+    return out
+
+
+def categorical(logits):
+    l = _c(logits, np.float32).reshape(-1, 2); n = l.shape[0]
+    nl = np.empty_like(l); p = np.empty_like(l); ent = np.empty(n, np.float32)
+    lib().ref_categorical(_p(l), n, _p(nl), _p(p), _p(ent))
+    return nl, p, ent
+
+
+class Storage:
+    """The six (T+1, N, ...) rollout tensors of ppo.py:93-98 plus advantages/returns."""
+
+    def __init__(self, T, N):
+        self.T, self.N = T, N
+        self.observations = np.zeros((T + 1, N, 4), np.float32)
+        self.values = np.zeros((T + 1, N), np.float32)
+        self.actions = np.zeros((T + 1, N), np.int64)
+        self.log_probs = np.zeros((T + 1, N), np.float32)
+        self.rewards = np.zeros((T + 1, N), np.float32)
+        self.dones = np.zeros((T + 1, N), np.float32)
+        self.advantages = np.zeros((T + 1, N), np.float32)
+        self.returns = np.zeros((T + 1, N), np.float32)
+
+
+def rollout(env, params, st, obs_cur, forced_actions=None, forced_uniforms=None, forced_resets=None, max_ep=0):
+    p = _c(params, np.float32)
+    fa = _c(forced_actions, np.int64); fu = _c(forced_uniforms, np.float32); fr = _c(forced_resets, np.float64)
+    eps = (Episode * max(max_ep, 1))()
+    n = lib().ref_ppo_rollout(env.h, _p(p), st.T, _p(obs_cur), _p(st.observations), _p(st.values), _p(st.actions),
+                              _p(st.log_probs), _p(st.rewards), _p(st.dones), _p(fa), _p(fu), _p(fr),
+                              C.cast(eps, C.c_void_p), max_ep)
+    return [(e.env, e.t, e.ret, e.len) for e in eps[: min(n, max_ep)]], n
+
+
+def gae(st, gamma=0.99, lam=0.95):
+    lib().ref_gae(_p(st.rewards), _p(st.dones), _p(st.values), st.T, st.N, gamma, lam, _p(st.advantages), _p(st.returns))
+
+
+def adv_stats(adv_flat, idx):
+    idx = _c(idx, np.int32); m = C.c_double(); s = C.c_double()
+    lib().ref_adv_stats(_p(adv_flat), _p(idx), len(idx), C.byref(m), C.byref(s))
+    return m.value, s.value
+
+
+def minibatch(params, st, idx, adv_mean=None, adv_std=None, clip_coef=0.2, ent_coef=0.01, vf_coef=0.5, inv_count=None):
+    p = _c(params, np.float32); idx = _c(idx, np.int32)
+    if adv_mean is None:
+        adv_mean, adv_std = adv_stats(st.advantages.reshape(-1), idx)
+    if inv_count is None:
+        inv_count = 1.0 / len(idx)
+    grads = np.empty(NPARAMS, np.float32); terms = np.empty(4, np.float32)
+    lib().ref_ppo_minibatch(_p(p), _p(st.observations), _p(st.actions), _p(st.log_probs), _p(st.advantages), _p(st.returns),
+                            _p(st.values), _p(idx), len(idx), adv_mean, adv_std, clip_coef, ent_coef, vf_coef, inv_count,
+                            _p(grads), _p(terms))
+    return grads, terms
+
+
+def clip_grad_norm(grads, max_norm=0.5):
+    return float(lib().ref_clip_grad_norm(_p(grads), grads.size, max_norm))
+
+
+def adam_step(params, grads, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-5):
+    lib().ref_adam_step(_p(params), _p(grads), _p(m), _p(v), params.size, step, lr, beta1, beta2, eps)
+
+
+def explained_var(values, returns):
+    v = _c(values, np.float32).reshape(-1); r = _c(returns, np.float32).reshape(-1)
+    return lib().ref_explained_var(_p(v), _p(r), v.size)
+
+
+def philox(seed, env, idx, stream):
+    out = np.empty(4, np.uint32)
+    lib().ref_philox(seed, env, idx, stream, _p(out))
+    return out
+
+
+def reset_noise(seed, env, episode):
+    out = np.empty(4, np.float64)
+    lib().ref_reset_noise(seed, env, episode, _p(out))
+    return out
+
+
+def action_uniform(seed, env, step):
+    return float(lib().ref_action_uniform(seed, env, step))
+
+
+def make_perm(n, key):
+    out = np.empty(n, np.int32)
+    lib().ref_make_perm(n, key, _p(out))
+    return out
+
+
+def perm_key(seed, update, epoch):
+    return int(lib().ref_perm_key(seed, update, epoch))
+
+
+class PPOBaseline:
+    """Whole-update CPU loop in production-RNG mode (bench.py cpu_baseline, kind="port")."""
+
+    def __init__(self, params, n_envs, T=128, seed=1, threads=None):
+        L = lib()
+        if threads:
+            L.ref_set_num_threads(threads)
+        self.threads = L.ref_num_threads()
+        self.T, self.N = T, n_envs
+        self.env = VecCartPole(n_envs, seed)
+        self.ws = L.ref_ppo_ws_create(T, n_envs)
+        self.params = np.array(params, np.float32, copy=True)
+        self.obs = self.env.reset()
+        self.update = 0
+        self.terms = np.zeros(4, np.float32)
+
+    def run_update(self, lr=2.5e-4):
+        n = lib().ref_ppo_update(self.env.h, self.ws, _p(self.params), _p(self.obs), self.T, self.update, 4, 4, 0.99, 0.95,
+                                 lr, 0.2, 0.01, 0.5, 0.5, _p(self.terms))
+        self.update += 1
+        return n
+
+    def __del__(self):
+        if getattr(self, "ws", None):
+            lib().ref_ppo_ws_destroy(self.ws)
+            self.ws = None
