@@ -1,0 +1,15 @@
+"""deep_rl_amd — MI355X-native vectorised-rollout + policy-update engine behind the call surface of
+qgallouedec/deep_rl's single-file scripts (ppo.py first).
+
+Host code is Python on PyTorch-ROCm for module / optimizer bookkeeping only; the hot path (batched
+CartPole stepper, rollout storage, GAE scan, tiny-MLP forward/backward, clip + Adam) is hand-written HIP
+for gfx950 in ``csrc/`` behind the C ABI of ``include/mi_rl.h``.  There is no CPU fallback: importing
+``deep_rl_amd._native`` without the built ``libmirl.so`` raises.
+"""
+from . import _native  # noqa: F401
+from .envs import make, CartPoleVecEnv  # noqa: F401
+from .agent import ActorCritic, layer_init  # noqa: F401
+from .optim import ClipAdam  # noqa: F401
+from .engine import PPOEngine  # noqa: F401
+
+__all__ = ["make", "CartPoleVecEnv", "ActorCritic", "layer_init", "ClipAdam", "PPOEngine"]

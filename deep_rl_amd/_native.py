@@ -1,0 +1,152 @@
+"""ctypes binding of libmirl.so — the C ABI declared in include/mi_rl.h.
+
+The HIP library IS the product: there is no Python/CPU fallback.  Importing this module without a
+built ``deep_rl_amd/libmirl.so`` raises, and every wrapper raises ``MiError`` on a non-zero return code.
+Build with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C deep_rl_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmirl.so")
+
+NPARAMS = 9155
+ACTOR_NPARAMS = 4610
+MI_OK = 0
+
+
+class MiError(RuntimeError):
+    pass
+
+
+class Episode(C.Structure):
+    _fields_ = [("env", C.c_int32), ("t", C.c_int32), ("ret", C.c_float), ("len", C.c_int32)]
+
+
+class PPOBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "params", "exp_avg", "exp_avg_sq", "grads", "loss_terms", "grad_norm", "obs_cur", "observations", "values",
+        "actions", "log_probs", "rewards", "dones", "advantages", "returns", "perm", "adv_sums", "workspace",
+        "episodes", "episode_stats")] + [("max_ep", C.c_int32)]
+
+
+class PPOHparams(C.Structure):
+    _fields_ = [("T", C.c_int32), ("n_minibatch", C.c_int32), ("update_epochs", C.c_int32), ("update_index", C.c_int32),
+                ("opt_step", C.c_int64),
+                ("gamma", C.c_float), ("gae_lambda", C.c_float), ("clip_coef", C.c_float), ("ent_coef", C.c_float),
+                ("vf_coef", C.c_float), ("max_grad_norm", C.c_float),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/mi_rl.h declares
+_VP, _I, _U64, _F, _D, _I64, _SZ, _U32 = C.c_void_p, C.c_int, C.c_uint64, C.c_float, C.c_double, C.c_int64, C.c_size_t, C.c_uint32
+SIGNATURES = {
+    "mi_version": (_I, []),
+    "mi_last_error": (C.c_char_p, []),
+    "mi_env_create": (_I, [_I, _I, _U64, _U64, C.POINTER(_VP)]),
+    "mi_env_destroy": (_I, [_VP]),
+    "mi_env_reset": (_I, [_VP, _VP, _VP, _VP]),
+    "mi_env_step": (_I, [_VP] * 10),
+    "mi_env_get_state": (_I, [_VP, _VP, _VP, _VP]),
+    "mi_ppo_forward": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
+    "mi_ppo_rollout": (_I, [_VP, _VP, _I] + [_VP] * 12 + [_I, _VP]),
+    "mi_gae": (_I, [_VP, _VP, _VP, _I, _I, _F, _F, _VP, _VP, _VP]),
+    "mi_make_perm": (_I, [_U32, _U64, _VP, _VP]),
+    "mi_perm_key": (_U64, [_U64, _U64, _U64]),
+    "mi_adv_stats": (_I, [_VP, _VP, _I, _I, _VP, _VP]),
+    "mi_ppo_workspace_bytes": (_SZ, []),
+    "mi_ppo_minibatch_grad": (_I, [_VP] * 8 + [_I, _VP, _F, _F, _F, _D, _VP, _VP, _VP, _VP]),
+    "mi_clip_adam": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _D, _D, _D, _D, _F, _VP, _VP]),
+    "mi_explained_var": (_I, [_VP, _VP, _SZ, _VP, _VP]),
+    "mi_ppo_update": (_I, [_VP, C.POINTER(PPOBuffers), C.POINTER(PPOHparams), _VP]),
+    "mi_selftest_mfma": (_I, [_VP, _VP, _VP]),
+    "mi_test_tanh": (_I, [_VP, _VP, _I, _VP]),
+    "mi_prof_begin": (_I, [_I, _U32]),
+    "mi_prof_end": (_I, [C.POINTER(_F), C.POINTER(C.c_int32)]),
+    "mi_timer_create": (_I, [C.POINTER(_VP)]),
+    "mi_timer_destroy": (_I, [_VP]),
+    "mi_timer_start": (_I, [_VP, _VP]),
+    "mi_timer_stop": (_I, [_VP, _VP]),
+    "mi_timer_elapsed_ms": (_I, [_VP, C.POINTER(_F)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmirl.so (once).  Fails loudly: the HIP extension is not optional."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise MiError("deep_rl_amd: %s is missing — build it with `make -C deep_rl_amd/csrc` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != MI_OK:
+        msg = lib().mi_last_error()
+        raise MiError("%s failed (rc=%d): %s" % (what or "libmirl call", rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libmirl needs contiguous tensors"
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    """The raw hipStream_t of torch's current stream, so kernels order with torch / RCCL work."""
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+PROF_TAGS = ("rollout", "gae", "grad", "reduce", "clip_adam", "stats")
+
+
+def prof_begin(max_launches, tags=None):
+    """Arm the in-library profiler for `tags` (names from PROF_TAGS; default all)."""
+    mask = 0
+    for t in (tags or PROF_TAGS):
+        mask |= 1 << PROF_TAGS.index(t)
+    check(lib().mi_prof_begin(int(max_launches), mask), "mi_prof_begin")
+
+
+def prof_end():
+    """-> {tag: (total_ms, launches)} of every tagged kernel launched since prof_begin (synchronises)."""
+    ms = (_F * len(PROF_TAGS))()
+    cnt = (C.c_int32 * len(PROF_TAGS))()
+    check(lib().mi_prof_end(ms, cnt), "mi_prof_end")
+    return {t: (ms[i], cnt[i]) for i, t in enumerate(PROF_TAGS)}
+
+
+class Timer:
+    """HIP-event timer on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self.h = _VP()
+        check(lib().mi_timer_create(C.byref(self.h)), "mi_timer_create")
+
+    def start(self, stream):
+        check(lib().mi_timer_start(self.h, stream), "mi_timer_start")
+
+    def stop(self, stream):
+        check(lib().mi_timer_stop(self.h, stream), "mi_timer_stop")
+
+    def elapsed_ms(self):
+        ms = _F()
+        check(lib().mi_timer_elapsed_ms(self.h, C.byref(ms)), "mi_timer_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mi_timer_destroy(self.h)
+            self.h = None

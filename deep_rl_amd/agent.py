@@ -1,0 +1,83 @@
+"""ActorCritic with the reference's constructor, initialisation and method surface (ppo.py:25-59), whose
+parameters are views into ONE flat fp32 device buffer — the layout the HIP kernels consume."""
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Categorical
+
+from . import _native as N
+
+
+def layer_init(layer, std=np.sqrt(2), bias_const=0.0):
+    """ppo.py:25-28."""
+    torch.nn.init.orthogonal_(layer.weight, std)
+    torch.nn.init.constant_(layer.bias, bias_const)
+    return layer
+
+
+class ActorCritic(nn.Module):
+    """actor 4->64->64->n_actions, critic 4->64->64->1, tanh (ppo.py:31-47).
+
+    Construction happens on the CPU in the reference's layer order so that ``torch.manual_seed(s)`` yields the
+    reference's initial weights; the 12 parameter tensors are then re-pointed at slices of ``self.flat``
+    (order of ``agent.parameters()`` == include/mi_rl.h "Parameter layout").
+    """
+
+    def __init__(self, env, device=None):
+        super().__init__()
+        obs_dim = int(np.array(env.observation_space.shape).prod())
+        n_act = env.action_space.n
+        if obs_dim != 4 or n_act != 2:
+            raise N.MiError("the HIP kernels are specialised for CartPole (obs 4, actions 2); got %d/%d" % (obs_dim, n_act))
+        self.actor = nn.Sequential(
+            layer_init(nn.Linear(obs_dim, 64)), nn.Tanh(),
+            layer_init(nn.Linear(64, 64)), nn.Tanh(),
+            layer_init(nn.Linear(64, n_act), std=0.01),
+        )
+        self.critic = nn.Sequential(
+            layer_init(nn.Linear(obs_dim, 64)), nn.Tanh(),
+            layer_init(nn.Linear(64, 64)), nn.Tanh(),
+            layer_init(nn.Linear(64, 1), std=1.0),
+        )
+        dev = torch.device(device if device is not None else getattr(env, "device", "cuda"))
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self.parameters()]).to(dev, torch.float32).contiguous()
+        assert flat.numel() == N.NPARAMS
+        self.flat = flat
+        off = 0
+        for p in self.parameters():
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self.device = dev
+
+    # -- helpers -------------------------------------------------------------------------------
+    def load_flat(self, vec):
+        """Overwrite all parameters from a flat vector (numpy or tensor) in parameters() order."""
+        self.flat.copy_(torch.as_tensor(vec, dtype=torch.float32).reshape(-1).to(self.device))
+
+    def _forward(self, observation, want_logits, want_value):
+        obs = observation.to(self.device, torch.float32)
+        lead = obs.shape[:-1]
+        obs = obs.reshape(-1, 4).contiguous()
+        n = obs.shape[0]
+        logits = torch.empty((n, 2), dtype=torch.float32, device=self.device) if want_logits else None
+        value = torch.empty(n, dtype=torch.float32, device=self.device) if want_value else None
+        N.check(N.lib().mi_ppo_forward(N.ptr(self.flat), N.ptr(obs), n, N.ptr(logits), N.ptr(value), N.stream_ptr(self.device)),
+                "mi_ppo_forward")
+        return (logits.reshape(*lead, 2) if want_logits else None), (value.reshape(lead) if want_value else None)
+
+    # -- reference surface (inference; training gradients come from mi_ppo_minibatch_grad) ----------------
+    def get_value(self, observation):
+        """ppo.py:49-50."""
+        return self._forward(observation, False, True)[1]
+
+    def get_action_distribution(self, observation):
+        """ppo.py:52-54."""
+        return Categorical(logits=self._forward(observation, True, False)[0])
+
+    def get_action(self, observation):
+        """ppo.py:56-59."""
+        distribution = self.get_action_distribution(observation)
+        action = distribution.sample()
+        return action, distribution.log_prob(action)

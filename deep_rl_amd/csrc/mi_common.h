@@ -1,0 +1,232 @@
+// mi_common.h — shared device/host helpers of libmirl (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mi_rl.h"
+
+// ---- flat parameter layout (== order of agent.parameters(), reference ppo.py:34-47) -------------
+#define OBS 4
+#define HID 64
+#define NACT 2
+#define A_W1 0
+#define A_B1 256
+#define A_W2 320
+#define A_B2 4416
+#define A_W3 4480
+#define A_B3 4608
+#define C_BASE 4610
+#define NPARAMS 9155
+// per-net offsets relative to the net's base
+#define N_W1 0
+#define N_B1 256
+#define N_W2 320
+#define N_B2 4416
+#define N_W3 4480
+
+// ---- error plumbing -----------------------------------------------------------------------------
+void mi_set_error(const char* fmt, ...);
+#define MI_CHECK_ARG(cond, msg)                                  \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            mi_set_error("%s: invalid argument: %s", __func__, msg); \
+            return MI_EINVAL;                                    \
+        }                                                        \
+    } while (0)
+#define MI_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            mi_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_));        \
+            return MI_EHIP;                                                                   \
+        }                                                                                     \
+    } while (0)
+#define MI_LAUNCH_CHECK() MI_HIP(hipGetLastError())
+
+// in-library profiler (mi_env.hip): brackets a tagged launch with HIP events on its stream when armed
+void mi_prof_mark(int tag, bool end, hipStream_t s);
+struct mi_prof_scope {
+    int tag; hipStream_t s;
+    mi_prof_scope(int t, hipStream_t st) : tag(t), s(st) { mi_prof_mark(tag, false, s); }
+    ~mi_prof_scope() { mi_prof_mark(tag, true, s); }
+};
+
+// ---- env handle ----------------------------------------------------------------------------------
+struct mi_env {
+    int kind, n, device;
+    uint64_t seed, env_id_base;
+    // struct-of-arrays device state: fp64 dynamics, int counters
+    double *x, *x_dot, *theta, *theta_dot;
+    int32_t* elapsed;    // TimeLimit._elapsed_steps
+    float* ep_ret;       // RecordEpisodeStatistics.episode_returns
+    int32_t* ep_len;
+    uint64_t* episode;   // resets so far (index of the next reset-noise draw)
+    uint64_t* step_ctr;  // actions sampled so far (index of the next action uniform)
+};
+
+// ---- RNG contract (include/mi_rl.h) ----------------------------------------------------------------
+#define STREAM_RESET 0u
+#define STREAM_ACTION 1u
+#define STREAM_PERM 2u
+
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__host__ __device__ inline void mi_philox(uint64_t seed, uint64_t env, uint64_t idx, uint32_t stream, uint32_t out[4]) {
+    out[0] = (uint32_t)env; out[1] = (uint32_t)(env >> 32); out[2] = (uint32_t)idx;
+    out[3] = ((uint32_t)(idx >> 32) << 4) | stream;
+    philox4x32_10(out, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// reset noise in [-0.05, 0.05): numpy's low + (high-low)*u restated in f64 (no contraction)
+__device__ inline void mi_reset_noise(uint64_t seed, uint64_t env, uint64_t episode, double s[4]) {
+    uint32_t r[4];
+    mi_philox(seed, env, episode, STREAM_RESET, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double u = __dmul_rn(__dadd_rn((double)r[i], 0.5), 1.0 / 4294967296.0);
+        s[i] = __dadd_rn(-0.05, __dmul_rn(0.05 - -0.05, u));
+    }
+}
+
+__device__ inline float mi_action_uniform(uint64_t seed, uint64_t env, uint64_t step) {
+    uint32_t r[4];
+    mi_philox(seed, env, step, STREAM_ACTION, r);
+    return (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+}
+
+__host__ __device__ inline uint32_t mi_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// keyed bijection on [0, n): 6-round alternating Feistel on `bits` bits (a = bits/2 low) + cycle walking
+__host__ __device__ inline uint32_t mi_feistel(uint32_t i, uint32_t n, uint32_t a, uint32_t b, uint32_t k0, uint32_t k1) {
+    const uint32_t ma = (1u << a) - 1u, mb = (1u << b) - 1u;
+    uint32_t x = i;
+    do {
+        uint32_t l = x & ma, r = x >> a;
+#pragma unroll
+        for (uint32_t rd = 0; rd < 6; rd += 2) {
+            l ^= mi_mix32(r * 0x9E3779B1u + k0 + rd) & ma;
+            r ^= mi_mix32(l * 0x85EBCA77u + k1 + rd + 1u) & mb;
+        }
+        x = (r << a) | l;
+    } while (x >= n);
+    return x;
+}
+
+// ---- math ------------------------------------------------------------------------------------------
+// tanh, <= ~2.5 ulp / 1.2e-7 abs vs libm (tests/test_gpu_kernels.py::test_tanh): odd polynomial below 0.6,
+// 1 - 2/(2^(2x log2 e) + 1) above.  Branch-free so the 64 lanes of a wave never diverge.
+__device__ __forceinline__ float mi_tanhf(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    float p = -5.883233055e-03f;
+    p = __builtin_fmaf(p, x2, 2.078514762e-02f);
+    p = __builtin_fmaf(p, x2, -5.378039939e-02f);
+    p = __builtin_fmaf(p, x2, 1.333188030e-01f);
+    p = __builtin_fmaf(p, x2, -3.333329618e-01f);
+    const float small = __builtin_fmaf(x, x2 * p, x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);  // v_exp_f32; inf for large |x| -> big = 1
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return ax < 0.6f ? small : __builtin_copysignf(big, x);
+}
+
+// Categorical(logits=l) for 2 actions (reference ppo.py:52-54 / torch.distributions.Categorical):
+// nl = l - logsumexp(l), p = softmax(nl), entropy = -sum(nl * p)
+__device__ __forceinline__ void mi_categorical2(float l0, float l1, float& nl0, float& nl1, float& p0, float& p1, float& ent) {
+    const float m = fmaxf(l0, l1);
+    const float s = expf(l0 - m) + expf(l1 - m);
+    const float lse = logf(s) + m;
+    nl0 = l0 - lse; nl1 = l1 - lse;
+    const float m2 = fmaxf(nl0, nl1);
+    const float e0 = expf(nl0 - m2), e1 = expf(nl1 - m2);
+    const float s2 = e0 + e1;
+    p0 = e0 / s2; p1 = e1 / s2;
+    ent = -(nl0 * p0 + nl1 * p1);
+}
+
+// sin/cos of the pole angle.  |theta| stays below ~0.25 rad while an episode is alive, so the fdlibm
+// __kernel_sin/__kernel_cos polynomials (|x| < pi/4, error < 1 ulp, Sun Microsystems public algorithm)
+// replace ocml's full-range routines; larger arguments (only reachable through forced states) fall back.
+// gym evaluates math.sin/math.cos (glibc); any < 1 ulp implementation can differ from it in the last bit,
+// which is why parity on the float64 state is asserted to tolerance and bit-exactness on obs_f32/done.
+__device__ __forceinline__ void mi_sincos(double x, double& s, double& c) {
+    if (fabs(x) < 0.5) {
+        const double z = x * x;
+        const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                     S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+        const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                     C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+        const double v = z * x;
+        const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+        s = __builtin_fma(v, __builtin_fma(z, rs, S1), x);
+        const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+        c = 1.0 - (0.5 * z - z * rc);
+    } else {
+        s = sin(x);
+        c = cos(x);
+    }
+}
+
+// ---- CartPole-v1 step (gym 0.21 cartpole.py), fp64, no FMA contraction (-ffp-contract=off) ---------
+#define CP_MAX_STEPS 500
+__device__ __forceinline__ void mi_cartpole_step(double& x, double& x_dot, double& theta, double& theta_dot, int action,
+                                                 int& terminated) {
+    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+    const double total_mass = masspole + masscart;
+    const double polemass_length = masspole * length;
+    const double theta_thr = 12 * 2 * 3.14159265358979323846 / 360;
+    const double x_thr = 2.4;
+    const double force = action == 1 ? force_mag : -force_mag;
+    double costheta, sintheta;
+    mi_sincos(theta, sintheta, costheta);
+    const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+    const double thetaacc = (gravity * sintheta - costheta * temp) /
+                            (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+    const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * thetaacc;
+    terminated = (x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr) ? 1 : 0;
+}
+
+// ---- wave-level reductions (64 lanes): DPP inside a 16-lane row, then two cross-row exchanges ------------
+__device__ __forceinline__ float dpp_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); }
+
+// sum over the 64 lanes of a wave, result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    v += dpp_mirror(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+
+// wave-private LDS traffic: LDS executes one wave's instructions in order, so only the COMPILER must be kept
+// from moving accesses across this point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}

@@ -1,0 +1,252 @@
+// mi_rollout.hip — the whole rollout loop of reference ppo.py:110-141 in ONE launch.
+//
+// Mapping (MI355X-first, SURVEY §7 hard part 1: 4096 envs is small for 256 CUs, the chain is 128 deep):
+//   * envs are independent for the whole rollout (weights are frozen), so there is no inter-workgroup
+//     communication at all: one WAVE owns E envs for all T steps; lane j owns hidden unit j of both nets.
+//   * W1/W2/W3 rows of unit j live in that lane's VGPRs for the whole kernel (36.6 KB of weights are read from
+//     HBM/L2 once per wave); the 64-wide hidden vector is broadcast through a wave-private LDS row
+//     (one ds_write_b32 + 16 broadcast ds_read_b128 per layer), no workgroup barrier anywhere.
+//   * the 64->{2,1} heads are DPP wave reductions; the Categorical draw, log-prob, fp64 CartPole step,
+//     TimeLimit, episode statistics and auto-reset are wave-uniform scalar work done redundantly per lane.
+//   * critic(obs[t+1]) and actor(obs[t+1]) see the same observation, so both nets are evaluated together
+//     once per step (ppo.py:139 and :120 of the next iteration).
+//   * E = 2 envs per wave gives two independent dependency chains per wave (ILP) at 2 waves/SIMD for N=4096.
+// Storage index convention (ppo.py:113-141): actions/log_probs at t, obs/values/rewards/dones at t+1; on
+// done the stored obs/value are those of the RESET state.
+#include "mi_common.h"
+
+struct net_regs {
+    float w1[OBS], b1, w2[HID], b2;
+};
+
+__device__ __forceinline__ void load_net(net_regs& r, const float* __restrict__ p, int j) {
+    const float4 w = *reinterpret_cast<const float4*>(p + N_W1 + 4 * j);
+    r.w1[0] = w.x; r.w1[1] = w.y; r.w1[2] = w.z; r.w1[3] = w.w;
+    r.b1 = p[N_B1 + j];
+#pragma unroll
+    for (int k = 0; k < HID; k += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p + N_W2 + HID * j + k);
+        r.w2[k] = q.x; r.w2[k + 1] = q.y; r.w2[k + 2] = q.z; r.w2[k + 3] = q.w;
+    }
+    r.b2 = p[N_B2 + j];
+}
+
+// hidden layer 2 for one env: hrow = wave-private LDS row holding tanh(layer 1) of all 64 units
+__device__ __forceinline__ float layer2(const net_regs& r, const float* hrow) {
+    float acc0 = 0.0f, acc1 = 0.0f;  // two chains for ILP
+#pragma unroll
+    for (int k = 0; k < HID; k += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(hrow + k);
+        const float4 b = *reinterpret_cast<const float4*>(hrow + k + 4);
+        acc0 = __builtin_fmaf(r.w2[k + 0], a.x, acc0); acc0 = __builtin_fmaf(r.w2[k + 1], a.y, acc0);
+        acc0 = __builtin_fmaf(r.w2[k + 2], a.z, acc0); acc0 = __builtin_fmaf(r.w2[k + 3], a.w, acc0);
+        acc1 = __builtin_fmaf(r.w2[k + 4], b.x, acc1); acc1 = __builtin_fmaf(r.w2[k + 5], b.y, acc1);
+        acc1 = __builtin_fmaf(r.w2[k + 6], b.z, acc1); acc1 = __builtin_fmaf(r.w2[k + 7], b.w, acc1);
+    }
+    return (acc0 + acc1) + r.b2;
+}
+
+#define ROLLOUT_WAVES 4
+
+__device__ __forceinline__ float bcast_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+// E envs per wave.  The 64-wide MLP work is done env by env with lane = hidden unit; the per-env SCALAR work
+// (Categorical draw, log-prob, fp64 CartPole step, TimeLimit, episode statistics, auto-reset, storage writes)
+// is done ONCE per step for all E envs at a time with lane e = env e (lanes >= E idle through it), so its
+// cost does not grow with E and env e's scalar state lives in lane e's registers only.
+template <int E>
+__global__ void __launch_bounds__(64 * ROLLOUT_WAVES, 2)
+rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restrict__ obs_cur, float* __restrict__ observations,
+               float* __restrict__ values, int64_t* __restrict__ actions, float* __restrict__ log_probs,
+               float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
+               const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
+               mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep) {
+    __shared__ __attribute__((aligned(16))) float hbuf[ROLLOUT_WAVES][E][2][HID];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int N = e.n;
+    const int env0 = (blockIdx.x * ROLLOUT_WAVES + wib) * E;
+    if (env0 >= N) return;  // wave-uniform
+
+    net_regs an, cn;
+    load_net(an, params, lane);
+    load_net(cn, params + C_BASE, lane);
+    const float w3a0 = params[A_W3 + lane], w3a1 = params[A_W3 + HID + lane], w3c = params[C_BASE + N_W3 + lane];
+    const float b3a0 = params[A_B3], b3a1 = params[A_B3 + 1], b3c = params[C_BASE + N_W3 + HID];
+
+    // scalar state of env (env0 + lane) in lane `lane` (< E)
+    const bool mine = lane < E && env0 + lane < N;
+    const int g = mine ? env0 + lane : env0;  // idle lanes shadow env0 and never write
+    double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
+    int elapsed = e.elapsed[g], eplen = e.ep_len[g];
+    float epret = e.ep_ret[g];
+    uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
+    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
+    float my_l0 = 0.0f, my_l1 = 0.0f, my_val = 0.0f;
+
+    for (int t = -1; t < T; ++t) {
+        float rew = 0.0f, dn = 0.0f;
+        if (t >= 0) {
+            // ---- sample from the logits of obs[t], step the env (ppo.py:120-129); lane = env ----
+            const size_t row = (size_t)t * N + g;
+            float nl0, nl1, p0, p1, ent;
+            mi_categorical2(my_l0, my_l1, nl0, nl1, p0, p1, ent);
+            int a;
+            if (forced_actions) a = (int)forced_actions[row];
+            else {
+                const float u = forced_uniforms ? forced_uniforms[row] : mi_action_uniform(e.seed, e.env_id_base + (uint64_t)g, stepctr);
+                a = (u >= p0) ? 1 : 0;
+            }
+            stepctr += 1;
+            if (mine) { actions[row] = a; log_probs[row] = a ? nl1 : nl0; }  // ppo.py:123-124
+            int term;
+            mi_cartpole_step(sx, sxd, sth, sthd, a, term);
+            elapsed += 1;
+            const bool d = term || elapsed >= CP_MAX_STEPS;
+            epret += 1.0f;
+            eplen += 1;
+            if (d) {
+                if (mine && episode_stats) {
+                    const int slot = atomicAdd(episode_stats, 1);
+                    atomicAdd(episode_stats + 1, eplen);
+                    atomicMax(episode_stats + 2, eplen);
+                    if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
+                }
+                epret = 0.0f; eplen = 0; elapsed = 0;
+                double s[4];
+                if (forced_resets) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] = forced_resets[4 * row + k];
+                } else {
+                    mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, s);
+                }
+                episode += 1;
+                sx = s[0]; sxd = s[1]; sth = s[2]; sthd = s[3];
+            }
+            ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
+            rew = 1.0f; dn = d ? 1.0f : 0.0f;
+        }
+        // ---- both nets on obs[t+1] (ppo.py:115/139 critic, :120 actor of the next step); lane = hidden unit ----
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const float o0 = bcast_lane(ob.x, i), o1 = bcast_lane(ob.y, i), o2 = bcast_lane(ob.z, i), o3 = bcast_lane(ob.w, i);
+            float za = an.b1, zc = cn.b1;
+            za = __builtin_fmaf(an.w1[0], o0, za); za = __builtin_fmaf(an.w1[1], o1, za);
+            za = __builtin_fmaf(an.w1[2], o2, za); za = __builtin_fmaf(an.w1[3], o3, za);
+            zc = __builtin_fmaf(cn.w1[0], o0, zc); zc = __builtin_fmaf(cn.w1[1], o1, zc);
+            zc = __builtin_fmaf(cn.w1[2], o2, zc); zc = __builtin_fmaf(cn.w1[3], o3, zc);
+            hbuf[wib][i][0][lane] = mi_tanhf(za);
+            hbuf[wib][i][1][lane] = mi_tanhf(zc);
+        }
+        wave_lds_fence();  // wave-private LDS rows: LDS is in-order per wave, only compiler motion must be stopped
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const float h2a = mi_tanhf(layer2(an, hbuf[wib][i][0]));
+            const float h2c = mi_tanhf(layer2(cn, hbuf[wib][i][1]));
+            const float l0 = wave_sum(w3a0 * h2a) + b3a0;
+            const float l1 = wave_sum(w3a1 * h2a) + b3a1;
+            const float vv = wave_sum(w3c * h2c) + b3c;
+            if (lane == i) { my_l0 = l0; my_l1 = l1; my_val = vv; }
+        }
+        wave_lds_fence();
+        if (mine) {
+            const size_t row = (size_t)(t + 1) * N + g;
+            reinterpret_cast<float4*>(observations)[row] = ob;  // :113,:137 (the reset obs where done)
+            values[row] = my_val;                               // :115,:139
+            if (t >= 0) { rewards[row] = rew; dones[row] = dn; }  // :140-141
+        }
+    }
+    // carry-over `observation` and env state for the next rollout
+    if (mine) {
+        e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
+        e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen;
+        e.episode[g] = episode; e.step_ctr[g] = stepctr;
+        reinterpret_cast<float4*>(obs_cur)[g] = ob;
+    }
+}
+
+__global__ void zero_i32x4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
+
+extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                              int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
+                              const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
+                              int32_t* episode_stats, int max_ep, void* stream) {
+    MI_CHECK_ARG(handle && params && obs_cur && observations && values && actions && log_probs && rewards && dones, "NULL pointer");
+    MI_CHECK_ARG(T > 0, "T must be positive");
+    MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
+    mi_env* e = (mi_env*)handle;
+    hipStream_t s = (hipStream_t)stream;
+    if (episode_stats) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    mi_prof_scope prof(MI_PROF_ROLLOUT, s);
+    // E=2 halves the wave count (2 waves/SIMD at N=4096); E=1 for tiny N keeps every env on its own wave.
+    if (e->n >= 512) {
+        const int waves = (e->n + 1) / 2, blocks = (waves + ROLLOUT_WAVES - 1) / ROLLOUT_WAVES;
+        rollout_kernel<2><<<blocks, 64 * ROLLOUT_WAVES, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards,
+                                                                 dones, forced_actions, forced_uniforms, forced_resets, episodes,
+                                                                 episode_stats, max_ep);
+    } else {
+        const int blocks = (e->n + ROLLOUT_WAVES - 1) / ROLLOUT_WAVES;
+        rollout_kernel<1><<<blocks, 64 * ROLLOUT_WAVES, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards,
+                                                                 dones, forced_actions, forced_uniforms, forced_resets, episodes,
+                                                                 episode_stats, max_ep);
+    }
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// ---- ActorCritic forward on an arbitrary batch (agent.get_value / get_action_distribution, ppo.py:49-54) ------
+// One lane per row, all weights in LDS (every lane reads the same address -> broadcast).  Not on the training
+// hot path (the rollout and update kernels fuse their own forwards); this backs the nn.Module-style API.
+__global__ void __launch_bounds__(256) forward_kernel(const float* __restrict__ params, const float* __restrict__ obs, int n,
+                                                      float* __restrict__ logits, float* __restrict__ value) {
+    __shared__ __attribute__((aligned(16))) float w[NPARAMS + 5];
+    for (int i = threadIdx.x; i < NPARAMS; i += blockDim.x) w[i] = params[i];
+    __syncthreads();
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+        const float4 o = reinterpret_cast<const float4*>(obs)[row];
+        const float x[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll 1
+        for (int net = 0; net < 2; ++net) {
+            if (net == 0 ? !logits : !value) continue;
+            const float* p = w + (net ? C_BASE : 0);
+            float h1[HID];
+#pragma unroll
+            for (int j = 0; j < HID; ++j) {
+                float z = p[N_B1 + j];
+#pragma unroll
+                for (int k = 0; k < OBS; ++k) z = __builtin_fmaf(p[N_W1 + 4 * j + k], x[k], z);
+                h1[j] = mi_tanhf(z);
+            }
+            float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll 4
+            for (int j = 0; j < HID; ++j) {
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < HID; k += 2) {
+                    a0 = __builtin_fmaf(p[N_W2 + HID * j + k], h1[k], a0);
+                    a1 = __builtin_fmaf(p[N_W2 + HID * j + k + 1], h1[k + 1], a1);
+                }
+                const float h2 = mi_tanhf((a0 + a1) + p[N_B2 + j]);
+                o0 = __builtin_fmaf(p[N_W3 + j], h2, o0);
+                if (net == 0) o1 = __builtin_fmaf(p[N_W3 + HID + j], h2, o1);
+            }
+            if (net == 0) {
+                logits[2 * (size_t)row] = o0 + p[N_W3 + 2 * HID];
+                logits[2 * (size_t)row + 1] = o1 + p[N_W3 + 2 * HID + 1];
+            } else {
+                value[row] = o0 + p[N_W3 + HID];
+            }
+        }
+    }
+}
+
+extern "C" int mi_ppo_forward(const float* params, const float* obs, int n, float* logits, float* value, void* stream) {
+    MI_CHECK_ARG(params && obs, "NULL pointer");
+    MI_CHECK_ARG(n >= 0, "n must be >= 0");
+    if (n == 0 || (!logits && !value)) return MI_OK;
+    int blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    forward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, obs, n, logits, value);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}

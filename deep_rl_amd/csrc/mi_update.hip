@@ -1,0 +1,790 @@
+// mi_update.hip — everything after the rollout in reference ppo.py:144-195:
+//   gae_kernel            GAE reverse scan                                   (ppo.py:144-151)
+//   perm_kernel           minibatch permutation (replaces np.random.permutation, :155)
+//   adv_stats_kernel      per-minibatch sum / sum of squares of advantages   (:169)
+//   grad_kernel<ACTOR>    forward + loss + backward of one minibatch on the f32 MFMA pipe (:166-190)
+//   grad_reduce_kernel    deterministic reduction of the per-workgroup partial gradients
+//   clip_adam_kernel      clip_grad_norm_ + Adam                             (:191-192)
+//   explained_var_kernel                                                     (:194-195)
+#include "mi_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =====================================================================================================
+// GAE: one lane per env walks t = T-1..0 over (T+1, N) time-major buffers (coalesced over envs at every t).
+// Expression order is the reference's, fp32, no contraction (this file is built with -ffp-contract=off).
+// =====================================================================================================
+__global__ void __launch_bounds__(64) gae_kernel(const float* __restrict__ rewards, const float* __restrict__ dones,
+                                                 const float* __restrict__ values, int T, int N, float gamma, float lam,
+                                                 float* __restrict__ adv, float* __restrict__ returns) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float last = 0.0f;
+    float vnext = values[(size_t)T * N + i];
+    adv[(size_t)T * N + i] = 0.0f;
+    returns[(size_t)T * N + i] = 0.0f + vnext;
+#pragma unroll 8
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t c = (size_t)t * N + i, n = c + N;
+        const float vcur = values[c];
+        const float a = gamma * (1.0f - dones[n]);
+        const float b = vnext + lam * last;
+        float v = rewards[n] + a * b;
+        v = v - vcur;
+        adv[c] = v;
+        returns[c] = v + vcur;
+        last = v;
+        vnext = vcur;
+    }
+}
+
+extern "C" int mi_gae(const float* rewards, const float* dones, const float* values, int T, int N, float gamma, float lam,
+                      float* advantages, float* returns, void* stream) {
+    MI_CHECK_ARG(rewards && dones && values && advantages && returns, "NULL pointer");
+    MI_CHECK_ARG(T > 0 && N > 0, "T and N must be positive");
+    mi_prof_scope prof(MI_PROF_GAE, (hipStream_t)stream);
+    gae_kernel<<<(N + 63) / 64, 64, 0, (hipStream_t)stream>>>(rewards, dones, values, T, N, gamma, lam, advantages, returns);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// =====================================================================================================
+// Permutation
+// =====================================================================================================
+__global__ void __launch_bounds__(256) perm_kernel(uint32_t n, uint32_t a, uint32_t b, uint32_t k0, uint32_t k1, int32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)mi_feistel(i, n, a, b, k0, k1);
+}
+
+extern "C" int mi_make_perm(uint32_t n, uint64_t key, int32_t* out, void* stream) {
+    MI_CHECK_ARG(out != nullptr, "out is NULL");
+    MI_CHECK_ARG(n > 0 && n <= (1u << 30), "n out of range");
+    uint32_t bits = 1;
+    while ((1u << bits) < n) ++bits;
+    if (bits < 2) bits = 2;
+    const uint32_t a = bits / 2, b = bits - a;
+    perm_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, a, b, (uint32_t)key, (uint32_t)(key >> 32), out);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" uint64_t mi_perm_key(uint64_t seed, uint64_t update, uint64_t epoch) {
+    uint32_t r[4];
+    mi_philox(seed, update, epoch, STREAM_PERM, r);
+    return ((uint64_t)r[1] << 32) | r[0];
+}
+
+// =====================================================================================================
+// Advantage statistics: sums[k] = {sum a, sum a^2, count} over idx[k*mb .. (k+1)*mb)
+// =====================================================================================================
+#define STATS_BLOCKS_PER_MB 32
+__global__ void __launch_bounds__(256) adv_stats_kernel(const float* __restrict__ adv, const int32_t* __restrict__ idx, int mb,
+                                                        double* __restrict__ sums) {
+    const int k = blockIdx.x / STATS_BLOCKS_PER_MB, part = blockIdx.x % STATS_BLOCKS_PER_MB;
+    const int32_t* id = idx + (size_t)k * mb;
+    double s = 0.0, q = 0.0;
+    for (int i = part * 256 + threadIdx.x; i < mb; i += 256 * STATS_BLOCKS_PER_MB) {
+        const double a = (double)adv[id[i]];
+        s += a;
+        q += a * a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    __shared__ double ss[4], qq[4];
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; qq[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[3 * k + 0], (ss[0] + ss[1]) + (ss[2] + ss[3]));
+        atomicAdd(&sums[3 * k + 1], (qq[0] + qq[1]) + (qq[2] + qq[3]));
+        if (part == 0) sums[3 * k + 2] = (double)mb;
+    }
+}
+
+extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb, int n_mb, double* sums, void* stream) {
+    MI_CHECK_ARG(advantages && idx && sums, "NULL pointer");
+    MI_CHECK_ARG(mb > 0 && n_mb > 0, "mb and n_mb must be positive");
+    MI_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 3 * (size_t)n_mb, (hipStream_t)stream));
+    mi_prof_scope prof(MI_PROF_STATS, (hipStream_t)stream);
+    adv_stats_kernel<<<n_mb * STATS_BLOCKS_PER_MB, 256, 0, (hipStream_t)stream>>>(advantages, idx, mb, sums);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// =====================================================================================================
+// Minibatch gradient on the f32 MFMA pipe.
+//
+// Work split: a workgroup (4 waves) serves ONE net — even blockIdx = actor, odd = critic; the two nets share
+// nothing but the observations (the joint grad-norm clip happens later), so each CU hosts one block of each.
+// A wave processes tiles of 32 minibatch rows; per tile and net (v_mfma_f32_32x32x2_f32 unless noted):
+//     z1^T = W1 x^T            4 MFMA     (rows on the lanes, hidden units in the accumulator registers)
+//     z2^T = W2 h1^T          64 MFMA     B operand = h1's accumulator registers as they stand
+//     dh1^T = W2^T dz2^T      64 MFMA     B operand = dz2's registers as they stand
+//     dW2 += dz2^T h1         64 MFMA     both operands re-read transposed through a wave-private LDS tile
+//     dW1 += dz1^T x, dW3 += dlogit^T h2   32 + 32 v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1 row)
+// "As they stand": a 32x32 accumulator holds, in lane (j = row, h = lane>>5), register r, the unit
+// u(r,h) = (r&3) + 8(r>>2) + 4h.  An MFMA sums over k in ANY order as long as A and B agree, so k-step s of the
+// next product takes B from register s and A = W[..][u(s&15,h) + 32(s>>4)] — no lane movement, no LDS
+// (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").  The sum order differs from a
+// sequential-k fp32 chain; parity is to tolerance, not bitwise.
+// Everything per tile is wave-private (no workgroup barrier in the loop); the only barriers are around the
+// weight staging at entry and the deterministic cross-wave reduction at exit.  Per-block partial gradients go
+// to a workspace slab and are summed in block order by grad_reduce_kernel (no float atomics: reproducible).
+// =====================================================================================================
+#define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row reads / writes conflict-free
+#define GRAD_WAVES 4
+#define PART_STRIDE 4624
+#define PART_LOSS 4610
+#define GRAD_MAX_BLOCKS 1024
+
+struct __attribute__((aligned(16))) grad_smem {
+    float W2[HID * W2S];              // W2[o][i] row-major, padded
+    float b1[HID], b2[HID];
+    float W3[2 * HID];
+    float bufA[GRAD_WAVES][16 * W2S];  // wave-private [row][unit] tiles for the transposed re-reads
+    float bufB[GRAD_WAVES][16 * W2S];
+    float xs[GRAD_WAVES][32 * 4];      // observations of the tile
+    float dls[GRAD_WAVES][32 * 4];     // d loss / d logits (or d value), zero padded to 4
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <bool ACTOR>
+__device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict__ params, const float* __restrict__ observations,
+                                          const int64_t* __restrict__ actions, const float* __restrict__ log_probs,
+                                          const float* __restrict__ advantages, const float* __restrict__ returns,
+                                          const float* __restrict__ values, const int32_t* __restrict__ idx, int mb,
+                                          const double* __restrict__ adv_sums, float clip_coef, float ent_coef, float vf_coef,
+                                          float invn, float* __restrict__ part) {
+    constexpr int NOUT = ACTOR ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const float* p = params + (ACTOR ? 0 : C_BASE);
+
+    // ---- stage this net's weights in LDS (once per block) ----
+    for (int i = tid; i < HID * HID; i += 64 * GRAD_WAVES) sm.W2[(i >> 6) * W2S + (i & 63)] = p[N_W2 + i];
+    if (tid < HID) { sm.b1[tid] = p[N_B1 + tid]; sm.b2[tid] = p[N_B2 + tid]; }
+    if (tid < NOUT * HID) sm.W3[tid] = p[N_W3 + tid];
+    // layer-1 A fragments live in registers: lane (i,h), m, k-step s holds W1[i+32m][2s+h]
+    float w1f[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w1f[m][s] = p[N_W1 + 4 * (li + 32 * m) + 2 * s + h];
+    float b3[NOUT];
+#pragma unroll
+    for (int a = 0; a < NOUT; ++a) b3[a] = p[N_W3 + NOUT * HID + a];
+    __syncthreads();
+
+    // advantage normalisation constants (ppo.py:169) from {sum, sum sq, count}
+    float adv_mean = 0.0f, adv_den = 1.0f;
+    if constexpr (ACTOR) {
+        const double s1 = adv_sums[0], s2 = adv_sums[1], cnt = adv_sums[2];
+        const double mean = s1 / cnt;
+        double var = (s2 - s1 * mean) / (cnt - 1.0);
+        var = var > 0.0 ? var : 0.0;
+        adv_mean = (float)mean;
+        adv_den = (float)sqrt(var) + 1e-8f;
+    }
+
+    // ---- accumulators that live across tiles ----
+    f32x16 dW2[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW2[m][n][r] = 0.0f;
+    f32x4 dW1a = {0.0f, 0.0f, 0.0f, 0.0f}, dW1b = dW1a, dW3a = dW1a, dW3b = dW1a;  // two chains each: 4x4x1 latency > issue
+    float db1 = 0.0f, db2[2] = {0.0f, 0.0f}, db3[2] = {0.0f, 0.0f};
+    float loss_a = 0.0f, loss_b = 0.0f;  // actor: sum pg, sum entropy; critic: sum max(vl1, vl2)
+
+    float* bufA = sm.bufA[wib];
+    float* bufB = sm.bufB[wib];
+    float* xs = sm.xs[wib];
+    float* dls = sm.dls[wib];
+
+    const int n_tiles = (mb + 31) >> 5;
+    const int wave_role = (blockIdx.x >> 1) * GRAD_WAVES + wib;
+    const int n_wave_role = (gridDim.x >> 1) * GRAD_WAVES;
+
+    for (int tile = wave_role; tile < n_tiles; tile += n_wave_role) {
+        // ---- gather the tile's rows (both lane halves load the same row) ----
+        const int row = tile * 32 + li;
+        const bool valid = row < mb;
+        const int rid = idx[valid ? row : mb - 1];
+        const float4 o = reinterpret_cast<const float4*>(observations)[rid];
+        int act = 0;
+        float old_lp = 0.0f, adv = 0.0f, ret = 0.0f, v_old = 0.0f;
+        if constexpr (ACTOR) { act = (int)actions[rid]; old_lp = log_probs[rid]; adv = advantages[rid]; }
+        else { ret = returns[rid]; v_old = values[rid]; }
+        if (h == 0) *reinterpret_cast<float4*>(xs + 4 * li) = o;
+
+        // ---- layer 1: z1^T = W1 x^T + b1 ----
+        f32x16 h1[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = *reinterpret_cast<const float4*>(&sm.b1[8 * q + 4 * h + 32 * m]);
+                h1[m][4 * q + 0] = b.x; h1[m][4 * q + 1] = b.y; h1[m][4 * q + 2] = b.z; h1[m][4 * q + 3] = b.w;
+            }
+            h1[m] = mfma32(w1f[m][0], h ? o.y : o.x, h1[m]);
+            h1[m] = mfma32(w1f[m][1], h ? o.w : o.z, h1[m]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[m][r] = mi_tanhf(h1[m][r]);
+        }
+        // ---- layer 2: z2^T = W2 h1^T + b2 ----
+        f32x16 h2[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = *reinterpret_cast<const float4*>(&sm.b2[8 * q + 4 * h + 32 * m]);
+                h2[m][4 * q + 0] = b.x; h2[m][4 * q + 1] = b.y; h2[m][4 * q + 2] = b.z; h2[m][4 * q + 3] = b.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {  // k-steps 4q..4q+3 <-> units 8(q&3) + 4h + 32(q>>2) + {0..3}
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float4 a = *reinterpret_cast<const float4*>(&sm.W2[(li + 32 * m) * W2S + 8 * (q & 3) + 4 * h + 32 * (q >> 2)]);
+                h2[m] = mfma32(a.x, h1[q >> 2][4 * (q & 3) + 0], h2[m]);
+                h2[m] = mfma32(a.y, h1[q >> 2][4 * (q & 3) + 1], h2[m]);
+                h2[m] = mfma32(a.z, h1[q >> 2][4 * (q & 3) + 2], h2[m]);
+                h2[m] = mfma32(a.w, h1[q >> 2][4 * (q & 3) + 3], h2[m]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[m][r] = mi_tanhf(h2[m][r]);
+
+        // ---- head: out[a] = W3[a] . h2 + b3[a]; each lane half holds 32 of the 64 units ----
+        float outp[NOUT];
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 8 * q + 4 * h + 32 * m]);
+                    acc = __builtin_fmaf(w.x, h2[m][4 * q + 0], acc); acc = __builtin_fmaf(w.y, h2[m][4 * q + 1], acc);
+                    acc = __builtin_fmaf(w.z, h2[m][4 * q + 2], acc); acc = __builtin_fmaf(w.w, h2[m][4 * q + 3], acc);
+                }
+            outp[a] = (acc + __shfl_xor(acc, 32)) + b3[a];
+        }
+
+        // ---- loss and d loss / d out (ppo.py:166-187), identical in both lane halves ----
+        float dl[NOUT];
+        const float count_me = (valid && h == 0) ? 1.0f : 0.0f;
+        if constexpr (ACTOR) {
+            float nl0, nl1, p0, p1, H;
+            mi_categorical2(outp[0], outp[NOUT - 1], nl0, nl1, p0, p1, H);
+            const float A = (adv - adv_mean) / adv_den;
+            const float ratio = expf((act ? nl1 : nl0) - old_lp);
+            const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
+            const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
+            const float pg1 = -A * ratio, pg2 = -A * rc;
+            loss_a += count_me * (pg1 > pg2 ? pg1 : pg2);
+            loss_b += count_me * H;
+            const bool inrange = (ratio >= lo) && (ratio <= hi);
+            float dpg;
+            if (pg1 > pg2) dpg = -A;
+            else if (pg1 < pg2) dpg = inrange ? -A : 0.0f;
+            else dpg = -0.5f * A + (inrange ? -0.5f * A : 0.0f);
+            const float g_lp = invn * dpg * ratio;
+            const float ec = ent_coef * invn;
+            dl[0] = g_lp * ((act == 0 ? 1.0f : 0.0f) - p0) + ec * (p0 * (nl0 + H));
+            dl[NOUT - 1] = g_lp * ((act == 1 ? 1.0f : 0.0f) - p1) + ec * (p1 * (nl1 + H));
+        } else {
+            const float v = outp[0];
+            const float d1 = v - ret;
+            const float vl1 = d1 * d1;
+            const float dv = v - v_old;
+            const float dvc = dv < -clip_coef ? -clip_coef : (dv > clip_coef ? clip_coef : dv);
+            const float vc = v_old + dvc;
+            const float d2 = vc - ret;
+            const float vl2 = d2 * d2;
+            loss_a += count_me * (vl1 > vl2 ? vl1 : vl2);
+            const bool vin = (dv >= -clip_coef) && (dv <= clip_coef);
+            float dmax;
+            if (vl1 > vl2) dmax = 2.0f * d1;
+            else if (vl1 < vl2) dmax = vin ? 2.0f * d2 : 0.0f;
+            else dmax = d1 + (vin ? d2 : 0.0f);
+            dl[0] = (vf_coef * 0.5f * invn) * dmax;
+        }
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) {
+            dl[a] = valid ? dl[a] : 0.0f;
+            db3[a] += (h == 0) ? dl[a] : 0.0f;
+        }
+        if (h == 0) *reinterpret_cast<float4*>(dls + 4 * li) = make_float4(dl[0], NOUT == 2 ? dl[NOUT - 1] : 0.0f, 0.0f, 0.0f);
+
+        // ---- dW3 += dl^T h2: stage h2 as a [row][unit] image (rows 0-15 in bufA, 16-31 in bufB) ----
+        // 4x4x1 (16 blocks, block b = lane>>2): D[b][i][j] += A[b][i] B[b][j]; A = dl[row][i], B = h2[row][4b+j]
+        wave_lds_fence();
+        {
+            float* dst = (li >> 4) ? bufB : bufA;
+            const int rl = li & 15;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dst + rl * W2S + 8 * q + 4 * h + 32 * m) =
+                        make_float4(h2[m][4 * q], h2[m][4 * q + 1], h2[m][4 * q + 2], h2[m][4 * q + 3]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += 2) {
+            const float* s0 = (rr < 16) ? bufA : bufB;
+            dW3a = mfma4(dls[4 * rr + (lane & 3)], s0[(rr & 15) * W2S + lane], dW3a);
+            dW3b = mfma4(dls[4 * (rr + 1) + (lane & 3)], s0[((rr + 1) & 15) * W2S + lane], dW3b);
+        }
+
+        // ---- dz2 = (W3^T dl) * (1 - h2^2); h2 is dead afterwards ----
+        f32x16 dz2[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int a = 0; a < NOUT; ++a) {
+                    const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 8 * q + 4 * h + 32 * m]);
+                    d[0] = __builtin_fmaf(w.x, dl[a], d[0]); d[1] = __builtin_fmaf(w.y, dl[a], d[1]);
+                    d[2] = __builtin_fmaf(w.z, dl[a], d[2]); d[3] = __builtin_fmaf(w.w, dl[a], d[3]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float t = h2[m][4 * q + c]; dz2[m][4 * q + c] = d[c] * (1.0f - t * t); }
+            }
+
+        // ---- dh1^T = W2^T dz2^T, dz1 = dh1 * (1 - h1^2) ----
+        f32x16 dz1[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz1[m][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {  // k-step s <-> output unit o = u(s&15, h) + 32(s>>4)
+            const int o_unit = ((s & 15) & 3) + 8 * ((s & 15) >> 2) + 4 * h + 32 * (s >> 4);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) dz1[m] = mfma32(sm.W2[o_unit * W2S + li + 32 * m], dz2[s >> 4][s & 15], dz1[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float t = h1[m][r]; dz1[m][r] = dz1[m][r] * (1.0f - t * t); }
+
+        // ---- dW1 += dz1^T x (4x4x1: A = dz1[row][4b+i], B = x[row][j]) and db1; dz1 is dead afterwards ----
+        wave_lds_fence();
+        {
+            float* dst = (li >> 4) ? bufB : bufA;
+            const int rl = li & 15;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dst + rl * W2S + 8 * q + 4 * h + 32 * m) =
+                        make_float4(dz1[m][4 * q], dz1[m][4 * q + 1], dz1[m][4 * q + 2], dz1[m][4 * q + 3]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += 2) {
+            const float* s0 = (rr < 16) ? bufA : bufB;
+            const float z0 = s0[(rr & 15) * W2S + lane], z1v = s0[((rr + 1) & 15) * W2S + lane];
+            db1 += z0 + z1v;
+            dW1a = mfma4(z0, xs[4 * rr + (lane & 3)], dW1a);
+            dW1b = mfma4(z1v, xs[4 * (rr + 1) + (lane & 3)], dW1b);
+        }
+
+        // ---- dW2[o][i] += sum_rows dz2[row][o] h1[row][i]: A[i=o][k=row], B[k=row][j=i]; 16 rows at a time ----
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            wave_lds_fence();
+            if ((li >> 4) == hf) {
+                const int rl = li & 15;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int off = rl * W2S + 8 * q + 4 * h + 32 * m;
+                        *reinterpret_cast<float4*>(bufA + off) = make_float4(h1[m][4 * q], h1[m][4 * q + 1], h1[m][4 * q + 2], h1[m][4 * q + 3]);
+                        *reinterpret_cast<float4*>(bufB + off) = make_float4(dz2[m][4 * q], dz2[m][4 * q + 1], dz2[m][4 * q + 2], dz2[m][4 * q + 3]);
+                    }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int ro = (2 * s + h) * W2S + li;
+                const float a0 = bufB[ro], a1 = bufB[ro + 32], b0 = bufA[ro], b1v = bufA[ro + 32];
+                db2[0] += a0; db2[1] += a1;
+                dW2[0][0] = mfma32(a0, b0, dW2[0][0]);
+                dW2[0][1] = mfma32(a0, b1v, dW2[0][1]);
+                dW2[1][0] = mfma32(a1, b0, dW2[1][0]);
+                dW2[1][1] = mfma32(a1, b1v, dW2[1][1]);
+            }
+        }
+    }
+    const f32x4 dW1 = dW1a + dW1b, dW3 = dW3a + dW3b;
+
+    // ---- deterministic cross-wave reduction, then one partial slab per block ----
+    __syncthreads();  // every wave is done with sm.W2 -> reuse it as the 64x64 reduction tile
+    float* red = sm.W2;
+    for (int w = 0; w < GRAD_WAVES; ++w) {
+        if (wib == w) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o_unit = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * m;
+                        const int at = o_unit * HID + li + 32 * n;
+                        red[at] = (w == 0) ? dW2[m][n][r] : red[at] + dW2[m][n][r];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < HID * HID; i += 64 * GRAD_WAVES) part[N_W2 + i] = red[i];
+    // small tensors: every wave drops its values in its own bufA slot, then a fixed-order sum over the 4 waves
+    {
+        float* slot = bufA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) slot[(4 * (lane >> 2) + i) * 4 + (lane & 3)] = dW1[i];  // dW1[unit 4b+i][k=j]
+        slot[256 + lane] = db1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float t = db2[m] + __shfl_xor(db2[m], 32);
+            if (h == 0) slot[320 + li + 32 * m] = t;
+        }
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) slot[384 + a * HID + lane] = dW3[a];  // dW3[a][unit = lane]
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) { const float t = wave_sum(db3[a]); if (lane == 0) slot[384 + NOUT * HID + a] = t; }
+        const float la = wave_sum(loss_a), lb = wave_sum(loss_b);
+        if (lane == 0) { slot[520] = la; slot[521] = lb; }
+    }
+    __syncthreads();
+    constexpr int N_SMALL = 384 + NOUT * HID + NOUT;
+    for (int i = tid; i < 522; i += 64 * GRAD_WAVES) {
+        if (i >= N_SMALL && i < 520) continue;
+        const float t = (sm.bufA[0][i] + sm.bufA[1][i]) + (sm.bufA[2][i] + sm.bufA[3][i]);
+        int dst;
+        if (i < 256) dst = N_W1 + i;
+        else if (i < 320) dst = N_B1 + (i - 256);
+        else if (i < 384) dst = N_B2 + (i - 320);
+        else if (i < N_SMALL) dst = N_W3 + (i - 384);
+        else dst = PART_LOSS + (i - 520);
+        part[dst] = t;
+    }
+}
+
+__global__ void __launch_bounds__(64 * GRAD_WAVES, 2)
+grad_kernel(const float* __restrict__ params, const float* __restrict__ observations, const int64_t* __restrict__ actions,
+            const float* __restrict__ log_probs, const float* __restrict__ advantages, const float* __restrict__ returns,
+            const float* __restrict__ values, const int32_t* __restrict__ idx, int mb, const double* __restrict__ adv_sums,
+            float clip_coef, float ent_coef, float vf_coef, float invn, float* __restrict__ workspace) {
+    __shared__ grad_smem sm;
+    float* part = workspace + (size_t)blockIdx.x * PART_STRIDE;
+    if ((blockIdx.x & 1) == 0)
+        grad_body<true>(sm, params, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
+                        ent_coef, vf_coef, invn, part);
+    else
+        grad_body<false>(sm, params, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
+                         ent_coef, vf_coef, invn, part);
+}
+
+// grads[p] = sum over the blocks of p's net, in block order; the last block finishes the loss terms.
+__global__ void __launch_bounds__(256) grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_coef,
+                                                          float vf_coef, double inv_count, float* __restrict__ grads,
+                                                          float* __restrict__ loss_terms) {
+    const int pblocks = (NPARAMS + 255) / 256;
+    if ((int)blockIdx.x < pblocks) {
+        const int p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= NPARAMS) return;
+        const int role = p < C_BASE ? 0 : 1;
+        const int local = p - (role ? C_BASE : 0);
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int k = 0;
+        for (int b = role; b < n_blocks; b += 2, k = (k + 1) & 3) acc[k] += workspace[(size_t)b * PART_STRIDE + local];
+        grads[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    } else {
+        // loss terms: pg / entropy from actor blocks, value loss from critic blocks
+        double pg = 0.0, en = 0.0, vl = 0.0;
+        for (int b = threadIdx.x; b < n_blocks; b += 256) {
+            const float* s = workspace + (size_t)b * PART_STRIDE + PART_LOSS;
+            if ((b & 1) == 0) { pg += s[0]; en += s[1]; } else { vl += s[0]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pg += __shfl_xor(pg, o); en += __shfl_xor(en, o); vl += __shfl_xor(vl, o); }
+        __shared__ double t[3][4];
+        if ((threadIdx.x & 63) == 0) { t[0][threadIdx.x >> 6] = pg; t[1][threadIdx.x >> 6] = en; t[2][threadIdx.x >> 6] = vl; }
+        __syncthreads();
+        if (threadIdx.x == 0 && loss_terms) {
+            const double PG = (t[0][0] + t[0][1]) + (t[0][2] + t[0][3]);
+            const double EN = (t[1][0] + t[1][1]) + (t[1][2] + t[1][3]);
+            const double VL = (t[2][0] + t[2][1]) + (t[2][2] + t[2][3]);
+            const float t0 = (float)(PG * inv_count), t1 = (float)(EN * inv_count), t2 = (float)(0.5 * VL * inv_count);
+            loss_terms[0] = t0; loss_terms[1] = t1; loss_terms[2] = t2;
+            loss_terms[3] = t0 - ent_coef * t1 + t2 * vf_coef;  // ppo.py:187
+        }
+    }
+}
+
+static int g_grad_blocks = 0;
+static int grad_blocks() {
+    if (g_grad_blocks == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        int b = 2 * cus;  // one actor + one critic workgroup per CU
+        if (b > GRAD_MAX_BLOCKS) b = GRAD_MAX_BLOCKS;
+        g_grad_blocks = b;
+    }
+    return g_grad_blocks;
+}
+
+extern "C" size_t mi_ppo_workspace_bytes(void) { return (size_t)GRAD_MAX_BLOCKS * PART_STRIDE * sizeof(float); }
+
+extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observations, const int64_t* actions,
+                                     const float* log_probs, const float* advantages, const float* returns,
+                                     const float* values, const int32_t* idx, int mb, const double* adv_sums, float clip_coef,
+                                     float ent_coef, float vf_coef, double inv_count, void* workspace, float* grads,
+                                     float* loss_terms, void* stream) {
+    MI_CHECK_ARG(params && observations && actions && log_probs && advantages && returns && values && idx && adv_sums, "NULL input");
+    MI_CHECK_ARG(workspace && grads, "NULL workspace/grads");
+    MI_CHECK_ARG(mb > 0, "mb must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = grad_blocks();
+    // small minibatches: no point launching blocks that would only write zero slabs
+    const int tiles = (mb + 31) / 32;
+    const int need = 2 * ((tiles + GRAD_WAVES - 1) / GRAD_WAVES);
+    if (need < blocks) blocks = need;
+    {
+        mi_prof_scope prof(MI_PROF_GRAD, s);
+        grad_kernel<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, observations, actions, log_probs, advantages, returns, values, idx, mb,
+                                                       adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace);
+    }
+    MI_LAUNCH_CHECK();
+    {
+        mi_prof_scope prof(MI_PROF_REDUCE, s);
+        grad_reduce_kernel<<<(NPARAMS + 255) / 256 + 1, 256, 0, s>>>((const float*)workspace, blocks, ent_coef, vf_coef, inv_count,
+                                                                     grads, loss_terms);
+    }
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// =====================================================================================================
+// clip_grad_norm_ + Adam, one workgroup (9,155 parameters)
+// =====================================================================================================
+__global__ void __launch_bounds__(1024) clip_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                                          float* __restrict__ m, float* __restrict__ v, int n, float w1, float b2,
+                                                          float w2, float step_size, float bc2_sqrt, float eps, float max_norm,
+                                                          float* __restrict__ grad_norm) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) { const double g = grads[i]; s += g * g; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ double ws[16];
+    __shared__ float coef_s;
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += ws[k];
+        const float total = (float)sqrt(t);
+        float coef = max_norm / (total + 1e-6f);
+        coef_s = coef > 1.0f ? 1.0f : coef;
+        if (grad_norm) *grad_norm = total;
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float g = grads[i] * coef;
+        const float mi = m[i] + w1 * (g - m[i]);
+        const float vi = v[i] * b2 + w2 * (g * g);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        m[i] = mi; v[i] = vi;
+        params[i] = params[i] + (-step_size) * (mi / denom);
+    }
+}
+
+extern "C" int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr,
+                            double beta1, double beta2, double eps, float max_norm, float* grad_norm, void* stream) {
+    MI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "NULL pointer");
+    MI_CHECK_ARG(n > 0 && step >= 1, "n must be positive and step 1-based");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    mi_prof_scope prof(MI_PROF_CLIP_ADAM, (hipStream_t)stream);
+    clip_adam_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
+                                                          (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps,
+                                                          max_norm, grad_norm);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// =====================================================================================================
+// explained variance (ppo.py:194-195): 1 - var(values - returns) / var(values), unbiased, NaN if var == 0
+// =====================================================================================================
+__device__ inline double block_sum_1024(double x, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += sh[k];
+    return t;
+}
+
+__global__ void __launch_bounds__(1024) explained_var_kernel(const float* __restrict__ values, const float* __restrict__ returns, size_t n,
+                                                              double* __restrict__ out) {
+    __shared__ double sh[16];
+    double sv = 0.0, sd = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) { sv += values[i]; sd += (double)values[i] - returns[i]; }
+    const double mv = block_sum_1024(sv, sh) / (double)n, md = block_sum_1024(sd, sh) / (double)n;
+    double vv = 0.0, vd = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const double a = values[i] - mv, b = ((double)values[i] - returns[i]) - md;
+        vv += a * a; vd += b * b;
+    }
+    vv = block_sum_1024(vv, sh) / (double)(n - 1);
+    vd = block_sum_1024(vd, sh) / (double)(n - 1);
+    if (threadIdx.x == 0) *out = vv == 0.0 ? __builtin_nan("") : 1.0 - vd / vv;
+}
+
+extern "C" int mi_explained_var(const float* values, const float* returns, size_t n, double* out, void* stream) {
+    MI_CHECK_ARG(values && returns && out, "NULL pointer");
+    MI_CHECK_ARG(n >= 2, "n must be >= 2");
+    explained_var_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(values, returns, n, out);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// =====================================================================================================
+// One whole outer update, enqueued back to back (single rank, production RNG)
+// =====================================================================================================
+extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* stream) {
+    MI_CHECK_ARG(handle && b && hp, "NULL pointer");
+    MI_CHECK_ARG(hp->T > 0 && hp->n_minibatch > 0 && hp->update_epochs > 0, "bad hyper-parameters");
+    mi_env* e = (mi_env*)handle;
+    const int N = e->n, B = hp->T * N;
+    MI_CHECK_ARG(B % hp->n_minibatch == 0, "T*N must be divisible by n_minibatch");
+    const int mb = B / hp->n_minibatch;
+    int rc = mi_ppo_rollout(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
+                            b->dones, nullptr, nullptr, nullptr, b->episodes, b->episode_stats, b->max_ep, stream);
+    if (rc) return rc;
+    rc = mi_gae(b->rewards, b->dones, b->values, hp->T, N, hp->gamma, hp->gae_lambda, b->advantages, b->returns, stream);
+    if (rc) return rc;
+    int64_t step = hp->opt_step;
+    for (int ep = 0; ep < hp->update_epochs; ++ep) {
+        rc = mi_make_perm((uint32_t)B, mi_perm_key(e->seed, (uint64_t)hp->update_index, (uint64_t)ep), b->perm, stream);
+        if (rc) return rc;
+        rc = mi_adv_stats(b->advantages, b->perm, mb, hp->n_minibatch, b->adv_sums, stream);
+        if (rc) return rc;
+        for (int k = 0; k < hp->n_minibatch; ++k) {
+            rc = mi_ppo_minibatch_grad(b->params, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
+                                       b->perm + (size_t)k * mb, mb, b->adv_sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef,
+                                       1.0 / mb, b->workspace, b->grads, b->loss_terms, stream);
+            if (rc) return rc;
+            step += 1;
+            rc = mi_clip_adam(b->params, b->grads, b->exp_avg, b->exp_avg_sq, NPARAMS, step, hp->lr, hp->beta1, hp->beta2, hp->eps,
+                              hp->max_grad_norm, b->grad_norm, stream);
+            if (rc) return rc;
+        }
+    }
+    return MI_OK;
+}
+
+// =====================================================================================================
+// Hardware self-test of the MFMA fragment layouts grad_kernel relies on (exact small-integer data).
+// report[0]: 32x32x2 A/B/D maps   report[1]: 4x4x1 (16 blocks) A/B/D maps   report[2]: accumulator-as-B chain
+// dump (nullable, f32 [3*64*16]): raw accumulators of the three probes for offline diagnosis.
+// =====================================================================================================
+__global__ void __launch_bounds__(64) selftest_kernel(int32_t* __restrict__ report, float* __restrict__ dump) {
+    const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
+    int bad0 = 0, bad1 = 0, bad2 = 0;
+    // probe 0: D = A B with A[i][k] = 1 + i + 37k (asymmetric), B[k][j] = 2 + 3j + 101k
+    {
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+        const float a = (float)(1 + li + 37 * h), b = (float)(2 + 3 * li + 101 * h);
+        d = mfma32(a, b, d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h, j = li;
+            const float want = (float)((1 + i) * (2 + 3 * j) + (1 + i + 37) * (2 + 3 * j + 101));
+            bad0 += d[r] != want;
+            if (dump) dump[(0 * 64 + lane) * 16 + r] = d[r];
+        }
+    }
+    // probe 1: 16 blocks of 4x4, K = 1: D[b][i][j] = A[b][i] B[b][j], A lane = 4b+i, B lane = 4b+j, D reg = i lane = 4b+j
+    {
+        f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float a = (float)(1 + lane), b = (float)(100 + 7 * lane);
+        d = mfma4(a, b, d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int blk = lane >> 2, j = lane & 3;
+            const float want = (float)(1 + 4 * blk + i) * (float)(100 + 7 * (4 * blk + j));
+            bad1 += d[i] != want;
+            if (dump) dump[(1 * 64 + lane) * 16 + i] = d[i];
+        }
+    }
+    // probe 2: Y^T = W X^T with X^T taken from a previous accumulator (permuted k): X[row j][unit u] = 1 + (j % 5) + 2u,
+    //          W[o][u] = 1 + ((o + 3u) % 7);  want Y[j][o] = sum_u W[o][u] X[j][u]
+    {
+        f32x16 x[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * m;
+                x[m][r] = (float)(1 + (li % 5) + 2 * u);
+            }
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int u = ((s & 15) & 3) + 8 * ((s & 15) >> 2) + 4 * h + 32 * (s >> 4);
+            const float a = (float)(1 + ((li + 3 * u) % 7));  // W[o = li][u]
+            y = mfma32(a, x[s >> 4][s & 15], y);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = (r & 3) + 8 * (r >> 2) + 4 * h, j = li;
+            int want = 0;
+            for (int u = 0; u < 64; ++u) want += (1 + ((o + 3 * u) % 7)) * (1 + (j % 5) + 2 * u);
+            bad2 += y[r] != (float)want;
+            if (dump) dump[(2 * 64 + lane) * 16 + r] = y[r];
+        }
+    }
+    const int t0 = (int)wave_sum((float)bad0), t1 = (int)wave_sum((float)bad1), t2 = (int)wave_sum((float)bad2);
+    if (lane == 0) { report[0] = t0; report[1] = t1; report[2] = t2; for (int k = 3; k < 16; ++k) report[k] = 0; }
+}
+
+extern "C" int mi_selftest_mfma(int32_t* report, float* dump, void* stream) {
+    MI_CHECK_ARG(report != nullptr, "report is NULL");
+    selftest_kernel<<<1, 64, 0, (hipStream_t)stream>>>(report, dump);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+__global__ void __launch_bounds__(256) tanh_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = mi_tanhf(x[i]);
+}
+
+extern "C" int mi_test_tanh(const float* x, float* y, int n, void* stream) {
+    MI_CHECK_ARG(x && y && n > 0, "bad arguments");
+    tanh_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, y, n);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}

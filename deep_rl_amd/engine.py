@@ -1,0 +1,172 @@
+"""PPOEngine — device-resident rollout storage + the per-update launch sequence of reference ppo.py:105-195.
+
+Owns the six ``(T+1, N, …)`` storage tensors with the reference's names (ppo.py:93-98, env axis added after
+time), the advantage / return buffers, the gradient workspace and the episode log; every method is one or
+two launches through the C ABI (include/mi_rl.h) on torch's current stream.  Nothing here computes: Python
+sequences launches and (for world_size > 1) the two tiny all-reduces.
+
+Multi-GPU: envs shard across ranks (rank r owns global envs [r*N, (r+1)*N)); parameters and
+Adam state are replicated.  Per epoch one all-reduce(SUM) of the (n_minibatch, 3) advantage statistics, per
+optimizer step one all-reduce(SUM) of the flat 9,155-float gradient (already scaled by 1/(world*mb));
+clip + Adam then run identically on every rank.  Minibatch permutations are per-rank-local.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from . import dist as D
+
+
+class PPOEngine:
+    def __init__(self, env, agent, optimizer, num_steps=128, n_minibatch=4, update_epochs=4, gamma=0.99, gae_lambda=0.95,
+                 clip_coef=0.2, ent_coef=0.01, vf_coef=0.5, max_episodes_logged=None, process_group=None):
+        self.env, self.agent, self.optimizer = env, agent, optimizer
+        self.T, self.N = int(num_steps), env.num_envs
+        self.device = env.device
+        self.n_minibatch, self.update_epochs = int(n_minibatch), int(update_epochs)
+        self.gamma, self.gae_lambda = float(gamma), float(gae_lambda)
+        self.clip_coef, self.ent_coef, self.vf_coef = float(clip_coef), float(ent_coef), float(vf_coef)
+        self.batch_size = self.T * self.N
+        if self.batch_size % self.n_minibatch:
+            raise N.MiError("num_steps*num_envs (%d) must be divisible by n_minibatch (%d)" % (self.batch_size, self.n_minibatch))
+        self.minibatch_size = self.batch_size // self.n_minibatch
+        self.pg = process_group
+        self.world_size = D.world_size(process_group)
+        T, Nn, dev = self.T, self.N, self.device
+        z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)  # noqa: E731
+        # storage (ppo.py:93-98): num_steps + 1 rows because the terminal values are needed for the advantages
+        self.observations = z(T + 1, Nn, 4)
+        self.values = z(T + 1, Nn)
+        self.actions = z(T + 1, Nn, dt=torch.int64)
+        self.log_probs = z(T + 1, Nn)
+        self.rewards = z(T + 1, Nn)
+        self.dones = z(T + 1, Nn)
+        self.advantages = z(T + 1, Nn)
+        self.returns = z(T + 1, Nn)
+        self.perm = z(self.batch_size, dt=torch.int32)
+        self.adv_sums = z(self.n_minibatch, 3, dt=torch.float64)
+        # gradient + loss terms share one buffer so that ONE all-reduce carries both when sharded
+        self._gradbuf = z(N.NPARAMS + 5)
+        self.grads = self._gradbuf[:N.NPARAMS]
+        self.loss_terms = self._gradbuf[N.NPARAMS:N.NPARAMS + 4]
+        self.explained_var = z(1, dt=torch.float64)
+        self.workspace = torch.empty(N.lib().mi_ppo_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else max(1024, 2 * Nn))
+        self.episodes = torch.zeros((self.max_ep, 4), dtype=torch.int32, device=dev)  # mi_episode_t = 4 x 32 bit
+        self.episode_stats = z(4, dt=torch.int32)  # {finished episodes, sum of lengths, longest, -} of the last rollout
+        self.observation = None  # the carried-over `observation` of the reference loop (ppo.py:101,127-129)
+        self.update_index = 0
+
+    # ---- pieces of one outer update ----------------------------------------------------------------
+    def _s(self):
+        return N.stream_ptr(self.device)
+
+    def reset(self, forced_state=None):
+        """observation = env.reset() (ppo.py:101)."""
+        self.observation = self.env.reset(forced_state)
+        return self.observation
+
+    def rollout(self, forced_actions=None, forced_uniforms=None, forced_resets=None):
+        """ppo.py:110-141 in one launch; returns nothing (episode log: drain_episodes())."""
+        if self.observation is None:
+            self.reset()
+        dev = self.device
+        fa = None if forced_actions is None else forced_actions.to(dev, torch.int64).contiguous()
+        fu = None if forced_uniforms is None else forced_uniforms.to(dev, torch.float32).contiguous()
+        fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
+        N.check(N.lib().mi_ppo_rollout(self.env.handle, N.ptr(self.agent.flat), self.T, N.ptr(self.observation),
+                                       N.ptr(self.observations), N.ptr(self.values), N.ptr(self.actions), N.ptr(self.log_probs),
+                                       N.ptr(self.rewards), N.ptr(self.dones), N.ptr(fa), N.ptr(fu), N.ptr(fr),
+                                       N.ptr(self.episodes), N.ptr(self.episode_stats), self.max_ep, self._s()), "mi_ppo_rollout")
+
+    def drain_episodes(self):
+        """Host sync.  -> (count, [(env, t, return, length), ...] sorted by (t, env)) of the last rollout."""
+        n = int(self.episode_stats[0].item())
+        k = min(n, self.max_ep)
+        if k == 0:
+            return n, []
+        raw = self.episodes[:k].cpu()
+        rets = raw[:, 2].contiguous().view(torch.float32)
+        eps = sorted((int(raw[i, 1]), int(raw[i, 0]), float(rets[i]), int(raw[i, 3])) for i in range(k))
+        return n, [(e, t, r, l) for (t, e, r, l) in eps]
+
+    def episode_summary_async(self, pinned):
+        """Non-blocking copy of {episodes, sum of lengths, longest, -} of the last rollout into a pinned host tensor
+        (read it after the next sync point; CartPole return == length)."""
+        pinned.copy_(self.episode_stats, non_blocking=True)
+
+    def compute_gae(self):
+        """ppo.py:144-151."""
+        N.check(N.lib().mi_gae(N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.values), self.T, self.N, self.gamma,
+                               self.gae_lambda, N.ptr(self.advantages), N.ptr(self.returns), self._s()), "mi_gae")
+
+    def make_perm(self, epoch, key=None):
+        """b_inds = permutation(T*N) (ppo.py:155) from the keyed Feistel bijection; or set_perm() explicit indices."""
+        if key is None:
+            key = N.lib().mi_perm_key(self.env._seed, self.update_index, epoch)
+        N.check(N.lib().mi_make_perm(self.batch_size, key, N.ptr(self.perm), self._s()), "mi_make_perm")
+
+    def set_perm(self, indices):
+        self.perm.copy_(torch.as_tensor(indices, dtype=torch.int32).reshape(-1).to(self.device))
+
+    def adv_stats(self, mb=None, n_mb=None):
+        """Per-minibatch {sum, sum of squares, count} of the advantages (ppo.py:169); all-reduced when sharded."""
+        mb = self.minibatch_size if mb is None else mb
+        n_mb = self.n_minibatch if n_mb is None else n_mb
+        N.check(N.lib().mi_adv_stats(N.ptr(self.advantages), N.ptr(self.perm), mb, n_mb, N.ptr(self.adv_sums), self._s()),
+                "mi_adv_stats")
+        D.allreduce_sum_(self.adv_sums, self.pg)
+
+    def minibatch_grad(self, k, mb=None):
+        """loss + gradient of minibatch k of the current permutation (ppo.py:159-190) -> self.grads, self.loss_terms."""
+        mb = self.minibatch_size if mb is None else mb
+        idx_ptr = self.perm.data_ptr() + 4 * k * mb
+        N.check(N.lib().mi_ppo_minibatch_grad(
+            N.ptr(self.agent.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.log_probs), N.ptr(self.advantages),
+            N.ptr(self.returns), N.ptr(self.values), idx_ptr, mb, self.adv_sums.data_ptr() + 24 * k, self.clip_coef, self.ent_coef,
+            self.vf_coef, 1.0 / (mb * self.world_size), N.ptr(self.workspace), N.ptr(self.grads), N.ptr(self.loss_terms), self._s()),
+            "mi_ppo_minibatch_grad")
+        D.allreduce_sum_(self._gradbuf, self.pg)
+
+    def optimizer_step(self):
+        """clip_grad_norm_ + optimizer.step() (ppo.py:191-192)."""
+        self.optimizer.step(self.grads)
+
+    def compute_explained_var(self):
+        """ppo.py:194-195 (over all T+1 rows of this rank)."""
+        N.check(N.lib().mi_explained_var(N.ptr(self.values), N.ptr(self.returns), (self.T + 1) * self.N,
+                                         N.ptr(self.explained_var), self._s()), "mi_explained_var")
+        return self.explained_var
+
+    # ---- one whole outer update ------------------------------------------------------------------------
+    def update(self):
+        """Rollout + GAE + update_epochs x n_minibatch optimizer steps (ppo.py:110-192), production RNG.
+
+        Single rank: ONE C call enqueues every launch (mi_ppo_update).  Sharded: the same launches are
+        sequenced from here with the two all-reduces in between.
+        """
+        if self.observation is None:
+            self.reset()
+        g = self.optimizer.param_groups[0]
+        if self.world_size == 1:
+            o = self.optimizer
+            buf = N.PPOBuffers(*[N.ptr(t) for t in (
+                self.agent.flat, o.exp_avg, o.exp_avg_sq, self.grads, self.loss_terms, o.grad_norm, self.observation,
+                self.observations, self.values, self.actions, self.log_probs, self.rewards, self.dones, self.advantages,
+                self.returns, self.perm, self.adv_sums, self.workspace, self.episodes, self.episode_stats)], self.max_ep)
+            hp = N.PPOHparams(self.T, self.n_minibatch, self.update_epochs, self.update_index, o.step_count, self.gamma,
+                              self.gae_lambda, self.clip_coef, self.ent_coef, self.vf_coef, float(g["max_grad_norm"]),
+                              float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"])
+            N.check(N.lib().mi_ppo_update(self.env.handle, C.byref(buf), C.byref(hp), self._s()), "mi_ppo_update")
+            o.step_count += self.update_epochs * self.n_minibatch
+        else:
+            self.rollout()
+            self.compute_gae()
+            for epoch in range(self.update_epochs):
+                self.make_perm(epoch)
+                self.adv_stats()
+                for k in range(self.n_minibatch):
+                    self.minibatch_grad(k)
+                    self.optimizer_step()
+        self.update_index += 1

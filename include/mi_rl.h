@@ -1,0 +1,179 @@
+/*
+ * mi_rl.h — C ABI of the MI355X-native rollout + policy-update engine (libmirl.so).
+ *
+ * This is the drop-in boundary for the reference's PPO/CartPole hot path.  The reference
+ * (qgallouedec/deep_rl) has no FFI of its own: the path sits behind three de-facto Python protocols
+ * (gym-0.21 Env, nn.Module methods, bare torch.Tensor storage).  Each entry point
+ * below names the reference lines it replaces; the deep_rl_amd Python modules bind them with ctypes and
+ * re-presents the reference's Python surface (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  Every pointer marked "dev" is DEVICE memory
+ *     owned by the caller (e.g. torch allocations passed by data_ptr()).
+ *   - every call returns MI_OK (0) or a negative MI_E* code; mi_last_error() gives the text.
+ *     Nothing throws, aborts, allocates or synchronises on the hot path: work is enqueued on the
+ *     hipStream_t that is passed (as void*; NULL = the null stream).
+ *   - an env handle is bound to the device that was current at mi_env_create and is not
+ *     thread-safe (the reference's caller is single-threaded).
+ *   - multi-GPU: one process per GPU, each with its own handle and env_id_base = rank * n_envs;
+ *     the only exchange is the caller's all-reduce of `grads` (and of the advantage statistics)
+ *     between mi_ppo_minibatch_grad and mi_clip_adam.
+ *
+ * Storage layout (reference ppo.py:93-98 with an env axis after time):
+ *   observations f32 [(T+1), N, 4]   values f32 [(T+1), N]    actions i64 [(T+1), N]
+ *   log_probs    f32 [(T+1), N]      rewards f32 [(T+1), N]   dones   f32 [(T+1), N]
+ *   advantages / returns f32 [(T+1), N];  a flattened row index is t*N + n.
+ *
+ * Parameter layout: one flat f32 vector of MI_PPO_NPARAMS in the order of agent.parameters()
+ * (ppo.py:34-47): actor {W1[64,4] b1[64] W2[64,64] b2[64] W3[2,64] b3[2]} then
+ * critic {W1 b1 W2 b2 W3[1,64] b3[1]}, torch Linear row-major [out][in].
+ *
+ * RNG contract (production mode; in parity mode every random input is supplied explicitly):
+ *   philox4x32-10, counter = {env_lo, env_hi, idx_lo, (idx_hi << 4) | stream}, key = {seed_lo, seed_hi}
+ *   stream 0: reset noise   idx = episode index of that env; word i -> s_i = -0.05 + 0.1*((w_i+0.5)/2^32) (f64)
+ *   stream 1: action draw   idx = number of actions that env has sampled; u = (w_0 >> 8) / 2^24 (f32),
+ *             action = #{j < n_actions-1 : u >= cumsum(probs)[j]}
+ *   stream 2: permutation key for (env := update, idx := epoch): key = w_0 | (w_1 << 32); the
+ *             permutation itself is the 6-round Feistel bijection with cycle walking of mi_make_perm.
+ *   `env` is the GLOBAL env id (env_id_base + local index) so a trajectory does not depend on how
+ *   envs are sharded over GPUs.  oracle/cpu_ref.c implements the same contract bit for bit.
+ */
+#ifndef MI_RL_H
+#define MI_RL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_VERSION 100
+#define MI_PPO_NPARAMS 9155
+#define MI_PPO_ACTOR_NPARAMS 4610
+#define MI_OBS_DIM 4
+#define MI_HIDDEN 64
+#define MI_N_ACTIONS 2
+
+enum { MI_OK = 0, MI_EINVAL = -1, MI_EHIP = -2, MI_ENOMEM = -3, MI_ESTATE = -4 };
+enum { MI_ENV_CARTPOLE_V1 = 0 };
+
+typedef struct {
+    int32_t env;   /* local env index */
+    int32_t t;     /* rollout step at which the episode ended */
+    float ret;     /* info["episode"]["r"] (ppo.py:130) */
+    int32_t len;   /* info["episode"]["l"] */
+} mi_episode_t;
+
+int mi_version(void);
+const char* mi_last_error(void); /* thread-local, valid until the next call on this thread */
+
+/* ---- gym-0.21 Env protocol for N envs (replaces TorchWrapper + gym.make + RecordEpisodeStatistics,
+ *      ppo.py:10-22,79-84; arithmetic of gym==0.21 cartpole.py / time_limit.py) ------------------ */
+int mi_env_create(int kind, int n_envs, uint64_t seed, uint64_t env_id_base, void** handle);
+int mi_env_destroy(void* handle);
+/* env.reset() (ppo.py:21,101).  obs: dev f32 [N,4].  forced_state: dev f64 [N,4] or NULL (keyed noise). */
+int mi_env_reset(void* handle, float* obs, const double* forced_state, void* stream);
+/* env.step(action) followed by ppo.py:128-129's `if done: observation = env.reset()`.
+ * actions dev i64 [N]; forced_reset dev f64 [N,4] or NULL; outputs (all dev, all required):
+ * obs f32 [N,4] (the reset observation where done), reward f32 [N], done u8 [N] (terminated OR
+ * truncated), truncated u8 [N] (info["TimeLimit.truncated"]), fin_ret f32 [N] / fin_len i32 [N]
+ * (episode statistics of envs that finished this step, else 0). */
+int mi_env_step(void* handle, const int64_t* actions, const double* forced_reset, float* obs, float* reward,
+                uint8_t* done, uint8_t* truncated, float* fin_ret, int32_t* fin_len, void* stream);
+/* debug/test: copy the float64 state out as dev f64 [N,4] and the TimeLimit counters as dev i32 [N] (nullable). */
+int mi_env_get_state(void* handle, double* state, int32_t* elapsed, void* stream);
+
+/* ---- ActorCritic forward on an arbitrary batch (ppo.py:49-54): logits dev f32 [n,2] and/or value dev f32 [n] */
+int mi_ppo_forward(const float* params, const float* obs, int n, float* logits, float* value, void* stream);
+
+/* ---- the rollout loop ppo.py:110-141 for N envs, T steps, one launch.
+ * obs_cur dev f32 [N,4]: carried-over `observation` (in/out).  Six storage buffers as above.
+ * Parity inputs (each NULL in production): forced_actions dev i64 [T,N]; forced_uniforms dev f32 [T,N];
+ * forced_resets dev f64 [T,N,4] (state used if env n resets at step t).
+ * episodes dev mi_episode_t [max_ep] + episode_stats dev i32 [4] (both nullable).  The call resets episode_stats and
+ * the kernel accumulates {[0] number of finished episodes, [1] sum of their lengths, [2] longest, [3] reserved}
+ * (CartPole: return == length); only the first max_ep episodes are stored individually. */
+int mi_ppo_rollout(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                   int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
+                   const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
+                   int32_t* episode_stats, int max_ep, void* stream);
+
+/* ---- GAE reverse scan ppo.py:144-151 (expression order preserved, no FMA contraction) */
+int mi_gae(const float* rewards, const float* dones, const float* values, int T, int N, float gamma, float lam,
+           float* advantages, float* returns, void* stream);
+
+/* ---- minibatch indices (replaces np.random.permutation, ppo.py:155): out dev i32 [n] = Feistel bijection on [0,n) */
+int mi_make_perm(uint32_t n, uint64_t key, int32_t* out, void* stream);
+uint64_t mi_perm_key(uint64_t seed, uint64_t update, uint64_t epoch); /* host helper, RNG contract stream 2 */
+
+/* ---- advantage statistics of n_mb consecutive minibatches of `mb` indices each (ppo.py:169):
+ * sums dev f64 [n_mb,3] = {sum a, sum a^2, count}; the caller may all-reduce(SUM) them across ranks. */
+int mi_adv_stats(const float* advantages, const int32_t* idx, int mb, int n_mb, double* sums, void* stream);
+
+/* ---- loss + gradient of one minibatch (ppo.py:159-190).  idx dev i32 [mb] (flattened rows, t < T);
+ * adv_sums dev f64 [3] as produced by mi_adv_stats; inv_count = 1 / (rows the means are taken over,
+ * i.e. world_size * mb).  Outputs: grads dev f32 [MI_PPO_NPARAMS] = d loss / d params (this rank's
+ * share, already scaled by inv_count, so a SUM all-reduce gives the global gradient);
+ * loss_terms dev f32 [4] = {pg_loss, entropy, v_loss, loss} shares scaled the same way.
+ * workspace: dev, at least mi_ppo_workspace_bytes() bytes. */
+size_t mi_ppo_workspace_bytes(void);
+int mi_ppo_minibatch_grad(const float* params, const float* observations, const int64_t* actions,
+                          const float* log_probs, const float* advantages, const float* returns, const float* values,
+                          const int32_t* idx, int mb, const double* adv_sums, float clip_coef, float ent_coef,
+                          float vf_coef, double inv_count, void* workspace, float* grads, float* loss_terms,
+                          void* stream);
+
+/* ---- clip_grad_norm_(max_norm) + Adam step (ppo.py:191-192, torch single-tensor Adam).
+ * step is 1-based.  grad_norm dev f32 [1] nullable: receives the pre-clip total norm. */
+int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr,
+                 double beta1, double beta2, double eps, float max_norm, float* grad_norm, void* stream);
+
+/* ---- explained variance ppo.py:194-195 over n = (T+1)*N entries: out dev f64 [1] */
+int mi_explained_var(const float* values, const float* returns, size_t n, double* out, void* stream);
+
+/* ---- one whole outer update (ppo.py:105-192) enqueued back to back on `stream`, production RNG,
+ * single rank (no collective).  All pointers dev.  perm: i32 [T*N]; adv_sums: f64 [n_minibatch*3]. */
+typedef struct {
+    float* params; float* exp_avg; float* exp_avg_sq; float* grads; float* loss_terms; float* grad_norm;
+    float* obs_cur; float* observations; float* values; int64_t* actions; float* log_probs; float* rewards;
+    float* dones; float* advantages; float* returns; int32_t* perm; double* adv_sums; void* workspace;
+    mi_episode_t* episodes; int32_t* episode_stats; int32_t max_ep;
+} mi_ppo_buffers_t;
+typedef struct {
+    int32_t T, n_minibatch, update_epochs, update_index; int64_t opt_step; /* optimizer steps done so far */
+    float gamma, gae_lambda, clip_coef, ent_coef, vf_coef, max_grad_norm;
+    double lr, beta1, beta2, eps;
+} mi_ppo_hparams_t;
+int mi_ppo_update(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* stream);
+
+/* ---- hardware self-test: probes the MFMA fragment layouts the update kernel relies on with exact
+ * integer data; report dev i32 [16] (0 = ok per probe); dump (nullable) dev f32 [3*64*16] receives the raw
+ * accumulators of the probes.  Used by tests and smoke(). */
+int mi_selftest_mfma(int32_t* report, float* dump, void* stream);
+
+/* ---- test hook: y[i] = the engine's device tanh(x[i]) (x, y dev f32 [n]); lets the tests bound its error */
+int mi_test_tanh(const float* x, float* y, int n, void* stream);
+
+/* ---- in-library kernel profiler for bench.py: while enabled, every launch of the tagged kernels is bracketed by a
+ * pair of HIP events on ITS stream (so the durations are measured live inside the timed region, on the stream the
+ * kernel runs on).  mi_prof_begin(max_launches, tag_mask) arms it for the tags whose bit is set (allocates the event
+ * pool, may synchronise);
+ * mi_prof_end synchronises, fills total_ms[MI_PROF_NTAGS] / count[MI_PROF_NTAGS] (host arrays) and disarms. */
+enum { MI_PROF_ROLLOUT = 0, MI_PROF_GAE = 1, MI_PROF_GRAD = 2, MI_PROF_REDUCE = 3, MI_PROF_CLIP_ADAM = 4, MI_PROF_STATS = 5,
+       MI_PROF_NTAGS = 6 };
+int mi_prof_begin(int max_launches, uint32_t tag_mask);
+int mi_prof_end(float* total_ms, int32_t* count);
+
+/* ---- timing helper for bench.py: HIP events on the given stream (torch.cuda.Event only sees torch's
+ * current stream).  mi_timer_* are host-side and may synchronise. */
+int mi_timer_create(void** timer);
+int mi_timer_destroy(void* timer);
+int mi_timer_start(void* timer, void* stream);
+int mi_timer_stop(void* timer, void* stream);
+int mi_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_RL_H */

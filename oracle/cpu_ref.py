@@ -69,9 +69,16 @@ def lib():
         L.ref_ppo_update.restype = C.c_int
         L.ref_ppo_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_float, C.c_float, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.ref_set_sincos_mode.argtypes = [C.c_int]
+        L.ref_get_sincos_mode.restype = C.c_int
         L.ref_num_threads.restype = C.c_int
         L.ref_set_num_threads.argtypes = [C.c_int]
     return _lib
+
+
+def set_sincos_mode(mode):
+    """0 = libm (gym-faithful, pinned to the reference trace); 1 = fdlibm kernels (bit-identical to the HIP engine)."""
+    lib().ref_set_sincos_mode({"libm": 0, "fdlibm": 1}.get(mode, mode))
 
 
 def _p(a):

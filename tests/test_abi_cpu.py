@@ -1,0 +1,69 @@
+"""CPU-only checks of the drop-in boundary: libmirl.so loads without a GPU, exports every symbol that
+include/mi_rl.h declares, reports errors through return codes, and its host helpers agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def N():
+    from deep_rl_amd import _native
+
+    if not os.path.exists(_native.SO_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _native
+
+
+def test_header_symbols_all_exported_and_bound(N):
+    hdr = open(os.path.join(ROOT, "include", "mi_rl.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = C.CDLL(N.SO_PATH)
+    for name in declared:
+        assert hasattr(L, name), "libmirl.so does not export %s" % name
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    assert N.lib().mi_version() == 100
+
+
+def test_struct_layouts_match_header(N):
+    assert C.sizeof(N.Episode) == 16
+    assert C.sizeof(N.PPOBuffers) == 20 * 8 + 8  # 20 pointers + int32 (padded)
+    assert C.sizeof(N.PPOHparams) == 4 * 4 + 8 + 6 * 4 + 4 * 8
+    assert N.lib().mi_ppo_workspace_bytes() >= 512 * 4624 * 4
+
+
+def test_errors_are_return_codes_not_crashes(N):
+    L = N.lib()
+    h = C.c_void_p()
+    assert L.mi_env_create(99, 8, 1, 0, C.byref(h)) == -1 and b"kind" in L.mi_last_error()
+    assert L.mi_env_create(0, 0, 1, 0, C.byref(h)) == -1 and b"n_envs" in L.mi_last_error()
+    assert L.mi_env_create(0, 8, 1, 0, None) == -1
+    assert L.mi_gae(None, None, None, 128, 8, 0.99, 0.95, None, None, None) == -1
+    assert L.mi_clip_adam(None, None, None, None, 9155, 1, 1e-3, 0.9, 0.999, 1e-5, 0.5, None, None) == -1
+    assert L.mi_env_destroy(None) == 0
+    with pytest.raises(N.MiError):
+        N.check(L.mi_make_perm(0, 1, None, None), "mi_make_perm")
+
+
+def test_host_perm_key_matches_oracle(N):
+    from oracle import cpu_ref as R
+
+    for seed, u, e in [(1, 0, 0), (1, 155, 3), (2 ** 40 + 7, 12, 1)]:
+        assert N.lib().mi_perm_key(seed, u, e) == R.perm_key(seed, u, e)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under deep_rl_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "deep_rl_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "cpu_ref" not in txt.replace("oracle/cpu_ref.c implements", "") or f in ("mi_common.h",), os.path.join(dirpath, f)
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dirpath, f)

@@ -1,0 +1,87 @@
+"""world_size-2 gloo test of the sharded update — runs on the CPU.
+
+Two ranks each own 4 envs (global ids 4r..4r+3), roll them out with the oracle under the keyed RNG, exchange
+{sum, sum sq, count} and their gradient shares through deep_rl_amd.dist (the product's collective helpers), and must
+reproduce a single process that owns all 8 envs and takes the union minibatch: same trajectories (N-invariance),
+same global advantage statistics, same gradient (fp32 tolerance), hence the same clip + Adam step on every rank.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = 32
+
+
+def _shard(R, params, n, base):
+    env = R.VecCartPole(n, seed=5, env_id_base=base)
+    st = R.Storage(T, n)
+    obs = env.reset()
+    R.rollout(env, params, st, obs)
+    R.gae(st)
+    return st
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from deep_rl_amd import dist as D
+    from oracle import cpu_ref as R
+
+    R.lib().ref_set_num_threads(1)
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world
+    params = np.load(os.path.join(ROOT, "tests", "golden", "ppo_ref_trace.npz"))["init_params"]
+    n = 4
+    st = _shard(R, params, n, base=rank * n)
+    mb = T * n // 2
+    idx = R.make_perm(T * n, R.perm_key(5, 0, rank))[:mb]  # per-rank-local permutation
+    a = st.advantages.reshape(-1)[idx].astype(np.float64)
+    sums = torch.tensor([a.sum(), (a * a).sum(), float(mb)], dtype=torch.float64)
+    D.allreduce_sum_(sums)
+    mean, std = D.global_adv_mean_std(sums)
+    grads, terms = R.minibatch(params, st, idx, adv_mean=mean, adv_std=std, inv_count=1.0 / (world * mb))
+    buf = torch.from_numpy(np.concatenate([grads, terms]))
+    D.allreduce_sum_(buf)
+    g = buf.numpy()[:9155].copy()
+    norm = R.clip_grad_norm(g, 0.5)
+    p, m, v = params.copy(), np.zeros_like(params), np.zeros_like(params)
+    R.adam_step(p, g, m, v, 1, 2.5e-4)
+    q.put((rank, idx, buf.numpy().copy(), float(mean), float(std), norm, p))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_with_all_envs():
+    sys.path.insert(0, ROOT)
+    from oracle import cpu_ref as R
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    # single process, 8 envs, union minibatch in global row numbering (t*8 + 4r + n)
+    params = np.load(os.path.join(ROOT, "tests", "golden", "ppo_ref_trace.npz"))["init_params"]
+    R.lib().ref_set_num_threads(1)
+    st = _shard(R, params, 8, base=0)
+    gidx = np.concatenate([(i // 4) * 8 + 4 * r + (i % 4) for r, i, *_ in res]).astype(np.int32)
+    mean, std = R.adv_stats(st.advantages.reshape(-1), gidx)
+    grads, terms = R.minibatch(params, st, gidx)
+    for r, idx, buf, m, s, norm, p in res:
+        assert abs(m - mean) < 1e-12 * max(1, abs(mean)) and abs(s - std) < 1e-9 * std
+        assert np.abs(buf[:9155] - grads).max() <= 2e-6 * np.abs(grads).max()
+        assert np.allclose(buf[9155:], terms, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][6], res[1][6])  # replicas stay identical
+    g = grads.copy()
+    assert abs(R.clip_grad_norm(g, 0.5) - res[0][5]) < 1e-5 * res[0][5]

@@ -1,0 +1,489 @@
+"""GPU parity tests: the HIP engine (through the C ABI of include/mi_rl.h) against the CPU oracle
+(oracle/cpu_ref.c, pinned to the reference by tests/test_oracle_pinned.py) and against the golden vectors
+captured from the unmodified reference ppo.py (tests/golden/ppo_ref_trace.npz).
+
+Bars (task ③ / SURVEY §8c): bit-exact for integer / index / flag work (actions, dones, rewards, step indices,
+permutations, episode statistics) and for the float64 env state + float32 observations against the oracle in
+its device-matched sin/cos mode; fp32 tolerances (written at each assert) for values, log-probs, advantages,
+losses, gradients and parameters.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+T = 128
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import cpu_ref
+
+    cpu_ref.lib().ref_set_num_threads(8)
+    return cpu_ref
+
+
+@pytest.fixture(autouse=True)
+def _fdlibm_mode(R):
+    R.set_sincos_mode("fdlibm")  # the device-matched mode (oracle/cpu_ref.c ref_sincos)
+    yield
+    R.set_sincos_mode("libm")
+
+
+def _engine(dev, n_envs, params=None, seed=1, env_id_base=0, T_=T, **kw):
+    import deep_rl_amd as D
+
+    env = D.make("CartPole-v1", num_envs=n_envs, device=dev, seed=seed, env_id_base=env_id_base)
+    torch.manual_seed(seed)
+    agent = D.ActorCritic(env)
+    if params is not None:
+        agent.load_flat(params)
+    opt = D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
+    return D.PPOEngine(env, agent, opt, num_steps=T_, **kw)
+
+
+def _storage_to_oracle(R, eng):
+    st = R.Storage(eng.T, eng.N)
+    for n in ["observations", "values", "actions", "log_probs", "rewards", "dones", "advantages", "returns"]:
+        getattr(st, n)[...] = getattr(eng, n).cpu().numpy()
+    return st
+
+
+def _ulp32(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_mfma_layout_selftest(dev):
+    """The fragment layouts the update kernel relies on, probed with exact integer data on this GPU."""
+    from deep_rl_amd import _native as N
+
+    rep = torch.full((16,), -1, dtype=torch.int32, device=dev)
+    dump = torch.zeros(3 * 64 * 16, dtype=torch.float32, device=dev)
+    N.check(N.lib().mi_selftest_mfma(N.ptr(rep), N.ptr(dump), N.stream_ptr(dev)))
+    rep = rep.cpu().numpy()
+    d = dump.cpu().numpy().reshape(3, 64, 16)
+    msg = "report=%s\nprobe1 (4x4x1) regs of lanes 0..7:\n%s" % (rep[:3], d[1, :8, :4])
+    assert rep[0] == 0, "32x32x2 A/B/D map wrong: " + msg
+    assert rep[1] == 0, "4x4x1_16b A/B/D map wrong: " + msg
+    assert rep[2] == 0, "accumulator-as-B-operand chain wrong: " + msg
+
+
+def test_device_tanh_accuracy(dev):
+    from deep_rl_amd import _native as N
+
+    x = np.concatenate([np.linspace(-12, 12, 400001), np.random.default_rng(0).normal(0, 1.5, 400000),
+                        [0.0, -0.0, 1e-30, -1e-30, 0.6, -0.6, 0.5999999, 40.0, -40.0, 1e30]]).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev)
+    yt = torch.empty_like(xt)
+    N.check(N.lib().mi_test_tanh(N.ptr(xt), N.ptr(yt), x.size, N.stream_ptr(dev)))
+    y = yt.cpu().numpy()
+    ref = np.tanh(x.astype(np.float64))
+    err = np.abs(y - ref)
+    ulp = err / np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert np.isfinite(y).all()
+    assert err.max() < 2.5e-7, err.max()       # absolute
+    assert ulp[np.abs(x) > 1e-20].max() < 4.0, ulp.max()  # relative, in float32 ulps
+    assert np.array_equal(np.sign(y[x != 0]), np.sign(x[x != 0]))
+
+
+def test_env_step_bit_exact_with_truncation(dev, R):
+    """N=96 envs, 700 steps of a balancing controller (so TimeLimit truncation at 500 is exercised) plus random
+    actions on half of them; keyed (Philox) resets.  Device vs oracle: fp64 state, obs, done, truncated,
+    episode statistics bit-exact."""
+    import deep_rl_amd as D
+
+    n = 96
+    env = D.make("CartPole-v1", num_envs=n, device=dev, seed=7, env_id_base=1000)
+    ref = R.VecCartPole(n, seed=7, env_id_base=1000)
+    obs = env.reset()
+    robs = ref.reset()
+    assert np.array_equal(obs.cpu().numpy(), robs)
+    rng = np.random.default_rng(3)
+    n_trunc = n_term = 0
+    for s in range(700):
+        o = robs
+        ctrl = ((o[:, 2] + 0.5 * o[:, 3] + 0.02 * o[:, 0] + 0.1 * o[:, 1]) > 0).astype(np.int64)
+        rnd = rng.integers(0, 2, n)
+        a = np.where(np.arange(n) < n // 2, ctrl, rnd)
+        obs, rew, done, info = env.step(torch.from_numpy(a).to(dev))
+        robs, rrew, rdone, rtr, rfret, rflen = ref.step(a)
+        st, el = env.get_state()
+        assert np.array_equal(st.cpu().numpy(), ref.state), "fp64 state diverged at step %d" % s
+        assert np.array_equal(obs.cpu().numpy(), robs), s
+        assert np.array_equal(done.cpu().numpy().astype(np.uint8), rdone), s
+        assert np.array_equal(info["TimeLimit.truncated"].cpu().numpy().astype(np.uint8), rtr), s
+        assert np.array_equal(info["episode"]["r"].cpu().numpy(), rfret) and np.array_equal(info["episode"]["l"].cpu().numpy(), rflen)
+        assert np.array_equal(rew.cpu().numpy(), rrew)
+        n_trunc += int(rtr.sum()); n_term += int(rdone.sum() - rtr.sum())
+    assert n_trunc > 0 and n_term > 0, (n_trunc, n_term)
+
+
+def test_env_against_golden_reference_trace(dev, ref_trace):
+    """N=1, the reference run's own actions and reset noise (19,968 steps): done flags exactly the reference's;
+    obs_f32 equal except where the device's sin/cos differs from glibc in the last float64 bit (<= 1 float32 ulp,
+    a handful of steps — the same bridge tests/test_oracle_pinned.py::test_sincos_modes_bridge pins on the CPU)."""
+    g = ref_trace
+    acts = torch.from_numpy(g["actions_all"].astype(np.int64)).to(dev).reshape(-1, T, 1)
+    n_upd = acts.shape[0]
+    eng = _engine(dev, 1, params=g["init_params"])
+    eng.reset(torch.from_numpy(g["reset_states"][:1]))
+    ar, resets = g["after_reset_all"], g["reset_states"]
+    ri = 1
+    n_mis = 0
+    for u in range(n_upd):
+        fr = np.zeros((T, 1, 4))
+        for t in range(T):
+            s = u * T + t
+            if s + 1 < len(ar) and ar[s + 1]:
+                fr[t, 0] = resets[ri]; ri += 1
+        eng.rollout(forced_actions=acts[u], forced_resets=torch.from_numpy(fr))
+        dn = eng.dones[1:, 0].cpu().numpy()
+        want_done = np.array([(u * T + t + 1 < len(ar) and ar[u * T + t + 1]) for t in range(T)], np.float32)
+        if u == n_upd - 1:
+            want_done[-1] = dn[-1]  # the step after the last one is not in the trace
+        assert np.array_equal(dn, want_done), "done flags differ from the reference in update %d" % u
+        ob = eng.observations[1:, 0].cpu().numpy()
+        want = g["obs_all"][u * T:(u + 1) * T].copy()
+        live = want_done == 0
+        d = _ulp32(ob[live], want[live])
+        assert d.max() <= 1.0, (u, d.max())
+        n_mis += int((d > 0).any(axis=1).sum())
+        assert (eng.rewards[1:, 0] == 1).all()
+    assert ri == len(resets)
+    assert n_mis <= 40, n_mis  # 9 on the CPU bridge; bounded well below 0.5 % of the 19,968 steps
+
+
+def test_forward_vs_oracle(dev, R):
+    import deep_rl_amd as D
+
+    env = D.make("CartPole-v1", num_envs=1, device=dev)
+    torch.manual_seed(5)
+    agent = D.ActorCritic(env)
+    rng = np.random.default_rng(0)
+    params = (agent.flat.cpu().numpy() + rng.normal(0, 0.05, 9155)).astype(np.float32)
+    agent.load_flat(params)
+    obs = (rng.normal(0, 1, (3, 777, 4)) * np.array([2.4, 3, 0.2, 3])).astype(np.float32)
+    v = agent.get_value(torch.from_numpy(obs).to(dev))
+    dist = agent.get_action_distribution(torch.from_numpy(obs).to(dev))
+    assert v.shape == (3, 777) and dist.logits.shape == (3, 777, 2)
+    rv = R.critic(params, obs).reshape(3, 777)
+    rl = R.actor(params, obs)
+    nl, p, ent = R.categorical(rl)
+    assert np.abs(v.cpu().numpy() - rv).max() < 3e-6            # fp32: tanh <= 4 ulp, 64-term dot products
+    assert np.abs(dist.logits.cpu().numpy().reshape(-1, 2) - nl).max() < 3e-6
+    a, lp = agent.get_action(torch.from_numpy(obs[0, 0]).to(dev))
+    assert a.shape == () and lp.shape == () and a.dtype == torch.int64
+
+
+@pytest.mark.parametrize("u", [0, 1, 2])
+def test_rollout_teacher_forced_vs_golden_and_oracle(dev, R, ref_trace, u):
+    """One reference rollout (update u) replayed on the device with the reference's params, actions and resets."""
+    g = ref_trace
+    eng = _engine(dev, 1, params=g["upd%d_params_before" % u])
+    # start state of update u: replay the env up to there on the oracle (bit-exact with the device)
+    env = R.VecCartPole(1)
+    R.set_sincos_mode("libm")
+    obs_cur = env.reset(g["reset_states"][:1]); ri = 1
+    for s in range(u * T):
+        o, _, d, _, _, _ = env.step([g["actions_all"][s]], g["reset_states"][ri:ri + 1])
+        if d[0]:
+            ri += 1
+        obs_cur = o
+    R.set_sincos_mode("fdlibm")
+    st0 = env.state.copy()
+    eng.reset(torch.from_numpy(st0))
+    # continue TimeLimit counter: the engine's forced reset zeroes `elapsed`; pick updates whose first episode is not
+    # truncated by construction of the check below (done flags must match the reference)
+    fa = g["actions_all"][u * T:(u + 1) * T].astype(np.int64).reshape(T, 1)
+    fr = np.zeros((T, 1, 4)); rj = ri
+    for t in range(T):
+        s = u * T + t
+        if s + 1 < len(g["after_reset_all"]) and g["after_reset_all"][s + 1]:
+            fr[t, 0] = g["reset_states"][rj]; rj += 1
+    eng.rollout(forced_actions=torch.from_numpy(fa), forced_resets=torch.from_numpy(fr))
+    eng.compute_gae()
+    got = {n: getattr(eng, n)[:, 0].cpu().numpy() for n in ["observations", "values", "actions", "log_probs", "rewards", "dones", "advantages", "returns"]}
+    for n in ["rewards", "dones"]:
+        assert np.array_equal(got[n], g["upd%d_%s" % (u, n)]), (u, n)
+    assert np.array_equal(got["actions"][:T], g["upd%d_actions" % u][:T])
+    assert _ulp32(got["observations"], g["upd%d_observations" % u]).max() <= 1.0
+    # fp32 tolerances: values/log-probs differ from torch by summation order and tanh (<= 4 ulp)
+    assert np.abs(got["values"] - g["upd%d_values" % u]).max() < 3e-6
+    assert np.abs(got["log_probs"][:T] - g["upd%d_log_probs" % u][:T]).max() < 3e-6
+    assert np.abs(got["advantages"] - g["upd%d_advantages" % u]).max() < 5e-5
+    assert np.abs(got["returns"] - g["upd%d_returns" % u]).max() < 5e-5
+
+
+@pytest.mark.parametrize("n_envs", [37, 1024])
+def test_rollout_production_rng_vs_oracle(dev, R, n_envs):
+    """Keyed Philox resets + action draws.  Device actions are replayed on the oracle (teacher forcing) so that a
+    last-bit difference in a probability cannot fork the trajectories; everything else must be bit-exact, and every
+    device draw must be the inverse-CDF of the contract's uniform against the oracle's probabilities."""
+    rng = np.random.default_rng(11)
+    eng = _engine(dev, n_envs, seed=3, env_id_base=500)
+    params = (eng.agent.flat.cpu().numpy() + rng.normal(0, 0.3, 9155) * (np.arange(9155) >= 4480) * (np.arange(9155) < 4610)).astype(np.float32)
+    eng.agent.load_flat(params)  # larger actor head -> non-trivial action probabilities
+    env = R.VecCartPole(n_envs, seed=3, env_id_base=500)
+    obs_cur = env.reset()
+    assert np.array_equal(eng.reset().cpu().numpy(), obs_cur)
+    st = R.Storage(T, n_envs)
+    for upd in range(2):  # second rollout checks the carried-over state / counters
+        eng.rollout()
+        n_ep, eps = eng.drain_episodes()
+        acts = eng.actions[:T].cpu().numpy()
+        reps, rn = R.rollout(env, params, st, obs_cur, forced_actions=acts, max_ep=4 * n_envs)
+        assert np.array_equal(eng.observations.cpu().numpy(), st.observations), upd
+        assert np.array_equal(eng.dones.cpu().numpy(), st.dones) and np.array_equal(eng.rewards.cpu().numpy(), st.rewards)
+        assert np.abs(eng.values.cpu().numpy() - st.values).max() < 3e-6
+        assert np.abs(eng.log_probs[:T].cpu().numpy() - st.log_probs[:T]).max() < 3e-6
+        assert n_ep == rn and sorted(eps) == sorted(reps), (n_ep, rn)
+        assert np.array_equal(eng.observation.cpu().numpy(), obs_cur)
+        # the draw itself: u from the RNG contract, p0 from the oracle's logits
+        logits = R.actor(params, st.observations[:T].reshape(-1, 4))
+        _, p, _ = R.categorical(logits)
+        p0 = p[:, 0].reshape(T, n_envs)
+        uu = np.array([[R.action_uniform(3, 500 + e, upd * T + t) for e in range(n_envs)] for t in range(0, T, 16)])
+        a_want = (uu >= p0[::16]).astype(np.int64)
+        near = np.abs(uu - p0[::16]) < 1e-5
+        assert np.array_equal(acts[::16][~near], a_want[~near])
+        assert 0.2 < acts.mean() < 0.8
+
+
+def test_n_invariance_across_shards(dev):
+    """Env i's trajectory depends on its GLOBAL id only: one rank with 64 envs == two ranks with 32 each."""
+    full = _engine(dev, 64, seed=9)
+    full.reset(); full.rollout()
+    for r in range(2):
+        part = _engine(dev, 32, seed=9, env_id_base=32 * r)
+        part.reset(); part.rollout()
+        sl = slice(32 * r, 32 * r + 32)
+        for n in ["observations", "values", "actions", "log_probs", "rewards", "dones"]:
+            assert torch.equal(getattr(full, n)[:, sl], getattr(part, n)), (r, n)
+
+
+def test_gae_bit_exact(dev, R):
+    eng = _engine(dev, 1000)
+    rng = np.random.default_rng(2)
+    eng.rewards.copy_(torch.from_numpy(rng.normal(1, 1, (T + 1, 1000)).astype(np.float32)))
+    eng.dones.copy_(torch.from_numpy((rng.random((T + 1, 1000)) < 0.05).astype(np.float32)))
+    eng.values.copy_(torch.from_numpy(rng.normal(10, 5, (T + 1, 1000)).astype(np.float32)))
+    eng.compute_gae()
+    st = _storage_to_oracle(R, eng)
+    R.gae(st)
+    assert np.array_equal(eng.advantages.cpu().numpy(), st.advantages)  # same op order, no contraction
+    assert np.array_equal(eng.returns.cpu().numpy(), st.returns)
+    # SURVEY §8a KAT
+    e4 = _engine(dev, 1, T_=4)
+    e4.rewards[:, 0] = torch.tensor([0, 1, 1, 1, 1.], device=dev)
+    e4.dones[:, 0] = torch.tensor([0, 0, 1, 0, 0.], device=dev)
+    e4.values[:, 0] = torch.tensor([.5, .6, .7, .8, .9], device=dev)
+    e4.compute_gae()
+    assert np.allclose(e4.advantages[:, 0].cpu().numpy(), [1.470200062, 0.399999976, 2.118085623, 1.091000080, 0], rtol=0, atol=1e-7)
+    assert np.allclose(e4.returns[:, 0].cpu().numpy(), [1.970200062, 1.0, 2.818085670, 1.891000032, 0.899999976], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 128, 1000, 4096, 524288])
+def test_perm_bit_exact(dev, R, n):
+    from deep_rl_amd import _native as N
+
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    key = N.lib().mi_perm_key(1, 5, 2)
+    assert key == R.perm_key(1, 5, 2)
+    N.check(N.lib().mi_make_perm(n, key, N.ptr(out), N.stream_ptr(dev)))
+    o = out.cpu().numpy()
+    assert np.array_equal(o, R.make_perm(n, key))
+    assert np.array_equal(np.sort(o), np.arange(n))
+
+
+def test_adv_stats(dev):
+    eng = _engine(dev, 64)
+    rng = np.random.default_rng(4)
+    adv = rng.normal(3, 7, (T + 1, 64)).astype(np.float32)
+    eng.advantages.copy_(torch.from_numpy(adv))
+    eng.make_perm(0)
+    eng.adv_stats()
+    s = eng.adv_sums.cpu().numpy()
+    perm = eng.perm.cpu().numpy().reshape(4, -1)
+    for k in range(4):
+        a = adv.reshape(-1)[perm[k]].astype(np.float64)
+        assert s[k, 2] == a.size
+        assert abs(s[k, 0] - a.sum()) < 1e-9 * np.abs(a).sum() and abs(s[k, 1] - (a * a).sum()) < 1e-9 * (a * a).sum()
+
+
+def test_minibatch_grad_vs_golden_first_16_steps(dev, R, ref_trace):
+    """The reference's first outer update: its storage, its minibatch indices, its parameters before each step
+    -> loss terms and gradients against both the reference's autograd and the oracle's analytic gradient."""
+    g = ref_trace
+    eng = _engine(dev, 1, params=g["init_params"])
+    for n in ["observations", "values", "actions", "log_probs", "rewards", "dones", "advantages", "returns"]:
+        getattr(eng, n)[:, 0].copy_(torch.from_numpy(g["upd0_" + n]).to(dev))
+    st = _storage_to_oracle(R, eng)
+    for k in range(16):
+        params = g["init_params"] if k == 0 else g["full_params"][k - 1]
+        eng.agent.load_flat(params)
+        idx = g["mb_inds"][k].astype(np.int32)
+        eng.perm[:32].copy_(torch.from_numpy(idx).to(dev))
+        eng.adv_stats(mb=32, n_mb=1)
+        eng.minibatch_grad(0, mb=32)
+        grads = eng.grads.cpu().numpy(); terms = eng.loss_terms.cpu().numpy()
+        rg = g["full_grads"][k]
+        og, ot = R.minibatch(params, st, idx)
+        scale = np.abs(rg).max()
+        assert np.abs(grads - og).max() <= 3e-6 * scale, ("vs oracle", k, np.abs(grads - og).max() / scale)
+        assert np.abs(grads - rg).max() <= 3e-6 * scale, ("vs reference autograd", k, np.abs(grads - rg).max() / scale)
+        assert np.allclose(terms, g["opt_terms"][k, :4], rtol=2e-5, atol=5e-6), (k, terms, g["opt_terms"][k, :4])
+        assert np.allclose(terms, ot, rtol=2e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize("n_envs,mb", [(16, 512), (16, 1000), (16, 33), (64, 2048), (64, 8192)])
+def test_minibatch_grad_vs_oracle_sizes(dev, R, n_envs, mb):
+    """Real rollouts, several minibatch sizes incl. ragged tails (mb % 32 != 0) and multi-tile / multi-block grids."""
+    eng = _engine(dev, n_envs, seed=4)
+    rng = np.random.default_rng(8)
+    params = (eng.agent.flat.cpu().numpy() + rng.normal(0, 0.05, 9155)).astype(np.float32)
+    eng.reset(); eng.rollout(); eng.compute_gae()
+    eng.agent.load_flat(params)  # params != behaviour params -> ratio != 1, clipping active on some rows
+    eng.make_perm(0)
+    eng.adv_stats(mb=mb, n_mb=1)
+    eng.minibatch_grad(0, mb=mb)
+    st = _storage_to_oracle(R, eng)
+    idx = eng.perm[:mb].cpu().numpy()
+    og, ot = R.minibatch(params, st, idx)
+    grads = eng.grads.cpu().numpy(); terms = eng.loss_terms.cpu().numpy()
+    scale = np.abs(og).max()
+    err = np.abs(grads - og)
+    assert err.max() <= 2e-5 * scale, (err.max() / scale, int(err.argmax()))
+    assert np.allclose(terms, ot, rtol=3e-5, atol=1e-5), (terms, ot)
+    # determinism: same launch twice -> bitwise the same gradient (no float atomics in the reduction)
+    eng.minibatch_grad(0, mb=mb)
+    assert np.array_equal(eng.grads.cpu().numpy(), grads)
+
+
+def test_clip_adam_vs_oracle(dev, R):
+    eng = _engine(dev, 1)
+    rng = np.random.default_rng(6)
+    p = eng.agent.flat.cpu().numpy().copy()
+    m = np.zeros_like(p); v = np.zeros_like(p)
+    for step in range(1, 6):
+        g = (rng.normal(0, 0.01 * step, 9155)).astype(np.float32)  # norms on both sides of max_grad_norm = 0.5
+        lr = 2.5e-4 * (1 - step / 10)
+        eng.optimizer.param_groups[0]["lr"] = lr
+        eng.grads.copy_(torch.from_numpy(g).to(dev))
+        eng.optimizer_step()
+        gc = g.copy()
+        nrm = R.clip_grad_norm(gc, 0.5)
+        R.adam_step(p, gc, m, v, step, lr)
+        assert abs(float(eng.optimizer.grad_norm.item()) - nrm) <= 2e-6 * nrm
+        assert np.abs(eng.agent.flat.cpu().numpy() - p).max() < 1e-7, step
+        assert np.abs(eng.optimizer.exp_avg.cpu().numpy() - m).max() < 1e-8
+
+
+def test_whole_reference_run_replayed_on_device(dev, ref_trace):
+    """All 156 updates / 2,496 optimizer steps of the reference run, teacher-forced on the GPU (N=1): every loss term
+    and grad norm tracks the reference, and the final parameters land on the reference's."""
+    g = ref_trace
+    eng = _engine(dev, 1, params=g["init_params"])
+    eng.reset(torch.from_numpy(g["reset_states"][:1]))
+    acts = torch.from_numpy(g["actions_all"].astype(np.int64)).to(dev).reshape(-1, T, 1)
+    ar, resets, opt = g["after_reset_all"], g["reset_states"], g["opt_terms"]
+    ri, k = 1, 0
+    worst = np.zeros(5)
+    for u in range(156):
+        fr = np.zeros((T, 1, 4))
+        for t in range(T):
+            s = u * T + t
+            if s + 1 < len(ar) and ar[s + 1]:
+                fr[t, 0] = resets[ri]; ri += 1
+        eng.rollout(forced_actions=acts[u], forced_resets=torch.from_numpy(fr))
+        eng.compute_gae()
+        eng.optimizer.param_groups[0]["lr"] = (1.0 - u / 156) * 2.5e-4
+        terms_u, norms_u = [], []
+        for _ in range(16):
+            eng.perm[:32].copy_(torch.from_numpy(g["mb_inds"][k].astype(np.int32)).to(dev))
+            eng.adv_stats(mb=32, n_mb=1)
+            eng.minibatch_grad(0, mb=32)
+            eng.optimizer_step()
+            terms_u.append(eng.loss_terms.clone()); norms_u.append(eng.optimizer.grad_norm.clone())
+            k += 1
+        terms = torch.stack(terms_u).cpu().numpy(); norms = torch.cat(norms_u).cpu().numpy()
+        ref_t = opt[k - 16:k, :4]
+        worst[:4] = np.maximum(worst[:4], (np.abs(terms - ref_t) / np.maximum(np.abs(ref_t), 1e-2)).max(axis=0))
+        worst[4] = max(worst[4], (np.abs(norms - g["clip_norm"][k - 16:k]) / g["clip_norm"][k - 16:k]).max())
+    final = eng.agent.flat.cpu().numpy()
+    dp = np.abs(final - g["final_params"]).max()
+    # fp32 tolerances after 2,496 chained Adam steps (the CPU oracle itself lands within 2e-7 / 1e-6)
+    assert worst[:4].max() < 2e-3, worst
+    assert worst[4] < 2e-3, worst
+    assert dp < 2e-4, dp
+    ev = float(eng.compute_explained_var().item())
+    assert abs(ev - g["final_explained_var"][0]) < 2e-2 * abs(ev)
+
+
+def test_full_update_production_vs_oracle_n8(dev, R):
+    """BASELINE config[0] shape (8 envs): two whole engine.update() calls (one fused C call each) against the oracle's
+    ref_ppo_update with the same keyed RNG: same actions, same episodes, parameters within fp32 tolerance."""
+    eng = _engine(dev, 8, seed=1)
+    base = R.PPOBaseline(eng.agent.flat.cpu().numpy(), 8, T=T, seed=1, threads=1)
+    eng.reset()
+    assert np.array_equal(eng.observation.cpu().numpy(), base.obs)
+    for u in range(2):
+        lr = (1.0 - u / 10) * 2.5e-4
+        eng.optimizer.param_groups[0]["lr"] = lr
+        eng.update()
+        n_ep, _ = eng.drain_episodes()
+        rn = base.run_update(lr)
+        assert n_ep == rn, (u, n_ep, rn)
+        assert np.abs(eng.agent.flat.cpu().numpy() - base.params).max() < 5e-6, u
+        assert np.allclose(eng.loss_terms.cpu().numpy(), base.terms, rtol=1e-4, atol=1e-5)
+    assert eng.optimizer.step_count == 32
+
+
+def test_headline_size_properties(dev):
+    """BASELINE config[1]: 4096 envs x 128 steps on one GPU.  Too big for the oracle in seconds, so size-independent
+    properties: permutation is a bijection, dones == logged episodes, GAE identity returns = adv + values, gradients
+    finite and reproducible, two updates change the parameters, the run is deterministic end to end."""
+    def run():
+        eng = _engine(dev, 4096, seed=1)
+        eng.reset()
+        out = []
+        for u in range(2):
+            eng.update()
+            n_ep, eps = eng.drain_episodes()
+            assert n_ep == int(eng.dones[1:].sum().item())
+            out.append((n_ep, eng.agent.flat.clone(), eng.loss_terms.clone()))
+        assert torch.equal(eng.returns, eng.advantages + eng.values)
+        assert (eng.advantages[T] == 0).all()
+        p = eng.perm.cpu().numpy()
+        assert np.array_equal(np.sort(p), np.arange(T * 4096))
+        assert torch.isfinite(eng.grads).all() and torch.isfinite(eng.agent.flat).all()
+        assert set(eng.actions[:T].unique().tolist()) == {0, 1}
+        return out
+
+    a, b = run(), run()
+    assert not torch.equal(a[0][1], a[1][1])
+    for (n1, p1, t1), (n2, p2, t2) in zip(a, b):
+        assert n1 == n2 and torch.equal(p1, p2) and torch.equal(t1, t2)  # bitwise reproducible
+
+
+def test_learning_smoke(dev):
+    """CartPole return rises under the engine's own RNG (SURVEY §4 tier 5): 64 envs, 40 updates."""
+    eng = _engine(dev, 64, seed=1)
+    eng.reset()
+    means = []
+    for u in range(40):
+        eng.optimizer.param_groups[0]["lr"] = (1.0 - u / 40) * 2.5e-4 * 4
+        eng.update()
+        n, eps = eng.drain_episodes()
+        if eps:
+            means.append(np.mean([e[2] for e in eps]))
+    assert np.mean(means[-5:]) > 2.0 * np.mean(means[:3]), (means[:3], means[-5:])

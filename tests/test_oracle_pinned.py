@@ -147,3 +147,28 @@ def test_reset_noise_and_uniform_ranges():
     assert s.min() >= -0.05 and s.max() < 0.05 and abs(s.mean()) < 5e-3
     u = np.array([R.action_uniform(1, e, t) for e in range(32) for t in range(64)])
     assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.03
+
+
+def test_sincos_modes_bridge(ref_trace):
+    """The oracle's device-matched sin/cos mode ("fdlibm": the polynomial kernels the HIP engine evaluates, bit-identical
+    on CPU and GPU) against the gym-faithful libm mode on the whole reference run: identical done flags / episode
+    structure, observations equal except for a handful of steps that differ by one float32 ulp."""
+    g = ref_trace
+    resets, acts, obs_all, ar = g["reset_states"], g["actions_all"], g["obs_all"], g["after_reset_all"]
+    R.set_sincos_mode("fdlibm")
+    try:
+        env = R.VecCartPole(1)
+        env.reset(resets[:1])
+        ri, n_mis = 1, 0
+        for s in range(len(acts) - 1):
+            o, r, d, tr, fret, flen = env.step([acts[s]], resets[ri:ri + 1] if ri < len(resets) else np.zeros((1, 4)))
+            assert bool(d[0]) == bool(ar[s + 1]), s
+            if d[0]:
+                ri += 1
+            else:
+                diff = np.abs(o[0].astype(np.float64) - obs_all[s])
+                assert (diff <= np.spacing(np.abs(obs_all[s]))).all(), s
+                n_mis += int((diff > 0).any())
+        assert n_mis <= 20, n_mis
+    finally:
+        R.set_sincos_mode("libm")
