@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of the SAME bench command,
+# and condenses them into small CSV/JSON summaries under gpurun_out/prof_<tag>/ (copy what you want judged to profiles/).
+TAG=${1:-r01}
+STEPS=${2:-10}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $CMD > $OUT/stats_run.log 2>&1
+find /tmp/rp_stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
+find /tmp/rp_stats -name '*kernel_trace.csv' -exec cp {} /tmp/kernel_trace.csv \;
+PCMD="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+i=0
+for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/rp_pmc$i -o pmc -- $PCMD > $OUT/pmc${i}_run.log 2>&1
+  find /tmp/rp_pmc$i -name '*counter_collection.csv' -exec cp {} /tmp/pmc$i.csv \;
+done
+python3 $REPO/tools/summarize_pmc.py /tmp/kernel_trace.csv /tmp/pmc*.csv > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
+ls -la $OUT
