@@ -116,39 +116,73 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 //
 // Work split: a workgroup (4 waves) serves ONE net — even blockIdx = actor, odd = critic; the two nets share
 // nothing but the observations (the joint grad-norm clip happens later), so each CU hosts one block of each.
-// A wave processes tiles of 32 minibatch rows; per tile and net (v_mfma_f32_32x32x2_f32 unless noted):
+// A wave processes tiles of 16 minibatch rows; per tile and net (v_mfma_f32_16x16x4_f32 unless noted):
 //     z1^T = W1 x^T            4 MFMA     (rows on the lanes, hidden units in the accumulator registers)
 //     z2^T = W2 h1^T          64 MFMA     B operand = h1's accumulator registers as they stand
 //     dh1^T = W2^T dz2^T      64 MFMA     B operand = dz2's registers as they stand
 //     dW2 += dz2^T h1         64 MFMA     both operands re-read transposed through a wave-private LDS tile
-//     dW1 += dz1^T x, dW3 += dlogit^T h2   32 + 32 v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1 row)
-// "As they stand": a 32x32 accumulator holds, in lane (j = row, h = lane>>5), register r, the unit
-// u(r,h) = (r&3) + 8(r>>2) + 4h.  An MFMA sums over k in ANY order as long as A and B agree, so k-step s of the
-// next product takes B from register s and A = W[..][u(s&15,h) + 32(s>>4)] — no lane movement, no LDS
+//     dW1 += dz1^T x, dW3 += dout^T h2    16 + 16 v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1 row)
+// "As they stand": a 16x16 accumulator tile mt holds, in lane (j = row = lane&15, g = lane>>4), register r, the hidden
+// unit 16mt + 4g + r.  An MFMA sums over k in ANY order as long as A and B agree, so k-step s of the next product
+// takes B from register (s&3) of tile (s>>2) and A = W[..][16(s>>2) + 4g + (s&3)] — no lane movement, no LDS
 // (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").  The sum order differs from a
 // sequential-k fp32 chain; parity is to tolerance, not bitwise.
+// 16-row tiles keep an activation in 16 registers (a 32-row tile on 32x32x2 spilled 100 VGPRs at 2 waves/SIMD and
+// wrote 62 MB of scratch per launch: profiles/r01a_*).  Row inputs are prefetched two tiles ahead (index) / one tile
+// ahead (gathered row), so no dependent global load sits on a tile's critical path.
 // Everything per tile is wave-private (no workgroup barrier in the loop); the only barriers are around the
 // weight staging at entry and the deterministic cross-wave reduction at exit.  Per-block partial gradients go
-// to a workspace slab and are summed in block order by grad_reduce_kernel (no float atomics: reproducible).
+// to a workspace slab and are summed in a fixed order by grad_reduce_kernel (no float atomics: reproducible).
 // =====================================================================================================
-#define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row reads / writes conflict-free
+#define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row reads / writes (nearly) conflict-free
 #define GRAD_WAVES 4
+#define TROWS 16
 #define PART_STRIDE 4624
 #define PART_LOSS 4610
 #define GRAD_MAX_BLOCKS 1024
 
 struct __attribute__((aligned(16))) grad_smem {
-    float W2[HID * W2S];              // W2[o][i] row-major, padded
+    float W2[HID * W2S];                  // W2[o][i] row-major, padded
     float b1[HID], b2[HID];
     float W3[2 * HID];
-    float bufA[GRAD_WAVES][16 * W2S];  // wave-private [row][unit] tiles for the transposed re-reads
-    float bufB[GRAD_WAVES][16 * W2S];
-    float xs[GRAD_WAVES][32 * 4];      // observations of the tile
-    float dls[GRAD_WAVES][32 * 4];     // d loss / d logits (or d value), zero padded to 4
+    float bufA[GRAD_WAVES][TROWS * W2S];   // wave-private [row][unit] images for the transposed re-reads
+    float bufB[GRAD_WAVES][TROWS * W2S];
+    float xs[GRAD_WAVES][TROWS * 4];       // observations of the tile
+    float dls[GRAD_WAVES][TROWS * 4];      // d loss / d logits (or d value), zero padded to 4
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// tanh for the update kernel: 1 - 2/(2^(2x log2 e) + 1), 5 instructions, absolute error <= ~2e-7 (relative error is
+// NOT bounded near 0, unlike mi_tanhf; activations enter O(1) sums, so absolute accuracy is what parity needs).
+__device__ __forceinline__ float mi_tanhf_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+struct row_in {
+    float x;          // observation component g of the row (lane (j,g))
+    int act;
+    float f0, f1;     // actor: old log-prob, advantage; critic: return, old value
+};
+
+template <bool ACTOR>
+__device__ __forceinline__ row_in gather_row(int rid, int g, const float* __restrict__ observations, const int64_t* __restrict__ actions,
+                                             const float* __restrict__ log_probs, const float* __restrict__ advantages,
+                                             const float* __restrict__ returns, const float* __restrict__ values) {
+    row_in r;
+    r.x = observations[4 * (size_t)rid + g];
+    if constexpr (ACTOR) {
+        r.act = reinterpret_cast<const int*>(actions)[2 * (size_t)rid];  // low dword of the int64 (0 or 1)
+        r.f0 = log_probs[rid]; r.f1 = advantages[rid];
+    } else {
+        r.act = 0;
+        r.f0 = returns[rid]; r.f1 = values[rid];
+    }
+    return r;
+}
 
 template <bool ACTOR>
 __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict__ params, const float* __restrict__ observations,
@@ -159,23 +193,29 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
                                           float invn, float* __restrict__ part) {
     constexpr int NOUT = ACTOR ? 2 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
-    const int li = lane & 31, h = lane >> 5;
+    const int j = lane & 15, g = lane >> 4;
     const float* p = params + (ACTOR ? 0 : C_BASE);
 
-    // ---- stage this net's weights in LDS (once per block) ----
-    for (int i = tid; i < HID * HID; i += 64 * GRAD_WAVES) sm.W2[(i >> 6) * W2S + (i & 63)] = p[N_W2 + i];
-    if (tid < HID) { sm.b1[tid] = p[N_B1 + tid]; sm.b2[tid] = p[N_B2 + tid]; }
-    if (tid < NOUT * HID) sm.W3[tid] = p[N_W3 + tid];
-    // layer-1 A fragments live in registers: lane (i,h), m, k-step s holds W1[i+32m][2s+h]
-    float w1f[2][2];
+    // ---- stage this net's weights in LDS (once per block): 4 float4 loads in flight per lane, then the LDS writes ----
+    {
+        float4 w[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int k = 0; k < 4; ++k) w[k] = reinterpret_cast<const float4*>(p + N_W2)[tid + 256 * k];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) w1f[m][s] = p[N_W1 + 4 * (li + 32 * m) + 2 * s + h];
+        for (int k = 0; k < 4; ++k) {
+            const int f = tid + 256 * k;  // float4 index: row = f / 16, col = 4 * (f % 16)
+            *reinterpret_cast<float4*>(&sm.W2[(f >> 4) * W2S + 4 * (f & 15)]) = w[k];
+        }
+        if (tid < HID) { sm.b1[tid] = p[N_B1 + tid]; sm.b2[tid] = p[N_B2 + tid]; }
+        if (tid < NOUT * HID) sm.W3[tid] = p[N_W3 + tid];
+    }
+    // layer-1 A fragments live in registers: lane (i = j, g), tile mt holds W1[16mt + i][k = g]
+    float w1f[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) w1f[mt] = p[N_W1 + 4 * (16 * mt + j) + g];
     float b3[NOUT];
 #pragma unroll
     for (int a = 0; a < NOUT; ++a) b3[a] = p[N_W3 + NOUT * HID + a];
-    __syncthreads();
 
     // advantage normalisation constants (ppo.py:169) from {sum, sum sq, count}
     float adv_mean = 0.0f, adv_den = 1.0f;
@@ -188,16 +228,24 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         adv_den = (float)sqrt(var) + 1e-8f;
     }
 
+    const int n_tiles = (mb + TROWS - 1) / TROWS;
+    const int wave_role = (blockIdx.x >> 1) * GRAD_WAVES + wib;
+    const int stride = (gridDim.x >> 1) * GRAD_WAVES;
+    // ---- input prefetch pipeline: row index two tiles ahead, gathered row one tile ahead ----
+    auto tile_rid = [&](int t) { const int row = t * TROWS + j; return idx[row < mb ? row : mb - 1]; };
+    int tile = wave_role;
+    int rid_next = tile_rid(tile + stride);
+    row_in cur = gather_row<ACTOR>(tile_rid(tile), g, observations, actions, log_probs, advantages, returns, values);
+    __syncthreads();  // weights staged
+
     // ---- accumulators that live across tiles ----
-    f32x16 dW2[2][2];
+    f32x4 dW2[4][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dW2[m][n][r] = 0.0f;
+        for (int mi = 0; mi < 4; ++mi) dW2[mo][mi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 dW1a = {0.0f, 0.0f, 0.0f, 0.0f}, dW1b = dW1a, dW3a = dW1a, dW3b = dW1a;  // two chains each: 4x4x1 latency > issue
-    float db1 = 0.0f, db2[2] = {0.0f, 0.0f}, db3[2] = {0.0f, 0.0f};
+    float db1 = 0.0f, db2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, db3[2] = {0.0f, 0.0f};
     float loss_a = 0.0f, loss_b = 0.0f;  // actor: sum pg, sum entropy; critic: sum max(vl1, vl2)
 
     float* bufA = sm.bufA[wib];
@@ -205,86 +253,73 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     float* xs = sm.xs[wib];
     float* dls = sm.dls[wib];
 
-    const int n_tiles = (mb + 31) >> 5;
-    const int wave_role = (blockIdx.x >> 1) * GRAD_WAVES + wib;
-    const int n_wave_role = (gridDim.x >> 1) * GRAD_WAVES;
+    for (; tile < n_tiles; tile += stride) {
+        const bool valid = tile * TROWS + j < mb;
+        // issue the next tile's gathers and the index after that; they land while this tile computes
+        const row_in nxt = gather_row<ACTOR>(rid_next, g, observations, actions, log_probs, advantages, returns, values);
+        rid_next = tile_rid(tile + 2 * stride);
 
-    for (int tile = wave_role; tile < n_tiles; tile += n_wave_role) {
-        // ---- gather the tile's rows (both lane halves load the same row) ----
-        const int row = tile * 32 + li;
-        const bool valid = row < mb;
-        const int rid = idx[valid ? row : mb - 1];
-        const float4 o = reinterpret_cast<const float4*>(observations)[rid];
-        int act = 0;
-        float old_lp = 0.0f, adv = 0.0f, ret = 0.0f, v_old = 0.0f;
-        if constexpr (ACTOR) { act = (int)actions[rid]; old_lp = log_probs[rid]; adv = advantages[rid]; }
-        else { ret = returns[rid]; v_old = values[rid]; }
-        if (h == 0) *reinterpret_cast<float4*>(xs + 4 * li) = o;
+        xs[4 * j + g] = cur.x;
 
-        // ---- layer 1: z1^T = W1 x^T + b1 ----
-        f32x16 h1[2];
+        // ---- layer 1: z1^T = W1 x^T + b1 (K = 4 = obs dim: one MFMA per 16-unit tile) ----
+        f32x4 h1[4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = *reinterpret_cast<const float4*>(&sm.b1[8 * q + 4 * h + 32 * m]);
-                h1[m][4 * q + 0] = b.x; h1[m][4 * q + 1] = b.y; h1[m][4 * q + 2] = b.z; h1[m][4 * q + 3] = b.w;
-            }
-            h1[m] = mfma32(w1f[m][0], h ? o.y : o.x, h1[m]);
-            h1[m] = mfma32(w1f[m][1], h ? o.w : o.z, h1[m]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h1[m][r] = mi_tanhf(h1[m][r]);
+        for (int mt = 0; mt < 4; ++mt) {
+            const float4 b = *reinterpret_cast<const float4*>(&sm.b1[16 * mt + 4 * g]);
+            h1[mt] = mfma16(w1f[mt], cur.x, f32x4{b.x, b.y, b.z, b.w});
         }
-        // ---- layer 2: z2^T = W2 h1^T + b2 ----
-        f32x16 h2[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = *reinterpret_cast<const float4*>(&sm.b2[8 * q + 4 * h + 32 * m]);
-                h2[m][4 * q + 0] = b.x; h2[m][4 * q + 1] = b.y; h2[m][4 * q + 2] = b.z; h2[m][4 * q + 3] = b.w;
+            for (int r = 0; r < 4; ++r) h1[mt][r] = mi_tanhf_fast(h1[mt][r]);
+
+        // ---- layer 2: z2^T = W2 h1^T + b2; k-steps 4c..4c+3 <-> units 16c + 4g + {0..3} ----
+        f32x4 h2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float4 b = *reinterpret_cast<const float4*>(&sm.b2[16 * mt + 4 * g]);
+            h2[mt] = f32x4{b.x, b.y, b.z, b.w};
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float4 a = *reinterpret_cast<const float4*>(&sm.W2[(16 * mt + j) * W2S + 16 * c + 4 * g]);
+                h2[mt] = mfma16(a.x, h1[c][0], h2[mt]);
+                h2[mt] = mfma16(a.y, h1[c][1], h2[mt]);
+                h2[mt] = mfma16(a.z, h1[c][2], h2[mt]);
+                h2[mt] = mfma16(a.w, h1[c][3], h2[mt]);
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {  // k-steps 4q..4q+3 <-> units 8(q&3) + 4h + 32(q>>2) + {0..3}
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const float4 a = *reinterpret_cast<const float4*>(&sm.W2[(li + 32 * m) * W2S + 8 * (q & 3) + 4 * h + 32 * (q >> 2)]);
-                h2[m] = mfma32(a.x, h1[q >> 2][4 * (q & 3) + 0], h2[m]);
-                h2[m] = mfma32(a.y, h1[q >> 2][4 * (q & 3) + 1], h2[m]);
-                h2[m] = mfma32(a.z, h1[q >> 2][4 * (q & 3) + 2], h2[m]);
-                h2[m] = mfma32(a.w, h1[q >> 2][4 * (q & 3) + 3], h2[m]);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h2[m][r] = mi_tanhf(h2[m][r]);
+            for (int r = 0; r < 4; ++r) h2[mt][r] = mi_tanhf_fast(h2[mt][r]);
 
-        // ---- head: out[a] = W3[a] . h2 + b3[a]; each lane half holds 32 of the 64 units ----
+        // ---- head: out[a] = W3[a] . h2 + b3[a]; the 4 lanes (g) of a row hold 16 units each ----
         float outp[NOUT];
 #pragma unroll
         for (int a = 0; a < NOUT; ++a) {
             float acc = 0.0f;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 8 * q + 4 * h + 32 * m]);
-                    acc = __builtin_fmaf(w.x, h2[m][4 * q + 0], acc); acc = __builtin_fmaf(w.y, h2[m][4 * q + 1], acc);
-                    acc = __builtin_fmaf(w.z, h2[m][4 * q + 2], acc); acc = __builtin_fmaf(w.w, h2[m][4 * q + 3], acc);
-                }
-            outp[a] = (acc + __shfl_xor(acc, 32)) + b3[a];
+            for (int mt = 0; mt < 4; ++mt) {
+                const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 16 * mt + 4 * g]);
+                acc = __builtin_fmaf(w.x, h2[mt][0], acc); acc = __builtin_fmaf(w.y, h2[mt][1], acc);
+                acc = __builtin_fmaf(w.z, h2[mt][2], acc); acc = __builtin_fmaf(w.w, h2[mt][3], acc);
+            }
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            outp[a] = acc + b3[a];
         }
 
-        // ---- loss and d loss / d out (ppo.py:166-187), identical in both lane halves ----
+        // ---- loss and d loss / d out (ppo.py:166-187), identical in the 4 lanes of a row ----
         float dl[NOUT];
-        const float count_me = (valid && h == 0) ? 1.0f : 0.0f;
+        const float count_me = (valid && g == 0) ? 1.0f : 0.0f;
         if constexpr (ACTOR) {
             float nl0, nl1, p0, p1, H;
             mi_categorical2(outp[0], outp[NOUT - 1], nl0, nl1, p0, p1, H);
-            const float A = (adv - adv_mean) / adv_den;
-            const float ratio = expf((act ? nl1 : nl0) - old_lp);
+            const float A = (cur.f1 - adv_mean) / adv_den;
+            const float ratio = expf((cur.act ? nl1 : nl0) - cur.f0);
             const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
             const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
             const float pg1 = -A * ratio, pg2 = -A * rc;
@@ -297,9 +332,10 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
             else dpg = -0.5f * A + (inrange ? -0.5f * A : 0.0f);
             const float g_lp = invn * dpg * ratio;
             const float ec = ent_coef * invn;
-            dl[0] = g_lp * ((act == 0 ? 1.0f : 0.0f) - p0) + ec * (p0 * (nl0 + H));
-            dl[NOUT - 1] = g_lp * ((act == 1 ? 1.0f : 0.0f) - p1) + ec * (p1 * (nl1 + H));
+            dl[0] = g_lp * ((cur.act == 0 ? 1.0f : 0.0f) - p0) + ec * (p0 * (nl0 + H));
+            dl[NOUT - 1] = g_lp * ((cur.act == 1 ? 1.0f : 0.0f) - p1) + ec * (p1 * (nl1 + H));
         } else {
+            const float ret = cur.f0, v_old = cur.f1;
             const float v = outp[0];
             const float d1 = v - ret;
             const float vl1 = d1 * d1;
@@ -319,114 +355,87 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #pragma unroll
         for (int a = 0; a < NOUT; ++a) {
             dl[a] = valid ? dl[a] : 0.0f;
-            db3[a] += (h == 0) ? dl[a] : 0.0f;
+            db3[a] += (g == 0) ? dl[a] : 0.0f;
         }
-        if (h == 0) *reinterpret_cast<float4*>(dls + 4 * li) = make_float4(dl[0], NOUT == 2 ? dl[NOUT - 1] : 0.0f, 0.0f, 0.0f);
+        dls[4 * j + g] = g == 0 ? dl[0] : ((NOUT == 2 && g == 1) ? dl[NOUT - 1] : 0.0f);
 
-        // ---- dW3 += dl^T h2: stage h2 as a [row][unit] image (rows 0-15 in bufA, 16-31 in bufB) ----
-        // 4x4x1 (16 blocks, block b = lane>>2): D[b][i][j] += A[b][i] B[b][j]; A = dl[row][i], B = h2[row][4b+j]
-        wave_lds_fence();
-        {
-            float* dst = (li >> 4) ? bufB : bufA;
-            const int rl = li & 15;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(dst + rl * W2S + 8 * q + 4 * h + 32 * m) =
-                        make_float4(h2[m][4 * q], h2[m][4 * q + 1], h2[m][4 * q + 2], h2[m][4 * q + 3]);
-        }
+        // ---- dW3 += dout^T h2: stage h2 as a [row][unit] image.
+        // 4x4x1 (16 blocks, block b = lane>>2): D[b][i][jj] += A[b][i] B[b][jj]; A = dout[row][i], B = h2[row][4b+jj]
         wave_lds_fence();
 #pragma unroll
-        for (int rr = 0; rr < 32; rr += 2) {
-            const float* s0 = (rr < 16) ? bufA : bufB;
-            dW3a = mfma4(dls[4 * rr + (lane & 3)], s0[(rr & 15) * W2S + lane], dW3a);
-            dW3b = mfma4(dls[4 * (rr + 1) + (lane & 3)], s0[((rr + 1) & 15) * W2S + lane], dW3b);
+        for (int mt = 0; mt < 4; ++mt)
+            *reinterpret_cast<float4*>(bufA + j * W2S + 16 * mt + 4 * g) = make_float4(h2[mt][0], h2[mt][1], h2[mt][2], h2[mt][3]);
+        wave_lds_fence();
+#pragma unroll
+        for (int rr = 0; rr < TROWS; rr += 2) {
+            dW3a = mfma4(dls[4 * rr + (lane & 3)], bufA[rr * W2S + lane], dW3a);
+            dW3b = mfma4(dls[4 * (rr + 1) + (lane & 3)], bufA[(rr + 1) * W2S + lane], dW3b);
         }
 
-        // ---- dz2 = (W3^T dl) * (1 - h2^2); h2 is dead afterwards ----
-        f32x16 dz2[2];
+        // ---- dz2 = (W3^T dout) * (1 - h2^2); h2 is dead afterwards ----
+        f32x4 dz2[4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int mt = 0; mt < 4; ++mt) {
+            float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int a = 0; a < NOUT; ++a) {
-                    const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 8 * q + 4 * h + 32 * m]);
-                    d[0] = __builtin_fmaf(w.x, dl[a], d[0]); d[1] = __builtin_fmaf(w.y, dl[a], d[1]);
-                    d[2] = __builtin_fmaf(w.z, dl[a], d[2]); d[3] = __builtin_fmaf(w.w, dl[a], d[3]);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const float t = h2[m][4 * q + c]; dz2[m][4 * q + c] = d[c] * (1.0f - t * t); }
+            for (int a = 0; a < NOUT; ++a) {
+                const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 16 * mt + 4 * g]);
+                d[0] = __builtin_fmaf(w.x, dl[a], d[0]); d[1] = __builtin_fmaf(w.y, dl[a], d[1]);
+                d[2] = __builtin_fmaf(w.z, dl[a], d[2]); d[3] = __builtin_fmaf(w.w, dl[a], d[3]);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float t = h2[mt][r]; dz2[mt][r] = d[r] * (1.0f - t * t); }
+        }
 
-        // ---- dh1^T = W2^T dz2^T, dz1 = dh1 * (1 - h1^2) ----
-        f32x16 dz1[2];
+        // ---- dh1^T = W2^T dz2^T, dz1 = dh1 * (1 - h1^2); k-step s <-> output unit o = 16(s>>2) + 4g + (s&3) ----
+        f32x4 dz1[4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int mt = 0; mt < 4; ++mt) dz1[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dz1[m][r] = 0.0f;
+        for (int s = 0; s < 16; ++s) {
+            const float* wrow = &sm.W2[(16 * (s >> 2) + 4 * g + (s & 3)) * W2S + j];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {  // k-step s <-> output unit o = u(s&15, h) + 32(s>>4)
-            const int o_unit = ((s & 15) & 3) + 8 * ((s & 15) >> 2) + 4 * h + 32 * (s >> 4);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) dz1[m] = mfma32(sm.W2[o_unit * W2S + li + 32 * m], dz2[s >> 4][s & 15], dz1[m]);
+            for (int mt = 0; mt < 4; ++mt) dz1[mt] = mfma16(wrow[16 * mt], dz2[s >> 2][s & 3], dz1[mt]);
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t = h1[m][r]; dz1[m][r] = dz1[m][r] * (1.0f - t * t); }
+            for (int r = 0; r < 4; ++r) { const float t = h1[mt][r]; dz1[mt][r] = dz1[mt][r] * (1.0f - t * t); }
 
-        // ---- dW1 += dz1^T x (4x4x1: A = dz1[row][4b+i], B = x[row][j]) and db1; dz1 is dead afterwards ----
-        wave_lds_fence();
-        {
-            float* dst = (li >> 4) ? bufB : bufA;
-            const int rl = li & 15;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(dst + rl * W2S + 8 * q + 4 * h + 32 * m) =
-                        make_float4(dz1[m][4 * q], dz1[m][4 * q + 1], dz1[m][4 * q + 2], dz1[m][4 * q + 3]);
-        }
+        // ---- dW1 += dz1^T x (4x4x1: A = dz1[row][4b+i], B = x[row][jj]) and db1; dz1 is dead afterwards ----
         wave_lds_fence();
 #pragma unroll
-        for (int rr = 0; rr < 32; rr += 2) {
-            const float* s0 = (rr < 16) ? bufA : bufB;
-            const float z0 = s0[(rr & 15) * W2S + lane], z1v = s0[((rr + 1) & 15) * W2S + lane];
+        for (int mt = 0; mt < 4; ++mt)
+            *reinterpret_cast<float4*>(bufB + j * W2S + 16 * mt + 4 * g) = make_float4(dz1[mt][0], dz1[mt][1], dz1[mt][2], dz1[mt][3]);
+        wave_lds_fence();
+#pragma unroll
+        for (int rr = 0; rr < TROWS; rr += 2) {
+            const float z0 = bufB[rr * W2S + lane], z1v = bufB[(rr + 1) * W2S + lane];
             db1 += z0 + z1v;
             dW1a = mfma4(z0, xs[4 * rr + (lane & 3)], dW1a);
             dW1b = mfma4(z1v, xs[4 * (rr + 1) + (lane & 3)], dW1b);
         }
 
-        // ---- dW2[o][i] += sum_rows dz2[row][o] h1[row][i]: A[i=o][k=row], B[k=row][j=i]; 16 rows at a time ----
+        // ---- dW2[o][i] += sum_rows dz2[row][o] h1[row][i]: A[i=o][k=row], B[k=row][j=i], rows 4s+g per k-step ----
+        wave_lds_fence();
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            wave_lds_fence();
-            if ((li >> 4) == hf) {
-                const int rl = li & 15;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int off = rl * W2S + 8 * q + 4 * h + 32 * m;
-                        *reinterpret_cast<float4*>(bufA + off) = make_float4(h1[m][4 * q], h1[m][4 * q + 1], h1[m][4 * q + 2], h1[m][4 * q + 3]);
-                        *reinterpret_cast<float4*>(bufB + off) = make_float4(dz2[m][4 * q], dz2[m][4 * q + 1], dz2[m][4 * q + 2], dz2[m][4 * q + 3]);
-                    }
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int ro = (2 * s + h) * W2S + li;
-                const float a0 = bufB[ro], a1 = bufB[ro + 32], b0 = bufA[ro], b1v = bufA[ro + 32];
-                db2[0] += a0; db2[1] += a1;
-                dW2[0][0] = mfma32(a0, b0, dW2[0][0]);
-                dW2[0][1] = mfma32(a0, b1v, dW2[0][1]);
-                dW2[1][0] = mfma32(a1, b0, dW2[1][0]);
-                dW2[1][1] = mfma32(a1, b1v, dW2[1][1]);
-            }
+        for (int mt = 0; mt < 4; ++mt) {
+            *reinterpret_cast<float4*>(bufA + j * W2S + 16 * mt + 4 * g) = make_float4(h1[mt][0], h1[mt][1], h1[mt][2], h1[mt][3]);
+            *reinterpret_cast<float4*>(bufB + j * W2S + 16 * mt + 4 * g) = make_float4(dz2[mt][0], dz2[mt][1], dz2[mt][2], dz2[mt][3]);
         }
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ro = (4 * s + g) * W2S + j;
+            float a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { a[m] = bufB[ro + 16 * m]; b[m] = bufA[ro + 16 * m]; db2[m] += a[m]; }
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) dW2[mo][mi] = mfma16(a[mo], b[mi], dW2[mo][mi]);
+        }
+        cur = nxt;
     }
     const f32x4 dW1 = dW1a + dW1b, dW3 = dW3a + dW3b;
 
@@ -436,14 +445,13 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     for (int w = 0; w < GRAD_WAVES; ++w) {
         if (wib == w) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int o_unit = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * m;
-                        const int at = o_unit * HID + li + 32 * n;
-                        red[at] = (w == 0) ? dW2[m][n][r] : red[at] + dW2[m][n][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int at = (16 * mo + 4 * g + r) * HID + 16 * mi + j;  // dW2[unit_out][unit_in]
+                        red[at] = (w == 0) ? dW2[mo][mi][r] : red[at] + dW2[mo][mi][r];
                     }
         }
         __syncthreads();
@@ -453,12 +461,14 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     {
         float* slot = bufA;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) slot[(4 * (lane >> 2) + i) * 4 + (lane & 3)] = dW1[i];  // dW1[unit 4b+i][k=j]
+        for (int i = 0; i < 4; ++i) slot[(4 * (lane >> 2) + i) * 4 + (lane & 3)] = dW1[i];  // dW1[unit 4b+i][k=jj]
         slot[256 + lane] = db1;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const float t = db2[m] + __shfl_xor(db2[m], 32);
-            if (h == 0) slot[320 + li + 32 * m] = t;
+        for (int m = 0; m < 4; ++m) {
+            float t = db2[m];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (g == 0) slot[320 + 16 * m + j] = t;
         }
 #pragma unroll
         for (int a = 0; a < NOUT; ++a) slot[384 + a * HID + lane] = dW3[a];  // dW3[a][unit = lane]
@@ -497,36 +507,50 @@ grad_kernel(const float* __restrict__ params, const float* __restrict__ observat
                          ent_coef, vf_coef, invn, part);
 }
 
-// grads[p] = sum over the blocks of p's net, in block order; the last block finishes the loss terms.
-__global__ void __launch_bounds__(256) grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_coef,
-                                                          float vf_coef, double inv_count, float* __restrict__ grads,
-                                                          float* __restrict__ loss_terms) {
-    const int pblocks = (NPARAMS + 255) / 256;
+// grads[p] = sum over the partial slabs of p's net in a FIXED order (reproducible); the last block finishes the loss terms.
+// 1024 threads = 64 consecutive parameters x 16 slab groups: every wave reads 256 contiguous bytes per slab, 16 independent
+// loads per lane, then the 16 group sums are added in group order through LDS.
+#define RED_PARAMS 64
+#define RED_GROUPS 16
+__global__ void __launch_bounds__(RED_PARAMS * RED_GROUPS)
+grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_coef, float vf_coef, double inv_count,
+                   float* __restrict__ grads, float* __restrict__ loss_terms) {
+    const int pblocks = (NPARAMS + RED_PARAMS - 1) / RED_PARAMS;
     if ((int)blockIdx.x < pblocks) {
-        const int p = blockIdx.x * 256 + threadIdx.x;
-        if (p >= NPARAMS) return;
-        const int role = p < C_BASE ? 0 : 1;
-        const int local = p - (role ? C_BASE : 0);
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int k = 0;
-        for (int b = role; b < n_blocks; b += 2, k = (k + 1) & 3) acc[k] += workspace[(size_t)b * PART_STRIDE + local];
-        grads[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __shared__ float part[RED_GROUPS][RED_PARAMS];
+        const int pl = threadIdx.x & (RED_PARAMS - 1), sg = threadIdx.x >> 6;
+        const int p = blockIdx.x * RED_PARAMS + pl;
+        float acc = 0.0f;
+        if (p < NPARAMS) {
+            const int role = p < C_BASE ? 0 : 1;
+            const float* src = workspace + (p - (role ? C_BASE : 0));
+            const int per_role = n_blocks >> 1;
+#pragma unroll 4
+            for (int k = sg; k < per_role; k += RED_GROUPS) acc += src[(size_t)(2 * k + role) * PART_STRIDE];
+        }
+        part[sg][pl] = acc;
+        __syncthreads();
+        if (sg == 0 && p < NPARAMS) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < RED_GROUPS; ++k) t += part[k][pl];
+            grads[p] = t;
+        }
     } else {
         // loss terms: pg / entropy from actor blocks, value loss from critic blocks
         double pg = 0.0, en = 0.0, vl = 0.0;
-        for (int b = threadIdx.x; b < n_blocks; b += 256) {
+        for (int b = threadIdx.x; b < n_blocks; b += RED_PARAMS * RED_GROUPS) {
             const float* s = workspace + (size_t)b * PART_STRIDE + PART_LOSS;
             if ((b & 1) == 0) { pg += s[0]; en += s[1]; } else { vl += s[0]; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { pg += __shfl_xor(pg, o); en += __shfl_xor(en, o); vl += __shfl_xor(vl, o); }
-        __shared__ double t[3][4];
+        __shared__ double t[3][16];
         if ((threadIdx.x & 63) == 0) { t[0][threadIdx.x >> 6] = pg; t[1][threadIdx.x >> 6] = en; t[2][threadIdx.x >> 6] = vl; }
         __syncthreads();
         if (threadIdx.x == 0 && loss_terms) {
-            const double PG = (t[0][0] + t[0][1]) + (t[0][2] + t[0][3]);
-            const double EN = (t[1][0] + t[1][1]) + (t[1][2] + t[1][3]);
-            const double VL = (t[2][0] + t[2][1]) + (t[2][2] + t[2][3]);
+            double PG = 0.0, EN = 0.0, VL = 0.0;
+            for (int k = 0; k < 16; ++k) { PG += t[0][k]; EN += t[1][k]; VL += t[2][k]; }
             const float t0 = (float)(PG * inv_count), t1 = (float)(EN * inv_count), t2 = (float)(0.5 * VL * inv_count);
             loss_terms[0] = t0; loss_terms[1] = t1; loss_terms[2] = t2;
             loss_terms[3] = t0 - ent_coef * t1 + t2 * vf_coef;  // ppo.py:187
@@ -562,7 +586,7 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
     hipStream_t s = (hipStream_t)stream;
     int blocks = grad_blocks();
     // small minibatches: no point launching blocks that would only write zero slabs
-    const int tiles = (mb + 31) / 32;
+    const int tiles = (mb + TROWS - 1) / TROWS;
     const int need = 2 * ((tiles + GRAD_WAVES - 1) / GRAD_WAVES);
     if (need < blocks) blocks = need;
     {
@@ -573,7 +597,7 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
     MI_LAUNCH_CHECK();
     {
         mi_prof_scope prof(MI_PROF_REDUCE, s);
-        grad_reduce_kernel<<<(NPARAMS + 255) / 256 + 1, 256, 0, s>>>((const float*)workspace, blocks, ent_coef, vf_coef, inv_count,
+        grad_reduce_kernel<<<(NPARAMS + RED_PARAMS - 1) / RED_PARAMS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>((const float*)workspace, blocks, ent_coef, vf_coef, inv_count,
                                                                      grads, loss_terms);
     }
     MI_LAUNCH_CHECK();
@@ -581,31 +605,27 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
 }
 
 // =====================================================================================================
-// clip_grad_norm_ + Adam, one workgroup (9,155 parameters)
+// clip_grad_norm_ + Adam.  Every 256-thread workgroup recomputes the total norm of the whole (9,155-float, L2-resident)
+// gradient in the same fixed order — so all workgroups get bitwise the same clip coefficient without a grid-wide
+// hand-off — and then updates its own 256-parameter slice.
 // =====================================================================================================
-__global__ void __launch_bounds__(1024) clip_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
-                                                          float* __restrict__ m, float* __restrict__ v, int n, float w1, float b2,
-                                                          float w2, float step_size, float bc2_sqrt, float eps, float max_norm,
-                                                          float* __restrict__ grad_norm) {
+__global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                                         float* __restrict__ m, float* __restrict__ v, int n, float w1, float b2,
+                                                         float w2, float step_size, float bc2_sqrt, float eps, float max_norm,
+                                                         float* __restrict__ grad_norm) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) { const double g = grads[i]; s += g * g; }
+    for (int i = threadIdx.x; i < n; i += 256) { const double g = grads[i]; s += g * g; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    __shared__ double ws[16];
-    __shared__ float coef_s;
+    __shared__ double ws[4];
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < 16; ++k) t += ws[k];
-        const float total = (float)sqrt(t);
-        float coef = max_norm / (total + 1e-6f);
-        coef_s = coef > 1.0f ? 1.0f : coef;
-        if (grad_norm) *grad_norm = total;
-    }
-    __syncthreads();
-    const float coef = coef_s;
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    const float total = (float)sqrt((ws[0] + ws[1]) + (ws[2] + ws[3]));
+    float coef = max_norm / (total + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+    if (grad_norm && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm = total;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
         const float g = grads[i] * coef;
         const float mi = m[i] + w1 * (g - m[i]);
         const float vi = v[i] * b2 + w2 * (g * g);
@@ -621,7 +641,7 @@ extern "C" int mi_clip_adam(float* params, const float* grads, float* exp_avg, f
     MI_CHECK_ARG(n > 0 && step >= 1, "n must be positive and step 1-based");
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     mi_prof_scope prof(MI_PROF_CLIP_ADAM, (hipStream_t)stream);
-    clip_adam_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
+    clip_adam_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
                                                           (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps,
                                                           max_norm, grad_norm);
     MI_LAUNCH_CHECK();
@@ -703,7 +723,8 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
 
 // =====================================================================================================
 // Hardware self-test of the MFMA fragment layouts grad_kernel relies on (exact small-integer data).
-// report[0]: 32x32x2 A/B/D maps   report[1]: 4x4x1 (16 blocks) A/B/D maps   report[2]: accumulator-as-B chain
+// report[0]: 32x32x2 A/B/D maps   report[1]: 4x4x1 (16 blocks) A/B/D maps   report[2]: accumulator-as-B chain (32x32x2)
+// report[3]: accumulator-as-B chain on 16x16x4 (the form grad_kernel uses)
 // dump (nullable, f32 [3*64*16]): raw accumulators of the three probes for offline diagnosis.
 // =====================================================================================================
 __global__ void __launch_bounds__(64) selftest_kernel(int32_t* __restrict__ report, float* __restrict__ dump) {
@@ -766,8 +787,35 @@ __global__ void __launch_bounds__(64) selftest_kernel(int32_t* __restrict__ repo
             if (dump) dump[(2 * 64 + lane) * 16 + r] = y[r];
         }
     }
+    // probe 3: the 16x16x4 form of probe 2 (what grad_kernel uses): lane (j = lane&15, g = lane>>4), tile mt, register r
+    //          holds X[row j][unit 16mt + 4g + r]; k-step s takes B from register (s&3) of tile (s>>2) and
+    //          A = W[o = j][16(s>>2) + 4g + (s&3)]; D: lane (j, g), register r = Y[row j][o = 4g + r]
+    int bad3 = 0;
+    {
+        const int j = lane & 15, g = lane >> 4;
+        f32x4 x[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[mt][r] = (float)(1 + (j % 5) + 2 * (16 * mt + 4 * g + r));
+        f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int u = 16 * (s >> 2) + 4 * g + (s & 3);
+            y = mfma16((float)(1 + ((j + 3 * u) % 7)), x[s >> 2][s & 3], y);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 4 * g + r;
+            int want = 0;
+            for (int u = 0; u < 64; ++u) want += (1 + ((o + 3 * u) % 7)) * (1 + (j % 5) + 2 * u);
+            bad3 += y[r] != (float)want;
+            if (dump) dump[(2 * 64 + lane) * 16 + 8 + r] = y[r];
+        }
+    }
     const int t0 = (int)wave_sum((float)bad0), t1 = (int)wave_sum((float)bad1), t2 = (int)wave_sum((float)bad2);
-    if (lane == 0) { report[0] = t0; report[1] = t1; report[2] = t2; for (int k = 3; k < 16; ++k) report[k] = 0; }
+    const int t3 = (int)wave_sum((float)bad3);
+    if (lane == 0) { report[0] = t0; report[1] = t1; report[2] = t2; report[3] = t3; for (int k = 4; k < 16; ++k) report[k] = 0; }
 }
 
 extern "C" int mi_selftest_mfma(int32_t* report, float* dump, void* stream) {

@@ -76,7 +76,8 @@ def test_mfma_layout_selftest(dev):
     msg = "report=%s\nprobe1 (4x4x1) regs of lanes 0..7:\n%s" % (rep[:3], d[1, :8, :4])
     assert rep[0] == 0, "32x32x2 A/B/D map wrong: " + msg
     assert rep[1] == 0, "4x4x1_16b A/B/D map wrong: " + msg
-    assert rep[2] == 0, "accumulator-as-B-operand chain wrong: " + msg
+    assert rep[2] == 0, "accumulator-as-B-operand chain (32x32x2) wrong: " + msg
+    assert rep[3] == 0, "accumulator-as-B-operand chain (16x16x4) wrong: " + msg + "\n%s" % d[2, :20, 8:12]
 
 
 def test_device_tanh_accuracy(dev):
