@@ -183,6 +183,20 @@ __device__ __forceinline__ void mi_sincos(double x, double& s, double& c) {
     }
 }
 
+// The same distribution for the hot kernels: one exp + one log for the log-sum-exp (exp(0) = 1 is exact), p = exp(nl)
+// (softmax of already-normalised logits), hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp) — absolute error ~1e-7,
+// well inside the fp32 parity tolerances, at a third of the instructions.
+__device__ __forceinline__ float mi_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float mi_fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ void mi_categorical2_fast(float l0, float l1, float& nl0, float& nl1, float& p0, float& p1, float& ent) {
+    const float m = fmaxf(l0, l1);
+    const float s = 1.0f + mi_fast_exp(-fabsf(l0 - l1));
+    const float lse = mi_fast_log(s) + m;
+    nl0 = l0 - lse; nl1 = l1 - lse;
+    p0 = mi_fast_exp(nl0); p1 = mi_fast_exp(nl1);
+    ent = -(nl0 * p0 + nl1 * p1);
+}
+
 // ---- CartPole-v1 step (gym 0.21 cartpole.py), fp64, no FMA contraction (-ffp-contract=off) ---------
 #define CP_MAX_STEPS 500
 __device__ __forceinline__ void mi_cartpole_step(double& x, double& x_dot, double& theta, double& theta_dot, int action,
@@ -211,6 +225,18 @@ __device__ __forceinline__ float dpp_xor1(float v) { return __builtin_bit_cast(f
 __device__ __forceinline__ float dpp_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); }
+
+// sum over the 64 lanes of a wave on the VALU only (no LDS round trip): row reduction by DPP, then row_bcast:15 /
+// row_bcast:31 carry the row totals upward so that lane 63 holds the wave total; v_readlane makes it wave-uniform.
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    v += dpp_mirror(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1,3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 
 // sum over the 64 lanes of a wave, result in every lane
 __device__ __forceinline__ float wave_sum(float v) {

@@ -90,7 +90,7 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
             // ---- sample from the logits of obs[t], step the env (ppo.py:120-129); lane = env ----
             const size_t row = (size_t)t * N + g;
             float nl0, nl1, p0, p1, ent;
-            mi_categorical2(my_l0, my_l1, nl0, nl1, p0, p1, ent);
+            mi_categorical2_fast(my_l0, my_l1, nl0, nl1, p0, p1, ent);
             int a;
             if (forced_actions) a = (int)forced_actions[row];
             else {
@@ -107,10 +107,14 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
             eplen += 1;
             if (d) {
                 if (mine && episode_stats) {
-                    const int slot = atomicAdd(episode_stats, 1);
                     atomicAdd(episode_stats + 1, eplen);
                     atomicMax(episode_stats + 2, eplen);
-                    if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
+                    if (max_ep > 0) {  // a returning atomic costs a device-memory round trip: only when the list is wanted
+                        const int slot = atomicAdd(episode_stats, 1);
+                        if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
+                    } else {
+                        atomicAdd(episode_stats, 1);
+                    }
                 }
                 epret = 0.0f; eplen = 0; elapsed = 0;
                 double s[4];
@@ -143,9 +147,9 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
         for (int i = 0; i < E; ++i) {
             const float h2a = mi_tanhf(layer2(an, hbuf[wib][i][0]));
             const float h2c = mi_tanhf(layer2(cn, hbuf[wib][i][1]));
-            const float l0 = wave_sum(w3a0 * h2a) + b3a0;
-            const float l1 = wave_sum(w3a1 * h2a) + b3a1;
-            const float vv = wave_sum(w3c * h2c) + b3c;
+            const float l0 = wave_sum_uniform(w3a0 * h2a) + b3a0;
+            const float l1 = wave_sum_uniform(w3a1 * h2a) + b3a1;
+            const float vv = wave_sum_uniform(w3c * h2c) + b3c;
             if (lane == i) { my_l0 = l0; my_l1 = l1; my_val = vv; }
         }
         wave_lds_fence();

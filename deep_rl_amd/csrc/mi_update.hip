@@ -136,6 +136,12 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 // =====================================================================================================
 #define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row reads / writes (nearly) conflict-free
 #define GRAD_WAVES 4
+#ifndef GRAD_OCC
+#define GRAD_OCC 2        // waves per SIMD the kernel is built for (blocks per CU = GRAD_OCC)
+#endif
+#ifndef GRAD_STAGGER
+#define GRAD_STAGGER 0    // s_sleep units (64 clk) the critic workgroups wait before their first tile
+#endif
 #define TROWS 16
 #define PART_STRIDE 4624
 #define PART_LOSS 4610
@@ -145,11 +151,11 @@ struct __attribute__((aligned(16))) grad_smem {
     float W2[HID * W2S];                  // W2[o][i] row-major, padded
     float b1[HID], b2[HID];
     float W3[2 * HID];
-    float bufA[GRAD_WAVES][TROWS * W2S];   // wave-private [row][unit] images for the transposed re-reads
-    float bufB[GRAD_WAVES][TROWS * W2S];
-    float xs[GRAD_WAVES][TROWS * 4];       // observations of the tile
-    float dls[GRAD_WAVES][TROWS * 4];      // d loss / d logits (or d value), zero padded to 4
+    float bufA[GRAD_WAVES][TROWS * W2S];   // wave-private [row][unit] images for the transposed re-reads; the 4 pad
+    float bufB[GRAD_WAVES][TROWS * W2S];   // columns (64..67) of a row hold x[row][0..3] (bufA) / dout[row][0..3] (bufB)
 };
+#define XS(row, k) bufA[(row) * W2S + HID + (k)]
+#define DLS(row, k) bufB[(row) * W2S + HID + (k)]
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -184,13 +190,20 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
     return r;
 }
 
+#ifdef GRAD_STAMPS
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      stamp_acc[k] += t_ - stamp_last; stamp_last = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 template <bool ACTOR>
 __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict__ params, const float* __restrict__ observations,
                                           const int64_t* __restrict__ actions, const float* __restrict__ log_probs,
                                           const float* __restrict__ advantages, const float* __restrict__ returns,
                                           const float* __restrict__ values, const int32_t* __restrict__ idx, int mb,
                                           const double* __restrict__ adv_sums, float clip_coef, float ent_coef, float vf_coef,
-                                          float invn, float* __restrict__ part) {
+                                          float invn, float* __restrict__ part, unsigned vb) {
     constexpr int NOUT = ACTOR ? 2 : 1;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -218,18 +231,18 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     for (int a = 0; a < NOUT; ++a) b3[a] = p[N_W3 + NOUT * HID + a];
 
     // advantage normalisation constants (ppo.py:169) from {sum, sum sq, count}
-    float adv_mean = 0.0f, adv_den = 1.0f;
+    float adv_mean = 0.0f, adv_rden = 1.0f;
     if constexpr (ACTOR) {
         const double s1 = adv_sums[0], s2 = adv_sums[1], cnt = adv_sums[2];
         const double mean = s1 / cnt;
         double var = (s2 - s1 * mean) / (cnt - 1.0);
         var = var > 0.0 ? var : 0.0;
         adv_mean = (float)mean;
-        adv_den = (float)sqrt(var) + 1e-8f;
+        adv_rden = 1.0f / ((float)sqrt(var) + 1e-8f);
     }
 
     const int n_tiles = (mb + TROWS - 1) / TROWS;
-    const int wave_role = (blockIdx.x >> 1) * GRAD_WAVES + wib;
+    const int wave_role = (int)(vb >> 1) * GRAD_WAVES + wib;
     const int stride = (gridDim.x >> 1) * GRAD_WAVES;
     // ---- input prefetch pipeline: row index two tiles ahead, gathered row one tile ahead ----
     auto tile_rid = [&](int t) { const int row = t * TROWS + j; return idx[row < mb ? row : mb - 1]; };
@@ -237,6 +250,9 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     int rid_next = tile_rid(tile + stride);
     row_in cur = gather_row<ACTOR>(tile_rid(tile), g, observations, actions, log_probs, advantages, returns, values);
     __syncthreads();  // weights staged
+#if GRAD_STAGGER > 0
+    if (!ACTOR) __builtin_amdgcn_s_sleep(GRAD_STAGGER);  // de-phase the critic wave from the actor wave sharing its SIMD
+#endif
 
     // ---- accumulators that live across tiles ----
     f32x4 dW2[4][4];
@@ -250,16 +266,20 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 
     float* bufA = sm.bufA[wib];
     float* bufB = sm.bufB[wib];
-    float* xs = sm.xs[wib];
-    float* dls = sm.dls[wib];
 
+#ifdef GRAD_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last, stamp_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+    stamp_t0 = stamp_last;
+#endif
     for (; tile < n_tiles; tile += stride) {
         const bool valid = tile * TROWS + j < mb;
         // issue the next tile's gathers and the index after that; they land while this tile computes
         const row_in nxt = gather_row<ACTOR>(rid_next, g, observations, actions, log_probs, advantages, returns, values);
         rid_next = tile_rid(tile + 2 * stride);
 
-        xs[4 * j + g] = cur.x;
+        XS(j, g) = cur.x;
+        STAMP(0);  // gathers issued
 
         // ---- layer 1: z1^T = W1 x^T + b1 (K = 4 = obs dim: one MFMA per 16-unit tile) ----
         f32x4 h1[4];
@@ -272,6 +292,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[mt][r] = mi_tanhf_fast(h1[mt][r]);
+        STAMP(1);  // layer 1 + tanh
 
         // ---- layer 2: z2^T = W2 h1^T + b2; k-steps 4c..4c+3 <-> units 16c + 4g + {0..3} ----
         f32x4 h2[4];
@@ -282,19 +303,25 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            float4 a[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float4 a = *reinterpret_cast<const float4*>(&sm.W2[(16 * mt + j) * W2S + 16 * c + 4 * g]);
-                h2[mt] = mfma16(a.x, h1[c][0], h2[mt]);
-                h2[mt] = mfma16(a.y, h1[c][1], h2[mt]);
-                h2[mt] = mfma16(a.z, h1[c][2], h2[mt]);
-                h2[mt] = mfma16(a.w, h1[c][3], h2[mt]);
-            }
+            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4*>(&sm.W2[(16 * mt + j) * W2S + 16 * c + 4 * g]);
+            // consecutive MFMAs go to different accumulators: the 16x16x4 dependent latency (40 clk) exceeds its issue (32)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].x, h1[c][0], h2[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].y, h1[c][1], h2[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].z, h1[c][2], h2[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].w, h1[c][3], h2[mt]);
         }
+        STAMP(2);  // layer 2 MFMAs issued
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h2[mt][r] = mi_tanhf_fast(h2[mt][r]);
+        STAMP(3);  // tanh h2 (includes waiting for the layer-2 accumulators)
 
         // ---- head: out[a] = W3[a] . h2 + b3[a]; the 4 lanes (g) of a row hold 16 units each ----
         float outp[NOUT];
@@ -317,9 +344,9 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         const float count_me = (valid && g == 0) ? 1.0f : 0.0f;
         if constexpr (ACTOR) {
             float nl0, nl1, p0, p1, H;
-            mi_categorical2(outp[0], outp[NOUT - 1], nl0, nl1, p0, p1, H);
-            const float A = (cur.f1 - adv_mean) / adv_den;
-            const float ratio = expf((cur.act ? nl1 : nl0) - cur.f0);
+            mi_categorical2_fast(outp[0], outp[NOUT - 1], nl0, nl1, p0, p1, H);
+            const float A = (cur.f1 - adv_mean) * adv_rden;
+            const float ratio = mi_fast_exp((cur.act ? nl1 : nl0) - cur.f0);
             const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
             const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
             const float pg1 = -A * ratio, pg2 = -A * rc;
@@ -357,7 +384,8 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
             dl[a] = valid ? dl[a] : 0.0f;
             db3[a] += (g == 0) ? dl[a] : 0.0f;
         }
-        dls[4 * j + g] = g == 0 ? dl[0] : ((NOUT == 2 && g == 1) ? dl[NOUT - 1] : 0.0f);
+        DLS(j, g) = g == 0 ? dl[0] : ((NOUT == 2 && g == 1) ? dl[NOUT - 1] : 0.0f);
+        STAMP(4);  // head + loss
 
         // ---- dW3 += dout^T h2: stage h2 as a [row][unit] image.
         // 4x4x1 (16 blocks, block b = lane>>2): D[b][i][jj] += A[b][i] B[b][jj]; A = dout[row][i], B = h2[row][4b+jj]
@@ -368,10 +396,11 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         wave_lds_fence();
 #pragma unroll
         for (int rr = 0; rr < TROWS; rr += 2) {
-            dW3a = mfma4(dls[4 * rr + (lane & 3)], bufA[rr * W2S + lane], dW3a);
-            dW3b = mfma4(dls[4 * (rr + 1) + (lane & 3)], bufA[(rr + 1) * W2S + lane], dW3b);
+            dW3a = mfma4(DLS(rr, lane & 3), bufA[rr * W2S + lane], dW3a);
+            dW3b = mfma4(DLS(rr + 1, lane & 3), bufA[(rr + 1) * W2S + lane], dW3b);
         }
 
+        STAMP(5);  // stage h2 + dW3
         // ---- dz2 = (W3^T dout) * (1 - h2^2); h2 is dead afterwards ----
         f32x4 dz2[4];
 #pragma unroll
@@ -384,9 +413,10 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
                 d[2] = __builtin_fmaf(w.z, dl[a], d[2]); d[3] = __builtin_fmaf(w.w, dl[a], d[3]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float t = h2[mt][r]; dz2[mt][r] = d[r] * (1.0f - t * t); }
+            for (int r = 0; r < 4; ++r) { const float t = h2[mt][r]; dz2[mt][r] = d[r] * __builtin_fmaf(-t, t, 1.0f); }
         }
 
+        STAMP(6);  // dz2
         // ---- dh1^T = W2^T dz2^T, dz1 = dh1 * (1 - h1^2); k-step s <-> output unit o = 16(s>>2) + 4g + (s&3) ----
         f32x4 dz1[4];
 #pragma unroll
@@ -400,8 +430,9 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float t = h1[mt][r]; dz1[mt][r] = dz1[mt][r] * (1.0f - t * t); }
+            for (int r = 0; r < 4; ++r) { const float t = h1[mt][r]; dz1[mt][r] = dz1[mt][r] * __builtin_fmaf(-t, t, 1.0f); }
 
+        STAMP(7);  // dh1 MFMAs + dz1
         // ---- dW1 += dz1^T x (4x4x1: A = dz1[row][4b+i], B = x[row][jj]) and db1; dz1 is dead afterwards ----
         wave_lds_fence();
 #pragma unroll
@@ -412,10 +443,11 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         for (int rr = 0; rr < TROWS; rr += 2) {
             const float z0 = bufB[rr * W2S + lane], z1v = bufB[(rr + 1) * W2S + lane];
             db1 += z0 + z1v;
-            dW1a = mfma4(z0, xs[4 * rr + (lane & 3)], dW1a);
-            dW1b = mfma4(z1v, xs[4 * (rr + 1) + (lane & 3)], dW1b);
+            dW1a = mfma4(z0, XS(rr, lane & 3), dW1a);
+            dW1b = mfma4(z1v, XS(rr + 1, lane & 3), dW1b);
         }
 
+        STAMP(8);  // stage dz1 + dW1
         // ---- dW2[o][i] += sum_rows dz2[row][o] h1[row][i]: A[i=o][k=row], B[k=row][j=i], rows 4s+g per k-step ----
         wave_lds_fence();
 #pragma unroll
@@ -435,15 +467,32 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) dW2[mo][mi] = mfma16(a[mo], b[mi], dW2[mo][mi]);
         }
+        STAMP(9);  // stage h1, dz2 + dW2
         cur = nxt;
+        STAMP(10);  // wait for the prefetched row
     }
+#ifdef GRAD_STAMPS
+    if (lane == 0) {  // diagnostic build: the unused upper half of the workspace (grid <= 512 blocks) receives the stamps
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(part + (size_t)512 * PART_STRIDE) + 16 * wib;
+        unsigned long long now;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
+        for (int k = 0; k < 11; ++k) dbg[k] = stamp_acc[k];
+        dbg[11] = now - stamp_t0;
+        dbg[12] = (unsigned long long)((n_tiles - wave_role + stride - 1) / stride);
+    }
+#endif
     const f32x4 dW1 = dW1a + dW1b, dW3 = dW3a + dW3b;
 
     // ---- deterministic cross-wave reduction, then one partial slab per block ----
-    __syncthreads();  // every wave is done with sm.W2 -> reuse it as the 64x64 reduction tile
-    float* red = sm.W2;
-    for (int w = 0; w < GRAD_WAVES; ++w) {
-        if (wib == w) {
+    __syncthreads();  // every wave is done with the weights and its staging tiles -> reuse LDS for the reduction
+    // two 64x64 tiles: R0 in sm.W2 (4352 floats), R1 across bufA[0..3] (4 x 1088 floats, contiguous).  Waves 0/1 store,
+    // waves 2/3 add (fixed order: (w0 + w2) + (w1 + w3)), then all threads write R0 + R1 to the slab.
+    float* red0 = sm.W2;
+    float* red1 = &sm.bufA[0][0];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if ((wib >> 1) == round) {
+            float* red = (wib & 1) ? red1 : red0;
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
@@ -451,15 +500,19 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int at = (16 * mo + 4 * g + r) * HID + 16 * mi + j;  // dW2[unit_out][unit_in]
-                        red[at] = (w == 0) ? dW2[mo][mi][r] : red[at] + dW2[mo][mi][r];
+                        red[at] = round == 0 ? dW2[mo][mi][r] : red[at] + dW2[mo][mi][r];
                     }
         }
         __syncthreads();
     }
-    for (int i = tid; i < HID * HID; i += 64 * GRAD_WAVES) part[N_W2 + i] = red[i];
+    for (int i = tid; i < HID * HID / 4; i += 64 * GRAD_WAVES) {
+        const float4 a = reinterpret_cast<const float4*>(red0)[i], b = reinterpret_cast<const float4*>(red1)[i];
+        reinterpret_cast<float4*>(part + N_W2)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();  // red1 overlaps the per-wave slots used next
     // small tensors: every wave drops its values in its own bufA slot, then a fixed-order sum over the 4 waves
     {
-        float* slot = bufA;
+        float* slot = bufB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) slot[(4 * (lane >> 2) + i) * 4 + (lane & 3)] = dW1[i];  // dW1[unit 4b+i][k=jj]
         slot[256 + lane] = db1;
@@ -481,7 +534,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     constexpr int N_SMALL = 384 + NOUT * HID + NOUT;
     for (int i = tid; i < 522; i += 64 * GRAD_WAVES) {
         if (i >= N_SMALL && i < 520) continue;
-        const float t = (sm.bufA[0][i] + sm.bufA[1][i]) + (sm.bufA[2][i] + sm.bufA[3][i]);
+        const float t = (sm.bufB[0][i] + sm.bufB[1][i]) + (sm.bufB[2][i] + sm.bufB[3][i]);
         int dst;
         if (i < 256) dst = N_W1 + i;
         else if (i < 320) dst = N_B1 + (i - 256);
@@ -492,19 +545,24 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     }
 }
 
-__global__ void __launch_bounds__(64 * GRAD_WAVES, 2)
+__global__ void __launch_bounds__(64 * GRAD_WAVES, GRAD_OCC)
 grad_kernel(const float* __restrict__ params, const float* __restrict__ observations, const int64_t* __restrict__ actions,
             const float* __restrict__ log_probs, const float* __restrict__ advantages, const float* __restrict__ returns,
             const float* __restrict__ values, const int32_t* __restrict__ idx, int mb, const double* __restrict__ adv_sums,
             float clip_coef, float ent_coef, float vf_coef, float invn, float* __restrict__ workspace) {
     __shared__ grad_smem sm;
-    float* part = workspace + (size_t)blockIdx.x * PART_STRIDE;
-    if ((blockIdx.x & 1) == 0)
+    // Workgroups are dealt round-robin over the 8 XCDs (b % 8), so role = b & 1 would give each XCD ONE net and leave the
+    // critic XCDs idle while the (heavier) actor ones finish.  Swap the two low bit fields instead: the slab index
+    // `vb` keeps role = vb & 1 for the reduce kernel, while physical blocks b, b+8 (same XCD) get different roles.
+    const unsigned vb = (gridDim.x & 15u) ? blockIdx.x  // small grids: identity
+                                          : ((blockIdx.x >> 3) & 1u) | (((blockIdx.x & 7u) | ((blockIdx.x >> 4) << 3)) << 1);
+    float* part = workspace + (size_t)vb * PART_STRIDE;
+    if ((vb & 1) == 0)
         grad_body<true>(sm, params, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
-                        ent_coef, vf_coef, invn, part);
+                        ent_coef, vf_coef, invn, part, vb);
     else
         grad_body<false>(sm, params, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
-                         ent_coef, vf_coef, invn, part);
+                         ent_coef, vf_coef, invn, part, vb);
 }
 
 // grads[p] = sum over the partial slabs of p's net in a FIXED order (reproducible); the last block finishes the loss terms.
@@ -566,7 +624,8 @@ static int grad_blocks() {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         }
-        int b = 2 * cus;  // one actor + one critic workgroup per CU
+        int b = GRAD_OCC * cus;  // GRAD_OCC workgroups per CU, alternating actor / critic
+        b &= ~1;
         if (b > GRAD_MAX_BLOCKS) b = GRAD_MAX_BLOCKS;
         g_grad_blocks = b;
     }
@@ -588,7 +647,7 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
     // small minibatches: no point launching blocks that would only write zero slabs
     const int tiles = (mb + TROWS - 1) / TROWS;
     const int need = 2 * ((tiles + GRAD_WAVES - 1) / GRAD_WAVES);
-    if (need < blocks) blocks = need;
+    if (need < blocks) blocks = need >= 16 ? ((need + 15) & ~15) : need;  // multiples of 16 keep the XCD-aware role swizzle
     {
         mi_prof_scope prof(MI_PROF_GRAD, s);
         grad_kernel<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, observations, actions, log_probs, advantages, returns, values, idx, mb,
@@ -613,8 +672,12 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ para
                                                          float* __restrict__ m, float* __restrict__ v, int n, float w1, float b2,
                                                          float w2, float step_size, float bc2_sqrt, float eps, float max_norm,
                                                          float* __restrict__ grad_norm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const float pm = live ? m[i] : 0.0f, pv = live ? v[i] : 0.0f, pp = live ? params[i] : 0.0f, pg = live ? grads[i] : 0.0f;
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { const double g = grads[i]; s += g * g; }
+#pragma unroll 4
+    for (int k = threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     __shared__ double ws[4];
@@ -624,14 +687,13 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ para
     float coef = max_norm / (total + 1e-6f);
     coef = coef > 1.0f ? 1.0f : coef;
     if (grad_norm && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm = total;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        const float g = grads[i] * coef;
-        const float mi = m[i] + w1 * (g - m[i]);
-        const float vi = v[i] * b2 + w2 * (g * g);
+    if (live) {
+        const float g = pg * coef;
+        const float mi = pm + w1 * (g - pm);
+        const float vi = pv * b2 + w2 * (g * g);
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         m[i] = mi; v[i] = vi;
-        params[i] = params[i] + (-step_size) * (mi / denom);
+        params[i] = pp + (-step_size) * (mi / denom);
     }
 }
 

@@ -52,8 +52,8 @@ class PPOEngine:
         self.loss_terms = self._gradbuf[N.NPARAMS:N.NPARAMS + 4]
         self.explained_var = z(1, dt=torch.float64)
         self.workspace = torch.empty(N.lib().mi_ppo_workspace_bytes(), dtype=torch.uint8, device=dev)
-        self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else max(1024, 2 * Nn))
-        self.episodes = torch.zeros((self.max_ep, 4), dtype=torch.int32, device=dev)  # mi_episode_t = 4 x 32 bit
+        self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (1024 if Nn <= 8 else 0))
+        self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)  # mi_episode_t = 4 x 32 bit
         self.episode_stats = z(4, dt=torch.int32)  # {finished episodes, sum of lengths, longest, -} of the last rollout
         self.observation = None  # the carried-over `observation` of the reference loop (ppo.py:101,127-129)
         self.update_index = 0

@@ -52,15 +52,16 @@ agent = ActorCritic(env)
 optimizer = ClipAdam(agent, lr=learning_rate, eps=1e-5, max_grad_norm=max_grad_norm)
 
 # Storage setup (:93-98) lives in the engine; expose the reference's names
+print_episodes = int(os.environ.get("PRINT_EPISODES", "1" if num_envs <= 8 else "0"))
 engine = PPOEngine(env, agent, optimizer, num_steps=num_steps, n_minibatch=4, update_epochs=update_epochs, gamma=gamma,
-                   gae_lambda=gae_lambda, clip_coef=clip_coef, ent_coef=ent_coef, vf_coef=vf_coef)
+                   gae_lambda=gae_lambda, clip_coef=clip_coef, ent_coef=ent_coef, vf_coef=vf_coef,
+                   max_episodes_logged=(4 * num_steps * num_envs if print_episodes else 0))
 observations, values, actions = engine.observations, engine.values, engine.actions
 log_probs, rewards, dones = engine.log_probs, engine.rewards, engine.dones
 
 # Init the env (:101-102)
 observation = engine.reset()
 global_step = 0
-print_episodes = int(os.environ.get("PRINT_EPISODES", "1" if num_envs <= 8 else "0"))
 
 # Loop (:105)
 for update in range(num_updates):
@@ -77,7 +78,7 @@ for update in range(num_updates):
         for e, t, r, _l in finished:
             print(f"global_step={global_step + t * num_envs + e}, episodic_return={r:.2f}")
     elif rank == 0 and n_finished:
-        mean_r = sum(f[2] for f in finished) / max(1, len(finished))
+        mean_r = int(engine.episode_stats[1].item()) / n_finished  # CartPole: return == length
         print(f"update={update}, global_step={global_step + num_steps * num_envs}, episodes={n_finished}, mean_episodic_return={mean_r:.2f}")
     global_step += num_steps * num_envs
 
