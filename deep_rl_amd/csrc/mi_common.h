@@ -102,10 +102,12 @@ __device__ inline void mi_reset_noise(uint64_t seed, uint64_t env, uint64_t epis
     }
 }
 
+// action draw of env-step `step`: word (step & 3) of the Philox block with idx = step >> 2 (one block feeds 4 steps)
+__device__ inline float mi_u32_to_uniform(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 __device__ inline float mi_action_uniform(uint64_t seed, uint64_t env, uint64_t step) {
     uint32_t r[4];
-    mi_philox(seed, env, step, STREAM_ACTION, r);
-    return (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+    mi_philox(seed, env, step >> 2, STREAM_ACTION, r);
+    return mi_u32_to_uniform(r[step & 3]);
 }
 
 __host__ __device__ inline uint32_t mi_mix32(uint32_t x) {
@@ -130,20 +132,13 @@ __host__ __device__ inline uint32_t mi_feistel(uint32_t i, uint32_t n, uint32_t 
 }
 
 // ---- math ------------------------------------------------------------------------------------------
-// tanh, <= ~2.5 ulp / 1.2e-7 abs vs libm (tests/test_gpu_kernels.py::test_tanh): odd polynomial below 0.6,
-// 1 - 2/(2^(2x log2 e) + 1) above.  Branch-free so the 64 lanes of a wave never diverge.
+// tanh = 1 - 2/(2^(2x log2 e) + 1): 5 instructions (v_exp_f32, v_rcp_f32), branch-free, exact limits at +-inf.
+// Absolute error <= ~2.5e-7 (tests/test_gpu_parity.py::test_device_tanh_accuracy); the RELATIVE error is not bounded
+// near 0 — activations enter O(1) sums, so absolute accuracy is what the fp32 parity tolerances need.  The rollout,
+// the forward API and the update kernel all use this one function, so new/old log-probs are consistent.
 __device__ __forceinline__ float mi_tanhf(float x) {
-    const float ax = fabsf(x);
-    const float x2 = x * x;
-    float p = -5.883233055e-03f;
-    p = __builtin_fmaf(p, x2, 2.078514762e-02f);
-    p = __builtin_fmaf(p, x2, -5.378039939e-02f);
-    p = __builtin_fmaf(p, x2, 1.333188030e-01f);
-    p = __builtin_fmaf(p, x2, -3.333329618e-01f);
-    const float small = __builtin_fmaf(x, x2 * p, x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);  // v_exp_f32; inf for large |x| -> big = 1
-    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return ax < 0.6f ? small : __builtin_copysignf(big, x);
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // Categorical(logits=l) for 2 actions (reference ppo.py:52-54 / torch.distributions.Categorical):
@@ -209,10 +204,15 @@ __device__ __forceinline__ void mi_cartpole_step(double& x, double& x_dot, doubl
     const double force = action == 1 ? force_mag : -force_mag;
     double costheta, sintheta;
     mi_sincos(theta, sintheta, costheta);
-    const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+    // x / total_mass, bit-identical to the IEEE quotient: with y = RN(1/c), q = RN(x*y), r = x - c*q (exact, one FMA),
+    // RN(q + r*y) is the correctly rounded x/c (Markstein 1990; 4e8 random operands checked on the CPU, and the
+    // float64-state parity tests compare against the oracle's true divisions).  Saves three v_rcp_f64 sequences per step.
+    const double inv_tm = 1.0 / total_mass;
+    auto div_tm = [&](double v) { const double q = v * inv_tm; return __builtin_fma(__builtin_fma(-total_mass, q, v), inv_tm, q); };
+    const double temp = div_tm(force + polemass_length * (theta_dot * theta_dot) * sintheta);
     const double thetaacc = (gravity * sintheta - costheta * temp) /
-                            (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
-    const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+                            (length * (4.0 / 3.0 - div_tm(masspole * (costheta * costheta))));
+    const double xacc = temp - div_tm(polemass_length * thetaacc * costheta);
     x = x + tau * x_dot;
     x_dot = x_dot + tau * xacc;
     theta = theta + tau * theta_dot;

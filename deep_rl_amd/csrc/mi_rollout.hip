@@ -83,6 +83,9 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
     uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
     float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
     float my_l0 = 0.0f, my_l1 = 0.0f, my_val = 0.0f;
+    uint32_t urand[4] = {0, 0, 0, 0};  // the current Philox block of action draws (steps 4k..4k+3 of this env)
+    const bool keyed_actions = !forced_actions && !forced_uniforms;
+    if (keyed_actions && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
 
     for (int t = -1; t < T; ++t) {
         float rew = 0.0f, dn = 0.0f;
@@ -94,7 +97,13 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
             int a;
             if (forced_actions) a = (int)forced_actions[row];
             else {
-                const float u = forced_uniforms ? forced_uniforms[row] : mi_action_uniform(e.seed, e.env_id_base + (uint64_t)g, stepctr);
+                float u;
+                if (forced_uniforms) u = forced_uniforms[row];
+                else {
+                    const uint32_t w = (uint32_t)stepctr & 3u;
+                    if (w == 0) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
+                    u = mi_u32_to_uniform(w == 0 ? urand[0] : w == 1 ? urand[1] : w == 2 ? urand[2] : urand[3]);
+                }
                 a = (u >= p0) ? 1 : 0;
             }
             stepctr += 1;

@@ -161,13 +161,6 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
-// tanh for the update kernel: 1 - 2/(2^(2x log2 e) + 1), 5 instructions, absolute error <= ~2e-7 (relative error is
-// NOT bounded near 0, unlike mi_tanhf; activations enter O(1) sums, so absolute accuracy is what parity needs).
-__device__ __forceinline__ float mi_tanhf_fast(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-}
-
 struct row_in {
     float x;          // observation component g of the row (lane (j,g))
     int act;
@@ -291,7 +284,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h1[mt][r] = mi_tanhf_fast(h1[mt][r]);
+            for (int r = 0; r < 4; ++r) h1[mt][r] = mi_tanhf(h1[mt][r]);
         STAMP(1);  // layer 1 + tanh
 
         // ---- layer 2: z2^T = W2 h1^T + b2; k-steps 4c..4c+3 <-> units 16c + 4g + {0..3} ----
@@ -320,7 +313,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h2[mt][r] = mi_tanhf_fast(h2[mt][r]);
+            for (int r = 0; r < 4; ++r) h2[mt][r] = mi_tanhf(h2[mt][r]);
         STAMP(3);  // tanh h2 (includes waiting for the layer-2 accumulators)
 
         // ---- head: out[a] = W3[a] . h2 + b3[a]; the 4 lanes (g) of a row hold 16 units each ----

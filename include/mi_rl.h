@@ -31,8 +31,8 @@
  * RNG contract (production mode; in parity mode every random input is supplied explicitly):
  *   philox4x32-10, counter = {env_lo, env_hi, idx_lo, (idx_hi << 4) | stream}, key = {seed_lo, seed_hi}
  *   stream 0: reset noise   idx = episode index of that env; word i -> s_i = -0.05 + 0.1*((w_i+0.5)/2^32) (f64)
- *   stream 1: action draw   idx = number of actions that env has sampled; u = (w_0 >> 8) / 2^24 (f32),
- *             action = #{j < n_actions-1 : u >= cumsum(probs)[j]}
+ *   stream 1: action draw   for the s-th action an env samples: idx = s >> 2, word w = w_(s & 3) (one Philox block feeds
+ *             four consecutive steps); u = (w >> 8) / 2^24 (f32), action = #{j < n_actions-1 : u >= cumsum(probs)[j]}
  *   stream 2: permutation key for (env := update, idx := epoch): key = w_0 | (w_1 << 32); the
  *             permutation itself is the 6-round Feistel bijection with cycle walking of mi_make_perm.
  *   `env` is the GLOBAL env id (env_id_base + local index) so a trajectory does not depend on how
