@@ -1,0 +1,49 @@
+"""The drop-in script: `python -m deep_rl_amd.ppo` keeps the reference's surface (module globals, print format)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_over):
+    env = dict(os.environ, PYTHONPATH=ROOT, **env_over)
+    code = ("import runpy, json; g = runpy.run_module('deep_rl_amd.ppo', run_name='__main__');"
+            "print('GLOBALS', json.dumps({k: (float(g[k]) if isinstance(g[k], float) else g[k]) for k in "
+            "['env_id','total_timesteps','num_steps','num_updates','minibatch_size','update_epochs','gamma','gae_lambda',"
+            "'learning_rate','clip_coef','ent_coef','vf_coef','max_grad_norm','seed','global_step','num_envs']}));"
+            "print('SHAPES', [tuple(g[k].shape) for k in ['observations','values','actions','log_probs','rewards','dones','advantages','returns']]);"
+            "print('LOSS', g['pg_loss'], g['entropy_loss'], g['v_loss'], g['loss'], g['explained_var'])")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def test_reference_shape_run_n1():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = _run({"NUM_ENVS": "1", "TOTAL_TIMESTEPS": "3840"})
+    lines = [ln for ln in out.splitlines() if ln.startswith("global_step=")]
+    assert len(lines) > 50
+    assert all(re.fullmatch(r"global_step=\d+, episodic_return=\d+\.\d\d", ln) for ln in lines)  # ppo.py:130
+    steps = [int(ln.split(",")[0].split("=")[1]) for ln in lines]
+    assert steps == sorted(steps) and steps[-1] < 3840
+    assert '"num_updates": 30' in out and '"minibatch_size": 32' in out and '"global_step": 3840' in out
+    assert "SHAPES [(129, 1, 4), (129, 1), (129, 1), (129, 1), (129, 1), (129, 1), (129, 1), (129, 1)]" in out
+
+
+def test_vector_run_learns():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = _run({"NUM_ENVS": "256", "TOTAL_TIMESTEPS": str(256 * 128 * 40)})
+    rets = [float(ln.split("mean_episodic_return=")[1]) for ln in out.splitlines() if "mean_episodic_return=" in ln]
+    assert len(rets) >= 30 and sum(rets[-5:]) / 5 > 2.0 * sum(rets[:3]) / 3, rets
+    assert '"minibatch_size": 8192' in out
