@@ -485,6 +485,33 @@ def test_headline_size_properties(dev):
         assert n1 == n2 and torch.equal(p1, p2) and torch.equal(t1, t2)  # bitwise reproducible
 
 
+def test_headline_size_gradient_linearity(dev):
+    """Full-size launch (131,072 rows, 512 workgroups, age-aware tile split) == sum of sixteen 8,192-row launches (the size
+    checked against the oracle above) when both use the same advantage statistics and 1/131072 scaling.  Catches any tile
+    that is skipped or counted twice by the full-grid tile assignment."""
+    eng = _engine(dev, 4096, seed=2)
+    eng.reset(); eng.rollout(); eng.compute_gae()
+    rng = np.random.default_rng(5)
+    eng.agent.load_flat((eng.agent.flat.cpu().numpy() + rng.normal(0, 0.05, 9155)).astype(np.float32))
+    eng.make_perm(0)
+    mb = eng.minibatch_size
+    eng.adv_stats()
+    eng.minibatch_grad(1)
+    full = eng.grads.double().cpu().numpy().copy(); full_terms = eng.loss_terms.double().cpu().numpy().copy()
+    from deep_rl_amd import _native as N
+    acc = np.zeros(9155); acc_t = np.zeros(4)
+    sub = mb // 16
+    for k in range(16):
+        N.check(N.lib().mi_ppo_minibatch_grad(
+            N.ptr(eng.agent.flat), N.ptr(eng.observations), N.ptr(eng.actions), N.ptr(eng.log_probs), N.ptr(eng.advantages),
+            N.ptr(eng.returns), N.ptr(eng.values), eng.perm.data_ptr() + 4 * (mb + k * sub), sub, eng.adv_sums.data_ptr() + 24,
+            eng.clip_coef, eng.ent_coef, eng.vf_coef, 1.0 / mb, N.ptr(eng.workspace), N.ptr(eng.grads), N.ptr(eng.loss_terms),
+            N.stream_ptr(dev)))
+        acc += eng.grads.double().cpu().numpy(); acc_t += eng.loss_terms.double().cpu().numpy()
+    assert np.abs(full - acc).max() <= 5e-6 * np.abs(acc).max(), np.abs(full - acc).max() / np.abs(acc).max()
+    assert np.allclose(full_terms, acc_t, rtol=2e-5, atol=1e-6), (full_terms, acc_t)
+
+
 def test_learning_smoke(dev):
     """CartPole return rises under the engine's own RNG (SURVEY §4 tier 5): 64 envs, 40 updates."""
     eng = _engine(dev, 64, seed=1)
