@@ -101,6 +101,33 @@ __global__ void __launch_bounds__(256) adv_stats_kernel(const float* __restrict_
     }
 }
 
+// mi_ppo_update's fused form: out[i] = Feistel(i) and, in the same pass, the advantage sums of the minibatch i belongs to
+// (mb is a multiple of 256 there, so a workgroup never straddles two minibatches).  sums must be zero on entry.
+#define PS_PER_BLOCK 4096  // elements per workgroup: few workgroups per minibatch touch the fp64 atomics (contention)
+__global__ void __launch_bounds__(256) perm_stats_kernel(uint32_t n, uint32_t a, uint32_t b, uint32_t k0, uint32_t k1, int mb,
+                                                         const float* __restrict__ adv, int32_t* __restrict__ out, double* __restrict__ sums) {
+    const uint32_t base = blockIdx.x * PS_PER_BLOCK;
+    double s = 0.0, q = 0.0;
+#pragma unroll 4
+    for (uint32_t i = base + threadIdx.x; i < base + PS_PER_BLOCK && i < n; i += 256) {
+        const uint32_t p = mi_feistel(i, n, a, b, k0, k1);
+        out[i] = (int32_t)p;
+        const double v = (double)adv[p];
+        s += v; q += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    __shared__ double ss[4], qq[4];
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; qq[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int k = (int)(base / (uint32_t)mb);
+        atomicAdd(&sums[3 * k + 0], (ss[0] + ss[1]) + (ss[2] + ss[3]));
+        atomicAdd(&sums[3 * k + 1], (qq[0] + qq[1]) + (qq[2] + qq[3]));
+        if (base % (uint32_t)mb == 0) sums[3 * k + 2] = (double)mb;
+    }
+}
+
 extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb, int n_mb, double* sums, void* stream) {
     MI_CHECK_ARG(advantages && idx && sums, "NULL pointer");
     MI_CHECK_ARG(mb > 0 && n_mb > 0, "mb and n_mb must be positive");
@@ -720,13 +747,31 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
 __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
                                                          float* __restrict__ m, float* __restrict__ v, int n, float w1, float b2,
                                                          float w2, float step_size, float bc2_sqrt, float eps, float max_norm,
-                                                         float* __restrict__ grad_norm) {
+                                                         float* __restrict__ grad_norm, int vec_ok) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n;
     const float pm = live ? m[i] : 0.0f, pv = live ? v[i] : 0.0f, pp = live ? params[i] : 0.0f, pg = live ? grads[i] : 0.0f;
+    // total norm: every workgroup reads the whole gradient (36.6 KB, L2-resident) with ALL its loads in flight at once
+    // (float4, compile-time trip count); a strided scalar loop costs nine dependent L2 round trips instead of one.
+    constexpr int NV4 = (MI_PPO_NPARAMS + 3) / 4, PER_T = (NV4 + 255) / 256;
+    float4 gv[PER_T];
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) {
+        const int q = threadIdx.x + 256 * k;
+        gv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (vec_ok && 4 * q + 3 < n) gv[k] = reinterpret_cast<const float4*>(grads)[q];
+        else {  // ragged tail (and the generic-n path): scalar, bounds-checked
+            if (4 * q + 0 < n) gv[k].x = grads[4 * q + 0];
+            if (4 * q + 1 < n) gv[k].y = grads[4 * q + 1];
+            if (4 * q + 2 < n) gv[k].z = grads[4 * q + 2];
+            if (4 * q + 3 < n) gv[k].w = grads[4 * q + 3];
+        }
+    }
     double s = 0.0;
-#pragma unroll 4
-    for (int k = threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k)
+        s += ((double)gv[k].x * gv[k].x + (double)gv[k].y * gv[k].y) + ((double)gv[k].z * gv[k].z + (double)gv[k].w * gv[k].w);
+    for (int k = 4 * 256 * PER_T + threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }  // n beyond the unrolled part
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     __shared__ double ws[4];
@@ -754,7 +799,7 @@ extern "C" int mi_clip_adam(float* params, const float* grads, float* exp_avg, f
     mi_prof_scope prof(MI_PROF_CLIP_ADAM, (hipStream_t)stream);
     clip_adam_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
                                                           (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps,
-                                                          max_norm, grad_norm);
+                                                          max_norm, grad_norm, ((uintptr_t)grads & 15) == 0 ? 1 : 0);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -813,14 +858,29 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
     rc = mi_gae(b->rewards, b->dones, b->values, hp->T, N, hp->gamma, hp->gae_lambda, b->advantages, b->returns, stream);
     if (rc) return rc;
     int64_t step = hp->opt_step;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass per epoch, one memset per update
+    if (fused) MI_HIP(hipMemsetAsync(b->adv_sums, 0, sizeof(double) * 3 * (size_t)hp->n_minibatch * hp->update_epochs, s));
     for (int ep = 0; ep < hp->update_epochs; ++ep) {
-        rc = mi_make_perm((uint32_t)B, mi_perm_key(e->seed, (uint64_t)hp->update_index, (uint64_t)ep), b->perm, stream);
-        if (rc) return rc;
-        rc = mi_adv_stats(b->advantages, b->perm, mb, hp->n_minibatch, b->adv_sums, stream);
-        if (rc) return rc;
+        const uint64_t key = mi_perm_key(e->seed, (uint64_t)hp->update_index, (uint64_t)ep);
+        double* sums = b->adv_sums + (size_t)3 * hp->n_minibatch * ep;
+        if (fused) {
+            uint32_t bits = 1;
+            while ((1u << bits) < (uint32_t)B) ++bits;
+            if (bits < 2) bits = 2;
+            mi_prof_scope prof(MI_PROF_STATS, s);
+            perm_stats_kernel<<<(B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, 256, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, (uint32_t)key, (uint32_t)(key >> 32), mb,
+                                                              b->advantages, b->perm, sums);
+            MI_LAUNCH_CHECK();
+        } else {
+            rc = mi_make_perm((uint32_t)B, key, b->perm, stream);
+            if (rc) return rc;
+            rc = mi_adv_stats(b->advantages, b->perm, mb, hp->n_minibatch, sums, stream);
+            if (rc) return rc;
+        }
         for (int k = 0; k < hp->n_minibatch; ++k) {
             rc = mi_ppo_minibatch_grad(b->params, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
-                                       b->perm + (size_t)k * mb, mb, b->adv_sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef,
+                                       b->perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef,
                                        1.0 / mb, b->workspace, b->grads, b->loss_terms, stream);
             if (rc) return rc;
             step += 1;

@@ -45,7 +45,8 @@ class PPOEngine:
         self.advantages = z(T + 1, Nn)
         self.returns = z(T + 1, Nn)
         self.perm = z(self.batch_size, dt=torch.int32)
-        self.adv_sums = z(self.n_minibatch, 3, dt=torch.float64)
+        self._adv_sums_all = z(self.update_epochs, self.n_minibatch, 3, dt=torch.float64)  # mi_ppo_update: one slab per epoch
+        self.adv_sums = self._adv_sums_all[0]
         # gradient + loss terms share one buffer so that ONE all-reduce carries both when sharded
         self._gradbuf = z(N.NPARAMS + 5)
         self.grads = self._gradbuf[:N.NPARAMS]
@@ -154,7 +155,7 @@ class PPOEngine:
             buf = N.PPOBuffers(*[N.ptr(t) for t in (
                 self.agent.flat, o.exp_avg, o.exp_avg_sq, self.grads, self.loss_terms, o.grad_norm, self.observation,
                 self.observations, self.values, self.actions, self.log_probs, self.rewards, self.dones, self.advantages,
-                self.returns, self.perm, self.adv_sums, self.workspace, self.episodes, self.episode_stats)], self.max_ep)
+                self.returns, self.perm, self._adv_sums_all, self.workspace, self.episodes, self.episode_stats)], self.max_ep)
             hp = N.PPOHparams(self.T, self.n_minibatch, self.update_epochs, self.update_index, o.step_count, self.gamma,
                               self.gae_lambda, self.clip_coef, self.ent_coef, self.vf_coef, float(g["max_grad_norm"]),
                               float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"])

@@ -133,7 +133,7 @@ int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_a
 int mi_explained_var(const float* values, const float* returns, size_t n, double* out, void* stream);
 
 /* ---- one whole outer update (ppo.py:105-192) enqueued back to back on `stream`, production RNG,
- * single rank (no collective).  All pointers dev.  perm: i32 [T*N]; adv_sums: f64 [n_minibatch*3]. */
+ * single rank (no collective).  All pointers dev.  perm: i32 [T*N]; adv_sums: f64 [update_epochs*n_minibatch*3]. */
 typedef struct {
     float* params; float* exp_avg; float* exp_avg_sq; float* grads; float* loss_terms; float* grad_norm;
     float* obs_cur; float* observations; float* values; int64_t* actions; float* log_probs; float* rewards;
