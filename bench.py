@@ -34,11 +34,27 @@ PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: f32-inpu
 PEAK_HBM_GBS = 8000.0
 
 
+def usable_cpus():
+    """CPUs this process may really use: min(logical CPUs, affinity mask, cgroup v2 cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(params, min_seconds=10.0):
-    """The oracle's whole-update loop (oracle/cpu_ref.c ref_ppo_update) on all host cores, same 4096-env workload."""
+    """The oracle's whole-update loop (oracle/cpu_ref.c ref_ppo_update) on the usable host cores, same 4096-env workload."""
     from oracle import cpu_ref as R
 
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     base = R.PPOBaseline(params, ENVS_PER_GPU, T=T, seed=1, threads=cores)
     t0 = time.perf_counter()
     k = 0
@@ -46,7 +62,7 @@ def cpu_baseline(params, min_seconds=10.0):
         base.run_update()
         k += 1
         dt = time.perf_counter() - t0
-        if dt >= min_seconds or k >= 8:
+        if dt >= min_seconds or k >= 16:
             break
     return {"value": round(k * T * ENVS_PER_GPU / dt, 1), "unit": "env-steps/s", "updates_per_s": round(k / dt, 4),
             "cores": base.threads, "kind": "port",
