@@ -83,6 +83,7 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
     uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
     float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
     float my_l0 = 0.0f, my_l1 = 0.0f, my_val = 0.0f;
+    int st_cnt = 0, st_len = 0, st_max = 0;  // finished episodes of this lane's env: count, sum of lengths, longest
     uint32_t urand[4] = {0, 0, 0, 0};  // the current Philox block of action draws (steps 4k..4k+3 of this env)
     const bool keyed_actions = !forced_actions && !forced_uniforms;
     if (keyed_actions && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
@@ -115,14 +116,13 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
             epret += 1.0f;
             eplen += 1;
             if (d) {
-                if (mine && episode_stats) {
-                    atomicAdd(episode_stats + 1, eplen);
-                    atomicMax(episode_stats + 2, eplen);
-                    if (max_ep > 0) {  // a returning atomic costs a device-memory round trip: only when the list is wanted
-                        const int slot = atomicAdd(episode_stats, 1);
+                if (mine) {
+                    // statistics stay in registers and are flushed once per wave at the end: early in training ~24k episodes
+                    // end per rollout and three atomics each on the same three words were a measurable hot spot
+                    st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
+                    if (max_ep > 0 && episode_stats) {  // the per-episode list (small N): slot from a returning atomic
+                        const int slot = atomicAdd(episode_stats + 3, 1);
                         if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
-                    } else {
-                        atomicAdd(episode_stats, 1);
                     }
                 }
                 epret = 0.0f; eplen = 0; elapsed = 0;
@@ -168,6 +168,16 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
             values[row] = my_val;                               // :115,:139
             if (t >= 0) { rewards[row] = rew; dones[row] = dn; }  // :140-141
         }
+    }
+    if (episode_stats) {  // one flush per wave (lanes < E hold the counters)
+        int c = 0, l = 0, m = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            c += __builtin_amdgcn_readlane(st_cnt, i); l += __builtin_amdgcn_readlane(st_len, i);
+            const int mi = __builtin_amdgcn_readlane(st_max, i);
+            m = mi > m ? mi : m;
+        }
+        if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
     }
     // carry-over `observation` and env state for the next rollout
     if (mine) {

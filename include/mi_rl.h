@@ -92,8 +92,8 @@ int mi_ppo_forward(const float* params, const float* obs, int n, float* logits, 
  * Parity inputs (each NULL in production): forced_actions dev i64 [T,N]; forced_uniforms dev f32 [T,N];
  * forced_resets dev f64 [T,N,4] (state used if env n resets at step t).
  * episodes dev mi_episode_t [max_ep] + episode_stats dev i32 [4] (both nullable).  The call resets episode_stats and
- * the kernel accumulates {[0] number of finished episodes, [1] sum of their lengths, [2] longest, [3] reserved}
- * (CartPole: return == length); only the first max_ep episodes are stored individually. */
+ * the kernel accumulates {[0] number of finished episodes, [1] sum of their lengths, [2] longest, [3] slots handed out in
+ * `episodes`} (CartPole: return == length); only the first max_ep episodes are stored individually. */
 int mi_ppo_rollout(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
                    int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
                    const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
