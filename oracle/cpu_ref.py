@@ -69,6 +69,14 @@ def lib():
         L.ref_ppo_update.restype = C.c_int
         L.ref_ppo_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_float, C.c_float, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.ref_dqn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_dqn_td_grads.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
+        L.ref_dqn_epsilon.restype = C.c_double
+        L.ref_dqn_epsilon.argtypes = [C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int64]
+        L.ref_dqn_explore_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.ref_dqn_act_steps.restype = C.c_int
+        L.ref_dqn_act_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                        C.c_int64] + [C.c_void_p] * 7
         L.ref_set_sincos_mode.argtypes = [C.c_int]
         L.ref_get_sincos_mode.restype = C.c_int
         L.ref_num_threads.restype = C.c_int
@@ -266,3 +274,52 @@ class PPOBaseline:
         if getattr(self, "ws", None):
             lib().ref_ppo_ws_destroy(self.ws)
             self.ws = None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DQN (reference dqn.py)
+DQN_NPARAMS = 10934
+
+
+class ReplayStorage:
+    """dqn.py:73-76 with an env axis: a [slots][N] time-major ring (slots = total_timesteps + 1 reproduces the reference)."""
+
+    def __init__(self, slots, n_envs):
+        self.slots, self.N = slots, n_envs
+        self.observations = np.zeros((slots, n_envs, 4), np.float32)
+        self.actions = np.zeros((slots, n_envs), np.int64)
+        self.rewards = np.zeros((slots, n_envs), np.float32)
+        self.terminated = np.zeros((slots, n_envs), np.uint8)
+
+
+def dqn_forward(params, obs):
+    p = _c(params, np.float32); o = _c(obs, np.float32).reshape(-1, 4)
+    q = np.empty((o.shape[0], 2), np.float32)
+    lib().ref_dqn_forward(_p(p), _p(o), o.shape[0], _p(q))
+    return q
+
+
+def dqn_td_grads(params, target_params, st, idx, gamma=0.99, inv_count=None):
+    p = _c(params, np.float32); tp = _c(target_params, np.float32); idx = _c(idx, np.int64)
+    grads = np.empty(DQN_NPARAMS, np.float32); loss = np.zeros(1, np.float32)
+    lib().ref_dqn_td_grads(_p(p), _p(tp), _p(st.observations), _p(st.actions), _p(st.rewards), _p(st.terminated), _p(idx), len(idx),
+                           st.N, st.slots, gamma, (1.0 / len(idx)) if inv_count is None else inv_count, _p(grads), _p(loss))
+    return grads, float(loss[0])
+
+
+def dqn_epsilon(gs, start_e=1.0, end_e=0.05, exploration_fraction=0.5, total_timesteps=100_000):
+    return lib().ref_dqn_epsilon(gs, start_e, end_e, exploration_fraction, total_timesteps)
+
+
+def dqn_explore_draw(seed, env, step):
+    u = C.c_float(); a = C.c_int()
+    lib().ref_dqn_explore_draw(seed, env, step, C.byref(u), C.byref(a))
+    return u.value, a.value
+
+
+def dqn_act_steps(env, params, st, obs_cur, n_steps, global_step, learning_starts=10_000, start_e=1.0, end_e=0.05,
+                  exploration_fraction=0.5, total_timesteps=100_000, forced_actions=None, forced_resets=None):
+    p = _c(params, np.float32); fa = _c(forced_actions, np.int64); fr = _c(forced_resets, np.float64)
+    return lib().ref_dqn_act_steps(env.h, _p(p), n_steps, global_step, st.slots, learning_starts, start_e, end_e, exploration_fraction,
+                                   total_timesteps, _p(obs_cur), _p(st.observations), _p(st.actions), _p(st.rewards), _p(st.terminated),
+                                   _p(fa), _p(fr))
