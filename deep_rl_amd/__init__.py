@@ -8,8 +8,9 @@ for gfx950 in ``csrc/`` behind the C ABI of ``include/mi_rl.h``.  There is no CP
 """
 from . import _native  # noqa: F401
 from .envs import make, CartPoleVecEnv  # noqa: F401
-from .agent import ActorCritic, layer_init  # noqa: F401
+from .agent import ActorCritic, QNetwork, layer_init  # noqa: F401
 from .optim import ClipAdam  # noqa: F401
 from .engine import PPOEngine  # noqa: F401
+from .dqn_engine import DQNEngine  # noqa: F401
 
-__all__ = ["make", "CartPoleVecEnv", "ActorCritic", "layer_init", "ClipAdam", "PPOEngine"]
+__all__ = ["make", "CartPoleVecEnv", "ActorCritic", "QNetwork", "layer_init", "ClipAdam", "PPOEngine", "DQNEngine"]

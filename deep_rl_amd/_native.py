@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
 NPARAMS = 9155
+DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
 MI_OK = 0
 
@@ -59,6 +60,11 @@ SIGNATURES = {
     "mi_clip_adam": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _D, _D, _D, _D, _F, _VP, _VP]),
     "mi_explained_var": (_I, [_VP, _VP, _SZ, _VP, _VP]),
     "mi_ppo_update": (_I, [_VP, C.POINTER(PPOBuffers), C.POINTER(PPOHparams), _VP]),
+    "mi_dqn_forward": (_I, [_VP, _VP, _I, _VP, _VP]),
+    "mi_dqn_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP]),
+    "mi_dqn_sample": (_I, [_U64, _U64, _I64, _I, _VP, _VP]),
+    "mi_dqn_workspace_bytes": (_SZ, [_I]),
+    "mi_dqn_td_grad": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _D, _VP, _VP, _VP, _VP]),
     "mi_selftest_mfma": (_I, [_VP, _VP, _VP]),
     "mi_test_tanh": (_I, [_VP, _VP, _I, _VP]),
     "mi_prof_begin": (_I, [_I, _U32]),

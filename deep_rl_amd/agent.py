@@ -81,3 +81,45 @@ class ActorCritic(nn.Module):
         distribution = self.get_action_distribution(observation)
         action = distribution.sample()
         return action, distribution.log_prob(action)
+
+
+class QNetwork(nn.Module):
+    """QNetwork of the reference dqn.py:24-36 (4 -> 120 -> 84 -> n_actions, ReLU, torch default init) whose 6 parameter
+    tensors are views into one flat fp32 device buffer (include/mi_rl.h "DQN")."""
+
+    def __init__(self, env, device=None):
+        super().__init__()
+        obs_dim = int(np.prod(env.observation_space.shape))
+        if obs_dim != 4 or env.action_space.n != 2:
+            raise N.MiError("the HIP kernels are specialised for CartPole (obs 4, actions 2)")
+        self.network = nn.Sequential(nn.Linear(obs_dim, 120), nn.ReLU(), nn.Linear(120, 84), nn.ReLU(), nn.Linear(84, env.action_space.n))
+        dev = torch.device(device if device is not None else getattr(env, "device", "cuda"))
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self.parameters()]).to(dev, torch.float32).contiguous()
+        assert flat.numel() == N.DQN_NPARAMS
+        self.flat = flat
+        off = 0
+        for p in self.parameters():
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self.device = dev
+
+    def load_flat(self, vec):
+        self.flat.copy_(torch.as_tensor(vec, dtype=torch.float32).reshape(-1).to(self.device))
+
+    def load_state_dict(self, state_dict, *a, **kw):
+        """target_network.load_state_dict(q_network.state_dict()) (dqn.py:70,137): keeps the flat-buffer views intact."""
+        own = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                own[k].copy_(v)
+
+    def forward(self, observation):
+        """dqn.py:35-36."""
+        obs = observation.to(self.device, torch.float32)
+        lead = obs.shape[:-1]
+        obs = obs.reshape(-1, 4).contiguous()
+        q = torch.empty((obs.shape[0], 2), dtype=torch.float32, device=self.device)
+        N.check(N.lib().mi_dqn_forward(N.ptr(self.flat), N.ptr(obs), obs.shape[0], N.ptr(q), N.stream_ptr(self.device)), "mi_dqn_forward")
+        return q.reshape(*lead, 2)

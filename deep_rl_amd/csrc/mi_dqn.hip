@@ -1,0 +1,402 @@
+// mi_dqn.hip — the DQN hot path of reference deep_rl/dqn.py on the device:
+//   dqn_forward_kernel   QNetwork.forward 4->120->84->2 ReLU                                   (dqn.py:24-36)
+//   dqn_act_kernel       n_steps x {epsilon-greedy, env.step + auto-reset, ring store} per env (dqn.py:84-108)
+//   dqn_sample_kernel    batch_inds = randint(upper, size=batch)                               (dqn.py:116)
+//   dqn_td_kernel        gather, target max, TD target, MSE loss, backward                      (dqn.py:118-128)
+//   dqn_reduce_kernel    fixed-order sum of the per-workgroup partial gradients
+// Widths 120 / 84 are not MFMA-tile multiples and the batches are small (128 rows in the reference), so this path is
+// VALU + LDS; the parameters (43.7 KB) stay L2-resident, activations of a row group live in LDS.
+#include "mi_common.h"
+
+#define DQ_H1 120
+#define DQ_H2 84
+#define DQ_W1 0
+#define DQ_B1 480
+#define DQ_W2 600
+#define DQ_B2 10680
+#define DQ_W3 10764
+#define DQ_B3 10932
+#define DQ_NP 10934
+#define STREAM_EXPLORE 3u
+#define STREAM_SAMPLE 4u
+
+// ---- one row through the net, weights from LDS (every lane reads the same address: broadcast) ----------------------
+__device__ __forceinline__ void dqn_row_forward(const float* __restrict__ w, const float x[4], float q[2]) {
+    float h1[DQ_H1];
+#pragma unroll
+    for (int j = 0; j < DQ_H1; ++j) {
+        float z = w[DQ_B1 + j];
+#pragma unroll
+        for (int k = 0; k < OBS; ++k) z = __builtin_fmaf(w[DQ_W1 + 4 * j + k], x[k], z);
+        h1[j] = fmaxf(z, 0.0f);
+        // h1 must stay a register array (constant indices => full unroll), but hipcc would then hoist all 600 LDS loads of
+        // the layer to the top (600 live VGPRs, spills).  Fence the scheduler every 8 units.
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    float q0 = w[DQ_B3], q1 = w[DQ_B3 + 1];
+#pragma unroll 1
+    for (int j = 0; j < DQ_H2; ++j) {
+        float a0 = 0.0f, a1 = 0.0f;
+        const float4* wr = reinterpret_cast<const float4*>(w + DQ_W2 + DQ_H1 * j);  // 480-byte rows: 16-byte aligned
+#pragma unroll
+        for (int k4 = 0; k4 < DQ_H1 / 4; ++k4) {
+            const float4 ww = wr[k4];
+            a0 = __builtin_fmaf(ww.x, h1[4 * k4], a0); a1 = __builtin_fmaf(ww.y, h1[4 * k4 + 1], a1);
+            a0 = __builtin_fmaf(ww.z, h1[4 * k4 + 2], a0); a1 = __builtin_fmaf(ww.w, h1[4 * k4 + 3], a1);
+        }
+        const float h2 = fmaxf((a0 + a1) + w[DQ_B2 + j], 0.0f);
+        q0 = __builtin_fmaf(w[DQ_W3 + j], h2, q0);
+        q1 = __builtin_fmaf(w[DQ_W3 + DQ_H2 + j], h2, q1);
+    }
+    q[0] = q0; q[1] = q1;
+}
+
+__device__ __forceinline__ void stage_params(float* __restrict__ w, const float* __restrict__ params) {
+    for (int i = threadIdx.x; i < DQ_NP; i += blockDim.x) w[i] = params[i];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) dqn_forward_kernel(const float* __restrict__ params, const float* __restrict__ obs, int n, float* __restrict__ q) {
+    __shared__ __attribute__((aligned(16))) float w[DQ_NP + 2];
+    stage_params(w, params);
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n; row += gridDim.x * blockDim.x) {
+        const float4 o = reinterpret_cast<const float4*>(obs)[row];
+        const float x[4] = {o.x, o.y, o.z, o.w};
+        float qq[2];
+        dqn_row_forward(w, x, qq);
+        q[2 * (size_t)row] = qq[0]; q[2 * (size_t)row + 1] = qq[1];
+    }
+}
+
+extern "C" int mi_dqn_forward(const float* params, const float* obs, int n, float* q, void* stream) {
+    MI_CHECK_ARG(params && obs && q, "NULL pointer");
+    MI_CHECK_ARG(n >= 0, "n must be >= 0");
+    if (n == 0) return MI_OK;
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    dqn_forward_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, obs, n, q);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+#define DQN_MAX_STEPS_PER_CALL 64
+struct dqn_eps_tab { float v[DQN_MAX_STEPS_PER_CALL]; };  // epsilon(global_step + k), passed by value
+
+// ---- acting: one lane per env, n_steps iterations in one launch (the online net is frozen between two updates) ---------
+__global__ void __launch_bounds__(64)
+dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long long global_step, long long slots, long long learning_starts,
+               dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
+               int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
+               const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
+               int32_t* __restrict__ episode_stats, int max_ep) {
+    __shared__ __attribute__((aligned(16))) float w[DQ_NP + 2];
+    stage_params(w, params);
+    const int N = e.n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = i < N;
+    const int g = mine ? i : N - 1;
+    double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
+    int elapsed = e.elapsed[g], eplen = e.ep_len[g];
+    float epret = e.ep_ret[g];
+    uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
+    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
+    int st_cnt = 0, st_len = 0, st_max = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        const long long gs = global_step + s, slot = gs % slots, nslot = (gs + 1) % slots;
+        int a;
+        if (forced_actions) a = (int)forced_actions[(size_t)s * N + g];
+        else {
+            uint32_t r[4];
+            mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr, STREAM_EXPLORE, r);
+            const float u = mi_u32_to_uniform(r[0]);
+            const bool explore = gs < learning_starts || u < eps.v[s];
+            a = (int)(r[1] & 1u);
+            if (__any(!explore)) {  // the greedy branch costs a whole forward: skip it while every lane explores
+                const float x[4] = {ob.x, ob.y, ob.z, ob.w};
+                float q[2];
+                dqn_row_forward(w, x, q);
+                if (!explore) a = q[1] > q[0] ? 1 : 0;  // torch.argmax: first index on ties (dqn.py:92)
+            }
+        }
+        stepctr += 1;
+        if (mine) actions[slot * N + g] = a;                                   // dqn.py:95
+        int term;
+        mi_cartpole_step(sx, sxd, sth, sthd, a, term);
+        elapsed += 1;
+        const bool trunc = !term && elapsed >= CP_MAX_STEPS;
+        const bool d = term || trunc;
+        epret += 1.0f; eplen += 1;
+        if (d) {
+            if (mine) {
+                st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
+                if (max_ep > 0 && episode_stats) {
+                    const int sl = atomicAdd(episode_stats + 3, 1);
+                    if (sl < max_ep) episodes[sl] = mi_episode_t{g, s, epret, eplen};
+                }
+            }
+            epret = 0.0f; eplen = 0; elapsed = 0;
+            double rs[4];
+            if (forced_resets) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rs[k] = forced_resets[4 * ((size_t)s * N + g) + k];
+            } else {
+                mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, rs);
+            }
+            episode += 1;
+            sx = rs[0]; sxd = rs[1]; sth = rs[2]; sthd = rs[3];
+        }
+        ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
+        if (mine) {
+            reinterpret_cast<float4*>(observations)[nslot * N + g] = ob;       // dqn.py:106 (the reset obs where done)
+            rewards[nslot * N + g] = 1.0f;                                     // :107
+            terminated[nslot * N + g] = (uint8_t)(term ? 1 : 0);               // :108: done and not TimeLimit.truncated
+        }
+    }
+    if (mine) {
+        e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
+        e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr;
+        reinterpret_cast<float4*>(obs_cur)[g] = ob;
+        if (episode_stats && st_cnt > 0) { atomicAdd(episode_stats, st_cnt); atomicAdd(episode_stats + 1, st_len); atomicMax(episode_stats + 2, st_max); }
+    }
+}
+
+__global__ void dqn_zero_stats_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
+
+extern "C" int mi_dqn_act_steps(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
+                                double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
+                                float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
+                                const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, void* stream) {
+    MI_CHECK_ARG(handle && params && obs_cur && observations && actions && rewards && terminated, "NULL pointer");
+    MI_CHECK_ARG(n_steps > 0 && n_steps <= DQN_MAX_STEPS_PER_CALL, "n_steps must be in [1, 64]");
+    MI_CHECK_ARG(slots >= 2 && global_step >= 0, "slots must be >= 2 and global_step >= 0");
+    MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
+    mi_env* e = (mi_env*)handle;
+    hipStream_t s = (hipStream_t)stream;
+    if (episode_stats) { dqn_zero_stats_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    // epsilon = max(slope * global_step + start_e, end_e) in the reference's double arithmetic (dqn.py:47,86), evaluated on
+    // the host for the n_steps of this call and handed over by value (no allocation, no copy to enqueue)
+    dqn_eps_tab tab;
+    const double slope = (end_e - start_e) / (exploration_fraction * (double)total_timesteps);
+    for (int k = 0; k < DQN_MAX_STEPS_PER_CALL; ++k) {
+        const double ev = slope * (double)(global_step + k) + start_e;
+        tab.v[k] = (float)(ev > end_e ? ev : end_e);
+    }
+    dqn_act_kernel<<<(e->n + 63) / 64, 64, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab,
+                                                  obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes,
+                                                  episode_stats, max_ep);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// ---- sampling: idx[b] = (w0 | w1 << 32) mod upper of Philox(seed, env := update, idx := b, stream 4) -----------------------
+__global__ void __launch_bounds__(256) dqn_sample_kernel(uint64_t seed, uint64_t update, uint64_t upper, int batch, int64_t* __restrict__ idx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    uint32_t r[4];
+    mi_philox(seed, update, (uint64_t)b, STREAM_SAMPLE, r);
+    idx[b] = (int64_t)((((uint64_t)r[1] << 32) | r[0]) % upper);
+}
+
+extern "C" int mi_dqn_sample(uint64_t seed, uint64_t update_index, int64_t upper_flat, int batch, int64_t* idx, void* stream) {
+    MI_CHECK_ARG(idx && batch > 0 && upper_flat > 0, "bad arguments");
+    dqn_sample_kernel<<<(batch + 255) / 256, 256, 0, (hipStream_t)stream>>>(seed, update_index, (uint64_t)upper_flat, batch, idx);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// ---- TD loss + gradient.  One 256-thread workgroup per TD_R rows; a thread owns a hidden unit, the rows' activations sit
+//      in LDS (post-ReLU: relu(z) > 0 <=> z > 0, so the mask for the backward pass needs no second copy) --------------------
+#define TD_R 8
+#define TD_SLAB (DQ_NP + 2)   // + loss
+struct __attribute__((aligned(16))) td_smem {
+    float x[2][TD_R][4];          // [0] obs, [1] next obs
+    float h1[2][TD_R][DQ_H1];     // [0] online on obs, [1] target on next obs
+    float h2[2][TD_R][DQ_H2];
+    float q[2][TD_R][2];
+    float dq[TD_R][2];
+    float dz2[DQ_H2][TD_R];       // [unit][row]: one broadcast b128 pair per unit in the dW2 pass
+    float dz1[TD_R][DQ_H1];
+    float td_err[TD_R];
+    int act[TD_R];
+};
+
+__global__ void __launch_bounds__(256)
+dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target_params, const float* __restrict__ observations,
+              const int64_t* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
+              const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, float gamma, float invn, float* __restrict__ workspace) {
+    __shared__ td_smem sm;
+    const int t = threadIdx.x;
+    const int row0 = blockIdx.x * TD_R;
+    float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
+    __shared__ long long nxt[TD_R];
+    __shared__ long long cur[TD_R];
+    if (t < TD_R) {
+        const int b = row0 + t < batch ? row0 + t : batch - 1;
+        const long long i = idx[b];
+        cur[t] = i;
+        nxt[t] = ((i / n_envs + 1) % slots) * n_envs + i % n_envs;
+        sm.act[t] = (int)actions[i];
+    }
+    __syncthreads();
+    if (t < 2 * TD_R * 4) {
+        const int net = t / (TD_R * 4), r = (t / 4) % TD_R, k = t & 3;
+        sm.x[net][r][k] = observations[4 * (net ? nxt[r] : cur[r]) + k];
+    }
+    __syncthreads();
+    const int net = t >> 7, u = t & 127;                 // threads 0..127: online net, 128..255: target net
+    const float* p = net ? target_params : params;
+    // ---- layer 1 ----
+    if (u < DQ_H1) {
+        const float4 w = *reinterpret_cast<const float4*>(p + DQ_W1 + 4 * u);
+        const float b = p[DQ_B1 + u];
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) {
+            float z = b;
+            z = __builtin_fmaf(w.x, sm.x[net][r][0], z); z = __builtin_fmaf(w.y, sm.x[net][r][1], z);
+            z = __builtin_fmaf(w.z, sm.x[net][r][2], z); z = __builtin_fmaf(w.w, sm.x[net][r][3], z);
+            sm.h1[net][r][u] = fmaxf(z, 0.0f);
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: unit u < 84; W2 row u streamed from L2 (float4), h1 of all rows broadcast from LDS ----
+    if (u < DQ_H2) {
+        float acc[TD_R];
+        const float b = p[DQ_B2 + u];
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) acc[r] = 0.0f;
+        const float4* wrow = reinterpret_cast<const float4*>(p + DQ_W2 + DQ_H1 * u);
+#pragma unroll 5
+        for (int k4 = 0; k4 < DQ_H1 / 4; ++k4) {
+            const float4 w = wrow[k4];
+#pragma unroll
+            for (int r = 0; r < TD_R; ++r) {
+                const float4 h = *reinterpret_cast<const float4*>(&sm.h1[net][r][4 * k4]);
+                acc[r] = __builtin_fmaf(w.x, h.x, acc[r]); acc[r] = __builtin_fmaf(w.y, h.y, acc[r]);
+                acc[r] = __builtin_fmaf(w.z, h.z, acc[r]); acc[r] = __builtin_fmaf(w.w, h.w, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) sm.h2[net][r][u] = fmaxf(acc[r] + b, 0.0f);
+    }
+    __syncthreads();
+    // ---- layer 3: 2 nets x TD_R rows x 2 actions = 32 dot products of length 84 ----
+    if (t < 2 * TD_R * 2) {
+        const int n3 = t / (TD_R * 2), r = (t >> 1) % TD_R, a = t & 1;
+        const float* pp = n3 ? target_params : params;
+        float acc = 0.0f;
+        for (int j = 0; j < DQ_H2; ++j) acc = __builtin_fmaf(pp[DQ_W3 + a * DQ_H2 + j], sm.h2[n3][r][j], acc);
+        sm.q[n3][r][a] = acc + pp[DQ_B3 + a];
+    }
+    __syncthreads();
+    // ---- TD target, loss, d loss / d q (dqn.py:119-123) ----
+    if (t < TD_R) {
+        const bool valid = row0 + t < batch;
+        const float target_max = fmaxf(sm.q[1][t][0], sm.q[1][t][1]);
+        const float td = rewards[nxt[t]] + gamma * target_max * (terminated[nxt[t]] ? 0.0f : 1.0f);
+        const int a = sm.act[t];
+        const float diff = valid ? td - sm.q[0][t][a] : 0.0f;
+        sm.td_err[t] = diff * diff;
+        sm.dq[t][0] = a == 0 ? -2.0f * diff * invn : 0.0f;
+        sm.dq[t][1] = a == 1 ? -2.0f * diff * invn : 0.0f;
+    }
+    __syncthreads();
+    // ---- backward through layer 3 (online net only): thread j < 84 ----
+    if (t < DQ_H2) {
+        const float w0 = params[DQ_W3 + t], w1 = params[DQ_W3 + DQ_H2 + t];
+        float g0 = 0.0f, g1 = 0.0f, gb = 0.0f;
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) {
+            const float h2 = sm.h2[0][r][t];
+            const float d = h2 > 0.0f ? __builtin_fmaf(w1, sm.dq[r][1], w0 * sm.dq[r][0]) : 0.0f;
+            sm.dz2[t][r] = d;
+            g0 = __builtin_fmaf(sm.dq[r][0], h2, g0); g1 = __builtin_fmaf(sm.dq[r][1], h2, g1);
+            gb += d;
+        }
+        part[DQ_W3 + t] = g0; part[DQ_W3 + DQ_H2 + t] = g1; part[DQ_B2 + t] = gb;
+    } else if (t < DQ_H2 + 2) {
+        const int a = t - DQ_H2;
+        float gb = 0.0f;
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) gb += sm.dq[r][a];
+        part[DQ_B3 + a] = gb;
+    } else if (t == DQ_H2 + 2) {
+        float l = 0.0f;
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) l += sm.td_err[r];
+        part[DQ_NP] = l;
+    }
+    __syncthreads();
+    // ---- dh1 = W2^T dz2 (thread k < 120; W2 columns: consecutive threads read consecutive addresses), dz1, db1, dW1 ----
+    if (t < DQ_H1) {
+        float dh[TD_R];
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) dh[r] = 0.0f;
+        for (int j = 0; j < DQ_H2; ++j) {
+            const float w = params[DQ_W2 + DQ_H1 * j + t];
+            const float4 da = *reinterpret_cast<const float4*>(&sm.dz2[j][0]), db = *reinterpret_cast<const float4*>(&sm.dz2[j][4]);
+            dh[0] = __builtin_fmaf(w, da.x, dh[0]); dh[1] = __builtin_fmaf(w, da.y, dh[1]); dh[2] = __builtin_fmaf(w, da.z, dh[2]); dh[3] = __builtin_fmaf(w, da.w, dh[3]);
+            dh[4] = __builtin_fmaf(w, db.x, dh[4]); dh[5] = __builtin_fmaf(w, db.y, dh[5]); dh[6] = __builtin_fmaf(w, db.z, dh[6]); dh[7] = __builtin_fmaf(w, db.w, dh[7]);
+        }
+        float gb = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < TD_R; ++r) {
+            const float d = sm.h1[0][r][t] > 0.0f ? dh[r] : 0.0f;
+            sm.dz1[r][t] = d;
+            gb += d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gw[c] = __builtin_fmaf(d, sm.x[0][r][c], gw[c]);
+        }
+        part[DQ_B1 + t] = gb;
+        *reinterpret_cast<float4*>(part + DQ_W1 + 4 * t) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+    }
+    // ---- dW2[j][k] = sum_r dz2[r][j] h1[r][k]: thread (k = t & 127, half = t >> 7) covers 42 rows j of W2 ----
+    {
+        const int k = t & 127, half = t >> 7;
+        if (k < DQ_H1) {
+            float h[TD_R];
+#pragma unroll
+            for (int r = 0; r < TD_R; ++r) h[r] = sm.h1[0][r][k];
+            for (int j = 42 * half; j < 42 * half + 42; ++j) {
+                const float4 da = *reinterpret_cast<const float4*>(&sm.dz2[j][0]), db = *reinterpret_cast<const float4*>(&sm.dz2[j][4]);
+                float gsum = da.x * h[0];
+                gsum = __builtin_fmaf(da.y, h[1], gsum); gsum = __builtin_fmaf(da.z, h[2], gsum); gsum = __builtin_fmaf(da.w, h[3], gsum);
+                gsum = __builtin_fmaf(db.x, h[4], gsum); gsum = __builtin_fmaf(db.y, h[5], gsum); gsum = __builtin_fmaf(db.z, h[6], gsum); gsum = __builtin_fmaf(db.w, h[7], gsum);
+                part[DQ_W2 + DQ_H1 * j + k] = gsum;
+            }
+        }
+    }
+}
+
+// grads[p] = sum over workgroup slabs in slab order; loss = sum of the slab losses * inv_count
+__global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
+                                                         float* __restrict__ grads, float* __restrict__ loss) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < DQ_NP) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int b = 0; b < n_slabs; ++b) acc[b & 3] += workspace[(size_t)b * TD_SLAB + p];
+        grads[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    } else if (p == DQ_NP && loss) {
+        double l = 0.0;
+        for (int b = 0; b < n_slabs; ++b) l += workspace[(size_t)b * TD_SLAB + DQ_NP];
+        loss[0] = (float)(l * inv_count);
+    }
+}
+
+extern "C" size_t mi_dqn_workspace_bytes(int batch) {
+    return (size_t)((batch + TD_R - 1) / TD_R) * TD_SLAB * sizeof(float);
+}
+
+extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, const float* observations, const int64_t* actions,
+                              const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                              float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream) {
+    MI_CHECK_ARG(params && target_params && observations && actions && rewards && terminated && idx && workspace && grads, "NULL pointer");
+    MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (batch + TD_R - 1) / TD_R;
+    dqn_td_kernel<<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
+                                         (long long)slots, gamma, (float)inv_count, (float*)workspace);
+    MI_LAUNCH_CHECK();
+    dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}

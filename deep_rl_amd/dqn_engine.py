@@ -1,0 +1,97 @@
+"""DQNEngine — device-resident replay ring + the launch sequence of reference dqn.py:84-137.
+
+Owns the four replay tensors with the reference's names (dqn.py:73-76) plus an env axis, laid out as a [slots, N]
+time-major ring (iqn.py:174-232 semantics; slots = total_timesteps + 1 gives the reference's linear storage).  Methods are
+thin launch wrappers over the C ABI (include/mi_rl.h "DQN"); nothing is computed in Python.
+"""
+import torch
+
+from . import _native as N
+from . import dist as D
+
+
+class DQNEngine:
+    def __init__(self, env, q_network, target_network, optimizer, slots, batch_size=128, gamma=0.99, learning_starts=10_000,
+                 start_e=1.0, end_e=0.05, exploration_fraction=0.5, total_timesteps=100_000, max_episodes_logged=None, process_group=None):
+        self.env, self.q, self.target, self.optimizer = env, q_network, target_network, optimizer
+        self.N, self.device, self.slots = env.num_envs, env.device, int(slots)
+        self.batch_size, self.gamma = int(batch_size), float(gamma)
+        self.learning_starts, self.total_timesteps = int(learning_starts), int(total_timesteps)
+        self.start_e, self.end_e, self.exploration_fraction = float(start_e), float(end_e), float(exploration_fraction)
+        self.pg = process_group
+        self.world_size = D.world_size(process_group)
+        dev, S, Nn = self.device, self.slots, self.N
+        self.observations = torch.zeros((S, Nn, 4), dtype=torch.float32, device=dev)   # dqn.py:73
+        self.actions = torch.zeros((S, Nn), dtype=torch.int64, device=dev)             # :74
+        self.rewards = torch.zeros((S, Nn), dtype=torch.float32, device=dev)           # :75
+        self.terminated = torch.zeros((S, Nn), dtype=torch.uint8, device=dev)          # :76 (bool)
+        self.batch_inds = torch.zeros(self.batch_size, dtype=torch.int64, device=dev)
+        self._gradbuf = torch.zeros(N.DQN_NPARAMS + 2, dtype=torch.float32, device=dev)
+        self.grads = self._gradbuf[:N.DQN_NPARAMS]
+        self.loss = self._gradbuf[N.DQN_NPARAMS:N.DQN_NPARAMS + 1]
+        self.workspace = torch.empty(N.lib().mi_dqn_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)
+        self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (1024 if Nn <= 8 else 0))
+        self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
+        self.episode_stats = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.observation = None
+        self.global_step = 0      # time steps taken (each advances every env once)
+        self.update_index = 0
+
+    def _s(self):
+        return N.stream_ptr(self.device)
+
+    def reset(self, forced_state=None):
+        """observation = env.reset(); observations[global_step] = observation (dqn.py:79-81)."""
+        self.observation = self.env.reset(forced_state)
+        self.observations[self.global_step % self.slots].copy_(self.observation)
+        return self.observation
+
+    def act(self, n_steps, forced_actions=None, forced_resets=None):
+        """n_steps iterations of dqn.py:84-108 for every env, one launch."""
+        dev = self.device
+        fa = None if forced_actions is None else forced_actions.to(dev, torch.int64).contiguous()
+        fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
+        N.check(N.lib().mi_dqn_act_steps(
+            self.env.handle, N.ptr(self.q.flat), int(n_steps), self.global_step, self.slots, self.learning_starts, self.start_e, self.end_e,
+            self.exploration_fraction, self.total_timesteps, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.actions),
+            N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fr), N.ptr(self.episodes), N.ptr(self.episode_stats), self.max_ep,
+            self._s()), "mi_dqn_act_steps")
+        self.global_step += int(n_steps)
+
+    def drain_episodes(self):
+        """Host sync. -> (count, [(env, step_in_call, return, length)] sorted by (step, env)) of the last act() call."""
+        st = self.episode_stats.tolist()
+        k = min(st[3], self.max_ep)
+        if k == 0:
+            return st[0], []
+        raw = self.episodes[:k].cpu()
+        rets = raw[:, 2].contiguous().view(torch.float32)
+        eps = sorted((int(raw[i, 1]), int(raw[i, 0]), float(rets[i]), int(raw[i, 3])) for i in range(k))
+        return st[0], [(e, t, r, l) for (t, e, r, l) in eps]
+
+    def sample(self, indices=None):
+        """batch_inds = np.random.randint(upper, size=batch_size) (dqn.py:116; iqn.py:225: upper = min(global_step, memory_size))."""
+        if indices is not None:
+            self.batch_inds.copy_(torch.as_tensor(indices, dtype=torch.int64).reshape(-1).to(self.device))
+            return
+        upper = min(self.global_step, self.slots) * self.N
+        N.check(N.lib().mi_dqn_sample(self.env._seed, self.update_index, upper, self.batch_size, N.ptr(self.batch_inds), self._s()), "mi_dqn_sample")
+
+    def td_grad(self):
+        """loss + gradient of the sampled batch (dqn.py:118-128) -> self.grads, self.loss (all-reduced when sharded)."""
+        N.check(N.lib().mi_dqn_td_grad(
+            N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+            N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma,
+            1.0 / (self.batch_size * self.world_size), N.ptr(self.workspace), N.ptr(self.grads), N.ptr(self.loss), self._s()), "mi_dqn_td_grad")
+        D.allreduce_sum_(self._gradbuf, self.pg)
+
+    def train_step(self, indices=None):
+        """One optimisation step (dqn.py:114-133)."""
+        self.sample(indices)
+        self.td_grad()
+        self.optimizer.step(self.grads)
+        self.update_index += 1
+
+    def sync_target(self):
+        """target_network.load_state_dict(q_network.state_dict()) (dqn.py:136-137)."""
+        self.target.flat.copy_(self.q.flat)

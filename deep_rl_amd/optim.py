@@ -9,6 +9,8 @@ from . import _native as N
 
 
 class ClipAdam(torch.optim.Optimizer):
+    """Also serves dqn.py's plain `optim.Adam(q_network.parameters(), lr)` (dqn.py:68): max_grad_norm = inf disables clipping."""
+
     def __init__(self, agent, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=float("inf")):
         self.agent = agent
         flat = agent.flat

@@ -147,6 +147,40 @@ typedef struct {
 } mi_ppo_hparams_t;
 int mi_ppo_update(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* stream);
 
+/* =====================================================================================================================
+ * DQN (reference deep_rl/dqn.py; SURVEY.md §8a d1-d8, BASELINE config 3).
+ * QNetwork 4 -> 120 -> 84 -> 2 ReLU; flat f32 parameters in q_network.parameters() order: W1[120,4] b1[120] W2[84,120] b2[84]
+ * W3[2,84] b3[2] = MI_DQN_NPARAMS.  Replay storage (dqn.py:73-76 with an env axis, ring semantics of iqn.py:174-232):
+ *   observations f32 [slots, N, 4], actions i64 [slots, N], rewards f32 [slots, N], terminated u8 [slots, N]
+ * time slot g % slots holds obs_g and the action taken from it; slot (g+1) % slots holds the resulting reward / terminated /
+ * next observation (the RESET observation after a done).  A flattened index is slot*N + env; its successor is
+ * ((slot+1) % slots)*N + env.  slots = total_timesteps + 1 reproduces the reference's linear storage.
+ * RNG contract additions: stream 3 = exploration (idx = env step counter; u = (w0 >> 8)/2^24 is compared with epsilon, w1 & 1 is
+ * the random action); stream 4 = minibatch sampling (env := update index, idx := row b; index = (w0 | w1 << 32) mod upper).
+ * ===================================================================================================================== */
+#define MI_DQN_NPARAMS 10934
+/* QNetwork.forward (dqn.py:35-36): q dev f32 [n,2] */
+int mi_dqn_forward(const float* params, const float* obs, int n, float* q, void* stream);
+/* n_steps iterations of the acting half of the loop (dqn.py:84-108) for the handle's N envs, one launch: epsilon-greedy
+ * (random while global_step < learning_starts or u < epsilon(global_step), else argmax Q), env.step with auto-reset, ring store.
+ * global_step = time steps already taken.  obs_cur dev f32 [N,4] carried in/out.  forced_actions dev i64 [n_steps,N] /
+ * forced_resets dev f64 [n_steps,N,4] nullable (parity mode).  episodes / episode_stats as for mi_ppo_rollout (t = step index
+ * within the call). */
+int mi_dqn_act_steps(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
+                     double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
+                     float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
+                     const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, void* stream);
+/* batch_inds = randint(upper, size=batch) (dqn.py:116 / iqn.py:225-226): idx dev i64 [batch], uniform in [0, upper_flat) */
+int mi_dqn_sample(uint64_t seed, uint64_t update_index, int64_t upper_flat, int batch, int64_t* idx, void* stream);
+/* TD loss + gradient of one batch (dqn.py:118-128): grads dev f32 [MI_DQN_NPARAMS] = d loss/d params scaled by inv_count
+ * (1/(world*batch)), loss dev f32 [1] = sum((td-old)^2)*inv_count.  workspace: mi_dqn_workspace_bytes(batch) bytes. */
+size_t mi_dqn_workspace_bytes(int batch);
+int mi_dqn_td_grad(const float* params, const float* target_params, const float* observations, const int64_t* actions,
+                   const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                   float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream);
+/* optimizer.step() (dqn.py:131-133) = mi_clip_adam(..., n = MI_DQN_NPARAMS, eps = 1e-8, max_norm = +inf);
+ * target_network.load_state_dict (dqn.py:136-137) = a device-to-device copy of the flat vector by the caller. */
+
 /* ---- hardware self-test: probes the MFMA fragment layouts the update kernel relies on with exact
  * integer data; report dev i32 [16] (0 = ok per probe); dump (nullable) dev f32 [3*64*16] receives the raw
  * accumulators of the probes.  Used by tests and smoke(). */

@@ -71,6 +71,7 @@ def lib():
                                      C.c_float, C.c_float, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.ref_dqn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_dqn_td_grads.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
+        L.ref_dqn_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p]
         L.ref_dqn_epsilon.restype = C.c_double
         L.ref_dqn_epsilon.argtypes = [C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int64]
         L.ref_dqn_explore_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -323,3 +324,9 @@ def dqn_act_steps(env, params, st, obs_cur, n_steps, global_step, learning_start
     return lib().ref_dqn_act_steps(env.h, _p(p), n_steps, global_step, st.slots, learning_starts, start_e, end_e, exploration_fraction,
                                    total_timesteps, _p(obs_cur), _p(st.observations), _p(st.actions), _p(st.rewards), _p(st.terminated),
                                    _p(fa), _p(fr))
+
+
+def dqn_sample(seed, update_index, upper_flat, batch):
+    idx = np.empty(batch, np.int64)
+    lib().ref_dqn_sample(seed, update_index, upper_flat, batch, _p(idx))
+    return idx

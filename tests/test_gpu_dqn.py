@@ -1,0 +1,242 @@
+"""GPU parity tests of the DQN path (deep_rl_amd/csrc/mi_dqn.hip through the C ABI) against the CPU oracle and the golden
+vectors of the unmodified reference dqn.py.  Integer / flag / index work bit-exact; fp32 tolerances written at each assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import cpu_ref
+
+    cpu_ref.lib().ref_set_num_threads(8)
+    return cpu_ref
+
+
+@pytest.fixture(scope="module")
+def dqn_trace():
+    with np.load(os.path.join(ROOT, "tests", "golden", "dqn_ref_trace.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(autouse=True)
+def _fdlibm(R):
+    R.set_sincos_mode("fdlibm")
+    yield
+    R.set_sincos_mode("libm")
+
+
+def _engine(dev, n_envs, slots, params=None, seed=1, base=0, **kw):
+    import deep_rl_amd as D
+
+    env = D.make("CartPole-v1", num_envs=n_envs, device=dev, seed=seed, env_id_base=base)
+    torch.manual_seed(seed)
+    q = D.QNetwork(env); tgt = D.QNetwork(env)
+    if params is not None:
+        q.load_flat(params)
+    tgt.load_state_dict(q.state_dict())
+    opt = D.ClipAdam(q, lr=2.5e-4, eps=1e-8)
+    kw.setdefault("max_episodes_logged", 4096)
+    return D.DQNEngine(env, q, tgt, opt, slots=slots, **kw)
+
+
+def _upload(eng, st):
+    eng.observations.copy_(torch.from_numpy(st.observations)); eng.actions.copy_(torch.from_numpy(st.actions))
+    eng.rewards.copy_(torch.from_numpy(st.rewards)); eng.terminated.copy_(torch.from_numpy(st.terminated))
+
+
+def test_qnetwork_surface_and_forward(dev, R):
+    import deep_rl_amd as D
+
+    env = D.make("CartPole-v1", num_envs=1, device=dev)
+    torch.manual_seed(1)
+    q = D.QNetwork(env)
+    assert [tuple(p.shape) for p in q.parameters()] == [(120, 4), (120,), (84, 120), (84,), (2, 84), (2,)]
+    t = D.QNetwork(env)
+    t.load_state_dict(q.state_dict())
+    assert torch.equal(t.flat, q.flat) and t.flat.data_ptr() != q.flat.data_ptr()
+    rng = np.random.default_rng(0)
+    obs = (rng.normal(0, 1, (5, 300, 4)) * np.array([2.4, 3, 0.2, 3])).astype(np.float32)
+    out = q(torch.from_numpy(obs).to(dev))
+    assert out.shape == (5, 300, 2)
+    ref = R.dqn_forward(q.flat.cpu().numpy(), obs).reshape(5, 300, 2)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())   # fp32, 120-term dot products
+
+
+def test_act_steps_teacher_forced_vs_reference_trace(dev, R, dqn_trace):
+    """The reference run's first 3,000 steps (its actions, its reset noise): ring storage bit-exact vs the oracle, terminated /
+    episode structure exactly the reference's."""
+    g = dqn_trace
+    n_steps = 3000
+    eng = _engine(dev, 1, slots=100_001, params=g["init_params"])
+    env = R.VecCartPole(1); st = R.ReplayStorage(100_001, 1)
+    obs_cur = env.reset(g["reset_states"][:1]); st.observations[0, 0] = obs_cur[0]
+    eng.reset(torch.from_numpy(g["reset_states"][:1]))
+    acts = g["actions_all"].astype(np.int64); ar = g["after_reset_all"]; resets = g["reset_states"]
+    ri, gs, n_ep = 1, 0, 0
+    while gs < n_steps:
+        n = 50
+        fr = np.zeros((n, 1, 4))
+        for s in range(n):
+            if ar[gs + s + 1]:
+                fr[s, 0] = resets[ri]; ri += 1
+        fa = acts[gs:gs + n].reshape(n, 1)
+        R.dqn_act_steps(env, g["init_params"], st, obs_cur, n, gs, forced_actions=fa, forced_resets=fr)
+        eng.act(n, forced_actions=torch.from_numpy(fa), forced_resets=torch.from_numpy(fr))
+        n_ep += eng.drain_episodes()[0]
+        gs += n
+    for name in ["actions", "rewards", "terminated"]:
+        assert np.array_equal(getattr(eng, name)[:n_steps + 1].cpu().numpy(), getattr(st, name)[:n_steps + 1]), name
+    # the oracle runs its device-matched sin/cos here -> bit-exact; the reference (libm) may differ by 1 ulp on a few steps
+    assert np.array_equal(eng.observations[:n_steps + 1].cpu().numpy(), st.observations[:n_steps + 1])
+    live = ~ar[1:n_steps + 1].astype(bool)
+    d = np.abs(eng.observations[1:n_steps + 1, 0].cpu().numpy()[live].astype(np.float64) - g["obs_first"][:n_steps][live])
+    assert (d <= np.spacing(np.abs(g["obs_first"][:n_steps][live]))).all() and (d > 0).sum() <= 20
+    assert n_ep == int(ar[1:n_steps + 1].sum()) == int((g["episode_global_step"] <= n_steps).sum())
+    assert np.array_equal(eng.terminated[1:n_steps + 1, 0].cpu().numpy(), g["terminated_all"][:n_steps])
+
+
+def test_act_steps_keyed_rng_ring_wrap(dev, R):
+    """96 envs, a 16-slot ring (wraps many times), epsilon decaying to 0.05 within the test: actions follow the RNG contract
+    (random action / greedy argmax decided by the keyed draw), storage bit-exact vs the oracle with the device's actions replayed."""
+    n, S, tt, ls = 96, 16, 400, 40
+    eng = _engine(dev, n, slots=S, seed=5, base=300, learning_starts=ls, total_timesteps=tt)
+    rng = np.random.default_rng(1)
+    params = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    eng.q.load_flat(params)
+    env = R.VecCartPole(n, seed=5, env_id_base=300); st = R.ReplayStorage(S, n)
+    obs_cur = env.reset(); st.observations[0] = obs_cur
+    assert np.array_equal(eng.reset().cpu().numpy(), obs_cur)
+    gs, n_greedy, n_checked = 0, 0, 0
+    for call in range(40):
+        k = 10
+        obs_before = eng.observation.cpu().numpy().copy()
+        eng.act(k)
+        # recover the device's actions of this call from the ring (slot (gs+s) % S), replay them on the oracle
+        fa = np.stack([eng.actions[(gs + s) % S].cpu().numpy() for s in range(k)]) if k <= S else None
+        R.dqn_act_steps(env, params, st, obs_cur, k, gs, learning_starts=ls, total_timesteps=tt, forced_actions=fa)
+        for name in ["observations", "actions", "rewards", "terminated"]:
+            assert np.array_equal(getattr(eng, name).cpu().numpy(), getattr(st, name)), (call, name)
+        assert np.array_equal(eng.observation.cpu().numpy(), obs_cur)
+        # first step of the call: the decision must follow the contract (obs known = obs_before)
+        eps = np.float32(R.dqn_epsilon(gs, total_timesteps=tt))
+        qv = R.dqn_forward(params, obs_before)
+        for e in range(0, n, 7):
+            u, ra = R.dqn_explore_draw(5, 300 + e, gs)
+            if gs < ls or u < eps:
+                assert fa[0, e] == ra
+            elif abs(qv[e, 0] - qv[e, 1]) > 1e-4:
+                assert fa[0, e] == int(qv[e, 1] > qv[e, 0]); n_greedy += 1
+            n_checked += 1
+        gs += k
+    assert n_greedy > 50 and n_checked > 400
+
+
+def test_sample_bit_exact(dev, R):
+    from deep_rl_amd import _native as N
+
+    for upper, batch in [(1, 128), (12345, 128), (1_000_000 * 64, 4096)]:
+        idx = torch.empty(batch, dtype=torch.int64, device=dev)
+        N.check(N.lib().mi_dqn_sample(9, 77, upper, batch, N.ptr(idx), N.stream_ptr(dev)))
+        assert np.array_equal(idx.cpu().numpy(), R.dqn_sample(9, 77, upper, batch))
+    assert idx.min() >= 0 and idx.max() < 1_000_000 * 64
+
+
+def _replay_reference(R, g, upto_steps):
+    R.set_sincos_mode("libm")
+    env = R.VecCartPole(1); st = R.ReplayStorage(100_001, 1)
+    obs_cur = env.reset(g["reset_states"][:1]); st.observations[0, 0] = obs_cur[0]
+    acts = g["actions_all"].astype(np.int64); ar = g["after_reset_all"]; resets = g["reset_states"]
+    ri, gs = 1, 0
+    while gs < upto_steps:
+        n = 10
+        fr = np.zeros((n, 1, 4))
+        for s in range(n):
+            if (gs + s + 1 < 100_000 and ar[gs + s + 1]) or (gs + s + 1 == 100_000 and ri < len(resets)):
+                fr[s, 0] = resets[ri]; ri += 1
+        R.dqn_act_steps(env, g["init_params"], st, obs_cur, n, gs, forced_actions=acts[gs:gs + n].reshape(n, 1), forced_resets=fr)
+        gs += n
+    R.set_sincos_mode("fdlibm")
+    return st
+
+
+def test_td_grad_vs_reference_checkpoints(dev, R, dqn_trace):
+    """Un-chained: the reference's online / target parameters, batch indices and (replayed) storage at updates 1000, 5000, 9000
+    -> loss and gradient of the HIP kernel against the reference's autograd and the oracle."""
+    g = dqn_trace
+    st = _replay_reference(R, g, 100_000)
+    eng = _engine(dev, 1, slots=100_001)
+    _upload(eng, st)
+    for i, k in enumerate(g["ck_update"]):
+        eng.q.load_flat(g["ck_params"][i]); eng.target.load_flat(g["ck_target"][i])
+        eng.sample(g["ck_inds"][i])
+        eng.td_grad()
+        grads = eng.grads.cpu().numpy(); loss = float(eng.loss.item())
+        og, ol = R.dqn_td_grads(g["ck_params"][i], g["ck_target"][i], st, g["ck_inds"][i])
+        scale = np.abs(g["ck_grads"][i]).max()
+        assert np.abs(grads - g["ck_grads"][i]).max() <= 5e-6 * scale, (k, np.abs(grads - g["ck_grads"][i]).max() / scale)
+        assert np.abs(grads - og).max() <= 5e-6 * scale
+        assert abs(loss - g["ck_loss"][i]) <= 1e-5 * g["ck_loss"][i] and abs(loss - ol) <= 1e-5 * ol
+        eng.td_grad()
+        assert np.array_equal(eng.grads.cpu().numpy(), grads)   # bitwise reproducible
+
+
+def test_first_300_updates_chained_on_device(dev, R, dqn_trace):
+    """The reference's first 300 TD updates chained through the device's own Adam (reference indices, replayed storage, target
+    sync every 500 steps): every loss within 2e-5 relative, parameters within 2e-6 of the reference's after the first 8 steps."""
+    from tests.test_oracle_dqn_pinned import regenerate_batch_inds
+
+    g = dqn_trace
+    inds, _ = regenerate_batch_inds(g)
+    st = _replay_reference(R, g, 13_100)
+    eng = _engine(dev, 1, slots=100_001, params=g["init_params"])
+    _upload(eng, st)
+    losses = []
+    for k in range(300):
+        # storage beyond the current global_step is not sampled: indices < gs by construction
+        eng.train_step(inds[k])
+        losses.append(eng.loss.clone())
+        if k < 8:
+            assert np.abs(eng.q.flat.cpu().numpy() - g["full_params"][k]).max() < 2e-6, k
+        if (10_000 + 10 * k) % 500 == 0:
+            eng.sync_target()
+    losses = torch.cat(losses).cpu().numpy()
+    rel = np.abs(losses - g["loss_all"][:300]) / np.maximum(np.abs(g["loss_all"][:300]), 1e-3)
+    assert rel.max() < 2e-5, rel.max()
+    assert abs(eng.q.flat.double().sum().item() - g["psum_all"][299]) < 1e-4
+
+
+@pytest.mark.parametrize("batch", [128, 1000, 4096])
+def test_td_grad_batches_and_ring(dev, R, batch):
+    """Bigger / ragged batches on a wrapped 64-slot ring of 32 envs (successor index crosses the ring end)."""
+    n, S = 32, 64
+    eng = _engine(dev, n, slots=S, seed=3, batch_size=batch, learning_starts=0, total_timesteps=1000)
+    rng = np.random.default_rng(4)
+    params = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    tparams = (params + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    eng.q.load_flat(params); eng.target.load_flat(tparams)
+    eng.reset()
+    for _ in range(10):
+        eng.act(20)   # 200 steps: the ring has wrapped three times
+    st = R.ReplayStorage(S, n)
+    for name in ["observations", "actions", "rewards", "terminated"]:
+        getattr(st, name)[...] = getattr(eng, name).cpu().numpy()
+    eng.sample()
+    idx = eng.batch_inds.cpu().numpy()
+    assert np.array_equal(idx, R.dqn_sample(3, 0, S * n, batch)) and (idx // n == S - 1).any()   # some successors wrap to slot 0
+    eng.td_grad()
+    og, ol = R.dqn_td_grads(params, tparams, st, idx)
+    assert np.abs(eng.grads.cpu().numpy() - og).max() <= 1e-5 * np.abs(og).max()
+    assert abs(float(eng.loss.item()) - ol) <= 2e-5 * ol

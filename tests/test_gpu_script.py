@@ -4,6 +4,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -47,3 +48,37 @@ def test_vector_run_learns():
     rets = [float(ln.split("mean_episodic_return=")[1]) for ln in out.splitlines() if "mean_episodic_return=" in ln]
     assert len(rets) >= 30 and sum(rets[-5:]) / 5 > 2.0 * sum(rets[:3]) / 3, rets
     assert '"minibatch_size": 8192' in out
+
+
+def _run_dqn(env_over):
+    env = dict(os.environ, PYTHONPATH=ROOT, **env_over)
+    code = ("import runpy, json; g = runpy.run_module('deep_rl_amd.dqn', run_name='__main__');"
+            "print('GLOBALS', json.dumps({k: g[k] for k in ['env_id','total_timesteps','learning_starts','train_frequency','batch_size',"
+            "'gamma','learning_rate','target_network_frequency','seed','global_step','num_envs','memory_size']}));"
+            "print('SHAPES', [tuple(g[k].shape) for k in ['observations','actions','rewards','terminated']]); print('LOSS', g['loss'])")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def test_dqn_script_reference_shape_n1():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = _run_dqn({"NUM_ENVS": "1", "TOTAL_TIMESTEPS": "6000"})
+    lines = [ln for ln in out.splitlines() if ln.startswith("global_step=")]
+    assert len(lines) > 100 and all(re.fullmatch(r"global_step=\d+, episodic_return=\d+\.\d\d", ln) for ln in lines)  # dqn.py:111
+    assert '"learning_starts": 600' in out and '"global_step": 6000' in out and '"memory_size": 6001' in out
+    assert "SHAPES [(6001, 1, 4), (6001, 1), (6001, 1), (6001, 1)]" in out
+
+
+def test_dqn_script_vector_ring_runs():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = _run_dqn({"NUM_ENVS": "256", "TOTAL_TIMESTEPS": "4000", "MEMORY_SIZE": "512", "BATCH_SIZE": "1024"})
+    assert '"memory_size": 512' in out and "SHAPES [(512, 256, 4)" in out
+    loss = float(out.split("LOSS")[1].split()[0])
+    assert np.isfinite(loss) and loss > 0
