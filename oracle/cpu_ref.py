@@ -78,6 +78,20 @@ def lib():
         L.ref_dqn_act_steps.restype = C.c_int
         L.ref_dqn_act_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                         C.c_int64] + [C.c_void_p] * 7
+        L.ref_pend_create.restype = C.c_void_p
+        L.ref_pend_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64]
+        L.ref_pend_destroy.argtypes = [C.c_void_p]
+        L.ref_pend_state.restype = C.POINTER(C.c_double)
+        L.ref_pend_state.argtypes = [C.c_void_p]
+        L.ref_pend_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_pend_step.argtypes = [C.c_void_p] * 8
+        L.ref_sac_actor_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_sac_q_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_sac_critic_grads.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
+        L.ref_sac_actor_grads.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_float, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_sac_mean_logp.restype = C.c_float
+        L.ref_sac_mean_logp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_polyak.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
         L.ref_set_sincos_mode.argtypes = [C.c_int]
         L.ref_get_sincos_mode.restype = C.c_int
         L.ref_num_threads.restype = C.c_int
@@ -330,3 +344,89 @@ def dqn_sample(seed, update_index, upper_flat, batch):
     idx = np.empty(batch, np.int64)
     lib().ref_dqn_sample(seed, update_index, upper_flat, batch, _p(idx))
     return idx
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SAC (reference sac.py on Pendulum-v1)
+SQ_NPARAMS = 67329
+AC_NPARAMS = 67330
+
+
+class VecPendulum:
+    """N Pendulum-v1 envs with TimeLimit(200), episode statistics and sac.py's auto-reset (sac.py:142-144)."""
+
+    def __init__(self, n, seed=1, env_id_base=0):
+        self.n = n
+        self.h = lib().ref_pend_create(n, seed, env_id_base)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ref_pend_destroy(self.h)
+            self.h = None
+
+    @property
+    def state(self):
+        return np.ctypeslib.as_array(lib().ref_pend_state(self.h), shape=(self.n, 2))
+
+    def reset(self, forced_state=None):
+        obs = np.empty((self.n, 3), np.float32)
+        lib().ref_pend_reset(self.h, _p(obs), _p(_c(forced_state, np.float64)))
+        return obs
+
+    def step(self, actions, forced_reset=None):
+        n = self.n
+        a = _c(actions, np.float32).reshape(n)
+        obs = np.empty((n, 3), np.float32); rew = np.empty(n, np.float32); done = np.empty(n, np.uint8)
+        fret = np.empty(n, np.float32); flen = np.empty(n, np.int32)
+        lib().ref_pend_step(self.h, _p(a), _p(_c(forced_reset, np.float64)), _p(obs), _p(rew), _p(done), _p(fret), _p(flen))
+        return obs, rew, done, fret, flen
+
+
+class SacStorage:
+    """sac.py:126-129 with an env axis: [slots][N] ring; actions are float32 (one action dim)."""
+
+    def __init__(self, slots, n_envs):
+        self.slots, self.N = slots, n_envs
+        self.observations = np.zeros((slots, n_envs, 3), np.float32)
+        self.actions = np.zeros((slots, n_envs), np.float32)
+        self.rewards = np.zeros((slots, n_envs), np.float32)
+        self.terminated = np.zeros((slots, n_envs), np.uint8)
+
+
+def sac_actor_sample(actor, obs, eps):
+    o = _c(obs, np.float32).reshape(-1, 3); e = _c(eps, np.float32).reshape(-1); n = o.shape[0]
+    a = np.empty(n, np.float32); lp = np.empty(n, np.float32)
+    lib().ref_sac_actor_sample(_p(_c(actor, np.float32)), _p(o), _p(e), n, _p(a), _p(lp))
+    return a, lp
+
+
+def sac_q_forward(q, obs, act):
+    o = _c(obs, np.float32).reshape(-1, 3); a = _c(act, np.float32).reshape(-1); out = np.empty(o.shape[0], np.float32)
+    lib().ref_sac_q_forward(_p(_c(q, np.float32)), _p(o), _p(a), o.shape[0], _p(out))
+    return out
+
+
+def sac_critic_grads(qparams, qtarget, actor, st, idx, eps, alpha, gamma=0.99, inv_count=None):
+    idx = _c(idx, np.int64); e = _c(eps, np.float32)
+    grads = np.empty(2 * SQ_NPARAMS, np.float32); losses = np.zeros(2, np.float32)
+    lib().ref_sac_critic_grads(_p(_c(qparams, np.float32)), _p(_c(qtarget, np.float32)), _p(_c(actor, np.float32)), _p(st.observations),
+                               _p(st.actions), _p(st.rewards), _p(st.terminated), _p(idx), len(idx), st.N, st.slots, _p(e), alpha, gamma,
+                               (1.0 / len(idx)) if inv_count is None else inv_count, _p(grads), _p(losses))
+    return grads, losses
+
+
+def sac_actor_grads(actor, qparams, st, idx, eps, alpha, inv_count=None):
+    idx = _c(idx, np.int64); e = _c(eps, np.float32)
+    grads = np.empty(AC_NPARAMS, np.float32); loss = np.zeros(1, np.float32); mlp = np.zeros(1, np.float32)
+    lib().ref_sac_actor_grads(_p(_c(actor, np.float32)), _p(_c(qparams, np.float32)), _p(st.observations), _p(idx), len(idx), _p(e), alpha,
+                              (1.0 / len(idx)) if inv_count is None else inv_count, _p(grads), _p(loss), _p(mlp))
+    return grads, float(loss[0]), float(mlp[0])
+
+
+def sac_mean_logp(actor, st, idx, eps):
+    idx = _c(idx, np.int64)
+    return float(lib().ref_sac_mean_logp(_p(_c(actor, np.float32)), _p(st.observations), _p(idx), len(idx), _p(_c(eps, np.float32))))
+
+
+def polyak(target, param, tau=0.005):
+    lib().ref_polyak(_p(target), _p(_c(param, np.float32)), target.size, tau)

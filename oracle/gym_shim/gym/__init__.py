@@ -16,6 +16,6 @@ ppo.py:3,10,17,21,79,84; dqn.py:16,20,56,61,64,89; sac.py:21,25,96,101,104,139.
 """
 from gym.core import Env, Wrapper  # noqa: F401
 from gym import spaces, wrappers, utils  # noqa: F401
-from gym.envs import make, register_trace_sink  # noqa: F401
+from gym.envs import make, register_trace_sink, alias  # noqa: F401
 
 __version__ = "0.21.0+shim"

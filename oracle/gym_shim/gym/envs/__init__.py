@@ -165,7 +165,16 @@ _REGISTRY = {
 }
 
 
+_ALIASES = {}
+
+
+def alias(id, target):
+    """Make gym.make(id) build `target` instead (used to run the unmodified sac.py, whose env id is a Bullet task, on Pendulum)."""
+    _ALIASES[id] = target
+
+
 def make(id, **kwargs):
+    id = _ALIASES.get(id, id)
     if id not in _REGISTRY:
         raise KeyError("gym shim: unknown env id {!r} (has {})".format(id, sorted(_REGISTRY)))
     cls, spec = _REGISTRY[id]
