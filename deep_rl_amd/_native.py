@@ -13,6 +13,8 @@ SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_S
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
+SAC_Q_NPARAMS = 67329
+SAC_ACTOR_NPARAMS = 67330
 MI_OK = 0
 
 
@@ -65,6 +67,18 @@ SIGNATURES = {
     "mi_dqn_sample": (_I, [_U64, _U64, _I64, _I, _VP, _VP]),
     "mi_dqn_workspace_bytes": (_SZ, [_I]),
     "mi_dqn_td_grad": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _D, _VP, _VP, _VP, _VP]),
+    "mi_env_step_cont": (_I, [_VP] * 10),
+    "mi_sac_actor_sample": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP]),
+    "mi_sac_q_forward": (_I, [_VP, _VP, _VP, _I, _VP, _VP]),
+    "mi_sac_act_step": (_I, [_VP, _VP, _I64, _I64, _I64] + [_VP] * 10 + [_I, _VP]),
+    "mi_sac_workspace_bytes": (_SZ, [_I]),
+    "mi_sac_critic_grad": (_I, [_VP] * 8 + [_I, _I, _I64, _VP, _U64, _U64, _VP, _F, _D, _VP, _VP, _VP, _VP]),
+    "mi_sac_actor_grad": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _D, _VP, _VP, _VP, _VP]),
+    "mi_sac_alpha_step": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP, _VP]),
+    "mi_sac_mean_logp": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _D, _VP, _VP, _VP]),
+    "mi_sac_alpha_adam": (_I, [_VP, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
+    "mi_adam": (_I, [_VP] * 4 + [_I, _I64, _D, _D, _D, _D, _VP]),
+    "mi_polyak": (_I, [_VP, _VP, _I, _F, _VP]),
     "mi_selftest_mfma": (_I, [_VP, _VP, _VP]),
     "mi_test_tanh": (_I, [_VP, _VP, _I, _VP]),
     "mi_prof_begin": (_I, [_I, _U32]),

@@ -123,3 +123,99 @@ class QNetwork(nn.Module):
         q = torch.empty((obs.shape[0], 2), dtype=torch.float32, device=self.device)
         N.check(N.lib().mi_dqn_forward(N.ptr(self.flat), N.ptr(obs), obs.shape[0], N.ptr(q), N.stream_ptr(self.device)), "mi_dqn_forward")
         return q.reshape(*lead, 2)
+
+
+def _bind_flat(module, flat):
+    """Re-point every parameter of `module` at its slice of `flat` (parameters() order)."""
+    off = 0
+    for p in module.parameters():
+        n = p.numel()
+        p.data = flat[off:off + n].view(p.shape)
+        off += n
+    assert off == flat.numel()
+    module.flat = flat
+
+
+class _FlatModule(nn.Module):
+    def _finish(self, env, device, nparams):
+        dev = torch.device(device if device is not None else getattr(env, "device", "cuda"))
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self.parameters()]).to(dev, torch.float32).contiguous()
+        assert flat.numel() == nparams
+        _bind_flat(self, flat)
+        self.device = dev
+
+    def load_flat(self, vec):
+        self.flat.copy_(torch.as_tensor(vec, dtype=torch.float32).reshape(-1).to(self.device))
+
+    def load_state_dict(self, state_dict, *a, **kw):
+        """qf1_target.load_state_dict(qf1.state_dict()) (sac.py:115-116): keeps the flat-buffer views intact."""
+        own = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                if k in own:
+                    own[k].copy_(v)
+
+
+def pack(*modules):
+    """Lay the flat buffers of several modules back to back in ONE buffer (the twin critics share one Adam, sac.py:117) and
+    re-point their parameters; returns the joint buffer."""
+    joint = torch.cat([m.flat for m in modules]).contiguous()
+    off = 0
+    for m in modules:
+        n = m.flat.numel()
+        _bind_flat(m, joint[off:off + n])
+        off += n
+    return joint
+
+
+class SoftQNetwork(_FlatModule):
+    """SoftQNetwork of the reference sac.py:29-43 (cat(obs, action) -> 256 -> 256 -> 1, ReLU, torch default init)."""
+
+    def __init__(self, env, device=None):
+        super().__init__()
+        obs_dim, act_dim = int(np.prod(env.observation_space.shape)), int(np.prod(env.action_space.shape))
+        if obs_dim != 3 or act_dim != 1:
+            raise N.MiError("the SAC kernels are specialised for Pendulum (obs 3, action 1); got %d/%d" % (obs_dim, act_dim))
+        self.network = nn.Sequential(nn.Linear(obs_dim + act_dim, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 1))
+        self._finish(env, device, N.SAC_Q_NPARAMS)
+
+    def forward(self, observation, action):
+        """sac.py:40-43."""
+        obs = observation.to(self.device, torch.float32).reshape(-1, 3).contiguous()
+        act = action.to(self.device, torch.float32).reshape(-1).contiguous()
+        out = torch.empty(obs.shape[0], dtype=torch.float32, device=self.device)
+        N.check(N.lib().mi_sac_q_forward(N.ptr(self.flat), N.ptr(obs), N.ptr(act), obs.shape[0], N.ptr(out), N.stream_ptr(self.device)), "mi_sac_q_forward")
+        return out
+
+
+class Actor(_FlatModule):
+    """Actor of the reference sac.py:46-78 (3 -> 256 -> 256 ReLU, mean head, tanh-bounded log-std head, tanh-squashed action)."""
+
+    def __init__(self, env, device=None):
+        super().__init__()
+        obs_dim, act_dim = int(np.prod(env.observation_space.shape)), int(np.prod(env.action_space.shape))
+        if obs_dim != 3 or act_dim != 1:
+            raise N.MiError("the SAC kernels are specialised for Pendulum (obs 3, action 1); got %d/%d" % (obs_dim, act_dim))
+        self.shared_net = nn.Sequential(nn.Linear(obs_dim, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU())
+        self.mean_net = nn.Linear(256, act_dim)
+        self.log_std_net = nn.Sequential(nn.Linear(256, act_dim), nn.Tanh())
+        hi, lo = np.asarray(env.action_space.high, np.float32), np.asarray(env.action_space.low, np.float32)
+        self.register_buffer("action_scale", torch.tensor((hi - lo) / 2.0, dtype=torch.float32))
+        self.register_buffer("action_bias", torch.tensor((hi + lo) / 2.0, dtype=torch.float32))
+        if float(self.action_scale) != 2.0 or float(self.action_bias) != 0.0:
+            raise N.MiError("the SAC kernels are specialised for Pendulum's action range [-2, 2]")
+        self._finish(env, device, N.SAC_ACTOR_NPARAMS)
+
+    def get_action(self, observation, eps=None):
+        """sac.py:65-78.  eps: the standard-normal draws of rsample() (default: torch.randn on the device)."""
+        obs = observation.to(self.device, torch.float32)
+        lead = obs.shape[:-1]
+        obs = obs.reshape(-1, 3).contiguous()
+        n = obs.shape[0]
+        e = torch.randn(n, device=self.device) if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+        action = torch.empty(n, dtype=torch.float32, device=self.device)
+        logp = torch.empty(n, dtype=torch.float32, device=self.device)
+        N.check(N.lib().mi_sac_actor_sample(N.ptr(self.flat), N.ptr(obs), N.ptr(e), n, N.ptr(action), N.ptr(logp), N.stream_ptr(self.device)),
+                "mi_sac_actor_sample")
+        return action.reshape(*lead, 1), logp.reshape(lead)

@@ -55,7 +55,7 @@ struct mi_prof_scope {
 
 // ---- env handle ----------------------------------------------------------------------------------
 struct mi_env {
-    int kind, n, device;
+    int kind, n, device;   // kind 1 (Pendulum): x = theta, x_dot = theta_dot; theta / theta_dot arrays unused
     uint64_t seed, env_id_base;
     // struct-of-arrays device state: fp64 dynamics, int counters
     double *x, *x_dot, *theta, *theta_dot;
@@ -65,6 +65,8 @@ struct mi_env {
     uint64_t* episode;   // resets so far (index of the next reset-noise draw)
     uint64_t* step_ctr;  // actions sampled so far (index of the next action uniform)
 };
+
+int mi_pend_reset_impl(mi_env* e, float* obs, const double* forced_state, hipStream_t s);
 
 // ---- RNG contract (include/mi_rl.h) ----------------------------------------------------------------
 #define STREAM_RESET 0u
@@ -190,6 +192,53 @@ __device__ __forceinline__ void mi_categorical2_fast(float l0, float l1, float& 
     nl0 = l0 - lse; nl1 = l1 - lse;
     p0 = mi_fast_exp(nl0); p1 = mi_fast_exp(nl1);
     ent = -(nl0 * p0 + nl1 * p1);
+}
+
+// full-range sin/cos (Pendulum's angle is unbounded): Cody-Waite reduction by pi/2 with two constants + the fdlibm kernels.
+// Bit-identical to oracle/cpu_ref.c ref_sincos_full in its device-matched mode (same IEEE operation sequence).
+__device__ __forceinline__ void mi_sincos_full(double x, double& s, double& c) {
+    const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double v = z * r;
+    const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+    const double ks = __builtin_fma(v, __builtin_fma(z, rs, S1), r);
+    const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+    const double kc = 1.0 - (0.5 * z - z * rc);
+    const long long q = (long long)n & 3;
+    s = q == 0 ? ks : q == 1 ? kc : q == 2 ? -ks : -kc;
+    c = q == 0 ? kc : q == 1 ? -ks : q == 2 ? -kc : ks;
+}
+
+// ---- Pendulum-v1 step (gym 0.21 pendulum.py), fp64, no FMA contraction; obs = (cos, sin, theta_dot) of the NEW state ----
+#define PEND_MAX_STEPS 200
+__device__ __forceinline__ void mi_pendulum_step(double& th, double& thdot, float u_in, double& reward) {
+    const double PI = 3.14159265358979323846, max_speed = 8.0, max_torque = 2.0, dt = 0.05, g = 10.0, m = 1.0, l = 1.0;
+    double u = (double)u_in;
+    u = u < -max_torque ? -max_torque : (u > max_torque ? max_torque : u);
+    double an = fmod(th + PI, 2 * PI);
+    if (an != 0.0 && an < 0.0) an += 2 * PI;
+    an -= PI;
+    reward = -(an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u));
+    double sn, cs;
+    mi_sincos_full(th, sn, cs);
+    double nd = thdot + (3 * g / (2 * l) * sn + 3.0 / (m * (l * l)) * u) * dt;
+    nd = nd < -max_speed ? -max_speed : (nd > max_speed ? max_speed : nd);
+    th = th + nd * dt;
+    thdot = nd;
+}
+__device__ __forceinline__ void mi_pendulum_reset_noise(uint64_t seed, uint64_t env, uint64_t episode, double& th, double& thdot) {
+    const double PI = 3.14159265358979323846;
+    uint32_t r[4];
+    mi_philox(seed, env, episode, STREAM_RESET, r);
+    const double u0 = __dmul_rn(__dadd_rn((double)r[0], 0.5), 1.0 / 4294967296.0), u1 = __dmul_rn(__dadd_rn((double)r[1], 0.5), 1.0 / 4294967296.0);
+    th = __dadd_rn(-PI, __dmul_rn(PI - -PI, u0));
+    thdot = __dadd_rn(-1.0, __dmul_rn(1.0 - -1.0, u1));
 }
 
 // ---- CartPole-v1 step (gym 0.21 cartpole.py), fp64, no FMA contraction (-ffp-contract=off) ---------

@@ -74,7 +74,9 @@ env_step_kernel(mi_env e, const int64_t* __restrict__ actions, const double* __r
 __global__ void __launch_bounds__(256) env_get_state_kernel(mi_env e, double* __restrict__ state, int32_t* __restrict__ elapsed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.n) return;
-    if (state) {
+    if (state && e.kind == MI_ENV_PENDULUM_V1) {   // [N,2]: theta, theta_dot
+        state[2 * (size_t)i + 0] = e.x[i]; state[2 * (size_t)i + 1] = e.x_dot[i];
+    } else if (state) {
         state[4 * (size_t)i + 0] = e.x[i]; state[4 * (size_t)i + 1] = e.x_dot[i];
         state[4 * (size_t)i + 2] = e.theta[i]; state[4 * (size_t)i + 3] = e.theta_dot[i];
     }
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(256) env_get_state_kernel(mi_env e, double* __
 extern "C" int mi_env_create(int kind, int n_envs, uint64_t seed, uint64_t env_id_base, void** handle) {
     MI_CHECK_ARG(handle != nullptr, "handle is NULL");
     *handle = nullptr;
-    MI_CHECK_ARG(kind == MI_ENV_CARTPOLE_V1, "unknown env kind (0 = CartPole-v1)");
+    MI_CHECK_ARG(kind == MI_ENV_CARTPOLE_V1 || kind == MI_ENV_PENDULUM_V1, "unknown env kind (0 = CartPole-v1, 1 = Pendulum-v1)");
     MI_CHECK_ARG(n_envs > 0, "n_envs must be positive");
     mi_env* e = new (std::nothrow) mi_env();
     if (!e) { mi_set_error("mi_env_create: out of host memory"); return MI_ENOMEM; }
@@ -121,6 +123,7 @@ extern "C" int mi_env_destroy(void* handle) {
 extern "C" int mi_env_reset(void* handle, float* obs, const double* forced_state, void* stream) {
     MI_CHECK_ARG(handle && obs, "handle/obs is NULL");
     mi_env* e = (mi_env*)handle;
+    if (e->kind == MI_ENV_PENDULUM_V1) return mi_pend_reset_impl(e, obs, forced_state, (hipStream_t)stream);
     env_reset_kernel<<<(e->n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*e, obs, forced_state);
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -130,6 +133,7 @@ extern "C" int mi_env_step(void* handle, const int64_t* actions, const double* f
                            uint8_t* done, uint8_t* truncated, float* fin_ret, int32_t* fin_len, void* stream) {
     MI_CHECK_ARG(handle && actions && obs && reward && done && truncated && fin_ret && fin_len, "NULL pointer");
     mi_env* e = (mi_env*)handle;
+    MI_CHECK_ARG(e->kind == MI_ENV_CARTPOLE_V1, "discrete-action step on a continuous-action env (use mi_env_step_cont)");
     env_step_kernel<<<(e->n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*e, actions, forced_reset, obs, reward, done,
                                                                         truncated, fin_ret, fin_len);
     MI_LAUNCH_CHECK();

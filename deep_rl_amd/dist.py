@@ -33,6 +33,10 @@ def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
 def allreduce_sum_(t, group=None):
     """In-place SUM all-reduce on the tensor's device/stream; no-op for a single process."""
     if world_size(group) > 1:

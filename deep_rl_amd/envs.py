@@ -27,6 +27,19 @@ class Box:
     def __init__(self, low, high, shape):
         self.low, self.high, self.shape = low, high, tuple(shape)
         self.dtype = torch.float32
+        self._gen = None
+
+    def seed(self, seed=None):
+        """env.action_space.seed(seed) (sac.py:104).  Host-side sampler only; the engine's warm-up actions are keyed in-kernel."""
+        self._gen = torch.Generator().manual_seed(0 if seed is None else int(seed))
+        return [seed]
+
+    def sample(self):
+        """env.action_space.sample() (sac.py:139): uniform in [low, high)."""
+        import numpy as np
+        lo, hi = np.asarray(self.low, np.float32), np.asarray(self.high, np.float32)
+        u = torch.rand(self.shape, generator=self._gen).numpy()
+        return (lo + (hi - lo) * u).astype(np.float32)
 
 
 class CartPoleVecEnv:
@@ -115,7 +128,63 @@ class CartPoleVecEnv:
         return st, el
 
 
-_REGISTRY = {"CartPole-v1": CartPoleVecEnv}
+class PendulumVecEnv(CartPoleVecEnv):
+    """N independent Pendulum-v1 envs (TimeLimit 200 + RecordEpisodeStatistics) — the continuous-control env the SAC path of
+    reference sac.py:80,96 is re-targeted to (pybullet's Hopper is not reproducible here)."""
+
+    def __init__(self, num_envs=1, device="cuda", seed=0, env_id_base=0):
+        import numpy as np
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise N.MiError("PendulumVecEnv runs on an MI355X only (device=%r)" % (device,))
+        self.env_id_base = int(env_id_base)
+        self.spec = SimpleNamespace(id="Pendulum-v1", max_episode_steps=200, reward_threshold=None)
+        self.observation_space = Box(np.array([-1.0, -1.0, -8.0], np.float32), np.array([1.0, 1.0, 8.0], np.float32), (3,))
+        self.action_space = Box(np.array([-2.0], np.float32), np.array([2.0], np.float32), (1,))
+        self.single_observation_space, self.single_action_space = self.observation_space, self.action_space
+        self._h = None
+        self._seed = int(seed)
+        self._create()
+
+    def _create(self):
+        self.close()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().mi_env_create(1, self.num_envs, self._seed, self.env_id_base, C.byref(h)), "mi_env_create")
+        self._h = h
+        n, dev = self.num_envs, self.device
+        self._obs = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        self._reward = torch.empty(n, dtype=torch.float32, device=dev)
+        self._done = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._trunc = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._fret = torch.empty(n, dtype=torch.float32, device=dev)
+        self._flen = torch.empty(n, dtype=torch.int32, device=dev)
+
+    def reset(self, forced_state=None):
+        """-> obs (N,3) f32 = (cos th, sin th, th_dot).  forced_state (N,2) f64 = (th, th_dot) replaces the keyed reset noise."""
+        return super().reset(forced_state)
+
+    def step(self, action, forced_reset=None):
+        """action (N,) or (N,1) f32 on device (clipped to +-2 by the env, pendulum.py) -> (obs, reward, done, info)."""
+        a = action.to(self.device, torch.float32).reshape(self.num_envs).contiguous()
+        fr = None if forced_reset is None else forced_reset.to(self.device, torch.float64).contiguous()
+        N.check(N.lib().mi_env_step_cont(self.handle, N.ptr(a), N.ptr(fr), N.ptr(self._obs), N.ptr(self._reward), N.ptr(self._done),
+                                        N.ptr(self._trunc), N.ptr(self._fret), N.ptr(self._flen), N.stream_ptr(self.device)),
+                "mi_env_step_cont")
+        done = self._done.bool()
+        info = {"TimeLimit.truncated": self._trunc.bool(), "episode": {"r": self._fret.clone(), "l": self._flen.clone()},
+                "_episode": done}
+        return self._obs.clone(), self._reward.clone(), done, info
+
+    def get_state(self):
+        st = torch.empty((self.num_envs, 2), dtype=torch.float64, device=self.device)
+        el = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        N.check(N.lib().mi_env_get_state(self.handle, N.ptr(st), N.ptr(el), N.stream_ptr(self.device)), "mi_env_get_state")
+        return st, el
+
+
+_REGISTRY = {"CartPole-v1": CartPoleVecEnv, "Pendulum-v1": PendulumVecEnv}
 
 
 def make(env_id, num_envs=1, device="cuda", seed=0, env_id_base=0):

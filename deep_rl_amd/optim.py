@@ -29,3 +29,22 @@ class ClipAdam(torch.optim.Optimizer):
         N.check(N.lib().mi_clip_adam(N.ptr(flat), N.ptr(grads), N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq), flat.numel(),
                                      self.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                                      float(g["max_grad_norm"]), N.ptr(self.grad_norm), N.stream_ptr(flat.device)), "mi_clip_adam")
+
+
+class Adam(torch.optim.Optimizer):
+    """optim.Adam over a flat fp32 device buffer (sac.py:108,117,122): one mi_adam launch per step, no clipping."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        flat = getattr(flat, "flat", flat)
+        self.flat = flat
+        super().__init__([torch.nn.Parameter(flat, requires_grad=False)], dict(lr=lr, betas=betas, eps=eps))
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count = 0
+
+    @torch.no_grad()
+    def step(self, grads):
+        g = self.param_groups[0]
+        self.step_count += 1
+        N.check(N.lib().mi_adam(N.ptr(self.flat), N.ptr(grads), N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq), self.flat.numel(), self.step_count,
+                                float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], N.stream_ptr(self.flat.device)), "mi_adam")

@@ -1,0 +1,172 @@
+"""SACEngine — device-resident replay ring + the launch sequence of reference sac.py:136-217.
+
+Owns the four replay tensors with the reference's names (sac.py:126-129) plus an env axis, laid out as a [slots, N]
+time-major ring (slots = total_timesteps + 1 gives the reference's linear storage), the twin critics / targets packed back to
+back in one flat buffer each, and the entropy coefficient as DEVICE scalars (log_alpha, alpha): `alpha = log_alpha.exp().item()`
+(sac.py:210) is the reference's one host round trip per actor update and it disappears here.  Methods are thin launch
+wrappers over the C ABI (include/mi_rl.h "SAC"); nothing is computed in Python.
+"""
+import torch
+
+from . import _native as N
+from . import dist as D
+from .agent import pack
+from .optim import Adam
+
+
+class SACEngine:
+    def __init__(self, env, actor, qf1, qf2, qf1_target, qf2_target, slots, batch_size=256, gamma=0.99, tau=0.005, policy_lr=3e-4,
+                 q_lr=1e-3, alpha_lr=None, learning_starts=5_000, target_entropy=None, max_episodes_logged=None, process_group=None):
+        self.env, self.actor = env, actor
+        self.N, self.device, self.slots = env.num_envs, env.device, int(slots)
+        self.batch_size, self.gamma, self.tau = int(batch_size), float(gamma), float(tau)
+        if self.batch_size % 4:
+            raise N.MiError("batch_size must be a multiple of 4 (MFMA k-step of the weight-gradient GEMM)")
+        self.learning_starts = int(learning_starts)
+        self.pg = process_group
+        self.world_size, self.rank = D.world_size(process_group), D.rank(process_group)
+        dev, S, Nn = self.device, self.slots, self.N
+        # twin critics share one optimizer (sac.py:117): one flat buffer [2 * MI_SAC_Q_NPARAMS] each for online / target
+        self.q_flat = pack(qf1, qf2)
+        self.qt_flat = pack(qf1_target, qf2_target)
+        self.qf1, self.qf2, self.qf1_target, self.qf2_target = qf1, qf2, qf1_target, qf2_target
+        self.actor_optimizer = Adam(actor.flat, lr=policy_lr)                                  # sac.py:108
+        self.q_optimizer = Adam(self.q_flat, lr=q_lr)                                          # :117
+        self.alpha_lr = float(q_lr if alpha_lr is None else alpha_lr)                          # :92
+        self.target_entropy = float(-1.0 if target_entropy is None else target_entropy)        # :119 (-prod(action shape))
+        self.log_alpha = torch.zeros(1, dtype=torch.float32, device=dev)                       # :120
+        self.alpha = torch.ones(1, dtype=torch.float32, device=dev)                            # :121 exp(0)
+        self._alpha_m = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._alpha_v = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.alpha_steps = 0
+        self.observations = torch.zeros((S, Nn, 3), dtype=torch.float32, device=dev)           # :126
+        self.actions = torch.zeros((S, Nn), dtype=torch.float32, device=dev)                   # :127 (one action dim)
+        self.rewards = torch.zeros((S, Nn), dtype=torch.float32, device=dev)                   # :128
+        self.terminated = torch.zeros((S, Nn), dtype=torch.uint8, device=dev)                  # :129 (bool)
+        self.batch_inds = torch.zeros(self.batch_size, dtype=torch.int64, device=dev)
+        self._qbuf = torch.zeros(2 * N.SAC_Q_NPARAMS + 2, dtype=torch.float32, device=dev)
+        self.q_grads, self.q_losses = self._qbuf[:2 * N.SAC_Q_NPARAMS], self._qbuf[2 * N.SAC_Q_NPARAMS:]
+        self._abuf = torch.zeros(N.SAC_ACTOR_NPARAMS + 2, dtype=torch.float32, device=dev)
+        self.actor_grads, self.actor_out = self._abuf[:N.SAC_ACTOR_NPARAMS], self._abuf[N.SAC_ACTOR_NPARAMS:]   # out = {actor_loss, mean logp}
+        self.alpha_out = torch.zeros(2, dtype=torch.float32, device=dev)                       # {alpha_loss, d/d log_alpha}
+        self._mean_logp = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.workspace = torch.empty(N.lib().mi_sac_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)
+        self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (64 if Nn <= 8 else 0))
+        self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
+        self.episode_stats = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.observation = None
+        self.global_step = 0
+        self.update_index = 0       # critic updates done
+        self.actor_updates = 0
+
+    def _s(self):
+        return N.stream_ptr(self.device)
+
+    def _key(self, counter):
+        """per-call key of the in-kernel normal draws, distinct per rank"""
+        return counter * self.world_size + self.rank
+
+    def reset(self, forced_state=None):
+        """observation = env.reset(); observations[global_step] = observation (sac.py:132-134)."""
+        self.observation = self.env.reset(forced_state)
+        self.observations[self.global_step % self.slots].copy_(self.observation)
+        return self.observation
+
+    def act(self, forced_actions=None, forced_eps=None, forced_resets=None):
+        """One iteration of sac.py:138-158 for every env, one launch."""
+        dev = self.device
+        fa = None if forced_actions is None else forced_actions.to(dev, torch.float32).reshape(self.N).contiguous()
+        fe = None if forced_eps is None else forced_eps.to(dev, torch.float32).reshape(self.N).contiguous()
+        fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
+        N.check(N.lib().mi_sac_act_step(
+            self.env.handle, N.ptr(self.actor.flat), self.global_step, self.slots, self.learning_starts, N.ptr(self.observation),
+            N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fe), N.ptr(fr),
+            N.ptr(self.episodes), N.ptr(self.episode_stats) if self.max_ep else None, self.max_ep, self._s()), "mi_sac_act_step")
+        self.global_step += 1
+
+    def drain_episodes(self):
+        """Host sync. -> [(env, return, length)] finished by the last act() call."""
+        if not self.max_ep:
+            return []
+        st = self.episode_stats.tolist()
+        k = min(st[3], self.max_ep)
+        if k == 0:
+            return []
+        raw = self.episodes[:k].cpu()
+        rets = raw[:, 2].contiguous().view(torch.float32)
+        return sorted((int(raw[i, 0]), float(rets[i]), int(raw[i, 3])) for i in range(k))
+
+    def sample(self, indices=None):
+        """batch_inds = np.random.randint(global_step, size=batch_size) (sac.py:162), flat over [slot][env]."""
+        if indices is not None:
+            self.batch_inds.copy_(torch.as_tensor(indices, dtype=torch.int64).reshape(-1).to(self.device))
+            return
+        upper = min(self.global_step, self.slots) * self.N
+        N.check(N.lib().mi_dqn_sample(self.env._seed, self._key(self.update_index), upper, self.batch_size, N.ptr(self.batch_inds), self._s()),
+                "mi_dqn_sample")
+
+    def critic_grad(self, eps=None):
+        """sac.py:170-182 + backward -> self.q_grads [2 * MI_SAC_Q_NPARAMS], self.q_losses (all-reduced when sharded)."""
+        e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+        N.check(N.lib().mi_sac_critic_grad(
+            N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+            N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
+            self._key(self.update_index), N.ptr(self.alpha), self.gamma, 1.0 / (self.batch_size * self.world_size), N.ptr(self.workspace),
+            N.ptr(self.q_grads), N.ptr(self.q_losses), self._s()), "mi_sac_critic_grad")
+        D.allreduce_sum_(self._qbuf, self.pg)
+
+    def update_critic(self, eps=None):
+        """sac.py:170-185."""
+        self.critic_grad(eps)
+        self.q_optimizer.step(self.q_grads)
+        self.update_index += 1
+
+    def actor_grad(self, eps=None):
+        """sac.py:189-193 + backward -> self.actor_grads, self.actor_out."""
+        e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+        N.check(N.lib().mi_sac_actor_grad(
+            N.ptr(self.actor.flat), N.ptr(self.q_flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e),
+            self.env._seed, self._key(self.actor_updates), N.ptr(self.alpha), 1.0 / (self.batch_size * self.world_size), N.ptr(self.workspace),
+            N.ptr(self.actor_grads), N.ptr(self.actor_out), self._s()), "mi_sac_actor_grad")
+        D.allreduce_sum_(self._abuf, self.pg)
+
+    def update_actor(self, eps=None):
+        """sac.py:189-197."""
+        self.actor_grad(eps)
+        self.actor_optimizer.step(self.actor_grads)
+
+    def update_alpha(self, eps=None):
+        """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
+        e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+        self.alpha_steps += 1
+        L = N.lib()
+        if self.world_size == 1:
+            N.check(L.mi_sac_alpha_step(
+                N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed,
+                self._key(self.actor_updates), self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v),
+                self.alpha_steps, self.alpha_lr, N.ptr(self.alpha), N.ptr(self.alpha_out), N.ptr(self.workspace), self._s()), "mi_sac_alpha_step")
+        else:
+            N.check(L.mi_sac_mean_logp(
+                N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed,
+                self._key(self.actor_updates), 1.0 / (self.batch_size * self.world_size), N.ptr(self._mean_logp), N.ptr(self.workspace), self._s()),
+                "mi_sac_mean_logp")
+            D.allreduce_sum_(self._mean_logp, self.pg)
+            N.check(L.mi_sac_alpha_adam(
+                N.ptr(self._mean_logp), self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v), self.alpha_steps,
+                self.alpha_lr, N.ptr(self.alpha), N.ptr(self.alpha_out), self._s()), "mi_sac_alpha_adam")
+        self.actor_updates += 1
+
+    def update_targets(self):
+        """sac.py:213-217 for both target critics in one launch."""
+        N.check(N.lib().mi_polyak(N.ptr(self.qt_flat), N.ptr(self.q_flat), self.q_flat.numel(), self.tau, self._s()), "mi_polyak")
+
+    def train_step(self, policy_frequency=2, target_network_frequency=1, indices=None):
+        """The optimisation half of one loop iteration (sac.py:161-217) at the current global_step."""
+        self.sample(indices)
+        self.update_critic()
+        if self.global_step % policy_frequency == 0:
+            for _ in range(policy_frequency):
+                self.update_actor()
+                self.update_alpha()
+        if self.global_step % target_network_frequency == 0:
+            self.update_targets()

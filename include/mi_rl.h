@@ -56,7 +56,7 @@ extern "C" {
 #define MI_N_ACTIONS 2
 
 enum { MI_OK = 0, MI_EINVAL = -1, MI_EHIP = -2, MI_ENOMEM = -3, MI_ESTATE = -4 };
-enum { MI_ENV_CARTPOLE_V1 = 0 };
+enum { MI_ENV_CARTPOLE_V1 = 0 };  /* MI_ENV_PENDULUM_V1 = 1: see the SAC section */
 
 typedef struct {
     int32_t env;   /* local env index */
@@ -180,6 +180,62 @@ int mi_dqn_td_grad(const float* params, const float* target_params, const float*
                    float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream);
 /* optimizer.step() (dqn.py:131-133) = mi_clip_adam(..., n = MI_DQN_NPARAMS, eps = 1e-8, max_norm = +inf);
  * target_network.load_state_dict (dqn.py:136-137) = a device-to-device copy of the flat vector by the caller. */
+
+/* =====================================================================================================================
+ * SAC (reference deep_rl/sac.py re-targeted to Pendulum-v1; SURVEY.md §8a s1-s8, BASELINE config 4).
+ * Env kind MI_ENV_PENDULUM_V1: obs f32 [N,3] = (cos th, sin th, th_dot), action f32 [N] (one dim, clipped to +-2), reward
+ * -(angle_normalize(th)^2 + .1 th_dot^2 + .001 u^2), never terminates, TimeLimit 200 (gym 0.21 pendulum.py, restated).
+ * SoftQNetwork (sac.py:29-43) cat(obs, act) 4 -> 256 -> 256 -> 1 ReLU: flat W1[256,4] b1 W2[256,256] b2 W3[1,256] b3 = MI_SAC_Q_NPARAMS;
+ * the two critics (and the two targets) are stored back to back: [2 * MI_SAC_Q_NPARAMS].
+ * Actor (sac.py:46-78) 3 -> 256 -> 256 ReLU, mean head, tanh-bounded log-std head: flat shared W1[256,3] b1 W2[256,256] b2,
+ * mean W[1,256] b, log_std W[1,256] b = MI_SAC_ACTOR_NPARAMS.  action = tanh(mean + std * eps) * 2.
+ * Replay ring as for DQN with observations [slots,N,3] and actions f32 [slots,N].  alpha lives on the device (f32 [1]) so that no
+ * update needs a host round trip.  eps arguments: standard-normal draws, dev f32 [batch]; NULL = keyed draws (Box-Muller on Philox
+ * stream 5, (env := call tag * 2^32 + update index, idx := row)).
+ * ===================================================================================================================== */
+#define MI_ENV_PENDULUM_V1 1
+#define MI_SAC_Q_NPARAMS 67329
+#define MI_SAC_ACTOR_NPARAMS 67330
+/* env.step for continuous actions (Pendulum): actions dev f32 [N]; forced_reset dev f64 [N,2]; obs dev f32 [N,3] */
+int mi_env_step_cont(void* handle, const float* actions, const double* forced_reset, float* obs, float* reward, uint8_t* done,
+                     uint8_t* truncated, float* fin_ret, int32_t* fin_len, void* stream);
+/* Actor.get_action (sac.py:65-78) on a batch: action / logp dev f32 [n] (logp nullable) */
+int mi_sac_actor_sample(const float* actor, const float* obs, const float* eps, int n, float* action, float* logp, void* stream);
+/* SoftQNetwork.forward (sac.py:40-43): out dev f32 [n] */
+int mi_sac_q_forward(const float* q, const float* obs, const float* act, int n, float* out, void* stream);
+/* one iteration of the acting half of the loop (sac.py:138-158) for the handle's N Pendulum envs: uniform random action while
+ * global_step < learning_starts (keyed), else actor.get_action; env.step with auto-reset; ring store. */
+int mi_sac_act_step(void* handle, const float* actor, int64_t global_step, int64_t slots, int64_t learning_starts, float* obs_cur,
+                    float* observations, float* actions, float* rewards, uint8_t* terminated, const float* forced_actions,
+                    const float* forced_eps, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
+                    void* stream);
+size_t mi_sac_workspace_bytes(int batch);
+/* critic update (sac.py:165-185): grads dev f32 [2*MI_SAC_Q_NPARAMS] of qf1_loss + qf2_loss, losses dev f32 [2] */
+int mi_sac_critic_grad(const float* q, const float* q_target, const float* actor, const float* observations, const float* actions,
+                       const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                       const float* eps, uint64_t seed, uint64_t update_index, const float* alpha, float gamma, double inv_count,
+                       void* workspace, float* grads, float* losses, void* stream);
+/* actor update (sac.py:193-197): grads dev f32 [MI_SAC_ACTOR_NPARAMS], out dev f32 [2] = {actor_loss, mean log_prob} */
+int mi_sac_actor_grad(const float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps,
+                      uint64_t seed, uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out,
+                      void* stream);
+/* alpha update (sac.py:203-210): fresh log-probs under the current actor, alpha_loss = mean(-log_alpha (logp + target_entropy)),
+ * one Adam step on log_alpha (dev f32 [1], moments dev f32 [1] each), alpha <- exp(log_alpha) (dev f32 [1]); out dev f32 [2] =
+ * {alpha_loss, d alpha_loss / d log_alpha} (nullable). */
+int mi_sac_alpha_step(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                      uint64_t update_index, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
+                      double lr, float* alpha, float* out, void* workspace, void* stream);
+/* the same in two halves for sharded runs (all-reduce *mean_logp between them): mean_logp dev f32 [1] = inv_count * sum of this rank's
+ * fresh log-probs; then the Adam step on log_alpha from the global mean. */
+int mi_sac_mean_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                     uint64_t update_index, double inv_count, float* mean_logp, void* workspace, void* stream);
+int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
+                      double lr, float* alpha, float* out, void* stream);
+/* optim.Adam.step without clipping (sac.py:108,117; torch single-tensor formula), any n */
+int mi_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1,
+            double beta2, double eps, void* stream);
+/* target <- tau * param + (1 - tau) * target (sac.py:213-217) */
+int mi_polyak(float* target, const float* param, int n, float tau, void* stream);
 
 /* ---- hardware self-test: probes the MFMA fragment layouts the update kernel relies on with exact
  * integer data; report dev i32 [16] (0 = ok per probe); dump (nullable) dev f32 [3*64*16] receives the raw

@@ -3,7 +3,7 @@
 import re, subprocess, sys, os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "..", "deep_rl_amd", "csrc")
-files = sys.argv[1:] or ["mi_env.hip", "mi_rollout.hip", "mi_update.hip"]
+files = sys.argv[1:] or ["mi_env.hip", "mi_rollout.hip", "mi_update.hip", "mi_dqn.hip", "mi_sac.hip"]
 for f in files:
     out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
                           "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(SRC, f), "-o", "/dev/null"],
