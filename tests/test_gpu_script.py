@@ -82,3 +82,42 @@ def test_dqn_script_vector_ring_runs():
     assert '"memory_size": 512' in out and "SHAPES [(512, 256, 4)" in out
     loss = float(out.split("LOSS")[1].split()[0])
     assert np.isfinite(loss) and loss > 0
+
+
+def _run_sac(env_over):
+    env = dict(os.environ, PYTHONPATH=ROOT, **env_over)
+    code = ("import runpy, json; g = runpy.run_module('deep_rl_amd.sac', run_name='__main__');"
+            "print('GLOBALS', json.dumps({k: g[k] for k in ['env_id','total_timesteps','learning_starts','policy_frequency','batch_size',"
+            "'target_network_frequency','gamma','tau','policy_lr','q_lr','alpha_lr','seed','global_step','num_envs','memory_size','target_entropy','alpha']}));"
+            "print('SHAPES', [tuple(g[k].shape) for k in ['observations','actions','rewards','terminated']]);"
+            "print('STEPS', g['q_optimizer'].step_count, g['actor_optimizer'].step_count, g['engine'].alpha_steps)")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def test_sac_script_reference_shape_n1():
+    """sac.py's surface at the reference's own shape (one env): globals, storage shapes, print format, update counts."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = _run_sac({"NUM_ENVS": "1", "TOTAL_TIMESTEPS": "3000"})
+    lines = [ln for ln in out.splitlines() if ln.startswith("global_step=")]
+    assert len(lines) == 15 and all(re.fullmatch(r"global_step=\d+, episodic_return=-\d+\.\d\d", ln) for ln in lines)  # sac.py:161
+    assert [int(ln.split(",")[0].split("=")[1]) for ln in lines] == list(range(200, 3001, 200))
+    assert '"env_id": "Pendulum-v1"' in out and '"learning_starts": 500' in out and '"global_step": 3000' in out and '"memory_size": 3001' in out
+    assert '"target_entropy": -1.0' in out and '"batch_size": 256' in out
+    assert "SHAPES [(3001, 1, 3), (3001, 1), (3001, 1), (3001, 1)]" in out
+    assert "STEPS 2501 2502 2502" in out    # one critic update per step from learning_starts on; 2 actor + 2 alpha updates every 2nd step
+    alpha = float(out.split('"alpha": ')[1].split("}")[0])
+    assert 0.0 < alpha < 1.0
+
+
+def test_sac_script_vector_ring_runs():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = _run_sac({"NUM_ENVS": "2048", "TOTAL_TIMESTEPS": "600", "MEMORY_SIZE": "128", "BATCH_SIZE": "1024", "LEARNING_STARTS": "50"})
+    assert '"memory_size": 128' in out and "SHAPES [(128, 2048, 3)" in out and "STEPS 551 552 552" in out
