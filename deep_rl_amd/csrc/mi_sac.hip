@@ -37,7 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SA_ACT_BIAS 0.0f
 #define STREAM_NORMAL 5u
 #define STREAM_UNIF_ACT 6u
-#define SR 8  // rows per workgroup
+#define SR 16  // rows per workgroup
 
 // ================================================ Pendulum env ==================================================================
 __global__ void __launch_bounds__(256) pend_reset_kernel(mi_env e, float* __restrict__ obs, const double* __restrict__ forced) {
@@ -112,15 +112,20 @@ extern "C" int mi_env_step_cont(void* handle, const float* actions, const double
 }
 
 // ================================================ row-group building blocks =====================================================
+// A 256-thread workgroup (4 waves) owns SR = 16 batch rows.  The 256 x 256 layers run on v_mfma_f32_16x16x4_f32 with
+//   A = the weight tile, streamed from L2 straight into registers (each weight element is needed by exactly one wave),
+//   B = the row group's activations, read from LDS ([row][unit], row stride LDW),
+//   D = [unit][row]: lane (row = lane & 15, g = lane >> 4) holds units 64 w + 16 t + 4 g + r of its row in acc[t][r],
+// wave w owning 64 output units.  The reduction index is consumed in the permuted order the float4 loads deliver (k-step s of a
+// 16-wide chunk pairs element s of lane group g, i.e. index 4 g + s, on both operands).  Thin layers (3/4 -> 256, the heads, bias
+// and thin weight gradients) are thread-per-unit VALU code on the same LDS images.
+#define LDW 260
 struct __attribute__((aligned(16))) sac_smem {
-    float x[SR][4];           // obs (3) + action
-    float xn[SR][4];          // next obs (3) + next action
-    float a1[SR][SA_H];       // activation buffers (post-ReLU), rows x units
-    float a2[SR][SA_H];
-    float s1[SR][SA_H];
-    float s2[SR][SA_H];
-    float red[4][SR][2];      // cross-wave partial sums
-    float rv[SR][16];         // per-row scalars
+    float b0[SR][LDW], b1[SR][LDW], b2[SR][LDW];   // activation images
+    float x[SR][4];            // obs (3) + action
+    float xn[SR][4];           // next obs (3) + next action
+    float red[4][SR][2];       // cross-wave partial sums
+    float rv[SR][16];          // per-row scalars
     long long cur[SR], nxt[SR];
 };
 
@@ -132,68 +137,135 @@ __device__ __forceinline__ float keyed_normal(uint64_t seed, uint64_t tag_update
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-// layer 1 of unit j for all rows: h[r][j] = relu(b[j] + W[j][:IN] . x[r][:IN])
+// pre-activation of layer 1, unit j, one row — ONE expression shared by every forward and by the backward's ReLU mask
 template <int IN>
-__device__ __forceinline__ void layer1(const float* __restrict__ W, const float* __restrict__ b, const float (*x)[4], float (*h)[SA_H], int j) {
+__device__ __forceinline__ float layer1_z(const float w[IN], float bj, const float* xr) {
+    float z = 0.0f;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) z = __builtin_fmaf(w[k], xr[k], z);
+    return z + bj;
+}
+
+// layer 1 of unit j = threadIdx.x for all rows: h[r][j] = relu(b[j] + W[j][:IN] . x[r][:IN])
+template <int IN>
+__device__ __forceinline__ void layer1(const float* __restrict__ W, const float* __restrict__ b, const float (*x)[4], float (*h)[LDW]) {
+    const int j = threadIdx.x;
     float w[IN];
 #pragma unroll
     for (int k = 0; k < IN; ++k) w[k] = W[j * IN + k];
     const float bj = b[j];
 #pragma unroll
-    for (int r = 0; r < SR; ++r) {
-        float z = 0.0f;
-#pragma unroll
-        for (int k = 0; k < IN; ++k) z = __builtin_fmaf(w[k], x[r][k], z);
-        h[r][j] = fmaxf(z + bj, 0.0f);
-    }
+    for (int r = 0; r < SR; ++r) h[r][j] = fmaxf(layer1_z<IN>(w, bj, x[r]), 0.0f);
 }
 
-// layer 2 of unit j for all rows: out[r][j] = relu(b[j] + W[j][:] . in[r][:]); W row j streamed as float4 (1 KB contiguous per thread)
-__device__ __forceinline__ void layer2(const float* __restrict__ W, const float* __restrict__ b, const float (*in)[SA_H], float (*out)[SA_H], int j) {
-    float acc[SR];
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define L2_STAGES 8       // 256 reduction indices in stages of 32
+#define L2_AHEAD 2        // stages of weights in flight ahead of the MFMAs
+
+// forward through a 256 x 256 layer: acc[t][r] (lane row i, group g) = sum_k W[64 w + 16 t + 4 g + r][k] * in[i][k]
+__device__ __forceinline__ void mfma_fwd(const float* __restrict__ W, const float (*in)[LDW], f32x4 acc[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const float* wp = W + (size_t)(64 * w + i) * SA_H + 4 * g;
+    const float* bp = &in[i][4 * g];
+    float4 wb[L2_AHEAD + 1][8];
 #pragma unroll
-    for (int r = 0; r < SR; ++r) acc[r] = 0.0f;
-    const float4* wrow = reinterpret_cast<const float4*>(W + (size_t)j * SA_H);
-#pragma unroll 4
-    for (int k4 = 0; k4 < SA_H / 4; ++k4) {
-        const float4 w = wrow[k4];
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            const float4 hv = *reinterpret_cast<const float4*>(&in[r][4 * k4]);
-            acc[r] = __builtin_fmaf(w.x, hv.x, acc[r]); acc[r] = __builtin_fmaf(w.y, hv.y, acc[r]);
-            acc[r] = __builtin_fmaf(w.z, hv.z, acc[r]); acc[r] = __builtin_fmaf(w.w, hv.w, acc[r]);
+    for (int st = 0; st < L2_AHEAD; ++st)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) wb[st][2 * t + h] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * SA_H + st * 32 + h * 16);
+#pragma unroll
+    for (int st = 0; st < L2_STAGES; ++st) {
+        if (st + L2_AHEAD < L2_STAGES) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    wb[(st + L2_AHEAD) % (L2_AHEAD + 1)][2 * t + h] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * SA_H + (st + L2_AHEAD) * 32 + h * 16);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 b = *reinterpret_cast<const float4*>(bp + st * 32 + h * 16);
+            const float4* a = &wb[st % (L2_AHEAD + 1)][0];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].x, b.x, acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].y, b.y, acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].z, b.z, acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].w, b.w, acc[t]);
         }
     }
-    const float bj = b[j];
-#pragma unroll
-    for (int r = 0; r < SR; ++r) out[r][j] = fmaxf(acc[r] + bj, 0.0f);
 }
 
-// backward-data through layer 2: dh[r] (for input unit k = this thread) = sum_j W[j][k] * dz[r][j]   (column k: coalesced over threads)
-__device__ __forceinline__ void layer2_bwd(const float* __restrict__ W, const float (*dz)[SA_H], float dh[SR], int k) {
+// backward-data through the same layer: acc[t][r] = sum_j W[j][64 w + 16 t + 4 g + r] * in[i][j]   (in = dZ of the layer's outputs)
+__device__ __forceinline__ void mfma_bwd(const float* __restrict__ W, const float (*in)[LDW], f32x4 acc[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const float* wp = W + (size_t)(4 * g) * SA_H + 64 * w + i;     // A lane (i, g), k-step s of chunk c: W[16 c + 4 g + s][64 w + 16 t + i]
+    const float* bp = &in[i][4 * g];
+    float wb[L2_AHEAD + 1][32];                                     // [h][s][t]
 #pragma unroll
-    for (int r = 0; r < SR; ++r) dh[r] = 0.0f;
-#pragma unroll 4
-    for (int j4 = 0; j4 < SA_H / 4; ++j4) {
-        const float w0 = W[(size_t)(4 * j4 + 0) * SA_H + k], w1 = W[(size_t)(4 * j4 + 1) * SA_H + k];
-        const float w2 = W[(size_t)(4 * j4 + 2) * SA_H + k], w3 = W[(size_t)(4 * j4 + 3) * SA_H + k];
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            const float4 d = *reinterpret_cast<const float4*>(&dz[r][4 * j4]);
-            dh[r] = __builtin_fmaf(w0, d.x, dh[r]); dh[r] = __builtin_fmaf(w1, d.y, dh[r]);
-            dh[r] = __builtin_fmaf(w2, d.z, dh[r]); dh[r] = __builtin_fmaf(w3, d.w, dh[r]);
+    for (int st = 0; st < L2_AHEAD; ++st)
+#pragma unroll
+        for (int hs = 0; hs < 8; ++hs)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wb[st][4 * hs + t] = wp[(size_t)(st * 32 + (hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
+#pragma unroll
+    for (int st = 0; st < L2_STAGES; ++st) {
+        if (st + L2_AHEAD < L2_STAGES) {
+#pragma unroll
+            for (int hs = 0; hs < 8; ++hs)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    wb[(st + L2_AHEAD) % (L2_AHEAD + 1)][4 * hs + t] = wp[(size_t)((st + L2_AHEAD) * 32 + (hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 b = *reinterpret_cast<const float4*>(bp + st * 32 + h * 16);
+            const float* a = &wb[st % (L2_AHEAD + 1)][16 * h];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[0 + t], b.x, acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[4 + t], b.y, acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[8 + t], b.z, acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[12 + t], b.w, acc[t]);
         }
     }
 }
 
-// sum over the 256 threads of v0[r], v1[r] for every row; result readable by everyone in sm.rv[r][slot0], [slot1] after the call
-__device__ __forceinline__ void block_rowsum2(sac_smem& sm, const float v0[SR], const float v1[SR], int slot0, int slot1) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// acc <- relu(acc + bias) in the D layout
+__device__ __forceinline__ void relu_bias(f32x4 acc[4], const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < SR; ++r) {
-        const float a = wave_sum_uniform(v0[r]), b = wave_sum_uniform(v1[r]);
-        if (lane == 0) { sm.red[wave][r][0] = a; sm.red[wave][r][1] = b; }
-    }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r] + bias[64 * w + 16 * t + 4 * g + r], 0.0f);
+}
+
+// this wave's share of a 256 -> 1 head for the lane's row (valid in every lane after the two cross-group exchanges)
+__device__ __forceinline__ float head_partial(const f32x4 acc[4], const float* __restrict__ wh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
+    float p = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p = __builtin_fmaf(wh[64 * w + 16 * t + 4 * g + r], acc[t][r], p);
+    p += __shfl_xor(p, 16);
+    p += __shfl_xor(p, 32);
+    return p;
+}
+
+// combine the four waves' per-row partials (fixed order): result in sm.rv[row][slot0 / slot1], visible to all threads on return
+__device__ __forceinline__ void rows_combine2(sac_smem& sm, float p0, float p1, int slot0, int slot1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < SR) { sm.red[w][lane][0] = p0; sm.red[w][lane][1] = p1; }
     __syncthreads();
     if (threadIdx.x < SR) {
         const int r = threadIdx.x;
@@ -203,33 +275,32 @@ __device__ __forceinline__ void block_rowsum2(sac_smem& sm, const float v0[SR], 
     __syncthreads();
 }
 
-// SoftQNetwork forward on the rows of `x` (obs + action): activations -> h1, h2; q[r] -> sm.rv[r][slot]
-__device__ __forceinline__ void q_forward(sac_smem& sm, const float* __restrict__ p, const float (*x)[4], float (*h1)[SA_H], float (*h2)[SA_H], int slot) {
-    const int j = threadIdx.x;
-    layer1<4>(p + SQ_W1, p + SQ_B1, x, h1, j);
-    __syncthreads();
-    layer2(p + SQ_W2, p + SQ_B2, h1, h2, j);
-    float v[SR], zero[SR];
-    const float w3 = p[SQ_W3 + j];
+// D layout -> LDS image [row][unit]
+__device__ __forceinline__ void store_acc(const f32x4 acc[4], float (*out)[LDW]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < SR; ++r) { v[r] = w3 * h2[r][j]; zero[r] = 0.0f; }
-    block_rowsum2(sm, v, zero, slot, 15);
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&out[i][64 * w + 16 * t + 4 * g]) = acc[t];
+}
+
+// SoftQNetwork forward on the rows of `x` (obs + action): h1 -> `h1` image, relu(h2) left in acc, q[r] -> sm.rv[r][slot]
+__device__ __forceinline__ void q_forward(sac_smem& sm, const float* __restrict__ p, const float (*x)[4], float (*h1)[LDW], f32x4 acc[4], int slot) {
+    layer1<4>(p + SQ_W1, p + SQ_B1, x, h1);
+    __syncthreads();
+    mfma_fwd(p + SQ_W2, h1, acc);
+    relu_bias(acc, p + SQ_B2);
+    rows_combine2(sm, head_partial(acc, p + SQ_W3), 0.0f, slot, 15);
     if (threadIdx.x < SR) sm.rv[threadIdx.x][slot] += p[SQ_B3];
     __syncthreads();
 }
 
-// rv slots used by the actor: 0 mean, 1 sraw, 2 ls, 3 sd, 4 u, 5 logp, 6 action, 7 eps
-__device__ __forceinline__ void actor_forward(sac_smem& sm, const float* __restrict__ p, const float (*x)[4], float (*h1)[SA_H], float (*h2)[SA_H],
+// rv slots used by the actor: 0 mean, 1 sraw, 2 ls, 3 sd, 4 u, 5 logp, 6 action, 7 eps.   relu(h2) left in acc, h1 in `h1`.
+__device__ __forceinline__ void actor_forward(sac_smem& sm, const float* __restrict__ p, const float (*x)[4], float (*h1)[LDW], f32x4 acc[4],
                                               const float eps_row /*valid in threads < SR*/) {
-    const int j = threadIdx.x;
-    layer1<3>(p + AC_W1, p + AC_B1, x, h1, j);
+    layer1<3>(p + AC_W1, p + AC_B1, x, h1);
     __syncthreads();
-    layer2(p + AC_W2, p + AC_B2, h1, h2, j);
-    float vm[SR], vl[SR];
-    const float wm = p[AC_WM + j], wl = p[AC_WL + j];
-#pragma unroll
-    for (int r = 0; r < SR; ++r) { vm[r] = wm * h2[r][j]; vl[r] = wl * h2[r][j]; }
-    block_rowsum2(sm, vm, vl, 0, 1);
+    mfma_fwd(p + AC_W2, h1, acc);
+    relu_bias(acc, p + AC_B2);
+    rows_combine2(sm, head_partial(acc, p + AC_WM), head_partial(acc, p + AC_WL), 0, 1);
     if (threadIdx.x < SR) {
         const int r = threadIdx.x;
         const float mean = sm.rv[r][0] + p[AC_BM], sraw = sm.rv[r][1] + p[AC_BL];
@@ -256,7 +327,8 @@ __global__ void __launch_bounds__(256) sac_actor_sample_kernel(const float* __re
     __syncthreads();
     float e = 0.0f;
     if (threadIdx.x < SR) e = eps[row0 + threadIdx.x < n ? row0 + threadIdx.x : n - 1];
-    actor_forward(sm, actor, sm.x, sm.a1, sm.a2, e);
+    f32x4 acc[4];
+    actor_forward(sm, actor, sm.x, sm.b0, acc, e);
     if (threadIdx.x < SR && row0 + threadIdx.x < n) { action[row0 + threadIdx.x] = sm.rv[threadIdx.x][6]; if (logp) logp[row0 + threadIdx.x] = sm.rv[threadIdx.x][5]; }
 }
 
@@ -276,7 +348,8 @@ __global__ void __launch_bounds__(256) sac_q_forward_kernel(const float* __restr
         sm.x[r][k] = k < 3 ? obs[3 * (size_t)b + k] : act[b];
     }
     __syncthreads();
-    q_forward(sm, q, sm.x, sm.s1, sm.s2, 8);
+    f32x4 acc[4];
+    q_forward(sm, q, sm.x, sm.b0, acc, 8);
     if (threadIdx.x < SR && row0 + threadIdx.x < n) out[row0 + threadIdx.x] = sm.rv[threadIdx.x][8];
 }
 
@@ -295,7 +368,7 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
                mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep) {
     __shared__ sac_smem sm;
     const int N = e.n, row0 = blockIdx.x * SR;
-    const bool policy = !forced_actions && global_step >= learning_starts;   // wave/block-uniform
+    const bool policy = !forced_actions && global_step >= learning_starts;   // block-uniform
     if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
     __syncthreads();
     if (policy) {
@@ -304,7 +377,8 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
             const int g = row0 + threadIdx.x < N ? row0 + threadIdx.x : N - 1;
             eps = forced_eps ? forced_eps[g] : keyed_normal(e.seed, (1ull << 40) + e.env_id_base + (uint64_t)g, (uint64_t)global_step);
         }
-        actor_forward(sm, actor, sm.x, sm.a1, sm.a2, eps);
+        f32x4 acc[4];
+        actor_forward(sm, actor, sm.x, sm.b0, acc, eps);
     }
     if (threadIdx.x < SR && row0 + threadIdx.x < N) {
         const int g = row0 + threadIdx.x;
@@ -356,12 +430,21 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 }
 
 // ================================================ workspace layout ==============================================================
-// [H1 mats: 3 x batch x 256][DZ2 mats: 3 x batch x 256][slabs: nblocks x SLAB]   (mats 0,1: critics; 2: actor)
+// Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536]
+// (mats 0,1: critics; 2: actor)
 #define SLAB 3600
-__host__ __device__ inline size_t ws_mat_floats(int batch) { return (size_t)batch * SA_H; }
+#define GEMM_MAX_SPLIT 16
+__host__ __device__ inline int ws_kp(int batch) { return (batch + SR - 1) / SR * SR; }
+__host__ __device__ inline size_t ws_mat_floats(int batch) { return (size_t)ws_kp(batch) * SA_H; }
+__host__ __device__ inline size_t ws_slab_off(int batch) { return 6 * ws_mat_floats(batch); }
+__host__ __device__ inline size_t ws_part_off(int batch) { return ws_slab_off(batch) + (size_t)(ws_kp(batch) / SR) * SLAB; }
 extern "C" size_t mi_sac_workspace_bytes(int batch) {
-    const size_t nb = (size_t)(batch + SR - 1) / SR;
-    return (6 * ws_mat_floats(batch) + nb * SLAB) * sizeof(float);
+    if (batch <= 0) return 0;
+    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H) * sizeof(float);
+}
+static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >= 32 batch rows, the grid covers the rest
+    int s = ws_kp(batch) / 128;
+    return s < 1 ? 1 : (s > GEMM_MAX_SPLIT ? GEMM_MAX_SPLIT : s);
 }
 
 // ================================================ critic update =================================================================
@@ -373,8 +456,10 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
                   const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
-    float* H1 = ws; float* DZ2 = ws + 3 * ws_mat_floats(batch);
-    float* slab = ws + 6 * ws_mat_floats(batch) + (size_t)blockIdx.x * SLAB;
+    const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
+    const size_t matf = ws_mat_floats(batch);
+    float* H1 = ws; float* DZ2 = ws + 3 * matf;
+    float* slab = ws + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
     if (t < SR) {
         const int b = row0 + t < batch ? row0 + t : batch - 1;
         const long long i = idx[b];
@@ -387,17 +472,18 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         sm.xn[r][k] = k < 3 ? observations[3 * sm.nxt[r] + k] : 0.0f;
     }
     __syncthreads();
+    f32x4 acc[4];
     // ---- next action + log-prob under the current actor (no grad; sac.py:172) ----
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
-    actor_forward(sm, actor, sm.xn, sm.a1, sm.a2, e_row);
+    actor_forward(sm, actor, sm.xn, sm.b0, acc, e_row);
     if (t < SR) { sm.xn[t][3] = sm.rv[t][6]; sm.rv[t][9] = sm.rv[t][5]; }   // a', log pi(a'|s')
     __syncthreads();
     // ---- target critics (:173-174) ----
-    q_forward(sm, qt, sm.xn, sm.s1, sm.s2, 8);
+    q_forward(sm, qt, sm.xn, sm.b0, acc, 8);
     if (t < SR) sm.rv[t][10] = sm.rv[t][8];
     __syncthreads();
-    q_forward(sm, qt + SQ_NP, sm.xn, sm.s1, sm.s2, 8);
+    q_forward(sm, qt + SQ_NP, sm.xn, sm.b0, acc, 8);
     if (t < SR) {
         const float alpha = alpha_p[0];
         const float mq = fminf(sm.rv[t][10], sm.rv[t][8]) - alpha * sm.rv[t][9];                                   // :176
@@ -405,39 +491,58 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     }
     __syncthreads();
     // ---- the two critics on (obs, action): forward, loss, backward (:179-185) ----
+#pragma unroll 1
     for (int net = 0; net < 2; ++net) {
         const float* p = q + (size_t)net * SQ_NP;
         float* sl = slab + net * 1793;
-        q_forward(sm, p, sm.x, sm.s1, sm.s2, 8);
+        q_forward(sm, p, sm.x, sm.b0, acc, 8);          // h1 -> b0, relu(h2) in acc
         if (t < SR) {
             const bool valid = row0 + t < batch;
             const float d = valid ? sm.rv[t][8] - sm.rv[t][10] : 0.0f;
-            sm.rv[t][9] = d * d;          // loss contribution
+            sm.rv[t][9] = d * d;           // loss contribution
             sm.rv[t][8] = 2.0f * d * invn; // d loss / d q
         }
         __syncthreads();
-        {   // unit j = t: dz2, thin gradients of layer 3 / bias 2, H1 / DZ2 rows for the GEMM
-            const float w3 = p[SQ_W3 + t];
+        {   // dz2 in the D layout: h2 image -> b2, dz2 image -> b1 and the GEMM operand in the workspace
+            const float dq = sm.rv[li][8];
+            store_acc(acc, sm.b2);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int u = 64 * wv + 16 * tt + 4 * lg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tt][r] = acc[tt][r] > 0.0f ? p[SQ_W3 + u + r] * dq : 0.0f;
+                *reinterpret_cast<f32x4*>(&DZ2[((size_t)net * ws_kp(batch) + row0 + li) * SA_H + u]) = acc[tt];
+            }
+            store_acc(acc, sm.b1);
+        }
+        __syncthreads();
+        {   // unit j = t: thin gradients of layer 3 / bias 2, H1 rows for the GEMM
             float gw3 = 0.0f, gb2 = 0.0f;
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
-                const float h2 = sm.s2[r][t], dq = sm.rv[r][8];
-                const float dz = h2 > 0.0f ? w3 * dq : 0.0f;
-                gw3 = __builtin_fmaf(dq, h2, gw3); gb2 += dz;
-                if (row0 + r < batch) { DZ2[((size_t)net * batch + row0 + r) * SA_H + t] = dz; H1[((size_t)net * batch + row0 + r) * SA_H + t] = sm.s1[r][t]; }
-                sm.s2[r][t] = dz;
+                gw3 = __builtin_fmaf(sm.rv[r][8], sm.b2[r][t], gw3); gb2 += sm.b1[r][t];
+                H1[((size_t)net * ws_kp(batch) + row0 + r) * SA_H + t] = sm.b0[r][t];
             }
             sl[1024 + 256 + t] = gb2; sl[1024 + 512 + t] = gw3;
             if (t == 0) { float gb3 = 0.0f, l = 0.0f; for (int r = 0; r < SR; ++r) { gb3 += sm.rv[r][8]; l += sm.rv[r][9]; } sl[1792] = gb3; slab[3586 + net] = l; }
         }
+        mfma_bwd(p + SQ_W2, sm.b1, acc);                // dh1 in the D layout
+        {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][64 * wv + 16 * tt + 4 * lg]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
+            }
+        }
+        __syncthreads();                                 // every thread is done reading b2 (h2)
+        store_acc(acc, sm.b2);                           // dz1 image
         __syncthreads();
-        {   // input unit k = t: dh1 -> dz1 -> thin gradients of layer 1
-            float dh[SR];
-            layer2_bwd(p + SQ_W2, sm.s2, dh, t);
+        {   // input unit k = t: thin gradients of layer 1
             float gb1 = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
-                const float d = sm.s1[r][t] > 0.0f ? dh[r] : 0.0f;
+                const float d = sm.b2[r][t];
                 gb1 += d;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) gw[c] = __builtin_fmaf(d, sm.x[r][c], gw[c]);
@@ -451,73 +556,90 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
 
 // ================================================ actor update ==================================================================
 // slab layout (actor): W1 768 | b1 256 | b2 256 | Wm 256 | bm 1 | Wl 256 | bl 1 | [1794] sum(alpha*logp - minq) | [1795] sum logp
+// d(-min Q)/d action of one critic for the lane's row: this wave's share (summed over lane groups), from dh1 in the D layout
+__device__ __forceinline__ float q_daction_partial(const sac_smem& sm, const float* __restrict__ p, const f32x4 acc[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    float v = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 64 * w + 16 * t + 4 * g + r;
+            const float4 w1 = *reinterpret_cast<const float4*>(p + SQ_W1 + 4 * k);
+            const float wk[4] = {w1.x, w1.y, w1.z, w1.w};
+            const float z1 = layer1_z<4>(wk, p[SQ_B1 + k], sm.x[i]);      // the forward's own expression => the forward's own mask
+            v += z1 > 0.0f ? w1.w * acc[t][r] : 0.0f;
+        }
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, const float* __restrict__ observations, const int64_t* __restrict__ idx,
                  int batch, const float* __restrict__ eps, uint64_t seed, uint64_t update, const float* __restrict__ alpha_p, float invn,
                  float* __restrict__ ws, int logp_only) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
-    float* H1 = ws + 2 * ws_mat_floats(batch); float* DZ2 = ws + 5 * ws_mat_floats(batch);
-    float* slab = ws + 6 * ws_mat_floats(batch) + (size_t)blockIdx.x * SLAB;
+    const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
+    const size_t matf = ws_mat_floats(batch);
+    float* H1 = ws + 2 * matf; float* DZ2 = ws + 5 * matf;
+    float* slab = ws + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
     if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; sm.x[r][k] = observations[3 * idx[b] + k]; }
     __syncthreads();
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, ((logp_only ? 4ull : 3ull) << 40) + update, (uint64_t)b); }
-    actor_forward(sm, actor, sm.x, sm.a1, sm.a2, e_row);
+    f32x4 acc[4], acc1[4], acc2[4];
+    actor_forward(sm, actor, sm.x, sm.b0, acc, e_row);           // h1 -> b0 (kept), relu(h2) in acc
     if (logp_only) {   // sac.py:203-204
         if (t == 0) { float s = 0.0f; for (int r = 0; r < SR; ++r) s += row0 + r < batch ? sm.rv[r][5] : 0.0f; slab[1795] = s; slab[1794] = 0.0f; }
         return;
     }
+    store_acc(acc, sm.b1);                                       // actor h2 image, kept until the actor's backward
     const float alpha = alpha_p[0];
     if (t < SR) sm.x[t][3] = sm.rv[t][6];   // the action enters the critics
     __syncthreads();
-    // ---- min(Q1, Q2)(obs, pi(obs)) and d(-min Q)/d action (:194-196) ----
-    q_forward(sm, q, sm.x, sm.s1, sm.s2, 8);
+    // ---- min(Q1, Q2)(obs, pi(obs)) (:194-196); both critics' relu(h2) stay in registers for the backward ----
+    q_forward(sm, q, sm.x, sm.b2, acc1, 8);
     if (t < SR) sm.rv[t][10] = sm.rv[t][8];
     __syncthreads();
-    q_forward(sm, q + SQ_NP, sm.x, sm.s1, sm.s2, 8);
+    q_forward(sm, q + SQ_NP, sm.x, sm.b2, acc2, 8);
     if (t < SR) {
         const float q1 = sm.rv[t][10], q2 = sm.rv[t][8];
         const bool valid = row0 + t < batch;
         sm.rv[t][9] = valid ? alpha * sm.rv[t][5] - fminf(q1, q2) : 0.0f;                    // loss term (:197)
         // torch.min routes the gradient to the smaller input, half / half on ties
         sm.rv[t][10] = !valid ? 0.0f : q1 < q2 ? 1.0f : (q2 < q1 ? 0.0f : 0.5f);               // weight of critic 1
-        sm.rv[t][11] = 0.0f;                                                                 // d loss / d action accumulator
+        sm.rv[t][12] = !valid ? 0.0f : q2 < q1 ? 1.0f : (q1 < q2 ? 0.0f : 0.5f);               // weight of critic 2
     }
     __syncthreads();
-    // net 1 first (its activations are still live in s1 / s2), then net 0 is recomputed
-    for (int pass = 0; pass < 2; ++pass) {
-        const int net = pass == 0 ? 1 : 0;
+    // ---- d(-min Q)/d action through both critics ----
+    float da_part[2];
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
         const float* p = q + (size_t)net * SQ_NP;
-        if (pass == 1) q_forward(sm, p, sm.x, sm.s1, sm.s2, 8);
-        {
-            const float w3 = p[SQ_W3 + t];
+        const float dq = -invn * sm.rv[li][net == 0 ? 10 : 12];
 #pragma unroll
-            for (int r = 0; r < SR; ++r) {
-                const float wgt = net == 0 ? sm.rv[r][10] : (row0 + r < batch ? 1.0f - sm.rv[r][10] : 0.0f);
-                const float dq = -invn * wgt;
-                sm.s2[r][t] = sm.s2[r][t] > 0.0f ? w3 * dq : 0.0f;
-            }
-        }
-        __syncthreads();
-        {
-            float dh[SR], v[SR], zero[SR];
-            layer2_bwd(p + SQ_W2, sm.s2, dh, t);
-            const float w13 = p[SQ_W1 + 4 * t + 3];
+        for (int tt = 0; tt < 4; ++tt) {
+            const int u = 64 * wv + 16 * tt + 4 * lg;
 #pragma unroll
-            for (int r = 0; r < SR; ++r) { v[r] = sm.s1[r][t] > 0.0f ? w13 * dh[r] : 0.0f; zero[r] = 0.0f; }
-            block_rowsum2(sm, v, zero, 8, 15);
-            if (t < SR) { sm.rv[t][11] += sm.rv[t][8]; }
+            for (int r = 0; r < 4; ++r) acc[tt][r] = (net == 0 ? acc1[tt][r] : acc2[tt][r]) > 0.0f ? p[SQ_W3 + u + r] * dq : 0.0f;
         }
+        if (net == 1) __syncthreads();                          // net 0's MFMA pass is done reading b2
+        store_acc(acc, sm.b2);
         __syncthreads();
+        mfma_bwd(p + SQ_W2, sm.b2, acc);
+        da_part[net] = q_daction_partial(sm, p, acc);
     }
+    rows_combine2(sm, da_part[0], da_part[1], 8, 11);
     // ---- d loss / d mean, d loss / d sraw per row ----
     if (t < SR) {
         const float u = sm.rv[t][4], sd = sm.rv[t][3], ls = sm.rv[t][2];
         const float omu2 = 1.0f - u * u;
         const bool valid = row0 + t < batch;
         const float c = valid ? invn : 0.0f;
-        const float du = SA_ACT_SCALE * sm.rv[t][11] + alpha * c * (2.0f * SA_ACT_SCALE * u) / (SA_ACT_SCALE * omu2 + 1e-6f);
+        const float dqa = sm.rv[t][8] + sm.rv[t][11];
+        const float du = SA_ACT_SCALE * dqa + alpha * c * (2.0f * SA_ACT_SCALE * u) / (SA_ACT_SCALE * omu2 + 1e-6f);
         const float dz_u = du * omu2;
         const float dL = dz_u * e_row * sd - alpha * c;
         sm.rv[t][0] = dz_u;                                                                          // d / d mean
@@ -529,11 +651,11 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         float gwm = 0.0f, gwl = 0.0f, gb2 = 0.0f;
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
-            const float h2 = sm.a2[r][t], dm = sm.rv[r][0], ds = sm.rv[r][1];
+            const float h2 = sm.b1[r][t], dm = sm.rv[r][0], ds = sm.rv[r][1];
             const float dz = h2 > 0.0f ? __builtin_fmaf(wl, ds, wm * dm) : 0.0f;
             gwm = __builtin_fmaf(dm, h2, gwm); gwl = __builtin_fmaf(ds, h2, gwl); gb2 += dz;
-            if (row0 + r < batch) { DZ2[(size_t)(row0 + r) * SA_H + t] = dz; H1[(size_t)(row0 + r) * SA_H + t] = sm.a1[r][t]; }
-            sm.a2[r][t] = dz;
+            DZ2[(size_t)(row0 + r) * SA_H + t] = dz; H1[(size_t)(row0 + r) * SA_H + t] = sm.b0[r][t];
+            sm.b2[r][t] = dz;
         }
         slab[768 + 256 + t] = gb2; slab[768 + 512 + t] = gwm; slab[768 + 512 + 257 + t] = gwl;
         if (t == 0) {
@@ -543,13 +665,20 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         }
     }
     __syncthreads();
+    mfma_bwd(actor + AC_W2, sm.b2, acc);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][64 * wv + 16 * tt + 4 * lg]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
+    }
+    store_acc(acc, sm.b1);                                       // dz1 image (the h2 image was last read before the previous barrier)
+    __syncthreads();
     {
-        float dh[SR];
-        layer2_bwd(actor + AC_W2, sm.a2, dh, t);
         float gb1 = 0.0f, gw[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
-            const float d = sm.a1[r][t] > 0.0f ? dh[r] : 0.0f;
+            const float d = sm.b1[r][t];
             gb1 += d;
 #pragma unroll
             for (int c = 0; c < 3; ++c) gw[c] = __builtin_fmaf(d, sm.x[r][c], gw[c]);
@@ -560,63 +689,118 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
 }
 
 // ================================================ dW2 = dZ2^T H1 on the f32 MFMA ================================================
-// One wave per 16 x 64 strip of the 256 x 256 output (A fragment shared by 4 column tiles), K = batch rows.
-// v_mfma_f32_16x16x4_f32: A lane (i = lane&15, g = lane>>4) = dZ2[row 4s+g][16mt + i], B lane = H1[row 4s+g][16nt + i];
-// D lane (j = lane&15, g), reg r = dW2[16mt + 4g + r][16nt + j].
-__global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(const float* __restrict__ ws, int batch, int mat0, int n_mats, float* __restrict__ grads,
-                                                           int grads_stride, int w2_off) {
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const int strips = 16 * 4;                  // 16 row tiles x 4 column groups of 64
-    const int mat = wave / strips, st = wave % strips;
-    if (mat >= n_mats) return;
-    const int mt = st >> 2, ng = st & 3, i = lane & 15, g = lane >> 4;
-    const float* H1 = ws + (size_t)(mat0 + mat) * ws_mat_floats(batch);
-    const float* DZ2 = ws + (size_t)(3 + mat0 + mat) * ws_mat_floats(batch);
-    f32x4 acc[4];
+// Workgroup = one 32 x 64 tile of one 256 x 256 weight gradient over one K-range of the (padded) batch; its 4 waves split that range
+// and are summed through LDS in wave order.  Per k-step (4 batch rows) a lane loads one float2 of dZ2 and one float4 of H1 and
+// issues 8 MFMAs; the element -> tile assignment follows the vector loads (A element e: row 32 mg + 2 i + e, B element e: column
+// 64 ng + 4 j + e), so the results leave as float4 stores.  Output: partial [blockIdx.y][mat][256*256] in the workspace.
+__global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(float* __restrict__ ws, int batch, int mat0, int n_mats) {
+    __shared__ f32x4 red[3][8][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x & 31, mat = blockIdx.x >> 5, mg = tile >> 2, ng = tile & 3;
+    const int Kp = ws_kp(batch), steps = Kp / 4, slices = 4 * gridDim.y, slice = 4 * blockIdx.y + w;
+    const int s0 = (int)((long long)steps * slice / slices), s1 = (int)((long long)steps * (slice + 1) / slices);
+    const float* H1 = ws + (size_t)(mat0 + mat) * ws_mat_floats(batch) + 64 * ng + 4 * j;
+    const float* DZ2 = ws + (size_t)(3 + mat0 + mat) * ws_mat_floats(batch) + 32 * mg + 2 * j;
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < batch / 4; ++s) {
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+        float2 av[4]; float4 bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t row = (size_t)(4 * (s + u) + g) * SA_H;
+            av[u] = *reinterpret_cast<const float2*>(DZ2 + row); bv[u] = *reinterpret_cast<const float4*>(H1 + row);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float a2[2] = {av[u].x, av[u].y}; const float b4[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = MFMA16(a2[a], b4[b], acc[a][b]);
+        }
+    }
+    for (; s < s1; ++s) {
         const size_t row = (size_t)(4 * s + g) * SA_H;
-        const float a = DZ2[row + 16 * mt + i];
+        const float2 av = *reinterpret_cast<const float2*>(DZ2 + row); const float4 bv = *reinterpret_cast<const float4*>(H1 + row);
+        const float a2[2] = {av.x, av.y}; const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, H1[row + 64 * ng + 16 * n + i], acc[n], 0, 0, 0);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = MFMA16(a2[a], b4[b], acc[a][b]);
     }
-    float* out = grads + (size_t)mat * grads_stride + w2_off;
+    if (w > 0) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * SA_H + 64 * ng + 16 * n + i] = acc[n][r];
-}
-
-// thin gradients: sum the slabs in slab order and scatter into the flat gradient; block.y selects the net
-__global__ void __launch_bounds__(256) sac_small_reduce_kernel(const float* __restrict__ ws, int batch, int n_slabs, int is_actor, double inv_count,
-                                                               float* __restrict__ grads, float* __restrict__ out2) {
-    const float* slabs = ws + 6 * ws_mat_floats(batch);
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int per = is_actor ? 1794 : 1793, nets = is_actor ? 1 : 2;
-    if (e < per * nets) {
-        const int net = e / per, l = e % per;
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int b = 0; b < n_slabs; ++b) acc[b & 3] += slabs[(size_t)b * SLAB + net * 1793 + l];
-        const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        int dst;
-        if (is_actor) dst = l < 768 ? AC_W1 + l : l < 1024 ? AC_B1 + (l - 768) : l < 1280 ? AC_B2 + (l - 1024) : l < 1536 ? AC_WM + (l - 1280)
-                          : l == 1536 ? AC_BM : l < 1793 ? AC_WL + (l - 1537) : AC_BL;
-        else dst = net * SQ_NP + (l < 1024 ? SQ_W1 + l : l < 1280 ? SQ_B1 + (l - 1024) : l < 1536 ? SQ_B2 + (l - 1280) : l < 1792 ? SQ_W3 + (l - 1536) : SQ_B3);
-        grads[dst] = v;
-    } else if (e < per * nets + 2 && out2) {
-        const int k = e - per * nets;
-        double s = 0.0;
-        const int off = is_actor ? 1794 + k : 3586 + k;
-        for (int b = 0; b < n_slabs; ++b) s += slabs[(size_t)b * SLAB + off];
-        out2[k] = (float)(s * inv_count);
+            for (int b = 0; b < 4; ++b) red[w - 1][4 * a + b][lane] = acc[a][b];
+    }
+    __syncthreads();
+    if (w == 0) {
+        float* out = ws + ws_part_off(batch) + ((size_t)blockIdx.y * 3 + mat) * SA_H * SA_H;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = ((acc[a][b] + red[0][4 * a + b][lane]) + red[1][4 * a + b][lane]) + red[2][4 * a + b][lane];
+            // acc[a][b][r] = dW2[32 mg + 2 (4 g + r) + a][64 ng + 4 j + b]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<f32x4*>(out + (size_t)(32 * mg + 2 * (4 * g + r) + a) * SA_H + 64 * ng + 4 * j) = f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+        }
     }
 }
 
-static int sac_launch_reduce(void* workspace, int batch, int is_actor, double inv_count, float* grads, float* out2, hipStream_t s) {
-    const int nb = (batch + SR - 1) / SR;
-    const int n_out = (is_actor ? 1794 : 2 * 1793) + 2;
-    sac_small_reduce_kernel<<<(n_out + 255) / 256, 256, 0, s>>>((const float*)workspace, batch, nb, is_actor, inv_count, grads, out2);
+// gradient assembly: (a) thin gradients = fixed-order sum of the per-workgroup slabs, scattered into the flat layout; (b) W2 gradients =
+// fixed-order sum of the GEMM's K-split partials; (c) the two loss scalars.
+#define RED_SMALL_PER_BLOCK 64
+__global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __restrict__ ws, int batch, int n_slabs, int n_split, int is_actor, double inv_count,
+                                                              float* __restrict__ grads, float* __restrict__ out2) {
+    __shared__ float part[4][RED_SMALL_PER_BLOCK];
+    const int per = is_actor ? 1794 : 1793, nets = is_actor ? 1 : 2, n_small = per * nets + 2;
+    const int nb_small = (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK;
+    if ((int)blockIdx.x < nb_small) {
+        const float* slabs = ws + ws_slab_off(batch);
+        const int e = blockIdx.x * RED_SMALL_PER_BLOCK + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+        int off = -1;
+        if (e < per * nets) off = (e / per) * 1793 + e % per;
+        else if (e < n_small) off = (is_actor ? 1794 : 3586) + (e - per * nets);
+        float acc = 0.0f;
+        if (off >= 0) for (int b = grp; b < n_slabs; b += 4) acc += slabs[(size_t)b * SLAB + off];
+        part[grp][threadIdx.x & 63] = acc;
+        __syncthreads();
+        if (grp == 0 && off >= 0) {
+            const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+            if (e < per * nets) {
+                const int net = e / per, l = e % per;
+                int dst;
+                if (is_actor) dst = l < 768 ? AC_W1 + l : l < 1024 ? AC_B1 + (l - 768) : l < 1280 ? AC_B2 + (l - 1024) : l < 1536 ? AC_WM + (l - 1280)
+                                  : l == 1536 ? AC_BM : l < 1793 ? AC_WL + (l - 1537) : AC_BL;
+                else dst = net * SQ_NP + (l < 1024 ? SQ_W1 + l : l < 1280 ? SQ_B1 + (l - 1024) : l < 1536 ? SQ_B2 + (l - 1280) : l < 1792 ? SQ_W3 + (l - 1536) : SQ_B3);
+                grads[dst] = v;
+            } else if (out2) out2[e - per * nets] = (float)((double)v * inv_count);
+        }
+    } else {
+        const int e4 = (blockIdx.x - nb_small) * 256 + threadIdx.x;          // float4 index over nets x 65536
+        if (e4 >= nets * (SA_H * SA_H / 4)) return;
+        const int net = e4 / (SA_H * SA_H / 4), l4 = e4 % (SA_H * SA_H / 4);
+        const float* part0 = ws + ws_part_off(batch) + (size_t)net * SA_H * SA_H + 4 * (size_t)l4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(part0);
+        for (int y = 1; y < n_split; ++y) acc += *reinterpret_cast<const f32x4*>(part0 + (size_t)y * 3 * SA_H * SA_H);
+        float* dst = grads + (is_actor ? AC_W2 : net * SQ_NP + SQ_W2) + 4 * (size_t)l4;    // the second critic's block is only 4-byte aligned
+        dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3];
+    }
+}
+
+static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv_count, float* grads, float* out2, hipStream_t s) {
+    const int nb = ws_kp(batch) / SR, nets = is_actor ? 1 : 2, split = gemm_split(batch);
+    sac_dw2_gemm_kernel<<<dim3(32 * nets, split), 256, 0, s>>>((float*)workspace, batch, is_actor ? 2 : 0, nets);
+    MI_LAUNCH_CHECK();
+    const int n_small = (is_actor ? 1794 : 2 * 1793) + 2;
+    const int nblk = (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK + nets * (SA_H * SA_H / 4) / 256;
+    sac_grad_reduce_kernel<<<nblk, 256, 0, s>>>((const float*)workspace, batch, nb, split, is_actor, inv_count, grads, out2);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -626,46 +810,40 @@ extern "C" int mi_sac_critic_grad(const float* q, const float* q_target, const f
                                   const float* eps, uint64_t seed, uint64_t update_index, const float* alpha, float gamma, double inv_count,
                                   void* workspace, float* grads, float* losses, void* stream) {
     MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads, "NULL pointer");
-    MI_CHECK_ARG(batch > 0 && batch % 4 == 0 && n_envs > 0 && slots >= 2, "batch must be a positive multiple of 4");
+    MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = (batch + SR - 1) / SR;
-    sac_critic_kernel<<<nb, 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps, seed,
-                                         update_index, alpha, gamma, (float)inv_count, (float*)workspace);
+    sac_critic_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+                                                       seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace);
     MI_LAUNCH_CHECK();
-    sac_dw2_gemm_kernel<<<(2 * 64 * 64 + 255) / 256, 256, 0, s>>>((const float*)workspace, batch, 0, 2, grads, SQ_NP, SQ_W2);
-    MI_LAUNCH_CHECK();
-    return sac_launch_reduce(workspace, batch, 0, inv_count, grads, losses, s);
+    return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, s);
 }
 
 extern "C" int mi_sac_actor_grad(const float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps,
                                  uint64_t seed, uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out,
                                  void* stream) {
     MI_CHECK_ARG(actor && q && observations && idx && alpha && workspace && grads, "NULL pointer");
-    MI_CHECK_ARG(batch > 0 && batch % 4 == 0, "batch must be a positive multiple of 4");
+    MI_CHECK_ARG(batch > 0, "bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = (batch + SR - 1) / SR;
-    sac_actor_kernel<<<nb, 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0);
+    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0);
     MI_LAUNCH_CHECK();
-    sac_dw2_gemm_kernel<<<(64 * 64 + 255) / 256, 256, 0, s>>>((const float*)workspace, batch, 2, 1, grads, AC_NP, AC_W2);
-    MI_LAUNCH_CHECK();
-    return sac_launch_reduce(workspace, batch, 1, inv_count, grads, out, s);
+    return sac_launch_grads(workspace, batch, 1, inv_count, grads, out, s);
 }
 
 // ================================================ alpha, Adam, polyak ============================================================
-// mean_in: nullable device scalar holding the (already all-reduced) mean log-prob; NULL = sum this rank's slabs
-__global__ void sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const float* __restrict__ mean_in, float inv_count,
-                                 float* __restrict__ mean_out, float target_entropy, float* __restrict__ log_alpha, float* __restrict__ m,
-                                 float* __restrict__ v, float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps,
-                                 float* __restrict__ alpha, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wave.  mean_in: nullable device scalar holding the (already all-reduced) mean log-prob; NULL = sum this rank's slabs (lane-strided, then the fixed DPP tree)
+__global__ void __launch_bounds__(64)
+sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const float* __restrict__ mean_in, float inv_count, float* __restrict__ mean_out,
+                 float target_entropy, float* __restrict__ log_alpha, float* __restrict__ m, float* __restrict__ v, float w1, float b2, float w2,
+                 float step_size, float bc2_sqrt, float eps, float* __restrict__ alpha, float* __restrict__ out) {
     float mean_lp;
     if (mean_in) mean_lp = mean_in[0];
     else {
-        const float* slabs = ws + 6 * ws_mat_floats(batch);
-        double s = 0.0;
-        for (int b = 0; b < n_slabs; ++b) s += slabs[(size_t)b * SLAB + 1795];
-        mean_lp = (float)(s * (double)inv_count);
+        const float* slabs = ws + ws_slab_off(batch);
+        float s = 0.0f;
+        for (int b = threadIdx.x; b < n_slabs; b += 64) s += slabs[(size_t)b * SLAB + 1795];
+        mean_lp = wave_sum(s) * inv_count;
     }
+    if (threadIdx.x != 0) return;
     if (mean_out) { mean_out[0] = mean_lp; return; }
     const float la = log_alpha[0];
     const float g = -(mean_lp + target_entropy);              // d/d log_alpha of mean(-log_alpha * (logp + target_entropy)), sac.py:205
@@ -680,7 +858,7 @@ __global__ void sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_
 
 static int sac_launch_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                            uint64_t update_index, void* workspace, hipStream_t s) {
-    sac_actor_kernel<<<(batch + SR - 1) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1);
+    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -688,7 +866,7 @@ static int sac_launch_logp(const float* actor, const float* observations, const 
 static int sac_launch_alpha(const float* ws, int batch, const float* mean_in, float inv_count, float target_entropy, float* log_alpha, float* exp_avg,
                             float* exp_avg_sq, int64_t step, double lr, float* alpha, float* out, hipStream_t s) {
     const double b1 = 0.9, b2 = 0.999, bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-    sac_alpha_kernel<<<1, 64, 0, s>>>(ws, batch, (batch + SR - 1) / SR, mean_in, inv_count, nullptr, target_entropy, log_alpha, exp_avg, exp_avg_sq,
+    sac_alpha_kernel<<<1, 64, 0, s>>>(ws, batch, ws_kp(batch) / SR, mean_in, inv_count, nullptr, target_entropy, log_alpha, exp_avg, exp_avg_sq,
                                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), 1e-8f, alpha, out);
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -710,7 +888,7 @@ extern "C" int mi_sac_mean_logp(const float* actor, const float* observations, c
     MI_CHECK_ARG(actor && observations && idx && mean_logp && workspace && batch > 0, "bad arguments");
     const int rc = sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace, (hipStream_t)stream);
     if (rc) return rc;
-    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, (batch + SR - 1) / SR, nullptr, (float)inv_count, mean_logp, 0.0f, nullptr,
+    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, (float)inv_count, mean_logp, 0.0f, nullptr,
                                                        nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, nullptr, nullptr);
     MI_LAUNCH_CHECK();
     return MI_OK;

@@ -20,8 +20,6 @@ class SACEngine:
         self.env, self.actor = env, actor
         self.N, self.device, self.slots = env.num_envs, env.device, int(slots)
         self.batch_size, self.gamma, self.tau = int(batch_size), float(gamma), float(tau)
-        if self.batch_size % 4:
-            raise N.MiError("batch_size must be a multiple of 4 (MFMA k-step of the weight-gradient GEMM)")
         self.learning_starts = int(learning_starts)
         self.pg = process_group
         self.world_size, self.rank = D.world_size(process_group), D.rank(process_group)
