@@ -116,12 +116,20 @@ extern "C" int mi_env_step_cont(void* handle, const float* actions, const double
 //   A = the weight tile, streamed from L2 straight into registers (each weight element is needed by exactly one wave),
 //   B = the row group's activations, read from LDS ([row][unit], row stride LDW),
 //   D = [unit][row]: lane (row = lane & 15, g = lane >> 4) holds units 64 w + 16 t + 4 g + r of its row in acc[t][r],
-// wave w owning 64 output units.  The reduction index is consumed in the permuted order the float4 loads deliver (k-step s of a
-// 16-wide chunk pairs element s of lane group g, i.e. index 4 g + s, on both operands).  Thin layers (3/4 -> 256, the heads, bias
+// wave w owning 64 output units.  The reduction index is consumed in the permuted order the vector loads deliver (k-step s of a
+// 16-wide chunk pairs element s of lane group g, i.e. index 4 g + s, on both operands).
+// A kernel is a fixed sequence of such passes (critic update: 7, actor update: 6), and its weights are ONE stream: a 4-deep ring of
+// 32-index stages, loads issued 3 stages (~1.3 us of MFMA work) ahead; the last 3 stages of a pass issue the first 3 of the NEXT
+// pass's matrix, so only the first pass of a kernel waits for L2.  Thin parameters (layer-1 rows, biases, head weights) are fetched
+// one pass ahead as one coalesced value per thread and handed to the D layout through LDS.  Thin layers (3/4 -> 256, heads, bias
 // and thin weight gradients) are thread-per-unit VALU code on the same LDS images.
 #define LDW 260
 struct __attribute__((aligned(16))) sac_smem {
     float b0[SR][LDW], b1[SR][LDW], b2[SR][LDW];   // activation images
+    float pb[3][SA_H];         // this pass's layer-2 bias and head weights per unit
+    float qw3[2][SA_H];        // actor update: the critics' W3, W1[:,3] and layer-1 ReLU masks (bit r = row r), kept for the backward
+    float qw13[2][SA_H];
+    uint32_t qmask[2][SA_H];
     float x[SR][4];            // obs (3) + action
     float xn[SR][4];           // next obs (3) + next action
     float red[4][SR][2];       // cross-wave partial sums
@@ -137,126 +145,139 @@ __device__ __forceinline__ float keyed_normal(uint64_t seed, uint64_t tag_update
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-// pre-activation of layer 1, unit j, one row — ONE expression shared by every forward and by the backward's ReLU mask
-template <int IN>
-__device__ __forceinline__ float layer1_z(const float w[IN], float bj, const float* xr) {
-    float z = 0.0f;
-#pragma unroll
-    for (int k = 0; k < IN; ++k) z = __builtin_fmaf(w[k], xr[k], z);
-    return z + bj;
+// ---- thin parameters of one net for thread j: layer-1 row, bias 1, bias 2, head weight(s) ----
+struct thin_t { float w1[4], b1, b2, h0, h1; };
+__device__ __forceinline__ void issue_thin_q(const float* __restrict__ p, thin_t& th) {
+    const int j = threadIdx.x;
+    const float4 w = *reinterpret_cast<const float4*>(p + SQ_W1 + 4 * j);   // dword-aligned x4 (the second critic's block is only 4-byte aligned)
+    th.w1[0] = w.x; th.w1[1] = w.y; th.w1[2] = w.z; th.w1[3] = w.w;
+    th.b1 = p[SQ_B1 + j]; th.b2 = p[SQ_B2 + j]; th.h0 = p[SQ_W3 + j]; th.h1 = 0.0f;
+}
+__device__ __forceinline__ void issue_thin_actor(const float* __restrict__ p, thin_t& th) {
+    const int j = threadIdx.x;
+    th.w1[0] = p[AC_W1 + 3 * j]; th.w1[1] = p[AC_W1 + 3 * j + 1]; th.w1[2] = p[AC_W1 + 3 * j + 2]; th.w1[3] = 0.0f;
+    th.b1 = p[AC_B1 + j]; th.b2 = p[AC_B2 + j]; th.h0 = p[AC_WM + j]; th.h1 = p[AC_WL + j];
 }
 
-// layer 1 of unit j = threadIdx.x for all rows: h[r][j] = relu(b[j] + W[j][:IN] . x[r][:IN])
+// layer 1 of unit j = threadIdx.x for all rows: h[r][j] = relu(b1 + w1 . x[r][:IN]); publishes bias 2 / head weights for the D layout;
+// returns the ReLU mask over rows.  ONE expression for z everywhere (FMA chain in index order, then + b1).
 template <int IN>
-__device__ __forceinline__ void layer1(const float* __restrict__ W, const float* __restrict__ b, const float (*x)[4], float (*h)[LDW]) {
+__device__ __forceinline__ uint32_t layer1(sac_smem& sm, const thin_t& th, const float (*x)[4], float (*h)[LDW]) {
     const int j = threadIdx.x;
-    float w[IN];
+    uint32_t mask = 0;
 #pragma unroll
-    for (int k = 0; k < IN; ++k) w[k] = W[j * IN + k];
-    const float bj = b[j];
+    for (int r = 0; r < SR; ++r) {
+        float z = 0.0f;
 #pragma unroll
-    for (int r = 0; r < SR; ++r) h[r][j] = fmaxf(layer1_z<IN>(w, bj, x[r]), 0.0f);
+        for (int k = 0; k < IN; ++k) z = __builtin_fmaf(th.w1[k], x[r][k], z);
+        z += th.b1;
+        mask |= (z > 0.0f ? 1u : 0u) << r;
+        h[r][j] = fmaxf(z, 0.0f);
+    }
+    sm.pb[0][j] = th.b2; sm.pb[1][j] = th.h0; sm.pb[2][j] = th.h1;
+    return mask;
 }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define L2_STAGES 8       // 256 reduction indices in stages of 32
-#define L2_AHEAD 2        // stages of weights in flight ahead of the MFMAs
+#define L2_NBUF 4         // ring of stage buffers (8 stages = 0 mod 4: every pass starts at slot 0)
+#define L2_AHEAD 3        // stages in flight ahead of the MFMAs
+#ifndef SAC_EXP
+#define SAC_EXP 0         // diagnostics (wrong results): 1 = stream only the first pass's first stages (MFMA-only time)
+#endif
+struct wstream { float r[L2_NBUF][32]; };
 
-// forward through a 256 x 256 layer: acc[t][r] (lane row i, group g) = sum_k W[64 w + 16 t + 4 g + r][k] * in[i][k]
-__device__ __forceinline__ void mfma_fwd(const float* __restrict__ W, const float (*in)[LDW], f32x4 acc[4]) {
+// one stage (32 reduction indices) of this wave's 64 output units.
+// forward  (out unit = weight row):    d[4 (2 t + h) + e] = W[64 w + 16 t + i][32 st + 16 h + 4 g + e]       (float4 loads)
+// backward (out unit = weight column): d[16 h + 4 s + t]  = W[32 st + 16 h + 4 g + s][64 w + 16 t + i]       (dword loads, 64 B per row)
+template <bool BWD>
+__device__ __forceinline__ void issue_stage(const float* __restrict__ W, const int st, float (&d)[32]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-    const float* wp = W + (size_t)(64 * w + i) * SA_H + 4 * g;
-    const float* bp = &in[i][4 * g];
-    float4 wb[L2_AHEAD + 1][8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int st = 0; st < L2_AHEAD; ++st)
+    if (!BWD) {
+        const float* wp = W + (size_t)(64 * w + i) * SA_H + 4 * g + st * 32;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) wb[st][2 * t + h] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * SA_H + st * 32 + h * 16);
-#pragma unroll
-    for (int st = 0; st < L2_STAGES; ++st) {
-        if (st + L2_AHEAD < L2_STAGES) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    wb[(st + L2_AHEAD) % (L2_AHEAD + 1)][2 * t + h] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * SA_H + (st + L2_AHEAD) * 32 + h * 16);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 b = *reinterpret_cast<const float4*>(bp + st * 32 + h * 16);
-            const float4* a = &wb[st % (L2_AHEAD + 1)][0];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].x, b.x, acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].y, b.y, acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].z, b.z, acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[2 * t + h].w, b.w, acc[t]);
-        }
-    }
-}
-
-// backward-data through the same layer: acc[t][r] = sum_j W[j][64 w + 16 t + 4 g + r] * in[i][j]   (in = dZ of the layer's outputs)
-__device__ __forceinline__ void mfma_bwd(const float* __restrict__ W, const float (*in)[LDW], f32x4 acc[4]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-    const float* wp = W + (size_t)(4 * g) * SA_H + 64 * w + i;     // A lane (i, g), k-step s of chunk c: W[16 c + 4 g + s][64 w + 16 t + i]
-    const float* bp = &in[i][4 * g];
-    float wb[L2_AHEAD + 1][32];                                     // [h][s][t]
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int st = 0; st < L2_AHEAD; ++st)
+            for (int h = 0; h < 2; ++h) {
+                const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * SA_H + h * 16);
+                d[4 * (2 * t + h) + 0] = v.x; d[4 * (2 * t + h) + 1] = v.y; d[4 * (2 * t + h) + 2] = v.z; d[4 * (2 * t + h) + 3] = v.w;
+            }
+    } else {
+        const float* wp = W + (size_t)(4 * g + st * 32) * SA_H + 64 * w + i;
 #pragma unroll
         for (int hs = 0; hs < 8; ++hs)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) wb[st][4 * hs + t] = wp[(size_t)(st * 32 + (hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
-#pragma unroll
-    for (int st = 0; st < L2_STAGES; ++st) {
-        if (st + L2_AHEAD < L2_STAGES) {
-#pragma unroll
-            for (int hs = 0; hs < 8; ++hs)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    wb[(st + L2_AHEAD) % (L2_AHEAD + 1)][4 * hs + t] = wp[(size_t)((st + L2_AHEAD) * 32 + (hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 b = *reinterpret_cast<const float4*>(bp + st * 32 + h * 16);
-            const float* a = &wb[st % (L2_AHEAD + 1)][16 * h];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[0 + t], b.x, acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[4 + t], b.y, acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[8 + t], b.z, acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[12 + t], b.w, acc[t]);
-        }
+            for (int t = 0; t < 4; ++t) d[4 * hs + t] = wp[(size_t)((hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
     }
 }
 
-// acc <- relu(acc + bias) in the D layout
-__device__ __forceinline__ void relu_bias(f32x4 acc[4], const float* __restrict__ bias) {
+// start a kernel's weight stream: the first L2_AHEAD stages of its first pass
+template <bool BWD>
+__device__ __forceinline__ void stream_prime(const float* __restrict__ W, wstream& ws) {
+#pragma unroll
+    for (int st = 0; st < L2_AHEAD; ++st) issue_stage<BWD>(W, st, ws.r[st]);
+}
+
+// one pass through a 256 x 256 layer.  forward: acc[t][r] = sum_k W[64 w + 16 t + 4 g + r][k] in[i][k];
+// backward-data: acc[t][r] = sum_j W[j][64 w + 16 t + 4 g + r] in[i][j].  Wn (nullable): the next pass's matrix (direction NBWD).
+template <bool BWD, bool NBWD>
+__device__ __forceinline__ void mfma_pass(const float* __restrict__ W, const float* __restrict__ Wn, const float (*in)[LDW], wstream& ws, f32x4 acc[4]) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const float* bp = &in[i][4 * g];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float4 bc[2], bn[2];                     // the B operand is read one stage ahead as well
+    bc[0] = *reinterpret_cast<const float4*>(bp); bc[1] = *reinterpret_cast<const float4*>(bp + 16);
+#pragma unroll
+    for (int st = 0; st < L2_STAGES; ++st) {
+        const int ld = st + L2_AHEAD;
+        if (SAC_EXP != 1) {
+            if (ld < L2_STAGES) issue_stage<BWD>(W, ld, ws.r[ld % L2_NBUF]);
+            else if (Wn) issue_stage<NBWD>(Wn, ld - L2_STAGES, ws.r[ld % L2_NBUF]);
+        }
+        if (st + 1 < L2_STAGES) { bn[0] = *reinterpret_cast<const float4*>(bp + (st + 1) * 32); bn[1] = *reinterpret_cast<const float4*>(bp + (st + 1) * 32 + 16); }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads L2_AHEAD stages ahead of their use: the scheduler would sink them next to the MFMAs
+        const float* a = ws.r[st % L2_NBUF];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float bs[4] = {bc[h].x, bc[h].y, bc[h].z, bc[h].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#if SAC_EXP == 2
+                    acc[t][s] += (BWD ? a[16 * h + 4 * s + t] : a[4 * (2 * t + h) + s]) * bs[s];
+#else
+                    acc[t] = MFMA16(BWD ? a[16 * h + 4 * s + t] : a[4 * (2 * t + h) + s], bs[s], acc[t]);
+#endif
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bc[0] = bn[0]; bc[1] = bn[1];
+    }
+}
+
+// acc <- relu(acc + bias 2) in the D layout (bias published by layer1)
+__device__ __forceinline__ void relu_bias(const sac_smem& sm, f32x4 acc[4]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&sm.pb[0][64 * w + 16 * t + 4 * g]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r] + bias[64 * w + 16 * t + 4 * g + r], 0.0f);
+        for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r] + b[r], 0.0f);
+    }
 }
 
 // this wave's share of a 256 -> 1 head for the lane's row (valid in every lane after the two cross-group exchanges)
-__device__ __forceinline__ float head_partial(const f32x4 acc[4], const float* __restrict__ wh) {
+__device__ __forceinline__ float head_partial(const f32x4 acc[4], const float* wh /* LDS, per unit */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
     float p = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 hw = *reinterpret_cast<const f32x4*>(&wh[64 * w + 16 * t + 4 * g]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p = __builtin_fmaf(wh[64 * w + 16 * t + 4 * g + r], acc[t][r], p);
+        for (int r = 0; r < 4; ++r) p = __builtin_fmaf(hw[r], acc[t][r], p);
+    }
     p += __shfl_xor(p, 16);
     p += __shfl_xor(p, 32);
     return p;
@@ -282,25 +303,23 @@ __device__ __forceinline__ void store_acc(const f32x4 acc[4], float (*out)[LDW])
     for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&out[i][64 * w + 16 * t + 4 * g]) = acc[t];
 }
 
-// SoftQNetwork forward on the rows of `x` (obs + action): h1 -> `h1` image, relu(h2) left in acc, q[r] -> sm.rv[r][slot]
-__device__ __forceinline__ void q_forward(sac_smem& sm, const float* __restrict__ p, const float (*x)[4], float (*h1)[LDW], f32x4 acc[4], int slot) {
-    layer1<4>(p + SQ_W1, p + SQ_B1, x, h1);
-    __syncthreads();
-    mfma_fwd(p + SQ_W2, h1, acc);
-    relu_bias(acc, p + SQ_B2);
-    rows_combine2(sm, head_partial(acc, p + SQ_W3), 0.0f, slot, 15);
+// SoftQNetwork forward, layer 2 onward (layer 1 image in `h1`, thin parameters published): relu(h2) left in acc, q[r] -> sm.rv[r][slot]
+template <bool NBWD>
+__device__ __forceinline__ void q_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[4], int slot) {
+    mfma_pass<false, NBWD>(p + SQ_W2, Wn, h1, ws, acc);
+    relu_bias(sm, acc);
+    rows_combine2(sm, head_partial(acc, sm.pb[1]), 0.0f, slot, 15);
     if (threadIdx.x < SR) sm.rv[threadIdx.x][slot] += p[SQ_B3];
     __syncthreads();
 }
 
-// rv slots used by the actor: 0 mean, 1 sraw, 2 ls, 3 sd, 4 u, 5 logp, 6 action, 7 eps.   relu(h2) left in acc, h1 in `h1`.
-__device__ __forceinline__ void actor_forward(sac_smem& sm, const float* __restrict__ p, const float (*x)[4], float (*h1)[LDW], f32x4 acc[4],
-                                              const float eps_row /*valid in threads < SR*/) {
-    layer1<3>(p + AC_W1, p + AC_B1, x, h1);
-    __syncthreads();
-    mfma_fwd(p + AC_W2, h1, acc);
-    relu_bias(acc, p + AC_B2);
-    rows_combine2(sm, head_partial(acc, p + AC_WM), head_partial(acc, p + AC_WL), 0, 1);
+// rv slots used by the actor: 0 mean, 1 sraw, 2 ls, 3 sd, 4 u, 5 logp, 6 action, 7 eps.   relu(h2) left in acc.
+template <bool NBWD>
+__device__ __forceinline__ void actor_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[4],
+                                               const float eps_row /*valid in threads < SR*/) {
+    mfma_pass<false, NBWD>(p + AC_W2, Wn, h1, ws, acc);
+    relu_bias(sm, acc);
+    rows_combine2(sm, head_partial(acc, sm.pb[1]), head_partial(acc, sm.pb[2]), 0, 1);
     if (threadIdx.x < SR) {
         const int r = threadIdx.x;
         const float mean = sm.rv[r][0] + p[AC_BM], sraw = sm.rv[r][1] + p[AC_BL];
@@ -323,12 +342,16 @@ __global__ void __launch_bounds__(256) sac_actor_sample_kernel(const float* __re
                                                                 int n, float* __restrict__ action, float* __restrict__ logp) {
     __shared__ sac_smem sm;
     const int row0 = blockIdx.x * SR;
+    wstream ws; thin_t th; f32x4 acc[4];
+    issue_thin_actor(actor, th);
+    stream_prime<false>(actor + AC_W2, ws);
     if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int b = row0 + r < n ? row0 + r : n - 1; sm.x[r][k] = obs[3 * (size_t)b + k]; }
-    __syncthreads();
     float e = 0.0f;
     if (threadIdx.x < SR) e = eps[row0 + threadIdx.x < n ? row0 + threadIdx.x : n - 1];
-    f32x4 acc[4];
-    actor_forward(sm, actor, sm.x, sm.b0, acc, e);
+    __syncthreads();
+    layer1<3>(sm, th, sm.x, sm.b0);
+    __syncthreads();
+    actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e);
     if (threadIdx.x < SR && row0 + threadIdx.x < n) { action[row0 + threadIdx.x] = sm.rv[threadIdx.x][6]; if (logp) logp[row0 + threadIdx.x] = sm.rv[threadIdx.x][5]; }
 }
 
@@ -339,18 +362,57 @@ extern "C" int mi_sac_actor_sample(const float* actor, const float* obs, const f
     return MI_OK;
 }
 
+#ifdef SAC_STAMPS   // diagnostics build: out[0..] of workgroup 0 receives phase durations in units of 10 ns (wall_clock64), results are destroyed
+#define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 0 && threadIdx.x == 0) stamp[k] = wall_clock64(); } while (0)
+#else
+#define STAMP(k)
+#endif
 __global__ void __launch_bounds__(256) sac_q_forward_kernel(const float* __restrict__ q, const float* __restrict__ obs, const float* __restrict__ act, int n,
                                                              float* __restrict__ out) {
     __shared__ sac_smem sm;
+#ifdef SAC_STAMPS
+    __shared__ unsigned long long stamp[8];
+#endif
     const int row0 = blockIdx.x * SR;
+    wstream ws; thin_t th; f32x4 acc[4];
+    STAMP(0);
+    issue_thin_q(q, th);
+    stream_prime<false>(q + SQ_W2, ws);
     if (threadIdx.x < SR * 4) {
         const int r = threadIdx.x / 4, k = threadIdx.x & 3; const int b = row0 + r < n ? row0 + r : n - 1;
         sm.x[r][k] = k < 3 ? obs[3 * (size_t)b + k] : act[b];
     }
     __syncthreads();
-    f32x4 acc[4];
-    q_forward(sm, q, sm.x, sm.b0, acc, 8);
+    STAMP(1);
+    layer1<4>(sm, th, sm.x, sm.b0);
+    __syncthreads();
+    STAMP(2);
+#ifdef SAC_STAMPS
+#ifndef SAC_STAMP_BWD
+#define SAC_STAMP_BWD false
+#endif
+    f32x4 accx[4];
+    mfma_pass<false, SAC_STAMP_BWD>(q + SQ_W2, q + SQ_W2, sm.b0, ws, accx);     // first touch of the matrix in this kernel
+    STAMP(6);
+    mfma_pass<SAC_STAMP_BWD, false>(q + SQ_W2, nullptr, sm.b0, ws, acc);
+    for (int t = 0; t < 4; ++t) acc[t] += accx[t];
+#else
+    mfma_pass<false, false>(q + SQ_W2, nullptr, sm.b0, ws, acc);
+#endif
+    STAMP(3);
+    relu_bias(sm, acc);
+    const float hp = head_partial(acc, sm.pb[1]);
+    STAMP(4);
+    rows_combine2(sm, hp, 0.0f, 8, 15);
+    if (threadIdx.x < SR) sm.rv[threadIdx.x][8] += q[SQ_B3];
+    __syncthreads();
+    STAMP(5);
     if (threadIdx.x < SR && row0 + threadIdx.x < n) out[row0 + threadIdx.x] = sm.rv[threadIdx.x][8];
+#ifdef SAC_STAMPS
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 5) out[threadIdx.x] = (float)(stamp[threadIdx.x + 1] - stamp[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x == 2) { out[2] = (float)(stamp[6] - stamp[2]); out[5] = (float)(stamp[3] - stamp[6]); }
+#endif
 }
 
 extern "C" int mi_sac_q_forward(const float* q, const float* obs, const float* act, int n, float* out, void* stream) {
@@ -369,16 +431,20 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
     __shared__ sac_smem sm;
     const int N = e.n, row0 = blockIdx.x * SR;
     const bool policy = !forced_actions && global_step >= learning_starts;   // block-uniform
-    if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
-    __syncthreads();
     if (policy) {
+        wstream ws; thin_t th; f32x4 acc[4];
+        issue_thin_actor(actor, th);
+        stream_prime<false>(actor + AC_W2, ws);
+        if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
         float eps = 0.0f;
         if (threadIdx.x < SR) {
             const int g = row0 + threadIdx.x < N ? row0 + threadIdx.x : N - 1;
             eps = forced_eps ? forced_eps[g] : keyed_normal(e.seed, (1ull << 40) + e.env_id_base + (uint64_t)g, (uint64_t)global_step);
         }
-        f32x4 acc[4];
-        actor_forward(sm, actor, sm.x, sm.b0, acc, eps);
+        __syncthreads();
+        layer1<3>(sm, th, sm.x, sm.b0);
+        __syncthreads();
+        actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, eps);
     }
     if (threadIdx.x < SR && row0 + threadIdx.x < N) {
         const int g = row0 + threadIdx.x;
@@ -449,22 +515,93 @@ static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >=
 
 // ================================================ critic update =================================================================
 // slab layout (critic): net n at n*1793: W1 1024 | b1 256 | b2 256 | W3 256 | b3 1;  then [3586] = sum (q1-y)^2, [3587] = sum (q2-y)^2
+// passes: actor fwd -> target 1 fwd -> target 2 fwd -> critic 1 fwd, bwd -> critic 2 fwd, bwd
+template <int NET>
+__device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __restrict__ q, const float* __restrict__ Wnext, wstream& ws, const thin_t& th,
+                                                  int batch, int row0, float invn, float* __restrict__ H1, float* __restrict__ DZ2, float* __restrict__ slab) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
+    const float* p = q + (size_t)NET * SQ_NP;
+    float* sl = slab + NET * 1793;
+    f32x4 acc[4];
+    layer1<4>(sm, th, sm.x, sm.b0);
+    __syncthreads();
+    q_forward2<true>(sm, p, p + SQ_W2, sm.b0, ws, acc, 8);          // h1 in b0, relu(h2) in acc; the stream continues with this net's backward
+    if (t < SR) {
+        const bool valid = row0 + t < batch;
+        const float d = valid ? sm.rv[t][8] - sm.rv[t][10] : 0.0f;
+        sm.rv[t][9] = d * d;           // loss contribution
+        sm.rv[t][8] = 2.0f * d * invn; // d loss / d q
+    }
+    __syncthreads();
+    {   // dz2 in the D layout: h2 image -> b2, dz2 image -> b1 and the GEMM operand in the workspace
+        const float dq = sm.rv[li][8];
+        store_acc(acc, sm.b2);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int u = 64 * wv + 16 * tt + 4 * lg;
+            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.pb[1][u]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tt][r] = acc[tt][r] > 0.0f ? w3[r] * dq : 0.0f;
+            *reinterpret_cast<f32x4*>(&DZ2[((size_t)NET * ws_kp(batch) + row0 + li) * SA_H + u]) = acc[tt];
+        }
+        store_acc(acc, sm.b1);
+    }
+    __syncthreads();
+    {   // unit j = t: thin gradients of layer 3 / bias 2, H1 rows for the GEMM
+        float gw3 = 0.0f, gb2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            gw3 = __builtin_fmaf(sm.rv[r][8], sm.b2[r][t], gw3); gb2 += sm.b1[r][t];
+            H1[((size_t)NET * ws_kp(batch) + row0 + r) * SA_H + t] = sm.b0[r][t];
+        }
+        sl[1024 + 256 + t] = gb2; sl[1024 + 512 + t] = gw3;
+        if (t == 0) { float gb3 = 0.0f, l = 0.0f; for (int r = 0; r < SR; ++r) { gb3 += sm.rv[r][8]; l += sm.rv[r][9]; } sl[1792] = gb3; slab[3586 + NET] = l; }
+    }
+    mfma_pass<true, false>(p + SQ_W2, Wnext, sm.b1, ws, acc);      // dh1 in the D layout
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][64 * wv + 16 * tt + 4 * lg]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
+    }
+    __syncthreads();                                 // every thread is done reading b2 (h2)
+    store_acc(acc, sm.b2);                           // dz1 image
+    __syncthreads();
+    {   // input unit k = t: thin gradients of layer 1
+        float gb1 = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const float d = sm.b2[r][t];
+            gb1 += d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gw[c] = __builtin_fmaf(d, sm.x[r][c], gw[c]);
+        }
+        *reinterpret_cast<float4*>(sl + 4 * t) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+        sl[1024 + t] = gb1;
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(256)
 sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, const float* __restrict__ actor, const float* __restrict__ observations,
                   const float* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
                   const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, const float* __restrict__ eps, uint64_t seed, uint64_t update,
-                  const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws) {
+                  const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
-    const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
     const size_t matf = ws_mat_floats(batch);
-    float* H1 = ws; float* DZ2 = ws + 3 * matf;
-    float* slab = ws + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
+    float* H1 = ws_; float* DZ2 = ws_ + 3 * matf;
+    float* slab = ws_ + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
+    wstream ws; thin_t th, th2; f32x4 acc[4];
+    issue_thin_actor(actor, th);
+    stream_prime<false>(actor + AC_W2, ws);
     if (t < SR) {
         const int b = row0 + t < batch ? row0 + t : batch - 1;
         const long long i = idx[b];
         sm.cur[t] = i; sm.nxt[t] = ((i / n_envs + 1) % slots) * n_envs + i % n_envs;
     }
+    float e_row = 0.0f;
+    if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
     __syncthreads();
     if (t < SR * 4) {
         const int r = t / 4, k = t & 3;
@@ -472,18 +609,25 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         sm.xn[r][k] = k < 3 ? observations[3 * sm.nxt[r] + k] : 0.0f;
     }
     __syncthreads();
-    f32x4 acc[4];
     // ---- next action + log-prob under the current actor (no grad; sac.py:172) ----
-    float e_row = 0.0f;
-    if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
-    actor_forward(sm, actor, sm.xn, sm.b0, acc, e_row);
+    layer1<3>(sm, th, sm.xn, sm.b0);
+    issue_thin_q(qt, th);
+    __syncthreads();
+    actor_forward2<false>(sm, actor, qt + SQ_W2, sm.b0, ws, acc, e_row);
     if (t < SR) { sm.xn[t][3] = sm.rv[t][6]; sm.rv[t][9] = sm.rv[t][5]; }   // a', log pi(a'|s')
     __syncthreads();
     // ---- target critics (:173-174) ----
-    q_forward(sm, qt, sm.xn, sm.b0, acc, 8);
+    layer1<4>(sm, th, sm.xn, sm.b0);
+    issue_thin_q(qt + SQ_NP, th);
+    __syncthreads();
+    q_forward2<false>(sm, qt, qt + SQ_NP + SQ_W2, sm.b0, ws, acc, 8);
     if (t < SR) sm.rv[t][10] = sm.rv[t][8];
     __syncthreads();
-    q_forward(sm, qt + SQ_NP, sm.xn, sm.b0, acc, 8);
+    layer1<4>(sm, th, sm.xn, sm.b0);
+    issue_thin_q(q, th);
+    issue_thin_q(q + SQ_NP, th2);
+    __syncthreads();
+    q_forward2<false>(sm, qt + SQ_NP, q + SQ_W2, sm.b0, ws, acc, 8);
     if (t < SR) {
         const float alpha = alpha_p[0];
         const float mq = fminf(sm.rv[t][10], sm.rv[t][8]) - alpha * sm.rv[t][9];                                   // :176
@@ -491,85 +635,26 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     }
     __syncthreads();
     // ---- the two critics on (obs, action): forward, loss, backward (:179-185) ----
-#pragma unroll 1
-    for (int net = 0; net < 2; ++net) {
-        const float* p = q + (size_t)net * SQ_NP;
-        float* sl = slab + net * 1793;
-        q_forward(sm, p, sm.x, sm.b0, acc, 8);          // h1 -> b0, relu(h2) in acc
-        if (t < SR) {
-            const bool valid = row0 + t < batch;
-            const float d = valid ? sm.rv[t][8] - sm.rv[t][10] : 0.0f;
-            sm.rv[t][9] = d * d;           // loss contribution
-            sm.rv[t][8] = 2.0f * d * invn; // d loss / d q
-        }
-        __syncthreads();
-        {   // dz2 in the D layout: h2 image -> b2, dz2 image -> b1 and the GEMM operand in the workspace
-            const float dq = sm.rv[li][8];
-            store_acc(acc, sm.b2);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int u = 64 * wv + 16 * tt + 4 * lg;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[tt][r] = acc[tt][r] > 0.0f ? p[SQ_W3 + u + r] * dq : 0.0f;
-                *reinterpret_cast<f32x4*>(&DZ2[((size_t)net * ws_kp(batch) + row0 + li) * SA_H + u]) = acc[tt];
-            }
-            store_acc(acc, sm.b1);
-        }
-        __syncthreads();
-        {   // unit j = t: thin gradients of layer 3 / bias 2, H1 rows for the GEMM
-            float gw3 = 0.0f, gb2 = 0.0f;
-#pragma unroll
-            for (int r = 0; r < SR; ++r) {
-                gw3 = __builtin_fmaf(sm.rv[r][8], sm.b2[r][t], gw3); gb2 += sm.b1[r][t];
-                H1[((size_t)net * ws_kp(batch) + row0 + r) * SA_H + t] = sm.b0[r][t];
-            }
-            sl[1024 + 256 + t] = gb2; sl[1024 + 512 + t] = gw3;
-            if (t == 0) { float gb3 = 0.0f, l = 0.0f; for (int r = 0; r < SR; ++r) { gb3 += sm.rv[r][8]; l += sm.rv[r][9]; } sl[1792] = gb3; slab[3586 + net] = l; }
-        }
-        mfma_bwd(p + SQ_W2, sm.b1, acc);                // dh1 in the D layout
-        {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][64 * wv + 16 * tt + 4 * lg]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
-            }
-        }
-        __syncthreads();                                 // every thread is done reading b2 (h2)
-        store_acc(acc, sm.b2);                           // dz1 image
-        __syncthreads();
-        {   // input unit k = t: thin gradients of layer 1
-            float gb1 = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int r = 0; r < SR; ++r) {
-                const float d = sm.b2[r][t];
-                gb1 += d;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) gw[c] = __builtin_fmaf(d, sm.x[r][c], gw[c]);
-            }
-            *reinterpret_cast<float4*>(sl + 4 * t) = make_float4(gw[0], gw[1], gw[2], gw[3]);
-            sl[1024 + t] = gb1;
-        }
-        __syncthreads();
-    }
+    critic_net_update<0>(sm, q, q + SQ_NP + SQ_W2, ws, th, batch, row0, invn, H1, DZ2, slab);
+    critic_net_update<1>(sm, q, nullptr, ws, th2, batch, row0, invn, H1, DZ2, slab);
 }
 
 // ================================================ actor update ==================================================================
 // slab layout (actor): W1 768 | b1 256 | b2 256 | Wm 256 | bm 1 | Wl 256 | bl 1 | [1794] sum(alpha*logp - minq) | [1795] sum logp
+// passes: actor fwd -> critic 1 fwd -> critic 2 fwd -> critic 1 bwd -> critic 2 bwd -> actor bwd
 // d(-min Q)/d action of one critic for the lane's row: this wave's share (summed over lane groups), from dh1 in the D layout
-__device__ __forceinline__ float q_daction_partial(const sac_smem& sm, const float* __restrict__ p, const f32x4 acc[4]) {
+__device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, const f32x4 acc[4]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     float v = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+        const int k = 64 * w + 16 * t + 4 * g;
+        const f32x4 w13 = *reinterpret_cast<const f32x4*>(&sm.qw13[net][k]);
+        const uint4 mk = *reinterpret_cast<const uint4*>(&sm.qmask[net][k]);
+        const uint32_t m[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 64 * w + 16 * t + 4 * g + r;
-            const float4 w1 = *reinterpret_cast<const float4*>(p + SQ_W1 + 4 * k);
-            const float wk[4] = {w1.x, w1.y, w1.z, w1.w};
-            const float z1 = layer1_z<4>(wk, p[SQ_B1 + k], sm.x[i]);      // the forward's own expression => the forward's own mask
-            v += z1 > 0.0f ? w1.w * acc[t][r] : 0.0f;
-        }
+        for (int r = 0; r < 4; ++r) v += (m[r] >> i) & 1u ? w13[r] * acc[t][r] : 0.0f;     // the forward's own layer-1 ReLU mask
+    }
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     return v;
@@ -578,32 +663,62 @@ __device__ __forceinline__ float q_daction_partial(const sac_smem& sm, const flo
 __global__ void __launch_bounds__(256)
 sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, const float* __restrict__ observations, const int64_t* __restrict__ idx,
                  int batch, const float* __restrict__ eps, uint64_t seed, uint64_t update, const float* __restrict__ alpha_p, float invn,
-                 float* __restrict__ ws, int logp_only) {
+                 float* __restrict__ ws_, int logp_only) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
     const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
     const size_t matf = ws_mat_floats(batch);
-    float* H1 = ws + 2 * matf; float* DZ2 = ws + 5 * matf;
-    float* slab = ws + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
+    float* H1 = ws_ + 2 * matf; float* DZ2 = ws_ + 5 * matf;
+    float* slab = ws_ + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
+    wstream ws; thin_t th; f32x4 acc[4];
+    uint32_t h2mask[2];                                           // the critics' layer-2 ReLU masks in the D layout (bit 4 t + r), kept for the backward
+    issue_thin_actor(actor, th);
+    stream_prime<false>(actor + AC_W2, ws);
     if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; sm.x[r][k] = observations[3 * idx[b] + k]; }
-    __syncthreads();
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, ((logp_only ? 4ull : 3ull) << 40) + update, (uint64_t)b); }
-    f32x4 acc[4], acc1[4], acc2[4];
-    actor_forward(sm, actor, sm.x, sm.b0, acc, e_row);           // h1 -> b0 (kept), relu(h2) in acc
+    __syncthreads();
+    layer1<3>(sm, th, sm.x, sm.b0);                              // actor h1 -> b0 (kept for the backward)
+    const float wm = th.h0, wl = th.h1;                          // this unit's head weights, kept for the actor's backward
     if (logp_only) {   // sac.py:203-204
+        __syncthreads();
+        actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e_row);
         if (t == 0) { float s = 0.0f; for (int r = 0; r < SR; ++r) s += row0 + r < batch ? sm.rv[r][5] : 0.0f; slab[1795] = s; slab[1794] = 0.0f; }
         return;
     }
+    issue_thin_q(q, th);
+    __syncthreads();
+    actor_forward2<false>(sm, actor, q + SQ_W2, sm.b0, ws, acc, e_row);
     store_acc(acc, sm.b1);                                       // actor h2 image, kept until the actor's backward
     const float alpha = alpha_p[0];
     if (t < SR) sm.x[t][3] = sm.rv[t][6];   // the action enters the critics
     __syncthreads();
-    // ---- min(Q1, Q2)(obs, pi(obs)) (:194-196); both critics' relu(h2) stay in registers for the backward ----
-    q_forward(sm, q, sm.x, sm.b2, acc1, 8);
-    if (t < SR) sm.rv[t][10] = sm.rv[t][8];
-    __syncthreads();
-    q_forward(sm, q + SQ_NP, sm.x, sm.b2, acc2, 8);
+    // ---- min(Q1, Q2)(obs, pi(obs)) (:194-196) ----
+    {
+        const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
+        sm.qmask[0][t] = mk; sm.qw13[0][t] = th.w1[3]; sm.qw3[0][t] = th.h0;
+        issue_thin_q(q + SQ_NP, th);
+        __syncthreads();
+        q_forward2<false>(sm, q, q + SQ_NP + SQ_W2, sm.b2, ws, acc, 8);
+        h2mask[0] = 0;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2mask[0] |= (acc[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
+        if (t < SR) sm.rv[t][10] = sm.rv[t][8];
+        __syncthreads();
+    }
+    {
+        const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
+        sm.qmask[1][t] = mk; sm.qw13[1][t] = th.w1[3]; sm.qw3[1][t] = th.h0;
+        __syncthreads();
+        q_forward2<true>(sm, q + SQ_NP, q + SQ_W2, sm.b2, ws, acc, 8);
+        h2mask[1] = 0;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2mask[1] |= (acc[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
+    }
     if (t < SR) {
         const float q1 = sm.rv[t][10], q2 = sm.rv[t][8];
         const bool valid = row0 + t < batch;
@@ -617,19 +732,19 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     float da_part[2];
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
-        const float* p = q + (size_t)net * SQ_NP;
         const float dq = -invn * sm.rv[li][net == 0 ? 10 : 12];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const int u = 64 * wv + 16 * tt + 4 * lg;
+            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.qw3[net][64 * wv + 16 * tt + 4 * lg]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tt][r] = (net == 0 ? acc1[tt][r] : acc2[tt][r]) > 0.0f ? p[SQ_W3 + u + r] * dq : 0.0f;
+            for (int r = 0; r < 4; ++r) acc[tt][r] = (h2mask[net] >> (4 * tt + r)) & 1u ? w3[r] * dq : 0.0f;
         }
         if (net == 1) __syncthreads();                          // net 0's MFMA pass is done reading b2
         store_acc(acc, sm.b2);
         __syncthreads();
-        mfma_bwd(p + SQ_W2, sm.b2, acc);
-        da_part[net] = q_daction_partial(sm, p, acc);
+        if (net == 0) mfma_pass<true, true>(q + SQ_W2, q + SQ_NP + SQ_W2, sm.b2, ws, acc);
+        else mfma_pass<true, true>(q + SQ_NP + SQ_W2, actor + AC_W2, sm.b2, ws, acc);
+        da_part[net] = q_daction_partial(sm, net, acc);
     }
     rows_combine2(sm, da_part[0], da_part[1], 8, 11);
     // ---- d loss / d mean, d loss / d sraw per row ----
@@ -647,7 +762,6 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     }
     __syncthreads();
     {   // unit j = t of the actor: dz2, thin gradients of the heads / bias 2, H1 / DZ2 rows
-        const float wm = actor[AC_WM + t], wl = actor[AC_WL + t];
         float gwm = 0.0f, gwl = 0.0f, gb2 = 0.0f;
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
@@ -665,7 +779,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         }
     }
     __syncthreads();
-    mfma_bwd(actor + AC_W2, sm.b2, acc);
+    mfma_pass<true, false>(actor + AC_W2, nullptr, sm.b2, ws, acc);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
         const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][64 * wv + 16 * tt + 4 * lg]);
