@@ -496,7 +496,8 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 }
 
 // ================================================ workspace layout ==============================================================
-// Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536]
+// Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536][ticket]
+// The caller zero-fills the workspace once (the ticket word resets itself after every use).
 // (mats 0,1: critics; 2: actor)
 #define SLAB 3600
 #define GEMM_MAX_SPLIT 16
@@ -506,7 +507,7 @@ __host__ __device__ inline size_t ws_slab_off(int batch) { return 6 * ws_mat_flo
 __host__ __device__ inline size_t ws_part_off(int batch) { return ws_slab_off(batch) + (size_t)(ws_kp(batch) / SR) * SLAB; }
 extern "C" size_t mi_sac_workspace_bytes(int batch) {
     if (batch <= 0) return 0;
-    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H) * sizeof(float);
+    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */) * sizeof(float);
 }
 static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >= 32 batch rows, the grid covers the rest
     int s = ws_kp(batch) / 128;
@@ -660,10 +661,24 @@ __device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, 
     return v;
 }
 
+// alpha step riding on the log-prob launch: the LAST workgroup to finish (ticket in the workspace) sums the slabs in fixed order and does the Adam step
+struct sac_alpha_t { float* log_alpha; float* m; float* v; float* alpha; float* out; unsigned int* ticket; float target_entropy, inv_count, w1, b2, w2, step_size, bc2_sqrt, eps; };
+__device__ __forceinline__ void sac_alpha_apply(const sac_alpha_t& a, float mean_lp) {
+    const float la = a.log_alpha[0];
+    const float g = -(mean_lp + a.target_entropy);            // d/d log_alpha of mean(-log_alpha * (logp + target_entropy)), sac.py:205
+    if (a.out) { a.out[0] = -la * (mean_lp + a.target_entropy); a.out[1] = g; }
+    const float mi = a.m[0] + a.w1 * (g - a.m[0]);
+    const float vi = a.v[0] * a.b2 + a.w2 * (g * g);
+    a.m[0] = mi; a.v[0] = vi;
+    const float nla = la + (-a.step_size) * (mi / (sqrtf(vi) / a.bc2_sqrt + a.eps));
+    a.log_alpha[0] = nla;
+    a.alpha[0] = expf(nla);                                    // :210
+}
+
 __global__ void __launch_bounds__(256)
 sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, const float* __restrict__ observations, const int64_t* __restrict__ idx,
                  int batch, const float* __restrict__ eps, uint64_t seed, uint64_t update, const float* __restrict__ alpha_p, float invn,
-                 float* __restrict__ ws_, int logp_only) {
+                 float* __restrict__ ws_, int logp_only, sac_alpha_t al) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
     const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
@@ -684,6 +699,16 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         __syncthreads();
         actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e_row);
         if (t == 0) { float s = 0.0f; for (int r = 0; r < SR; ++r) s += row0 + r < batch ? sm.rv[r][5] : 0.0f; slab[1795] = s; slab[1794] = 0.0f; }
+        if (!al.ticket) return;
+        if (t == 0) { __threadfence(); sm.cur[0] = atomicAdd(al.ticket, 1u) == gridDim.x - 1 ? 1 : 0; }
+        __syncthreads();
+        if (!sm.cur[0] || t >= 64) return;
+        __threadfence();
+        const volatile float* slabs = ws_ + ws_slab_off(batch);
+        float s = 0.0f;
+        for (int b = t; b < (int)gridDim.x; b += 64) s += slabs[(size_t)b * SLAB + 1795];
+        const float mean_lp = wave_sum(s) * al.inv_count;
+        if (t == 0) { sac_alpha_apply(al, mean_lp); *al.ticket = 0u; }
         return;
     }
     issue_thin_q(q, th);
@@ -868,10 +893,21 @@ __global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(float* __restrict__ w
 }
 
 // gradient assembly: (a) thin gradients = fixed-order sum of the per-workgroup slabs, scattered into the flat layout; (b) W2 gradients =
-// fixed-order sum of the GEMM's K-split partials; (c) the two loss scalars.
+// fixed-order sum of the GEMM's K-split partials; (c) the two loss scalars.  With `opt.params` set, the same launch also applies the Adam
+// step to every element it has just assembled and (critics) the polyak step of the target copy: optimizer.step() and the target update
+// (sac.py:185,213-217) cost no launch of their own.
+struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, bc2_sqrt, eps, tau; };
+__device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g) {
+    const float mi = o.m[i] + o.w1 * (g - o.m[i]);
+    const float vi = o.v[i] * o.b2 + o.w2 * (g * g);
+    o.m[i] = mi; o.v[i] = vi;
+    const float p = o.params[i] + (-o.step_size) * (mi / (sqrtf(vi) / o.bc2_sqrt + o.eps));
+    o.params[i] = p;
+    if (o.target) o.target[i] = o.tau * p + (1.0f - o.tau) * o.target[i];
+}
 #define RED_SMALL_PER_BLOCK 64
 __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __restrict__ ws, int batch, int n_slabs, int n_split, int is_actor, double inv_count,
-                                                              float* __restrict__ grads, float* __restrict__ out2) {
+                                                              float* __restrict__ grads, float* __restrict__ out2, sac_opt_t opt) {
     __shared__ float part[4][RED_SMALL_PER_BLOCK];
     const int per = is_actor ? 1794 : 1793, nets = is_actor ? 1 : 2, n_small = per * nets + 2;
     const int nb_small = (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK;
@@ -894,6 +930,7 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
                                   : l == 1536 ? AC_BM : l < 1793 ? AC_WL + (l - 1537) : AC_BL;
                 else dst = net * SQ_NP + (l < 1024 ? SQ_W1 + l : l < 1280 ? SQ_B1 + (l - 1024) : l < 1536 ? SQ_B2 + (l - 1280) : l < 1792 ? SQ_W3 + (l - 1536) : SQ_B3);
                 grads[dst] = v;
+                if (opt.params) sac_apply(opt, dst, v);
             } else if (out2) out2[e - per * nets] = (float)((double)v * inv_count);
         }
     } else {
@@ -903,20 +940,40 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
         const float* part0 = ws + ws_part_off(batch) + (size_t)net * SA_H * SA_H + 4 * (size_t)l4;
         f32x4 acc = *reinterpret_cast<const f32x4*>(part0);
         for (int y = 1; y < n_split; ++y) acc += *reinterpret_cast<const f32x4*>(part0 + (size_t)y * 3 * SA_H * SA_H);
-        float* dst = grads + (is_actor ? AC_W2 : net * SQ_NP + SQ_W2) + 4 * (size_t)l4;    // the second critic's block is only 4-byte aligned
-        dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3];
+        const int d0 = (is_actor ? AC_W2 : net * SQ_NP + SQ_W2) + 4 * l4;    // the second critic's block is only 4-byte aligned: scalar stores
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { grads[d0 + c] = acc[c]; if (opt.params) sac_apply(opt, d0 + c, acc[c]); }
     }
 }
 
-static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv_count, float* grads, float* out2, hipStream_t s) {
+static sac_opt_t sac_no_opt() { sac_opt_t o; memset(&o, 0, sizeof(o)); return o; }
+static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, int64_t step, double lr, double beta1, double beta2, double eps, float tau) {
+    sac_opt_t o;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    o.params = params; o.m = m; o.v = v; o.target = target;
+    o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2); o.step_size = (float)(lr / bc1); o.bc2_sqrt = (float)sqrt(bc2); o.eps = (float)eps; o.tau = tau;
+    return o;
+}
+
+static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv_count, float* grads, float* out2, const sac_opt_t& opt, hipStream_t s) {
     const int nb = ws_kp(batch) / SR, nets = is_actor ? 1 : 2, split = gemm_split(batch);
     sac_dw2_gemm_kernel<<<dim3(32 * nets, split), 256, 0, s>>>((float*)workspace, batch, is_actor ? 2 : 0, nets);
     MI_LAUNCH_CHECK();
     const int n_small = (is_actor ? 1794 : 2 * 1793) + 2;
     const int nblk = (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK + nets * (SA_H * SA_H / 4) / 256;
-    sac_grad_reduce_kernel<<<nblk, 256, 0, s>>>((const float*)workspace, batch, nb, split, is_actor, inv_count, grads, out2);
+    sac_grad_reduce_kernel<<<nblk, 256, 0, s>>>((const float*)workspace, batch, nb, split, is_actor, inv_count, grads, out2, opt);
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+
+static int sac_critic_impl(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                           const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                           uint64_t update_index, const float* alpha, float gamma, double inv_count, void* workspace, float* grads, float* losses,
+                           const sac_opt_t& opt, hipStream_t s) {
+    sac_critic_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+                                                       seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace);
+    MI_LAUNCH_CHECK();
+    return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, opt, s);
 }
 
 extern "C" int mi_sac_critic_grad(const float* q, const float* q_target, const float* actor, const float* observations, const float* actions,
@@ -925,11 +982,27 @@ extern "C" int mi_sac_critic_grad(const float* q, const float* q_target, const f
                                   void* workspace, float* grads, float* losses, void* stream) {
     MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "bad sizes");
-    hipStream_t s = (hipStream_t)stream;
-    sac_critic_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
-                                                       seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace);
+    return sac_critic_impl((float*)q, (float*)q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha,
+                           gamma, inv_count, workspace, grads, losses, sac_no_opt(), (hipStream_t)stream);
+}
+
+extern "C" int mi_sac_critic_update(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                                    const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                                    uint64_t update_index, const float* alpha, float gamma, void* workspace, float* grads, float* losses, float* exp_avg,
+                                    float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, void* stream) {
+    MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads && exp_avg && exp_avg_sq, "NULL pointer");
+    MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2 && step >= 1, "bad sizes");
+    return sac_critic_impl(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
+                           1.0 / batch, workspace, grads, losses, sac_make_opt(q, exp_avg, exp_avg_sq, tau >= 0.0f ? q_target : nullptr, step, lr, beta1, beta2, adam_eps, tau),
+                           (hipStream_t)stream);
+}
+
+static int sac_actor_impl(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                          uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out, const sac_opt_t& opt, hipStream_t s) {
+    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0,
+                                                      sac_alpha_t{});
     MI_LAUNCH_CHECK();
-    return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, s);
+    return sac_launch_grads(workspace, batch, 1, inv_count, grads, out, opt, s);
 }
 
 extern "C" int mi_sac_actor_grad(const float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps,
@@ -937,73 +1010,69 @@ extern "C" int mi_sac_actor_grad(const float* actor, const float* q, const float
                                  void* stream) {
     MI_CHECK_ARG(actor && q && observations && idx && alpha && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(batch > 0, "bad sizes");
-    hipStream_t s = (hipStream_t)stream;
-    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0);
-    MI_LAUNCH_CHECK();
-    return sac_launch_grads(workspace, batch, 1, inv_count, grads, out, s);
+    return sac_actor_impl((float*)actor, q, observations, idx, batch, eps, seed, update_index, alpha, inv_count, workspace, grads, out, sac_no_opt(), (hipStream_t)stream);
+}
+
+extern "C" int mi_sac_actor_update(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                                   uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
+                                   int64_t step, double lr, double beta1, double beta2, double adam_eps, void* stream) {
+    MI_CHECK_ARG(actor && q && observations && idx && alpha && workspace && grads && exp_avg && exp_avg_sq, "NULL pointer");
+    MI_CHECK_ARG(batch > 0 && step >= 1, "bad sizes");
+    return sac_actor_impl(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / batch, workspace, grads, out,
+                          sac_make_opt(actor, exp_avg, exp_avg_sq, nullptr, step, lr, beta1, beta2, adam_eps, 0.0f), (hipStream_t)stream);
 }
 
 // ================================================ alpha, Adam, polyak ============================================================
 // one wave.  mean_in: nullable device scalar holding the (already all-reduced) mean log-prob; NULL = sum this rank's slabs (lane-strided, then the fixed DPP tree)
 __global__ void __launch_bounds__(64)
-sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const float* __restrict__ mean_in, float inv_count, float* __restrict__ mean_out,
-                 float target_entropy, float* __restrict__ log_alpha, float* __restrict__ m, float* __restrict__ v, float w1, float b2, float w2,
-                 float step_size, float bc2_sqrt, float eps, float* __restrict__ alpha, float* __restrict__ out) {
+sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const float* __restrict__ mean_in, float* __restrict__ mean_out, sac_alpha_t al) {
     float mean_lp;
     if (mean_in) mean_lp = mean_in[0];
     else {
         const float* slabs = ws + ws_slab_off(batch);
         float s = 0.0f;
         for (int b = threadIdx.x; b < n_slabs; b += 64) s += slabs[(size_t)b * SLAB + 1795];
-        mean_lp = wave_sum(s) * inv_count;
+        mean_lp = wave_sum(s) * al.inv_count;
     }
     if (threadIdx.x != 0) return;
     if (mean_out) { mean_out[0] = mean_lp; return; }
-    const float la = log_alpha[0];
-    const float g = -(mean_lp + target_entropy);              // d/d log_alpha of mean(-log_alpha * (logp + target_entropy)), sac.py:205
-    if (out) { out[0] = -la * (mean_lp + target_entropy); out[1] = g; }
-    const float mi = m[0] + w1 * (g - m[0]);
-    const float vi = v[0] * b2 + w2 * (g * g);
-    m[0] = mi; v[0] = vi;
-    const float nla = la + (-step_size) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
-    log_alpha[0] = nla;
-    alpha[0] = expf(nla);                                      // :210
+    sac_alpha_apply(al, mean_lp);
+}
+
+static sac_alpha_t sac_make_alpha(float target_entropy, float inv_count, float* log_alpha, float* m, float* v, int64_t step, double lr, float* alpha, float* out,
+                                  unsigned int* ticket) {
+    sac_alpha_t a;
+    const double b1 = 0.9, b2 = 0.999, bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    a.log_alpha = log_alpha; a.m = m; a.v = v; a.alpha = alpha; a.out = out; a.ticket = ticket; a.target_entropy = target_entropy; a.inv_count = inv_count;
+    a.w1 = (float)(1.0 - b1); a.b2 = (float)b2; a.w2 = (float)(1.0 - b2); a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = 1e-8f;
+    return a;
 }
 
 static int sac_launch_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
-                           uint64_t update_index, void* workspace, hipStream_t s) {
-    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1);
+                           uint64_t update_index, void* workspace, const sac_alpha_t& al, hipStream_t s) {
+    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
 
-static int sac_launch_alpha(const float* ws, int batch, const float* mean_in, float inv_count, float target_entropy, float* log_alpha, float* exp_avg,
-                            float* exp_avg_sq, int64_t step, double lr, float* alpha, float* out, hipStream_t s) {
-    const double b1 = 0.9, b2 = 0.999, bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-    sac_alpha_kernel<<<1, 64, 0, s>>>(ws, batch, ws_kp(batch) / SR, mean_in, inv_count, nullptr, target_entropy, log_alpha, exp_avg, exp_avg_sq,
-                                      (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), 1e-8f, alpha, out);
-    MI_LAUNCH_CHECK();
-    return MI_OK;
-}
-
+// one launch: the log-prob workgroups, the last of which to finish does the alpha step (ticket word behind the GEMM partials, self-resetting)
 extern "C" int mi_sac_alpha_step(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                                  uint64_t update_index, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
                                  double lr, float* alpha, float* out, void* workspace, void* stream) {
     MI_CHECK_ARG(actor && observations && idx && log_alpha && exp_avg && exp_avg_sq && alpha && workspace, "NULL pointer");
     MI_CHECK_ARG(batch > 0 && step >= 1, "bad arguments");
-    const int rc = sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace, (hipStream_t)stream);
-    if (rc) return rc;
-    return sac_launch_alpha((const float*)workspace, batch, nullptr, 1.0f / (float)batch, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out,
-                            (hipStream_t)stream);
+    unsigned int* ticket = (unsigned int*)((float*)workspace + ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H);
+    return sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace,
+                           sac_make_alpha(target_entropy, 1.0f / (float)batch, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, ticket), (hipStream_t)stream);
 }
 
 extern "C" int mi_sac_mean_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                                 uint64_t update_index, double inv_count, float* mean_logp, void* workspace, void* stream) {
     MI_CHECK_ARG(actor && observations && idx && mean_logp && workspace && batch > 0, "bad arguments");
-    const int rc = sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace, (hipStream_t)stream);
+    const int rc = sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace, sac_alpha_t{}, (hipStream_t)stream);
     if (rc) return rc;
-    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, (float)inv_count, mean_logp, 0.0f, nullptr,
-                                                       nullptr, nullptr, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, nullptr, nullptr);
+    sac_alpha_t al{}; al.inv_count = (float)inv_count;
+    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, mean_logp, al);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -1011,7 +1080,10 @@ extern "C" int mi_sac_mean_logp(const float* actor, const float* observations, c
 extern "C" int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
                                  double lr, float* alpha, float* out, void* stream) {
     MI_CHECK_ARG(mean_logp && log_alpha && exp_avg && exp_avg_sq && alpha && step >= 1, "bad arguments");
-    return sac_launch_alpha(nullptr, 0, mean_logp, 0.0f, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, (hipStream_t)stream);
+    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>(nullptr, 0, 0, mean_logp, nullptr,
+                                                       sac_make_alpha(target_entropy, 0.0f, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr));
+    MI_LAUNCH_CHECK();
+    return MI_OK;
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,

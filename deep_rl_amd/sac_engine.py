@@ -48,7 +48,7 @@ class SACEngine:
         self.actor_grads, self.actor_out = self._abuf[:N.SAC_ACTOR_NPARAMS], self._abuf[N.SAC_ACTOR_NPARAMS:]   # out = {actor_loss, mean logp}
         self.alpha_out = torch.zeros(2, dtype=torch.float32, device=dev)                       # {alpha_loss, d/d log_alpha}
         self._mean_logp = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.workspace = torch.empty(N.lib().mi_sac_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)
+        self.workspace = torch.zeros(N.lib().mi_sac_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)   # zero-filled once (ticket word)
         self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (64 if Nn <= 8 else 0))
         self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
         self.episode_stats = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -113,10 +113,25 @@ class SACEngine:
             N.ptr(self.q_grads), N.ptr(self.q_losses), self._s()), "mi_sac_critic_grad")
         D.allreduce_sum_(self._qbuf, self.pg)
 
-    def update_critic(self, eps=None):
-        """sac.py:170-185."""
-        self.critic_grad(eps)
-        self.q_optimizer.step(self.q_grads)
+    def update_critic(self, eps=None, polyak=False):
+        """sac.py:170-185 (+ the target update of :213-217 when `polyak`).  Single process: ONE fused call — the launch that assembles the
+        gradient also applies Adam and the polyak step; sharded: gradient, all-reduce, Adam (, polyak)."""
+        if self.world_size == 1:
+            e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+            o = self.q_optimizer
+            g = o.param_groups[0]
+            o.step_count += 1
+            N.check(N.lib().mi_sac_critic_update(
+                N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+                N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
+                self._key(self.update_index), N.ptr(self.alpha), self.gamma, N.ptr(self.workspace), N.ptr(self.q_grads), N.ptr(self.q_losses),
+                N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                self.tau if polyak else -1.0, self._s()), "mi_sac_critic_update")
+        else:
+            self.critic_grad(eps)
+            self.q_optimizer.step(self.q_grads)
+            if polyak:
+                self.update_targets()
         self.update_index += 1
 
     def actor_grad(self, eps=None):
@@ -129,9 +144,20 @@ class SACEngine:
         D.allreduce_sum_(self._abuf, self.pg)
 
     def update_actor(self, eps=None):
-        """sac.py:189-197."""
-        self.actor_grad(eps)
-        self.actor_optimizer.step(self.actor_grads)
+        """sac.py:189-197 (single process: one fused call, as update_critic)."""
+        if self.world_size == 1:
+            e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+            o = self.actor_optimizer
+            g = o.param_groups[0]
+            o.step_count += 1
+            N.check(N.lib().mi_sac_actor_update(
+                N.ptr(self.actor.flat), N.ptr(self.q_flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e),
+                self.env._seed, self._key(self.actor_updates), N.ptr(self.alpha), N.ptr(self.workspace), N.ptr(self.actor_grads),
+                N.ptr(self.actor_out), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                self._s()), "mi_sac_actor_update")
+        else:
+            self.actor_grad(eps)
+            self.actor_optimizer.step(self.actor_grads)
 
     def update_alpha(self, eps=None):
         """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
@@ -159,12 +185,11 @@ class SACEngine:
         N.check(N.lib().mi_polyak(N.ptr(self.qt_flat), N.ptr(self.q_flat), self.q_flat.numel(), self.tau, self._s()), "mi_polyak")
 
     def train_step(self, policy_frequency=2, target_network_frequency=1, indices=None):
-        """The optimisation half of one loop iteration (sac.py:161-217) at the current global_step."""
+        """The optimisation half of one loop iteration (sac.py:161-217) at the current global_step.  The target update uses the critic
+        parameters, which the actor / alpha updates do not touch, so it rides on the critic update's last launch."""
         self.sample(indices)
-        self.update_critic()
+        self.update_critic(polyak=self.global_step % target_network_frequency == 0)
         if self.global_step % policy_frequency == 0:
             for _ in range(policy_frequency):
                 self.update_actor()
                 self.update_alpha()
-        if self.global_step % target_network_frequency == 0:
-            self.update_targets()

@@ -209,6 +209,7 @@ int mi_sac_act_step(void* handle, const float* actor, int64_t global_step, int64
                     float* observations, float* actions, float* rewards, uint8_t* terminated, const float* forced_actions,
                     const float* forced_eps, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
                     void* stream);
+/* scratch for the update calls below; the caller zero-fills it ONCE before first use (it carries a self-resetting ticket word) */
 size_t mi_sac_workspace_bytes(int batch);
 /* critic update (sac.py:165-185): grads dev f32 [2*MI_SAC_Q_NPARAMS] of qf1_loss + qf2_loss, losses dev f32 [2] */
 int mi_sac_critic_grad(const float* q, const float* q_target, const float* actor, const float* observations, const float* actions,
@@ -219,6 +220,16 @@ int mi_sac_critic_grad(const float* q, const float* q_target, const float* actor
 int mi_sac_actor_grad(const float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps,
                       uint64_t seed, uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out,
                       void* stream);
+/* single-process fusions (no gradient exchange in between): the same launches as the *_grad calls, whose last kernel also applies
+ * optimizer.step() (torch Adam, sac.py:185 / :197) to every gradient element it has just assembled and, for the critics, the polyak step of the
+ * target copy (sac.py:213-217; tau < 0 skips it).  inv_count = 1 / batch.  grads / losses / out are still written. */
+int mi_sac_critic_update(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                         const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                         uint64_t update_index, const float* alpha, float gamma, void* workspace, float* grads, float* losses, float* exp_avg,
+                         float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, void* stream);
+int mi_sac_actor_update(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                        uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
+                        int64_t step, double lr, double beta1, double beta2, double adam_eps, void* stream);
 /* alpha update (sac.py:203-210): fresh log-probs under the current actor, alpha_loss = mean(-log_alpha (logp + target_entropy)),
  * one Adam step on log_alpha (dev f32 [1], moments dev f32 [1] each), alpha <- exp(log_alpha) (dev f32 [1]); out dev f32 [2] =
  * {alpha_loss, d alpha_loss / d log_alpha} (nullable). */

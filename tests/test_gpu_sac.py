@@ -346,6 +346,44 @@ def test_adam_and_polyak_vs_oracle(dev, R):
     assert np.array_equal(tt.cpu().numpy(), want)
 
 
+def test_fused_updates_equal_grad_then_adam(dev, R):
+    """mi_sac_critic_update / mi_sac_actor_update / fused alpha step == the *_grad call followed by mi_adam (and mi_polyak), bit for bit."""
+    from deep_rl_amd import _native as N
+
+    rng = np.random.default_rng(77)
+    n, slots, batch = 4, 40, 300
+    a_p, q_p = _rand_nets(R, rng, 1.5)
+    _, qt_p = _rand_nets(R, rng, 1.5)
+    st = _random_storage(R, rng, slots, n)
+    idx = rng.integers(0, slots * n, batch)
+    eps = [torch.from_numpy(rng.standard_normal(batch).astype(np.float32)) for _ in range(3)]
+    engs = []
+    for fused in (True, False):
+        eng = _engine(dev, n, slots, actor=a_p, q=q_p, qt=qt_p, batch_size=batch)
+        _upload(eng, st)
+        eng.alpha.fill_(0.3)
+        eng.sample(idx)
+        for it in range(2):      # two rounds so that the Adam moments and step counts matter
+            if fused:
+                eng.update_critic(eps[0], polyak=True); eng.update_actor(eps[1]); eng.update_alpha(eps[2])
+            else:
+                eng.critic_grad(eps[0]); eng.q_optimizer.step(eng.q_grads); eng.update_targets(); eng.update_index += 1
+                eng.actor_grad(eps[1]); eng.actor_optimizer.step(eng.actor_grads)
+                eng.alpha_steps += 1
+                N.check(N.lib().mi_sac_mean_logp(N.ptr(eng.actor.flat), N.ptr(eng.observations), N.ptr(eng.batch_inds), batch, N.ptr(eps[2].to(dev)), 1, 0, 1.0 / batch,
+                                                 N.ptr(eng._mean_logp), N.ptr(eng.workspace), N.stream_ptr(dev)), "mi_sac_mean_logp")
+                N.check(N.lib().mi_sac_alpha_adam(N.ptr(eng._mean_logp), eng.target_entropy, N.ptr(eng.log_alpha), N.ptr(eng._alpha_m), N.ptr(eng._alpha_v), eng.alpha_steps,
+                                                  eng.alpha_lr, N.ptr(eng.alpha), N.ptr(eng.alpha_out), N.stream_ptr(dev)), "mi_sac_alpha_adam")
+                eng.actor_updates += 1
+        engs.append(eng)
+    f, u = engs
+    for name in ("q_flat", "qt_flat", "q_grads", "q_losses", "actor_grads", "actor_out", "log_alpha", "alpha", "alpha_out"):
+        assert torch.equal(getattr(f, name), getattr(u, name)), name
+    assert torch.equal(f.actor.flat, u.actor.flat)
+    assert torch.equal(f.q_optimizer.exp_avg_sq, u.q_optimizer.exp_avg_sq) and torch.equal(f.actor_optimizer.exp_avg, u.actor_optimizer.exp_avg)
+    assert not torch.equal(f.qt_flat, torch.from_numpy(qt_p).to(dev))      # the polyak step happened
+
+
 # ---------------------------------------------------------------- against the reference --------------------------------------------
 def test_chained_first_30_steps_on_device(dev, R, sac_trace):
     """The reference run's global steps 5000..5029 on the DEVICE (30 critic, 30 actor, 30 alpha updates, 30 polyak steps chained through the
