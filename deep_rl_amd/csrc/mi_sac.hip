@@ -590,6 +590,9 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
                   const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
+    // gridDim.y == 2: the two critics' forward + backward run in two workgroups per row group (each repeats the actor / target forwards):
+    // 5 passes on the critical path instead of 7, used while the row groups do not fill the chip anyway
+    const bool split = gridDim.y == 2, second = split && blockIdx.y == 1;
     const size_t matf = ws_mat_floats(batch);
     float* H1 = ws_; float* DZ2 = ws_ + 3 * matf;
     float* slab = ws_ + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
@@ -628,7 +631,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     issue_thin_q(q, th);
     issue_thin_q(q + SQ_NP, th2);
     __syncthreads();
-    q_forward2<false>(sm, qt + SQ_NP, q + SQ_W2, sm.b0, ws, acc, 8);
+    q_forward2<false>(sm, qt + SQ_NP, q + (second ? SQ_NP : 0) + SQ_W2, sm.b0, ws, acc, 8);
     if (t < SR) {
         const float alpha = alpha_p[0];
         const float mq = fminf(sm.rv[t][10], sm.rv[t][8]) - alpha * sm.rv[t][9];                                   // :176
@@ -636,8 +639,8 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     }
     __syncthreads();
     // ---- the two critics on (obs, action): forward, loss, backward (:179-185) ----
-    critic_net_update<0>(sm, q, q + SQ_NP + SQ_W2, ws, th, batch, row0, invn, H1, DZ2, slab);
-    critic_net_update<1>(sm, q, nullptr, ws, th2, batch, row0, invn, H1, DZ2, slab);
+    if (!second) critic_net_update<0>(sm, q, split ? nullptr : q + SQ_NP + SQ_W2, ws, th, batch, row0, invn, H1, DZ2, slab);
+    if (!split || second) critic_net_update<1>(sm, q, nullptr, ws, th2, batch, row0, invn, H1, DZ2, slab);
 }
 
 // ================================================ actor update ==================================================================
@@ -970,7 +973,8 @@ static int sac_critic_impl(float* q, float* q_target, const float* actor, const 
                            const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
                            uint64_t update_index, const float* alpha, float gamma, double inv_count, void* workspace, float* grads, float* losses,
                            const sac_opt_t& opt, hipStream_t s) {
-    sac_critic_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+    const int nrg = ws_kp(batch) / SR;
+    sac_critic_kernel<<<dim3(nrg, nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
                                                        seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace);
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, opt, s);
