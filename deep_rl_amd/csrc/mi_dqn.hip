@@ -82,25 +82,70 @@ extern "C" int mi_dqn_forward(const float* params, const float* obs, int n, floa
 #define DQN_MAX_STEPS_PER_CALL 64
 struct dqn_eps_tab { float v[DQN_MAX_STEPS_PER_CALL]; };  // epsilon(global_step + k), passed by value
 
-// ---- acting: one lane per env, n_steps iterations in one launch (the online net is frozen between two updates) ---------
-__global__ void __launch_bounds__(64)
+// ---- acting: n_steps iterations of {epsilon-greedy, env.step + auto-reset, ring store} in one launch (the online net is frozen
+// between two updates).  A workgroup of 3 waves owns 16 envs; the forward runs on v_mfma_f32_16x16x4_f32 in the [unit][env] orientation
+// with EVERY weight resident in registers as an A operand for the whole launch (wave w owns output tiles 2w, 2w+1 of layer 2):
+//   layer 1  D1[unit][env] = W1[unit][0..3] . obs[env][0..3]            one k-step per 16-unit tile (8 tiles, 120 units padded to 128)
+//   layer 2  D2[out][env] += W2[out][u] * h1[u][env]                    the layer-1 accumulators ARE the B operands: accumulator
+//            register r of tile t in lane group g is unit 16 t + 4 g + r, so k-step (t, r) contracts over g with A = W2[out][16 t + 4 g + r]
+//   layer 3  two dot products over the wave's 32 units, summed across lane groups (2 shuffles) and across the 3 waves (LDS, one barrier)
+// All 64 lanes of every wave carry the fp64 state of env (lane & 15) and step it redundantly (same IEEE sequence => same bits), so the
+// observation never has to be exchanged; wave 0, lane group 0 writes the ring.  72 MFMAs per wave and step.
+#define DA_ENVS 16
+#define DA_WAVES 3
+typedef float dq_f32x4 __attribute__((ext_vector_type(4)));
+#define DQ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__global__ void __launch_bounds__(64 * DA_WAVES)
 dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long long global_step, long long slots, long long learning_starts,
                dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
                int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
                const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
                int32_t* __restrict__ episode_stats, int max_ep) {
-    __shared__ __attribute__((aligned(16))) float w[DQ_NP + 2];
-    stage_params(w, params);
+    __shared__ float qp[2][DA_WAVES][DA_ENVS][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
     const int N = e.n;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = i < N;
+    const int i = blockIdx.x * DA_ENVS + j;
+    const bool mine = i < N, writer = mine && w == 0 && lg == 0;
     const int g = mine ? i : N - 1;
+    // ---- resident operands ----
+    float w1a[8];
+    dq_f32x4 b1v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int ua = 16 * t + j;
+        w1a[t] = ua < DQ_H1 ? params[DQ_W1 + 4 * ua + lg] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int u = 16 * t + 4 * lg + r; b1v[t][r] = u < DQ_H1 ? params[DQ_B1 + u] : 0.0f; }
+    }
+    float w2a[2][8][4];
+    dq_f32x4 b2v[2], w3v[2][2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const int row = 16 * (2 * w + T) + j;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int col = 16 * t + 4 * lg;
+            if (row < DQ_H2 && col < DQ_H1) {      // 120 = 7.5 tiles: a lane's 4 columns are all inside or all outside
+                const float4 v = *reinterpret_cast<const float4*>(params + DQ_W2 + DQ_H1 * row + col);
+                w2a[T][t][0] = v.x; w2a[T][t][1] = v.y; w2a[T][t][2] = v.z; w2a[T][t][3] = v.w;
+            } else { w2a[T][t][0] = w2a[T][t][1] = w2a[T][t][2] = w2a[T][t][3] = 0.0f; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * (2 * w + T) + 4 * lg + r;
+            b2v[T][r] = o < DQ_H2 ? params[DQ_B2 + o] : 0.0f;
+            w3v[T][0][r] = o < DQ_H2 ? params[DQ_W3 + o] : 0.0f;
+            w3v[T][1][r] = o < DQ_H2 ? params[DQ_W3 + DQ_H2 + o] : 0.0f;
+        }
+    }
+    const float b30 = params[DQ_B3], b31 = params[DQ_B3 + 1];
+    // ---- env state (every lane group holds a copy) ----
     double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
     int elapsed = e.elapsed[g], eplen = e.ep_len[g];
     float epret = e.ep_ret[g];
     uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
     float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
-    int st_cnt = 0, st_len = 0, st_max = 0;
+    int st_cnt = 0, st_len = 0, st_max = 0, par = 0;
     for (int s = 0; s < n_steps; ++s) {
         const long long gs = global_step + s, slot = gs % slots, nslot = (gs + 1) % slots;
         int a;
@@ -111,15 +156,43 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
             const float u = mi_u32_to_uniform(r[0]);
             const bool explore = gs < learning_starts || u < eps.v[s];
             a = (int)(r[1] & 1u);
-            if (__any(!explore)) {  // the greedy branch costs a whole forward: skip it while every lane explores
-                const float x[4] = {ob.x, ob.y, ob.z, ob.w};
-                float q[2];
-                dqn_row_forward(w, x, q);
-                if (!explore) a = q[1] > q[0] ? 1 : 0;  // torch.argmax: first index on ties (dqn.py:92)
+            if (__any(!explore)) {  // skip the forward while every env of the group explores (same envs in all three waves: block-uniform)
+                const float b0 = lg == 0 ? ob.x : lg == 1 ? ob.y : lg == 2 ? ob.z : ob.w;
+                dq_f32x4 h1[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    h1[t] = DQ_MFMA(w1a[t], b0, b1v[t]);          // the bias enters as the accumulator
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) h1[t][r2] = fmaxf(h1[t][r2], 0.0f);
+                }
+                dq_f32x4 h2[2] = {b2v[0], b2v[1]};
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) {
+                        h2[0] = DQ_MFMA(w2a[0][t][r2], h1[t][r2], h2[0]);
+                        h2[1] = DQ_MFMA(w2a[1][t][r2], h1[t][r2], h2[1]);
+                    }
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) {
+                        const float hv = fmaxf(h2[T][r2], 0.0f);
+                        p0 = __builtin_fmaf(w3v[T][0][r2], hv, p0); p1 = __builtin_fmaf(w3v[T][1][r2], hv, p1);
+                    }
+                p0 += __shfl_xor(p0, 16); p0 += __shfl_xor(p0, 32);
+                p1 += __shfl_xor(p1, 16); p1 += __shfl_xor(p1, 32);
+                if (lg == 0) { qp[par][w][j][0] = p0; qp[par][w][j][1] = p1; }
+                __syncthreads();
+                const float q0 = ((qp[par][0][j][0] + qp[par][1][j][0]) + qp[par][2][j][0]) + b30;
+                const float q1 = ((qp[par][0][j][1] + qp[par][1][j][1]) + qp[par][2][j][1]) + b31;
+                par ^= 1;                                          // the other buffer next time: one barrier per step is enough
+                if (!explore) a = q1 > q0 ? 1 : 0;                 // torch.argmax: first index on ties (dqn.py:92)
             }
         }
         stepctr += 1;
-        if (mine) actions[slot * N + g] = a;                                   // dqn.py:95
+        if (writer) actions[slot * N + g] = a;                                   // dqn.py:95
         int term;
         mi_cartpole_step(sx, sxd, sth, sthd, a, term);
         elapsed += 1;
@@ -127,7 +200,7 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
         const bool d = term || trunc;
         epret += 1.0f; eplen += 1;
         if (d) {
-            if (mine) {
+            if (writer) {
                 st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
                 if (max_ep > 0 && episode_stats) {
                     const int sl = atomicAdd(episode_stats + 3, 1);
@@ -146,13 +219,13 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
             sx = rs[0]; sxd = rs[1]; sth = rs[2]; sthd = rs[3];
         }
         ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
-        if (mine) {
+        if (writer) {
             reinterpret_cast<float4*>(observations)[nslot * N + g] = ob;       // dqn.py:106 (the reset obs where done)
             rewards[nslot * N + g] = 1.0f;                                     // :107
             terminated[nslot * N + g] = (uint8_t)(term ? 1 : 0);               // :108: done and not TimeLimit.truncated
         }
     }
-    if (mine) {
+    if (writer) {
         e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
         e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr;
         reinterpret_cast<float4*>(obs_cur)[g] = ob;
@@ -181,7 +254,7 @@ extern "C" int mi_dqn_act_steps(void* handle, const float* params, int n_steps, 
         const double ev = slope * (double)(global_step + k) + start_e;
         tab.v[k] = (float)(ev > end_e ? ev : end_e);
     }
-    dqn_act_kernel<<<(e->n + 63) / 64, 64, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab,
+    dqn_act_kernel<<<(e->n + DA_ENVS - 1) / DA_ENVS, 64 * DA_WAVES, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab,
                                                   obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes,
                                                   episode_stats, max_ep);
     MI_LAUNCH_CHECK();
