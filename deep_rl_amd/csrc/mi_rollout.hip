@@ -188,6 +188,175 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
     }
 }
 
+// ---- the same rollout on the matrix cores ----------------------------------------------------------------------------------------
+// A workgroup of 4 waves owns 16 envs for all T steps.  Wave w evaluates net (w >> 1) (0 actor, 1 critic), output tiles 2 (w & 1) and
+// 2 (w & 1) + 1 of its second layer, on v_mfma_f32_16x16x4_f32 in the [unit][env] orientation, every weight register-resident as an A
+// operand for the whole launch:
+//   layer 1  D1[unit][env] = b1[unit] + W1[unit][0..3] . obs[env][0..3]        one k-step per 16-unit tile (the bias is the accumulator input)
+//   layer 2  D2[out][env] += W2[out][u] * tanh(D1)[u][env]                     the layer-1 accumulators ARE the B operands: register r of tile t
+//            in lane group g is unit 16 t + 4 g + r, so k-step (t, r) contracts over g with A = W2[out][16 t + 4 g + r]
+//   heads    dot products over the wave's 32 units, summed across lane groups (2 shuffles) and the net's two waves (LDS, ONE barrier per step)
+// All 64 lanes of all 4 waves carry the fp64 state of env (lane & 15) and run the scalar section (Categorical draw, log-prob, CartPole
+// step, TimeLimit, auto-reset) redundantly — identical IEEE sequences, identical bits — so neither action nor observation is ever
+// exchanged; wave 0 / lane group 0 writes the storage.  36 MFMAs + 24 tanh per wave and step (was: 2 x 4,500 VALU FMAs per env-step).
+#define RM_ENVS 16
+typedef float rm_f32x4 __attribute__((ext_vector_type(4)));
+#define RM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__global__ void __launch_bounds__(256)
+rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __restrict__ obs_cur, float* __restrict__ observations,
+                    float* __restrict__ values, int64_t* __restrict__ actions, float* __restrict__ log_probs,
+                    float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
+                    const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
+                    mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep) {
+    __shared__ float hp[2][4][RM_ENVS][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
+    const int net = w >> 1, half = w & 1;
+    const int N = e.n;
+    const int i = blockIdx.x * RM_ENVS + j;
+    const bool mine = i < N, writer = mine && w == 0 && lg == 0;
+    const int g = mine ? i : N - 1;
+    // ---- resident operands of this wave's net ----
+    const float* p = params + (net ? C_BASE : 0);
+    float w1a[4], w2a[2][4][4];
+    rm_f32x4 b1v[4], b2v[2], w3v[2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        w1a[t] = p[N_W1 + 4 * (16 * t + j) + lg];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1v[t][r] = p[N_B1 + 16 * t + 4 * lg + r];
+    }
+#pragma unroll
+    for (int TT = 0; TT < 2; ++TT) {
+        const int row = 16 * (2 * half + TT) + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w2a[TT][t][r] = p[N_W2 + HID * row + 16 * t + 4 * lg + r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * (2 * half + TT) + 4 * lg + r;
+            b2v[TT][r] = p[N_B2 + o];
+            w3v[TT][0][r] = p[N_W3 + o];
+            w3v[TT][1][r] = net == 0 ? p[N_W3 + HID + o] : 0.0f;
+        }
+    }
+    const float b3a0 = params[A_B3], b3a1 = params[A_B3 + 1], b3c = params[C_BASE + N_W3 + HID];
+    // ---- env state: every lane group of every wave holds a copy of env (lane & 15) ----
+    double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
+    int elapsed = e.elapsed[g], eplen = e.ep_len[g];
+    float epret = e.ep_ret[g];
+    uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
+    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
+    float my_l0 = 0.0f, my_l1 = 0.0f, my_val = 0.0f;
+    int st_cnt = 0, st_len = 0, st_max = 0;
+    uint32_t urand[4] = {0, 0, 0, 0};
+    const bool keyed_actions = !forced_actions && !forced_uniforms;
+    if (keyed_actions && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
+
+    for (int t = -1; t < T; ++t) {
+        float rew = 0.0f, dn = 0.0f;
+        if (t >= 0) {
+            // ---- sample from the logits of obs[t], step the env (ppo.py:120-129) ----
+            const size_t row = (size_t)t * N + g;
+            float nl0, nl1, p0, p1, ent;
+            mi_categorical2_fast(my_l0, my_l1, nl0, nl1, p0, p1, ent);
+            int a;
+            if (forced_actions) a = (int)forced_actions[row];
+            else {
+                float u;
+                if (forced_uniforms) u = forced_uniforms[row];
+                else {
+                    const uint32_t wd = (uint32_t)stepctr & 3u;
+                    if (wd == 0) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
+                    u = mi_u32_to_uniform(wd == 0 ? urand[0] : wd == 1 ? urand[1] : wd == 2 ? urand[2] : urand[3]);
+                }
+                a = (u >= p0) ? 1 : 0;
+            }
+            stepctr += 1;
+            if (writer) { actions[row] = a; log_probs[row] = a ? nl1 : nl0; }  // ppo.py:123-124
+            int term;
+            mi_cartpole_step(sx, sxd, sth, sthd, a, term);
+            elapsed += 1;
+            const bool d = term || elapsed >= CP_MAX_STEPS;
+            epret += 1.0f;
+            eplen += 1;
+            if (d) {
+                if (writer) {
+                    st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
+                    if (max_ep > 0 && episode_stats) {
+                        const int slot = atomicAdd(episode_stats + 3, 1);
+                        if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
+                    }
+                }
+                epret = 0.0f; eplen = 0; elapsed = 0;
+                double sr[4];
+                if (forced_resets) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sr[k] = forced_resets[4 * row + k];
+                } else {
+                    mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, sr);
+                }
+                episode += 1;
+                sx = sr[0]; sxd = sr[1]; sth = sr[2]; sthd = sr[3];
+            }
+            ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
+            rew = 1.0f; dn = d ? 1.0f : 0.0f;
+        }
+        // ---- this wave's net on obs[t+1] (ppo.py:115/139 critic, :120 actor of the next step) ----
+        const float b0 = lg == 0 ? ob.x : lg == 1 ? ob.y : lg == 2 ? ob.z : ob.w;
+        rm_f32x4 h1[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) h1[tt] = RM_MFMA(w1a[tt], b0, b1v[tt]);
+        rm_f32x4 h2[2] = {b2v[0], b2v[1]};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[tt][r] = mi_tanhf(h1[tt][r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                h2[0] = RM_MFMA(w2a[0][tt][r], h1[tt][r], h2[0]);
+                h2[1] = RM_MFMA(w2a[1][tt][r], h1[tt][r], h2[1]);
+            }
+        }
+        float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+        for (int TT = 0; TT < 2; ++TT)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hv = mi_tanhf(h2[TT][r]);
+                q0 = __builtin_fmaf(w3v[TT][0][r], hv, q0); q1 = __builtin_fmaf(w3v[TT][1][r], hv, q1);
+            }
+        q0 += __shfl_xor(q0, 16); q0 += __shfl_xor(q0, 32);
+        q1 += __shfl_xor(q1, 16); q1 += __shfl_xor(q1, 32);
+        const int par = (t + 1) & 1;                             // alternate buffers: one barrier per step is enough
+        if (lg == 0) { hp[par][w][j][0] = q0; hp[par][w][j][1] = q1; }
+        __syncthreads();
+        my_l0 = (hp[par][0][j][0] + hp[par][1][j][0]) + b3a0;
+        my_l1 = (hp[par][0][j][1] + hp[par][1][j][1]) + b3a1;
+        my_val = (hp[par][2][j][0] + hp[par][3][j][0]) + b3c;
+        if (writer) {
+            const size_t row = (size_t)(t + 1) * N + g;
+            reinterpret_cast<float4*>(observations)[row] = ob;  // :113,:137 (the reset obs where done)
+            values[row] = my_val;                               // :115,:139
+            if (t >= 0) { rewards[row] = rew; dones[row] = dn; }  // :140-141
+        }
+    }
+    if (w == 0 && lg == 0) {   // lanes 0..15 of wave 0: one flush per workgroup
+        if (episode_stats) {
+            int c = mine ? st_cnt : 0, l = mine ? st_len : 0, m = mine ? st_max : 0;
+#pragma unroll
+            for (int sft = 1; sft < 16; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
+            if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
+        }
+        if (mine) {   // carry-over `observation` and env state for the next rollout
+            e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
+            e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen;
+            e.episode[g] = episode; e.step_ctr[g] = stepctr;
+            reinterpret_cast<float4*>(obs_cur)[g] = ob;
+        }
+    }
+}
+
 __global__ void zero_i32x4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
 extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
@@ -201,7 +370,13 @@ extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* o
     hipStream_t s = (hipStream_t)stream;
     if (episode_stats) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
     mi_prof_scope prof(MI_PROF_ROLLOUT, s);
-    // E=2 halves the wave count (2 waves/SIMD at N=4096); E=1 for tiny N keeps every env on its own wave.
+#ifndef ROLLOUT_VALU
+    rollout_mfma_kernel<<<(e->n + RM_ENVS - 1) / RM_ENVS, 256, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones,
+                                                                      forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+#endif
+    // the VALU formulation (-DROLLOUT_VALU, kept for A/B): E=2 halves the wave count (2 waves/SIMD at N=4096); E=1 for tiny N keeps every env on its own wave.
     if (e->n >= 512) {
         const int waves = (e->n + 1) / 2, blocks = (waves + ROLLOUT_WAVES - 1) / ROLLOUT_WAVES;
         rollout_kernel<2><<<blocks, 64 * ROLLOUT_WAVES, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards,

@@ -34,8 +34,9 @@ def _worker(rank, world, port, q):
     dev = torch.device("cuda", 0)
     eng = _mk(dev, NL, rank * NL, True)
     assert eng.world_size == world
+    params0 = eng.agent.flat.cpu().numpy().copy()
     eng.reset(); eng.rollout(); eng.compute_gae()
-    out = {"storage": {n: getattr(eng, n).cpu().numpy() for n in ["observations", "actions", "dones", "advantages"]}}
+    out = {"params0": params0, "storage": {n: getattr(eng, n).cpu().numpy() for n in ["observations", "actions", "dones", "advantages"]}}
     eng.make_perm(0)                       # same key on every rank, applied to the rank's local rows
     out["perm"] = eng.perm.cpu().numpy()
     eng.adv_stats()                        # all-reduce #1
@@ -69,12 +70,19 @@ def test_two_ranks_on_one_gpu_match_single_process():
         assert p.exitcode == 0
     dev = torch.device("cuda", 0)
     eng = _mk(dev, 2 * NL, 0, False)
+    # torch's CPU orthogonal init (QR) may differ in the last bit between a fresh process and this one (thread count / code path
+    # chosen after other tests ran); the comparison is about the device path, so start from the ranks' own initial parameters
+    assert np.array_equal(res[0]["params0"], res[1]["params0"])
+    assert np.abs(eng.agent.flat.cpu().numpy() - res[0]["params0"]).max() < 1e-6
+    eng.agent.load_flat(res[0]["params0"])
     eng.reset(); eng.rollout(); eng.compute_gae()
     # N-invariance: each rank's trajectories are the matching columns of the big run
     for r in range(2):
         sl = slice(r * NL, (r + 1) * NL)
         for n in ["observations", "actions", "dones", "advantages"]:
-            assert np.array_equal(getattr(eng, n)[:, sl].cpu().numpy(), res[r]["storage"][n]), (r, n)
+            big, small = getattr(eng, n)[:, sl].cpu().numpy(), res[r]["storage"][n]
+            bad = np.argwhere(big != small)
+            assert bad.shape[0] == 0, (r, n, bad.shape[0], bad[:8].tolist(), [(float(big[tuple(b)]), float(small[tuple(b)])) for b in bad[:4]])
     # union minibatch in the big run's row numbering: local row t*NL + e  ->  t*(2 NL) + r*NL + e
     mb = T * NL // 4
     gidx = np.concatenate([(res[r]["perm"][:mb] // NL) * (2 * NL) + r * NL + res[r]["perm"][:mb] % NL for r in range(2)]).astype(np.int32)
