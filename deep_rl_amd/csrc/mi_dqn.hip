@@ -4,8 +4,9 @@
 //   dqn_sample_kernel    batch_inds = randint(upper, size=batch)                               (dqn.py:116)
 //   dqn_td_kernel        gather, target max, TD target, MSE loss, backward                      (dqn.py:118-128)
 //   dqn_reduce_kernel    fixed-order sum of the per-workgroup partial gradients
-// Widths 120 / 84 are not MFMA-tile multiples and the batches are small (128 rows in the reference), so this path is
-// VALU + LDS; the parameters (43.7 KB) stay L2-resident, activations of a row group live in LDS.
+// Acting runs on the f32 MFMA (16 envs per workgroup, weights register-resident, 120 / 84 units zero-padded to 128 / 96); the TD
+// update's batches are small (128 rows in the reference), so it is VALU + LDS: parameters (43.7 KB) stay L2-resident, activations of
+// a row group live in LDS.
 #include "mi_common.h"
 
 #define DQ_H1 120

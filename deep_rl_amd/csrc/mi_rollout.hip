@@ -1,6 +1,7 @@
 // mi_rollout.hip — the whole rollout loop of reference ppo.py:110-141 in ONE launch.
 //
-// Mapping (MI355X-first, SURVEY §7 hard part 1: 4096 envs is small for 256 CUs, the chain is 128 deep):
+// Two formulations share the step logic: rollout_mfma_kernel (default; further down) and the original VALU one below
+// (-DROLLOUT_VALU, kept for A/B).  Mapping of the VALU form (SURVEY §7 hard part 1: 4096 envs is small for 256 CUs, the chain is 128 deep):
 //   * envs are independent for the whole rollout (weights are frozen), so there is no inter-workgroup
 //     communication at all: one WAVE owns E envs for all T steps; lane j owns hidden unit j of both nets.
 //   * W1/W2/W3 rows of unit j live in that lane's VGPRs for the whole kernel (36.6 KB of weights are read from

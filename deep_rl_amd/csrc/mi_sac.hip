@@ -1,15 +1,15 @@
 // mi_sac.hip — the SAC hot path of reference deep_rl/sac.py (re-targeted to Pendulum-v1) on the device:
-//   pend_*_kernel           Pendulum-v1 reset / step (gym 0.21 pendulum.py + TimeLimit 200 + episode statistics)
-//   sac_act_kernel          sac.py:138-158: uniform random action before learning_starts, else actor.get_action; step; ring store
-//   sac_critic_kernel       sac.py:165-185: actor on next obs, two target critics, TD target, two critics forward + backward
-//   sac_actor_kernel        sac.py:193-197: actor forward (rsample), min(Q1,Q2) forward, d(-minQ)/d action, actor backward
-//   sac_logp_kernel         sac.py:203-204: log-probs of fresh actions for the alpha loss
-//   sac_dw2_gemm_kernel     the 256x256 weight gradients as batch GEMMs dW2 = dZ2^T H1 on v_mfma_f32_16x16x4_f32
-//   sac_small_reduce_kernel fixed-order sum of the per-workgroup slabs of the thin gradients
-//   adam_kernel / polyak_kernel / sac_alpha_kernel
-// Row-group layout: a 256-thread workgroup owns SR = 8 batch rows; thread j owns hidden unit j of whichever net is being
-// evaluated; a row group's activations live in LDS, 256x256 weight matrices are streamed from L2 (forward: row j per thread;
-// backward-data: column k per thread, coalesced).  All reductions are fixed-order (bitwise reproducible).
+//   pend_*_kernel            Pendulum-v1 reset / step (gym 0.21 pendulum.py + TimeLimit 200 + episode statistics)
+//   sac_act_kernel           sac.py:138-158: uniform random action before learning_starts, else actor.get_action; step; ring store
+//   sac_critic_kernel        sac.py:165-185: actor on next obs, two target critics, TD target, two critics forward + backward
+//   sac_actor_kernel         sac.py:193-197: actor forward (rsample), min(Q1,Q2) forward, d(-minQ)/d action, actor backward;
+//                            logp_only: sac.py:203-204 (+ the alpha step by the last workgroup to finish)
+//   sac_dw2_gemm_kernel      the 256x256 weight gradients as split-K batch GEMMs dW2 = dZ2^T H1 on v_mfma_f32_16x16x4_f32
+//   sac_grad_reduce_kernel   fixed-order assembly of slabs and K-split partials (+ Adam + polyak in the single-process fusion)
+//   adam_kernel / polyak_kernel / sac_alpha_kernel   the unfused pieces (sharded runs all-reduce between them)
+// Row-group layout: a 256-thread workgroup owns SR = 16 batch rows; 256x256 layers on the f32 MFMA with weights streamed from L2
+// into registers as one continuous stream per kernel, activations in LDS; see "row-group building blocks" below and DESIGN.md §7c.
+// All reductions are fixed-order (bitwise reproducible).
 #include "mi_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
