@@ -85,3 +85,85 @@ def test_two_ranks_equal_one_rank_with_all_envs():
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][6], res[1][6])  # replicas stay identical
     g = grads.copy()
     assert abs(R.clip_grad_norm(g, 0.5) - res[0][5]) < 1e-5 * res[0][5]
+
+
+# ---------------------------------------------------------------- DQN / SAC: the same sharding rule --------------------------------
+def _worker_offpolicy(rank, world, port, q):
+    """Each rank owns half of the batch rows of ONE shared replay storage snapshot and contributes inv_count = 1 / (world * rows)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from deep_rl_amd import dist as D
+    from oracle import cpu_ref as R
+
+    R.lib().ref_set_num_threads(1)
+    D.init_from_env("gloo")
+    assert D.rank() == rank
+    fx = _offpolicy_fixture(R)
+    half = slice(rank * 32, (rank + 1) * 32)
+    # DQN: TD gradient share (dqn.py:118-130)
+    g, loss = R.dqn_td_grads(fx["dq"], fx["dqt"], fx["dst"], fx["didx"][half], inv_count=1.0 / (world * 32))
+    buf = torch.from_numpy(np.concatenate([g, np.array([loss], np.float32)]))
+    D.allreduce_sum_(buf)
+    # SAC: critic and actor gradient shares, mean log-prob of the alpha step (sac.py:165-205)
+    qg, ql = R.sac_critic_grads(fx["sq"], fx["sqt"], fx["sa"], fx["sst"], fx["sidx"][half], fx["eps"][0][half], 0.3, inv_count=1.0 / (world * 32))
+    ag, al, amlp = R.sac_actor_grads(fx["sa"], fx["sq"], fx["sst"], fx["sidx"][half], fx["eps"][1][half], 0.3, inv_count=1.0 / (world * 32))
+    mlp = R.sac_mean_logp(fx["sa"], fx["sst"], fx["sidx"][half], fx["eps"][2][half]) / world
+    sbuf = torch.from_numpy(np.concatenate([qg, ql, ag, np.array([al, amlp, mlp], np.float32)]))
+    D.allreduce_sum_(sbuf)
+    q.put((rank, buf.numpy().copy(), sbuf.numpy().copy()))
+    torch.distributed.destroy_process_group()
+
+
+def _offpolicy_fixture(R):
+    rng = np.random.default_rng(99)
+    fx = {}
+    # DQN
+    st = R.ReplayStorage(40, 3)
+    st.observations[:] = rng.normal(0, 1, st.observations.shape) * np.array([2.4, 3, 0.2, 3], np.float32)
+    st.actions[:] = rng.integers(0, 2, st.actions.shape); st.rewards[:] = 1.0
+    st.terminated[:] = rng.random(st.terminated.shape) < 0.1
+    fx["dst"] = st
+    fx["dq"] = rng.normal(0, 0.1, 10934).astype(np.float32); fx["dqt"] = rng.normal(0, 0.1, 10934).astype(np.float32)
+    fx["didx"] = rng.integers(0, 40 * 3, 64)
+    # SAC
+    sst = R.SacStorage(40, 3)
+    th = rng.uniform(-np.pi, np.pi, (40, 3))
+    sst.observations[..., 0] = np.cos(th); sst.observations[..., 1] = np.sin(th); sst.observations[..., 2] = rng.uniform(-8, 8, (40, 3))
+    sst.actions[:] = rng.uniform(-2, 2, (40, 3)); sst.rewards[:] = -rng.uniform(0, 16, (40, 3))
+    fx["sst"] = sst
+    fx["sq"] = rng.normal(0, 0.05, 2 * R.SQ_NPARAMS).astype(np.float32); fx["sqt"] = rng.normal(0, 0.05, 2 * R.SQ_NPARAMS).astype(np.float32)
+    fx["sa"] = rng.normal(0, 0.05, R.AC_NPARAMS).astype(np.float32)
+    fx["sidx"] = rng.integers(0, 40 * 3, 64)
+    fx["eps"] = rng.standard_normal((3, 64)).astype(np.float32)
+    return fx
+
+
+def test_offpolicy_gradient_shares_sum_to_the_union_batch():
+    """DQN TD gradient and SAC critic / actor gradients + alpha-step mean log-prob: two ranks' shares (inv_count = 1/(world*rows)),
+    SUM-all-reduced through deep_rl_amd.dist, equal one process on the union batch — the rule DQNEngine / SACEngine shard by."""
+    sys.path.insert(0, ROOT)
+    from oracle import cpu_ref as R
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_offpolicy, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    R.lib().ref_set_num_threads(1)
+    fx = _offpolicy_fixture(R)
+    g, loss = R.dqn_td_grads(fx["dq"], fx["dqt"], fx["dst"], fx["didx"])
+    qg, ql = R.sac_critic_grads(fx["sq"], fx["sqt"], fx["sa"], fx["sst"], fx["sidx"], fx["eps"][0], 0.3)
+    ag, al, amlp = R.sac_actor_grads(fx["sa"], fx["sq"], fx["sst"], fx["sidx"], fx["eps"][1], 0.3)
+    mlp = R.sac_mean_logp(fx["sa"], fx["sst"], fx["sidx"], fx["eps"][2])
+    want_d = np.concatenate([g, np.array([loss], np.float32)])
+    want_s = np.concatenate([qg, ql, ag, np.array([al, amlp, mlp], np.float32)])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])     # every rank holds the same sum
+    assert np.abs(res[0][1] - want_d).max() <= 2e-6 * np.abs(want_d).max()                    # fp32 sums in a different grouping
+    assert np.abs(res[0][2] - want_s).max() <= 5e-6 * np.abs(want_s).max()

@@ -102,3 +102,108 @@ def test_two_ranks_on_one_gpu_match_single_process():
     # replicas never diverge: bitwise identical parameters on both ranks after every step
     assert np.array_equal(res[0]["params1"], res[1]["params1"]) and np.array_equal(res[0]["params3"], res[1]["params3"])
     assert np.isfinite(res[0]["params3"]).all() and not np.array_equal(res[0]["params1"], res[0]["params3"])
+
+
+# ---------------------------------------------------------------- DQN / SAC engines, sharded branch --------------------------------
+OFF_N, OFF_STEPS, OFF_B = 8, 40, 64   # envs per rank, acting steps, batch rows per rank
+
+
+def _mk_sac(dev, n, base):
+    import deep_rl_amd as D
+
+    env = D.make("Pendulum-v1", num_envs=n, device=dev, seed=7, env_id_base=base)
+    torch.manual_seed(7)
+    a = D.Actor(env)
+    qs = [D.SoftQNetwork(env) for _ in range(4)]
+    qs[2].load_state_dict(qs[0].state_dict()); qs[3].load_state_dict(qs[1].state_dict())
+    return D.SACEngine(env, a, *qs, slots=OFF_STEPS + 1, batch_size=OFF_B if n == OFF_N else 2 * OFF_B, learning_starts=10, max_episodes_logged=0)
+
+
+def _mk_dqn(dev, n, base):
+    import deep_rl_amd as D
+
+    env = D.make("CartPole-v1", num_envs=n, device=dev, seed=7, env_id_base=base)
+    torch.manual_seed(7)
+    q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
+    opt = D.ClipAdam(q, lr=2.5e-4, eps=1e-8)
+    return D.DQNEngine(env, q, t, opt, slots=OFF_STEPS + 1, batch_size=OFF_B if n == OFF_N else 2 * OFF_B, learning_starts=10, total_timesteps=100,
+                       max_episodes_logged=0)
+
+
+def _off_inputs(rank):
+    rng = np.random.default_rng(1000 + rank)
+    return rng.integers(0, OFF_STEPS * OFF_N, OFF_B), rng.standard_normal((3, OFF_B)).astype(np.float32)
+
+
+def _worker_off(rank, world, port, q, init):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from deep_rl_amd import dist as D
+
+    D.init_from_env("gloo")
+    dev = torch.device("cuda", 0)
+    idx, eps = _off_inputs(rank)
+    sac = _mk_sac(dev, OFF_N, rank * OFF_N)
+    assert sac.world_size == world and sac.rank == rank
+    sac.actor.load_flat(init["actor"]); sac.q_flat.copy_(torch.from_numpy(init["q"]).to(dev)); sac.qt_flat.copy_(torch.from_numpy(init["q"]).to(dev))
+    sac.reset()
+    for _ in range(OFF_STEPS):
+        sac.act()
+    sac.sample(idx)
+    sac.update_critic(torch.from_numpy(eps[0]), polyak=True); sac.update_actor(torch.from_numpy(eps[1])); sac.update_alpha(torch.from_numpy(eps[2]))
+    dqn = _mk_dqn(dev, OFF_N, rank * OFF_N)
+    dqn.q.load_flat(init["dq"]); dqn.target.load_flat(init["dq"])
+    dqn.reset(); dqn.act(OFF_STEPS)
+    dqn.train_step(idx)
+    out = {"obs": sac.observations.cpu().numpy(), "q": sac.q_flat.cpu().numpy(), "qt": sac.qt_flat.cpu().numpy(), "actor": sac.actor.flat.cpu().numpy(),
+           "log_alpha": float(sac.log_alpha), "q_losses": sac.q_losses.cpu().numpy(), "actor_out": sac.actor_out.cpu().numpy(),
+           "dobs": dqn.observations.cpu().numpy(), "dq": dqn.q.flat.cpu().numpy(), "dloss": float(dqn.loss)}
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_offpolicy_engines_two_ranks_match_single_process():
+    """SACEngine / DQNEngine with world_size 2 (gradient shares + the alpha step's mean log-prob all-reduced over gloo, unfused Adam /
+    polyak launches) against one process that owns all 16 envs, takes the union batch and uses the fused single-process calls."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    dev = torch.device("cuda", 0)
+    big = _mk_sac(dev, 2 * OFF_N, 0)
+    bigd = _mk_dqn(dev, 2 * OFF_N, 0)
+    init = {"actor": big.actor.flat.cpu().numpy().copy(), "q": big.q_flat.cpu().numpy().copy(), "dq": bigd.q.flat.cpu().numpy().copy()}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_off, args=(r, 2, port, q, init)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    big.reset()
+    for _ in range(OFF_STEPS):
+        big.act()
+    bigd.reset(); bigd.act(OFF_STEPS)
+    gidx, geps = [], []
+    for r in range(2):   # shard invariance of the acting kernels, then the union batch in the big run's numbering
+        sl = slice(r * OFF_N, (r + 1) * OFF_N)
+        assert np.array_equal(big.observations[:, sl].cpu().numpy(), res[r]["obs"]) and np.array_equal(bigd.observations[:, sl].cpu().numpy(), res[r]["dobs"])
+        idx, eps = _off_inputs(r)
+        gidx.append((idx // OFF_N) * (2 * OFF_N) + r * OFF_N + idx % OFF_N); geps.append(eps)
+    gidx = np.concatenate(gidx); geps = np.concatenate(geps, axis=1)
+    big.sample(gidx)
+    big.update_critic(torch.from_numpy(geps[0]), polyak=True); big.update_actor(torch.from_numpy(geps[1])); big.update_alpha(torch.from_numpy(geps[2]))
+    bigd.train_step(gidx)
+    for r in range(2):
+        o = res[r]
+        assert np.allclose(o["q_losses"], big.q_losses.cpu().numpy(), rtol=2e-5) and np.allclose(o["actor_out"], big.actor_out.cpu().numpy(), rtol=2e-5, atol=1e-6)
+        # one Adam step moves a parameter by at most lr; gradient shares summed in a different grouping flip only last bits of it
+        assert np.abs(o["q"] - big.q_flat.cpu().numpy()).max() < 2e-5 and np.abs(o["qt"] - big.qt_flat.cpu().numpy()).max() < 1e-6
+        assert np.abs(o["actor"] - big.actor.flat.cpu().numpy()).max() < 2e-5
+        assert abs(o["log_alpha"] - float(big.log_alpha)) < 1e-6
+        assert np.abs(o["dq"] - bigd.q.flat.cpu().numpy()).max() < 5e-6 and abs(o["dloss"] - float(bigd.loss)) < 2e-5 * max(1.0, abs(float(bigd.loss)))
+    assert np.array_equal(res[0]["q"], res[1]["q"]) and np.array_equal(res[0]["actor"], res[1]["actor"]) and np.array_equal(res[0]["dq"], res[1]["dq"])
