@@ -8,11 +8,11 @@ for gfx950 in ``csrc/`` behind the C ABI of ``include/mi_rl.h``.  There is no CP
 """
 from . import _native  # noqa: F401
 from .envs import make, CartPoleVecEnv, PendulumVecEnv  # noqa: F401
-from .agent import ActorCritic, QNetwork, SoftQNetwork, Actor, layer_init, pack  # noqa: F401
+from .agent import ActorCritic, QNetwork, DuelingQNetwork, SoftQNetwork, Actor, layer_init, pack  # noqa: F401
 from .optim import ClipAdam, Adam  # noqa: F401
 from .engine import PPOEngine  # noqa: F401
-from .dqn_engine import DQNEngine  # noqa: F401
+from .dqn_engine import DQNEngine, DuelingDQNEngine  # noqa: F401
 from .sac_engine import SACEngine  # noqa: F401
 
 __all__ = ["make", "CartPoleVecEnv", "ActorCritic", "QNetwork", "layer_init", "ClipAdam", "PPOEngine", "DQNEngine",
-           "PendulumVecEnv", "SoftQNetwork", "Actor", "Adam", "SACEngine", "pack"]
+           "DuelingQNetwork", "DuelingDQNEngine", "PendulumVecEnv", "SoftQNetwork", "Actor", "Adam", "SACEngine", "pack"]

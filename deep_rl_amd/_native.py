@@ -13,6 +13,7 @@ SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_S
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
+DUELING_NPARAMS = 11019
 SAC_Q_NPARAMS = 67329
 SAC_ACTOR_NPARAMS = 67330
 MI_OK = 0
@@ -67,6 +68,8 @@ SIGNATURES = {
     "mi_dqn_sample": (_I, [_U64, _U64, _I64, _I, _VP, _VP]),
     "mi_dqn_workspace_bytes": (_SZ, [_I]),
     "mi_dqn_td_grad": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _D, _VP, _VP, _VP, _VP]),
+    "mi_dueling_pack": (_I, [_VP, _VP, _VP]),
+    "mi_dueling_unpack_grads": (_I, [_VP, _VP, _VP]),
     "mi_env_step_cont": (_I, [_VP] * 10),
     "mi_sac_actor_sample": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "mi_sac_q_forward": (_I, [_VP, _VP, _VP, _I, _VP, _VP]),

@@ -219,3 +219,42 @@ class Actor(_FlatModule):
         N.check(N.lib().mi_sac_actor_sample(N.ptr(self.flat), N.ptr(obs), N.ptr(e), n, N.ptr(action), N.ptr(logp), N.stream_ptr(self.device)),
                 "mi_sac_actor_sample")
         return action.reshape(*lead, 1), logp.reshape(lead)
+
+
+class DuelingQNetwork(_FlatModule):
+    """QNetwork of the reference dueling_dqn.py:24-40 (features 4 -> 120 -> 84 ReLU, value stream 84 -> 1, advantage stream 84 -> n,
+    values + (advantages - mean advantages)); attribute names as in the reference (incl. its `feauture_layer` spelling).
+    `flat` holds the dueling parameters; `eff` the equivalent plain-DQN vector the kernels consume (refresh with `repack()`)."""
+
+    def __init__(self, env, device=None):
+        super().__init__()
+        obs_dim = int(np.prod(env.observation_space.shape))
+        if obs_dim != 4 or env.action_space.n != 2:
+            raise N.MiError("the HIP kernels are specialised for CartPole (obs 4, actions 2)")
+        self.feauture_layer = nn.Sequential(nn.Linear(obs_dim, 120), nn.ReLU(), nn.Linear(120, 84), nn.ReLU())
+        self.value_stream = nn.Linear(84, 1)
+        self.advantage_stream = nn.Linear(84, env.action_space.n)
+        self._finish(env, device, N.DUELING_NPARAMS)
+        self.eff = torch.empty(N.DQN_NPARAMS, dtype=torch.float32, device=self.device)
+        self.repack()
+
+    def repack(self):
+        """refresh the plain-DQN image of the parameters (after an optimizer step / load_state_dict)"""
+        N.check(N.lib().mi_dueling_pack(N.ptr(self.flat), N.ptr(self.eff), N.stream_ptr(self.device)), "mi_dueling_pack")
+
+    def load_flat(self, vec):
+        super().load_flat(vec)
+        self.repack()
+
+    def load_state_dict(self, state_dict, *a, **kw):
+        super().load_state_dict(state_dict, *a, **kw)
+        self.repack()
+
+    def forward(self, observation):
+        """dueling_dqn.py:36-40."""
+        obs = observation.to(self.device, torch.float32)
+        lead = obs.shape[:-1]
+        obs = obs.reshape(-1, 4).contiguous()
+        q = torch.empty((obs.shape[0], 2), dtype=torch.float32, device=self.device)
+        N.check(N.lib().mi_dqn_forward(N.ptr(self.eff), N.ptr(obs), obs.shape[0], N.ptr(q), N.stream_ptr(self.device)), "mi_dqn_forward")
+        return q.reshape(*lead, 2)

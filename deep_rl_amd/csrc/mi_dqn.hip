@@ -474,3 +474,55 @@ extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, c
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
+
+// ---- Dueling head (reference deep_rl/dueling_dqn.py:24-40) as an epilogue on the DQN kernels -----------------
+// values + (advantages - mean(advantages)) is LINEAR in the 84 features, so a dueling net equals a plain 4->120->84->2 net whose
+// head is W3eff[a] = Wv + (Wa[a] - mean_a Wa), b3eff[a] = bv + (ba[a] - mean_a ba): the acting and TD kernels run unchanged on the
+// packed parameters, and the chain rule maps the plain head's gradient back: dWv = sum_a g3[a], dWa[k] = g3[k] - mean_a g3[a].
+// Dueling layout (q_network1.parameters()): features as DQN | value W[84] b | advantage W[2][84] b[2] = MI_DUELING_NPARAMS.
+#define DU_WV 10764
+#define DU_BV 10848
+#define DU_WA 10849
+#define DU_BA 11017
+#define DU_NP 11019
+__global__ void __launch_bounds__(256) dueling_pack_kernel(const float* __restrict__ d, float* __restrict__ q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < DQ_W3) q[i] = d[i];                                   // feature layers
+    else if (i < DQ_W3 + 2 * DQ_H2) {
+        const int a = (i - DQ_W3) / DQ_H2, j = (i - DQ_W3) % DQ_H2;
+        const float mean = (d[DU_WA + j] + d[DU_WA + DQ_H2 + j]) / 2.0f;
+        q[i] = d[DU_WV + j] + (d[DU_WA + a * DQ_H2 + j] - mean);
+    } else if (i < DQ_NP) {
+        const int a = i - DQ_B3;
+        const float mean = (d[DU_BA] + d[DU_BA + 1]) / 2.0f;
+        q[i] = d[DU_BV] + (d[DU_BA + a] - mean);
+    }
+}
+
+__global__ void __launch_bounds__(256) dueling_unpack_kernel(const float* __restrict__ g, float* __restrict__ dg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < DQ_W3) dg[i] = g[i];
+    else if (i < DU_BV) { const int j = i - DU_WV; dg[i] = g[DQ_W3 + j] + g[DQ_W3 + DQ_H2 + j]; }
+    else if (i == DU_BV) dg[i] = g[DQ_B3] + g[DQ_B3 + 1];
+    else if (i < DU_BA) {
+        const int a = (i - DU_WA) / DQ_H2, j = (i - DU_WA) % DQ_H2;
+        dg[i] = g[DQ_W3 + a * DQ_H2 + j] - (g[DQ_W3 + j] + g[DQ_W3 + DQ_H2 + j]) / 2.0f;
+    } else if (i < DU_NP) {
+        const int a = i - DU_BA;
+        dg[i] = g[DQ_B3 + a] - (g[DQ_B3] + g[DQ_B3 + 1]) / 2.0f;
+    }
+}
+
+extern "C" int mi_dueling_pack(const float* dueling_params, float* dqn_params, void* stream) {
+    MI_CHECK_ARG(dueling_params && dqn_params, "NULL pointer");
+    dueling_pack_kernel<<<(DQ_NP + 255) / 256, 256, 0, (hipStream_t)stream>>>(dueling_params, dqn_params);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_grads, void* stream) {
+    MI_CHECK_ARG(dqn_grads && dueling_grads, "NULL pointer");
+    dueling_unpack_kernel<<<(DU_NP + 255) / 256, 256, 0, (hipStream_t)stream>>>(dqn_grads, dueling_grads);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}

@@ -95,3 +95,47 @@ class DQNEngine:
     def sync_target(self):
         """target_network.load_state_dict(q_network.state_dict()) (dqn.py:136-137)."""
         self.target.flat.copy_(self.q.flat)
+
+
+class DuelingDQNEngine(DQNEngine):
+    """The same ring and launches for reference dueling_dqn.py: the dueling head is linear in the features, so acting and the TD
+    update run on the networks' plain-DQN images (`.eff`); the gradient is mapped back to the dueling parameters by
+    mi_dueling_unpack_grads and the optimizer steps on those (dueling_dqn.py:71-75,109-129)."""
+
+    def __init__(self, env, q_network, target_network, optimizer, slots, **kw):
+        super().__init__(env, q_network, target_network, optimizer, slots, **kw)
+        dev = self.device
+        self._dgradbuf = torch.zeros(N.DUELING_NPARAMS + 2, dtype=torch.float32, device=dev)
+        self.dueling_grads = self._dgradbuf[:N.DUELING_NPARAMS]
+
+    def act(self, n_steps, forced_actions=None, forced_resets=None):
+        dev = self.device
+        fa = None if forced_actions is None else forced_actions.to(dev, torch.int64).contiguous()
+        fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
+        N.check(N.lib().mi_dqn_act_steps(
+            self.env.handle, N.ptr(self.q.eff), int(n_steps), self.global_step, self.slots, self.learning_starts, self.start_e, self.end_e,
+            self.exploration_fraction, self.total_timesteps, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.actions),
+            N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fr), N.ptr(self.episodes), N.ptr(self.episode_stats), self.max_ep,
+            self._s()), "mi_dqn_act_steps")
+        self.global_step += int(n_steps)
+
+    def td_grad(self):
+        N.check(N.lib().mi_dqn_td_grad(
+            N.ptr(self.q.eff), N.ptr(self.target.eff), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+            N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma,
+            1.0 / (self.batch_size * self.world_size), N.ptr(self.workspace), N.ptr(self.grads), N.ptr(self.loss), self._s()), "mi_dqn_td_grad")
+        N.check(N.lib().mi_dueling_unpack_grads(N.ptr(self.grads), N.ptr(self.dueling_grads), self._s()), "mi_dueling_unpack_grads")
+        self._dgradbuf[N.DUELING_NPARAMS:N.DUELING_NPARAMS + 1].copy_(self.loss)
+        D.allreduce_sum_(self._dgradbuf, self.pg)
+        self.loss.copy_(self._dgradbuf[N.DUELING_NPARAMS:N.DUELING_NPARAMS + 1])
+
+    def train_step(self, indices=None):
+        self.sample(indices)
+        self.td_grad()
+        self.optimizer.step(self.dueling_grads)
+        self.q.repack()
+        self.update_index += 1
+
+    def sync_target(self):
+        self.target.flat.copy_(self.q.flat)
+        self.target.eff.copy_(self.q.eff)

@@ -181,6 +181,15 @@ int mi_dqn_td_grad(const float* params, const float* target_params, const float*
 /* optimizer.step() (dqn.py:131-133) = mi_clip_adam(..., n = MI_DQN_NPARAMS, eps = 1e-8, max_norm = +inf);
  * target_network.load_state_dict (dqn.py:136-137) = a device-to-device copy of the flat vector by the caller. */
 
+/* ---- Dueling head (reference deep_rl/dueling_dqn.py:24-40: values + (advantages - mean advantages)) as an epilogue on the DQN calls.
+ * Dueling flat layout = q_network1.parameters(): feature W1[120,4] b1 W2[84,120] b2 | value W[1,84] b | advantage W[2,84] b[2].
+ * The head is linear in the features, so mi_dueling_pack writes the EQUIVALENT plain-DQN parameter vector (W3[a] = Wv + Wa[a] - mean Wa,
+ * b3 likewise) that mi_dqn_forward / mi_dqn_act_steps / mi_dqn_td_grad consume (both for the online and the target copy), and
+ * mi_dueling_unpack_grads maps the plain gradient back (dWv = sum_a g3[a], dWa[k] = g3[k] - mean_a g3[a]; features unchanged). */
+#define MI_DUELING_NPARAMS 11019
+int mi_dueling_pack(const float* dueling_params, float* dqn_params, void* stream);
+int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_grads, void* stream);
+
 /* =====================================================================================================================
  * SAC (reference deep_rl/sac.py re-targeted to Pendulum-v1; SURVEY.md §8a s1-s8, BASELINE config 4).
  * Env kind MI_ENV_PENDULUM_V1: obs f32 [N,3] = (cos th, sin th, th_dot), action f32 [N] (one dim, clipped to +-2), reward

@@ -5,7 +5,7 @@ Same method as capture_ppo_trace.py: runpy + oracle/gym_shim + instrumentation o
   * the shim's raw env mirrors every reset / step                                   (dqn.py:78,98-100)
   * ``torch.optim.Adam.__init__`` snapshots the initial q_network parameters        (dqn.py:67-68)
   * ``torch.optim.Adam.step`` records loss, batch indices (module globals), gradients, parameters (dqn.py:116-133)
-Output: tests/golden/dqn_ref_trace.npz.  The batch indices of all 9,001 updates are NOT stored: they come from numpy's
+Output: tests/golden/dqn_ref_trace.npz (``--script dueling_dqn``: tests/golden/dueling_ref_trace.npz from deep_rl/dueling_dqn.py).  The batch indices of all 9,001 updates are NOT stored: they come from numpy's
 legacy global generator (np.random.seed(1); rand() once per step after learning_starts; randint(gs, size=128) per update,
 dqn.py:63,88,116), which numpy guarantees stable — tests regenerate them with RandomState(1) and check the stored sums.
 """
@@ -28,8 +28,13 @@ def flat(params, grad=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden", "dqn_ref_trace.npz"))
+    ap.add_argument("--script", default="dqn", choices=["dqn", "dueling_dqn"],
+                    help="dueling_dqn: the same instrumentation on deep_rl/dueling_dqn.py (its optimizer owns q_network1, dueling_dqn.py:71-73)")
+    ap.add_argument("--out", default=None)
     args = ap.parse_args()
+    ref = "/root/reference/deep_rl/%s.py" % args.script
+    if args.out is None:
+        args.out = os.path.join(HERE, "..", "tests", "golden", "dqn_ref_trace.npz" if args.script == "dqn" else "dueling_ref_trace.npz")
     sys.path.insert(0, os.path.join(HERE, "gym_shim"))
     import gym, torch
     torch.set_num_threads(1)
@@ -78,7 +83,7 @@ def main():
     torch.optim.Adam.__init__, torch.optim.Adam.step = p_init, p_step
     buf = io.StringIO(); t0 = time.time()
     with contextlib.redirect_stdout(buf):
-        g = runpy.run_path(REF, run_name="__ref_dqn__")
+        g = runpy.run_path(ref, run_name="__ref_dqn__")
     wall = time.time() - t0
     torch.optim.Adam.__init__, torch.optim.Adam.step = orig_init, orig_step
     lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("global_step=")]
@@ -106,7 +111,7 @@ def main():
         "ck_inds": np.stack([c[4] for c in rec["ck"]]), "ck_loss": np.array([c[5] for c in rec["ck"]]),
     }
     np.savez_compressed(args.out, **out)
-    print("reference dqn.py: %d env steps, %d updates, %d episodes, %.1fs -> %s (%.0f KB); last loss %.5f" % (
+    print("reference " + args.script + ".py: %d env steps, %d updates, %d episodes, %.1fs -> %s (%.0f KB); last loss %.5f" % (
         len(log["action"]), len(rec["loss"]), len(lines), wall, args.out, os.path.getsize(args.out) / 1024, rec["loss"][-1]))
 
 

@@ -71,6 +71,8 @@ def lib():
                                      C.c_float, C.c_float, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.ref_dqn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_dqn_td_grads.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
+        L.ref_dueling_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_dueling_td_grads.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
         L.ref_dqn_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p]
         L.ref_dqn_epsilon.restype = C.c_double
         L.ref_dqn_epsilon.argtypes = [C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int64]
@@ -319,6 +321,25 @@ def dqn_td_grads(params, target_params, st, idx, gamma=0.99, inv_count=None):
     grads = np.empty(DQN_NPARAMS, np.float32); loss = np.zeros(1, np.float32)
     lib().ref_dqn_td_grads(_p(p), _p(tp), _p(st.observations), _p(st.actions), _p(st.rewards), _p(st.terminated), _p(idx), len(idx),
                            st.N, st.slots, gamma, (1.0 / len(idx)) if inv_count is None else inv_count, _p(grads), _p(loss))
+    return grads, float(loss[0])
+
+
+DUELING_NPARAMS = 11019
+
+
+def dueling_forward(params, obs):
+    """QNetwork.forward of dueling_dqn.py:36-40."""
+    p = _c(params, np.float32); o = _c(obs, np.float32).reshape(-1, 4)
+    q = np.empty((o.shape[0], 2), np.float32)
+    lib().ref_dueling_forward(_p(p), _p(o), o.shape[0], _p(q))
+    return q
+
+
+def dueling_td_grads(params, target_params, st, idx, gamma=0.99, inv_count=None):
+    p = _c(params, np.float32); tp = _c(target_params, np.float32); idx = _c(idx, np.int64)
+    grads = np.empty(DUELING_NPARAMS, np.float32); loss = np.zeros(1, np.float32)
+    lib().ref_dueling_td_grads(_p(p), _p(tp), _p(st.observations), _p(st.actions), _p(st.rewards), _p(st.terminated), _p(idx), len(idx),
+                               st.N, st.slots, gamma, (1.0 / len(idx)) if inv_count is None else inv_count, _p(grads), _p(loss))
     return grads, float(loss[0])
 
 
