@@ -71,6 +71,11 @@ def lib():
                                      C.c_float, C.c_float, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.ref_dqn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_dqn_td_grads.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
+        L.ref_per_sums.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_per_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.ref_per_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_double, C.c_double, C.c_void_p]
+        L.ref_per_td_grads.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_per_update_priorities.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_dueling_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_dueling_td_grads.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
         L.ref_dqn_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p]
@@ -325,6 +330,47 @@ def dqn_td_grads(params, target_params, st, idx, gamma=0.99, inv_count=None):
 
 
 DUELING_NPARAMS = 11019
+PER_CHUNK = 64
+
+
+def per_sums(prio, n, alpha=0.6):
+    """-> (s0, s1, total, total_alpha): the sampler's three-level prefix structure over prio[:n] (flat [slot][env])."""
+    p = _c(prio, np.float32).reshape(-1)
+    n0 = (n + PER_CHUNK - 1) // PER_CHUNK; n1 = (n0 + PER_CHUNK - 1) // PER_CHUNK
+    s0 = np.zeros(n0, np.float64); s1 = np.zeros(n1, np.float64); tot = np.zeros(2, np.float64)
+    lib().ref_per_sums(_p(p), n, alpha, _p(s0), _p(s1), _p(tot))
+    return s0, s1, float(tot[0]), float(tot[1])
+
+
+def per_sample(seed, update, prio, n, s0, s1, total, batch):
+    p = _c(prio, np.float32).reshape(-1)
+    idx = np.empty(batch, np.int64)
+    lib().ref_per_sample(seed, update, _p(p), n, _p(s0), _p(s1), total, batch, _p(idx))
+    return idx
+
+
+def per_weights(prio, idx, alpha, beta, total_alpha, count):
+    p = _c(prio, np.float32).reshape(-1); idx = _c(idx, np.int64)
+    w = np.empty(len(idx), np.float32)
+    lib().ref_per_weights(_p(p), _p(idx), len(idx), alpha, beta, total_alpha, float(count), _p(w))
+    return w
+
+
+def per_td_grads(params, target_params, st, idx, weights, gamma=0.99, inv_count=None):
+    p = _c(params, np.float32); tp = _c(target_params, np.float32); idx = _c(idx, np.int64); w = _c(weights, np.float32)
+    grads = np.empty(DQN_NPARAMS, np.float32); loss = np.zeros(1, np.float32); td = np.empty(len(idx), np.float32)
+    lib().ref_per_td_grads(_p(p), _p(tp), _p(st.observations), _p(st.actions), _p(st.rewards), _p(st.terminated), _p(idx), len(idx),
+                           st.N, st.slots, gamma, (1.0 / len(idx)) if inv_count is None else inv_count, _p(w), _p(td), _p(grads), _p(loss))
+    return grads, float(loss[0]), td
+
+
+def per_update_priorities(prio, idx, td_abs, max_priority):
+    """in place on prio (flat view); returns the new max_priority"""
+    idx = _c(idx, np.int64); td = _c(td_abs, np.float32); mp = np.array([max_priority], np.float32)
+    flatp = prio.reshape(-1)
+    assert flatp.base is not None or flatp is prio
+    lib().ref_per_update_priorities(_p(flatp), _p(idx), _p(td), len(idx), _p(mp))
+    return float(mp[0])
 
 
 def dueling_forward(params, obs):
