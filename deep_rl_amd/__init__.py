@@ -11,8 +11,8 @@ from .envs import make, CartPoleVecEnv, PendulumVecEnv  # noqa: F401
 from .agent import ActorCritic, QNetwork, DuelingQNetwork, SoftQNetwork, Actor, layer_init, pack  # noqa: F401
 from .optim import ClipAdam, Adam  # noqa: F401
 from .engine import PPOEngine  # noqa: F401
-from .dqn_engine import DQNEngine, DuelingDQNEngine  # noqa: F401
+from .dqn_engine import DQNEngine, DuelingDQNEngine, PERDQNEngine  # noqa: F401
 from .sac_engine import SACEngine  # noqa: F401
 
 __all__ = ["make", "CartPoleVecEnv", "ActorCritic", "QNetwork", "layer_init", "ClipAdam", "PPOEngine", "DQNEngine",
-           "DuelingQNetwork", "DuelingDQNEngine", "PendulumVecEnv", "SoftQNetwork", "Actor", "Adam", "SACEngine", "pack"]
+           "DuelingQNetwork", "DuelingDQNEngine", "PERDQNEngine", "PendulumVecEnv", "SoftQNetwork", "Actor", "Adam", "SACEngine", "pack"]

@@ -297,7 +297,8 @@ struct __attribute__((aligned(16))) td_smem {
 __global__ void __launch_bounds__(256)
 dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target_params, const float* __restrict__ observations,
               const int64_t* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
-              const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, float gamma, float invn, float* __restrict__ workspace) {
+              const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, float gamma, float invn, float* __restrict__ workspace,
+              const float* __restrict__ row_w, float* __restrict__ td_abs) {
     __shared__ td_smem sm;
     const int t = threadIdx.x;
     const int row0 = blockIdx.x * TD_R;
@@ -369,9 +370,11 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         const float td = rewards[nxt[t]] + gamma * target_max * (terminated[nxt[t]] ? 0.0f : 1.0f);
         const int a = sm.act[t];
         const float diff = valid ? td - sm.q[0][t][a] : 0.0f;
-        sm.td_err[t] = diff * diff;
-        sm.dq[t][0] = a == 0 ? -2.0f * diff * invn : 0.0f;
-        sm.dq[t][1] = a == 1 ? -2.0f * diff * invn : 0.0f;
+        const float wb = (row_w && valid) ? row_w[row0 + t] : 1.0f;      // importance weight (per.py:145-147); 1 for plain DQN
+        if (td_abs && valid) td_abs[row0 + t] = fabsf(diff);               // the new priority (per.py:141)
+        sm.td_err[t] = wb * (diff * diff);
+        sm.dq[t][0] = a == 0 ? -2.0f * (wb * diff) * invn : 0.0f;
+        sm.dq[t][1] = a == 1 ? -2.0f * (wb * diff) * invn : 0.0f;
     }
     __syncthreads();
     // ---- backward through layer 3 (online net only): thread j < 84 ----
@@ -460,19 +463,26 @@ extern "C" size_t mi_dqn_workspace_bytes(int batch) {
     return (size_t)((batch + TD_R - 1) / TD_R) * TD_SLAB * sizeof(float);
 }
 
-extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, const float* observations, const int64_t* actions,
-                              const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
-                              float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream) {
+static int dqn_td_impl(const float* params, const float* target_params, const float* observations, const int64_t* actions,
+                       const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                       float gamma, double inv_count, void* workspace, float* grads, float* loss, const float* weights, float* td_abs, void* stream) {
     MI_CHECK_ARG(params && target_params && observations && actions && rewards && terminated && idx && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (batch + TD_R - 1) / TD_R;
     dqn_td_kernel<<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
-                                         (long long)slots, gamma, (float)inv_count, (float*)workspace);
+                                         (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs);
     MI_LAUNCH_CHECK();
     dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss);
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+
+extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, const float* observations, const int64_t* actions,
+                              const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                              float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream) {
+    return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace, grads, loss,
+                       nullptr, nullptr, stream);
 }
 
 // ---- Dueling head (reference deep_rl/dueling_dqn.py:24-40) as an epilogue on the DQN kernels -----------------
@@ -523,6 +533,230 @@ extern "C" int mi_dueling_pack(const float* dueling_params, float* dqn_params, v
 extern "C" int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_grads, void* stream) {
     MI_CHECK_ARG(dqn_grads && dueling_grads, "NULL pointer");
     dueling_unpack_kernel<<<(DU_NP + 255) / 256, 256, 0, (hipStream_t)stream>>>(dqn_grads, dueling_grads);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// ---- Prioritized replay (reference deep_rl/per.py) as epilogues on the DQN path ---------------------------------
+// priorities: f32 ring [slots][N] beside the replay ring.  per.py samples with torch.multinomial(priorities) — an O(buffer) scan on
+// the host generator; here: a keyed three-level prefix-sum descent with a FIXED evaluation order (the contract the oracle implements
+// bit for bit): s0 = sums of 64-entry chunks, s1 = sums of 64 s0's, total — all sequential, in double (-ffp-contract=off: no FMA).
+#define PER_CHUNK 64
+#define STREAM_PER 7u
+struct per_ws_t { double* s0; double* a0; double* s1; double* totals; };   // a0: chunk sums of p^alpha; totals = {sum p, sum p^alpha}
+__host__ __device__ inline int64_t per_n0(int64_t n) { return (n + PER_CHUNK - 1) / PER_CHUNK; }
+static per_ws_t per_ws(void* workspace, int64_t capacity) {
+    per_ws_t w;
+    const int64_t c0 = per_n0(capacity), c1 = per_n0(c0);
+    w.s0 = (double*)workspace; w.a0 = w.s0 + c0; w.s1 = w.a0 + c0; w.totals = w.s1 + c1;
+    return w;
+}
+extern "C" size_t mi_per_workspace_bytes(int64_t capacity) {
+    const int64_t c0 = per_n0(capacity), c1 = per_n0(c0);
+    return (size_t)(2 * c0 + c1 + 2) * sizeof(double);
+}
+
+// priorities[global_step .. + n_steps) = max_priority (per.py:106; max_priority only changes at an update, i.e. between acting calls);
+// the slot after the last written one is the ring's write head (its successor data is not there yet): priority 0, never sampled
+__global__ void __launch_bounds__(256) per_mark_kernel(float* __restrict__ prio, int N, long long slots, long long gs, int n_steps, const float* __restrict__ max_prio) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)(n_steps + 1) * N) return;
+    const int s = (int)(t / N), e = (int)(t % N);
+    prio[((gs + s) % slots) * N + e] = s < n_steps ? max_prio[0] : 0.0f;
+}
+
+// level 0: one workgroup per 64 chunks (4,096 priorities).  p^alpha is evaluated with all 256 threads (16 entries each, coalesced), the
+// chunk sums are then taken by 64 threads in index order from the LDS image (row stride 65: conflict-free column walks).
+__global__ void __launch_bounds__(256) per_sums0_kernel(const float* __restrict__ prio, long long n, float alpha, double* __restrict__ s0, double* __restrict__ a0) {
+    __shared__ float pv[PER_CHUNK][PER_CHUNK + 1], pa[PER_CHUNK][PER_CHUNK + 1];
+    const long long base = (long long)blockIdx.x * PER_CHUNK * PER_CHUNK;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = it * 256 + threadIdx.x;                  // entry within the workgroup's 4,096
+        const long long i = base + e;
+        const float p = i < n ? prio[i] : 0.0f;
+        pv[e >> 6][e & 63] = p; pa[e >> 6][e & 63] = i < n ? powf(p, alpha) : 0.0f;
+    }
+    __syncthreads();
+    const long long k = (long long)blockIdx.x * PER_CHUNK + threadIdx.x;
+    if (threadIdx.x < PER_CHUNK && k < per_n0(n)) {
+        const long long lo = k * PER_CHUNK;
+        const int cnt = (int)(lo + PER_CHUNK < n ? PER_CHUNK : n - lo);
+        double sum = 0.0, sa = 0.0;
+        for (int j = 0; j < cnt; ++j) { sum += (double)pv[threadIdx.x][j]; sa += (double)pa[threadIdx.x][j]; }
+        s0[k] = sum; a0[k] = sa;
+    }
+}
+
+// level 1 + totals: thread m sums its 64 level-0 values in index order (32 loads of each array in flight at a time), thread 0 then the
+// level-1 values.  One workgroup; n1 <= PER_MAX_L1 (capacity <= 4M entries).
+#define PER_MAX_L1 1024
+__global__ void __launch_bounds__(256) per_sums1_kernel(const double* __restrict__ s0, const double* __restrict__ a0, long long n0, double* __restrict__ s1,
+                                                        double* __restrict__ totals) {
+    __shared__ double l1[PER_MAX_L1], a1[PER_MAX_L1];
+    const long long n1 = per_n0(n0);
+    for (long long m = threadIdx.x; m < n1; m += 256) {
+        const long long lo = m * PER_CHUNK;
+        const int cnt = (int)(lo + PER_CHUNK < n0 ? PER_CHUNK : n0 - lo);
+        double sum = 0.0, sa = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double v[32], va[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { v[j] = 32 * h + j < cnt ? s0[lo + 32 * h + j] : 0.0; va[j] = 32 * h + j < cnt ? a0[lo + 32 * h + j] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) if (32 * h + j < cnt) { sum += v[j]; sa += va[j]; }
+        }
+        s1[m] = sum; l1[m] = sum; a1[m] = sa;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, ta = 0.0;
+#pragma unroll 16
+        for (long long m2 = 0; m2 < n1; ++m2) { t += l1[m2]; ta += a1[m2]; }
+        totals[0] = t; totals[1] = ta;
+    }
+}
+
+// indices (sample != 0) by the prefix-sum descent, then the importance weights of per.py:131,145-146, normalised by their maximum
+__global__ void __launch_bounds__(256)
+per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio, long long n, const double* __restrict__ s0, const double* __restrict__ s1,
+                  const double* __restrict__ totals, int batch, float count, float alpha, float beta, int sample, int64_t* __restrict__ idx,
+                  float* __restrict__ weights) {
+    __shared__ float wmax[4];
+    __shared__ double l1s[PER_MAX_L1];                      // the level-1 sums: walked by every draw
+    const long long n0 = per_n0(n), n1 = per_n0(n0);
+    for (long long m = threadIdx.x; m < n1; m += 256) l1s[m] = s1[m];
+    __syncthreads();
+    const double total = totals[0];
+    const float total_alpha = (float)totals[1];
+    float mx = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        long long i;
+        if (sample) {
+            uint32_t r[4];
+            mi_philox(seed, update, (uint64_t)b, STREAM_PER, r);
+            const double u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
+            double x = u * total;
+            // the three walks subtract in index order (the contract); each level's 64 values are requested together, so a draw costs
+            // three memory round trips instead of up to 384 dependent ones
+            long long m = 0;
+            for (long long gq = 0; gq < n1; gq += PER_CHUNK) {        // level 2 in groups of 64 register-resident values (same subtraction order)
+                const int cnt = (int)(gq + PER_CHUNK < n1 ? PER_CHUNK : n1 - gq);
+                double v[PER_CHUNK];
+#pragma unroll
+                for (int j = 0; j < PER_CHUNK; ++j) v[j] = j < cnt ? l1s[gq + j] : 0.0;
+                int j = 0;
+#pragma unroll
+                for (int jj = 0; jj < PER_CHUNK; ++jj) if (j == jj && gq + jj + 1 < n1 && x >= v[jj]) { x -= v[jj]; j = jj + 1; }
+                m = gq + j;
+                if (j < PER_CHUNK) break;                              // stopped inside this group
+            }
+            long long k = m * PER_CHUNK;
+            {
+                const int cnt = (int)(k + PER_CHUNK < n0 ? PER_CHUNK : n0 - k);
+                double v[PER_CHUNK];
+#pragma unroll
+                for (int j = 0; j < PER_CHUNK; ++j) v[j] = j < cnt ? s0[k + j] : 0.0;
+                int j = 0;
+#pragma unroll
+                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) if (j == jj && jj + 1 < cnt && x >= v[jj]) { x -= v[jj]; j = jj + 1; }
+                k += j;
+            }
+            i = k * PER_CHUNK;
+            {
+                const int cnt = (int)(i + PER_CHUNK < n ? PER_CHUNK : n - i);
+                float v[PER_CHUNK];
+#pragma unroll
+                for (int j = 0; j < PER_CHUNK; ++j) v[j] = j < cnt ? prio[i + j] : 0.0f;
+                int j = 0;
+#pragma unroll
+                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) if (j == jj && jj + 1 < cnt && x >= (double)v[jj]) { x -= (double)v[jj]; j = jj + 1; }
+                i += j;
+            }
+            while (i > 0 && prio[i] == 0.0f) --i;
+            idx[b] = i;
+        } else i = idx[b];
+        const float prob = powf(prio[i], alpha) / total_alpha;
+        const float w = powf(count * prob, -beta);
+        weights[b] = w;
+        mx = fmaxf(mx, w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = wmax[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) mx = fmaxf(mx, wmax[k]);
+    for (int b = threadIdx.x; b < batch; b += 256) weights[b] = weights[b] / mx;
+}
+
+// priorities[idx[b]] = |td_b| with the LAST occurrence of a duplicated index winning (per.py:141 on the host is sequential), and
+// max_priority = max(max_priority, surviving |td|) — every entry is <= the running max_priority at all times, so this equals
+// max(torch.max(priorities), max_priority) (per.py:142) without a pass over the buffer.  owner: int32 per ring entry, all -1 between calls.
+__global__ void __launch_bounds__(1024) per_scatter_kernel(float* __restrict__ prio, const int64_t* __restrict__ idx, const float* __restrict__ td_abs, int batch,
+                                                           int32_t* __restrict__ owner, float* __restrict__ max_prio) {
+    __shared__ float wmax[16];
+    for (int b = threadIdx.x; b < batch; b += 1024) atomicMax(&owner[idx[b]], b);
+    __syncthreads();
+    float mx = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 1024)
+        if (owner[idx[b]] == b) { prio[idx[b]] = td_abs[b]; mx = fmaxf(mx, td_abs[b]); }
+    __syncthreads();
+    for (int b = threadIdx.x; b < batch; b += 1024) owner[idx[b]] = -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = max_prio[0];
+        for (int k = 0; k < 16; ++k) m = fmaxf(m, wmax[k]);
+        max_prio[0] = m;
+    }
+}
+
+extern "C" int mi_per_mark(float* priorities, int n_envs, int64_t slots, int64_t global_step, int n_steps, const float* max_priority, void* stream) {
+    MI_CHECK_ARG(priorities && max_priority && n_envs > 0 && slots >= 2 && n_steps > 0 && n_steps < slots && global_step >= 0, "bad arguments");
+    const long long total = (long long)(n_steps + 1) * n_envs;
+    per_mark_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(priorities, n_envs, (long long)slots, (long long)global_step, n_steps, max_priority);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+static int per_launch_sums(const float* priorities, int64_t n_valid, float alpha, const per_ws_t& w, hipStream_t s) {
+    const int64_t n0 = per_n0(n_valid);
+    per_sums0_kernel<<<(unsigned)((n0 + PER_CHUNK - 1) / PER_CHUNK), 256, 0, s>>>(priorities, (long long)n_valid, alpha, w.s0, w.a0);
+    MI_LAUNCH_CHECK();
+    per_sums1_kernel<<<1, 256, 0, s>>>(w.s0, w.a0, (long long)n0, w.s1, w.totals);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" int mi_per_sample(uint64_t seed, uint64_t update_index, const float* priorities, int64_t n_valid, int64_t capacity, double count, float alpha,
+                             float beta, int batch, int sample, void* workspace, int64_t* idx, float* weights, void* stream) {
+    MI_CHECK_ARG(priorities && workspace && idx && weights && n_valid > 0 && n_valid <= capacity && batch > 0, "bad arguments");
+    MI_CHECK_ARG(capacity <= (int64_t)PER_MAX_L1 * PER_CHUNK * PER_CHUNK, "prioritized sampler: capacity above 4,194,304 entries needs a fourth level");
+    const per_ws_t w = per_ws(workspace, capacity);
+    const int rc = per_launch_sums(priorities, n_valid, alpha, w, (hipStream_t)stream);
+    if (rc) return rc;
+    per_sample_kernel<<<1, 256, 0, (hipStream_t)stream>>>(seed, update_index, priorities, (long long)n_valid, w.s0, w.s1, w.totals, batch, (float)count, alpha, beta,
+                                                          sample, idx, weights);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" int mi_per_td_grad(const float* params, const float* target_params, const float* observations, const int64_t* actions,
+                              const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                              float gamma, double inv_count, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, void* stream) {
+    MI_CHECK_ARG(weights && td_abs, "NULL weights / td_abs");
+    return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace, grads, loss,
+                       weights, td_abs, stream);
+}
+
+extern "C" int mi_per_update_priorities(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, void* stream) {
+    MI_CHECK_ARG(priorities && idx && td_abs && owner && max_priority && batch > 0, "bad arguments");
+    per_scatter_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(priorities, idx, td_abs, batch, owner, max_priority);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }

@@ -139,3 +139,49 @@ class DuelingDQNEngine(DQNEngine):
     def sync_target(self):
         self.target.flat.copy_(self.q.flat)
         self.target.eff.copy_(self.q.eff)
+
+
+class PERDQNEngine(DQNEngine):
+    """The same ring and launches for reference per.py (prioritized replay): a priorities ring beside the replay ring, a keyed
+    prefix-sum sampler instead of torch.multinomial's O(buffer) scan, importance-weighted TD loss, priority scatter and the running
+    max_priority on the device (per.py:75-84,103-106,124-153)."""
+
+    def __init__(self, env, q_network, target_network, optimizer, slots, alpha=0.6, beta_0=0.4, **kw):
+        super().__init__(env, q_network, target_network, optimizer, slots, **kw)
+        dev, S, Nn = self.device, self.slots, self.N
+        self.alpha, self.beta_0 = float(alpha), float(beta_0)
+        self.priorities = torch.zeros((S, Nn), dtype=torch.float32, device=dev)             # per.py:79
+        self.max_priority = torch.full((1,), 1e-2, dtype=torch.float32, device=dev)         # :84
+        self.weights = torch.zeros(self.batch_size, dtype=torch.float32, device=dev)
+        self.td_abs = torch.zeros(self.batch_size, dtype=torch.float32, device=dev)
+        self._owner = torch.full((S * Nn,), -1, dtype=torch.int32, device=dev)
+        self._per_ws = torch.empty(N.lib().mi_per_workspace_bytes(S * Nn), dtype=torch.uint8, device=dev)
+
+    def act(self, n_steps, forced_actions=None, forced_resets=None):
+        gs = self.global_step
+        super().act(n_steps, forced_actions, forced_resets)
+        N.check(N.lib().mi_per_mark(N.ptr(self.priorities), self.N, self.slots, gs, int(n_steps), N.ptr(self.max_priority), self._s()), "mi_per_mark")   # :106
+
+    def beta(self):
+        """per.py:126: beta starts at beta_0 and increases linearly to 1."""
+        return (1 - self.beta_0) * self.global_step / self.total_timesteps + self.beta_0
+
+    def sample(self, indices=None):
+        """batch_inds ~ priorities (per.py:128) and the importance weights (:131,145-146); `indices` keeps the caller's batch."""
+        stored = min(self.global_step, self.slots) * self.N
+        if indices is not None:
+            self.batch_inds.copy_(torch.as_tensor(indices, dtype=torch.int64).reshape(-1).to(self.device))
+        N.check(N.lib().mi_per_sample(self.env._seed, self.update_index, N.ptr(self.priorities), stored, self.slots * self.N, float(stored), self.alpha,
+                                      self.beta(), self.batch_size, 0 if indices is not None else 1, N.ptr(self._per_ws), N.ptr(self.batch_inds),
+                                      N.ptr(self.weights), self._s()), "mi_per_sample")
+
+    def td_grad(self):
+        """weighted loss + gradient (per.py:133-147), |td| per row; then priorities[batch_inds] = |td| and max_priority (:141-142)."""
+        N.check(N.lib().mi_per_td_grad(
+            N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+            N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma,
+            1.0 / (self.batch_size * self.world_size), N.ptr(self.weights), N.ptr(self.td_abs), N.ptr(self.workspace), N.ptr(self.grads),
+            N.ptr(self.loss), self._s()), "mi_per_td_grad")
+        N.check(N.lib().mi_per_update_priorities(N.ptr(self.priorities), N.ptr(self.batch_inds), N.ptr(self.td_abs), self.batch_size, N.ptr(self._owner),
+                                                 N.ptr(self.max_priority), self._s()), "mi_per_update_priorities")
+        D.allreduce_sum_(self._gradbuf, self.pg)

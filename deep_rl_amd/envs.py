@@ -21,6 +21,16 @@ class Discrete:
         self.n = n
         self.shape = ()
         self.dtype = torch.int64
+        self._gen = None
+
+    def seed(self, seed=None):
+        """env.action_space.seed(seed) (per.py:67).  Host-side sampler only; the engines' random actions are keyed in-kernel."""
+        self._gen = torch.Generator().manual_seed(0 if seed is None else int(seed))
+        return [seed]
+
+    def sample(self):
+        """env.action_space.sample() (per.py:96)."""
+        return int(torch.randint(self.n, (), generator=self._gen))
 
 
 class Box:

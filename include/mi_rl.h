@@ -190,6 +190,25 @@ int mi_dqn_td_grad(const float* params, const float* target_params, const float*
 int mi_dueling_pack(const float* dueling_params, float* dqn_params, void* stream);
 int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_grads, void* stream);
 
+/* ---- Prioritized replay (reference deep_rl/per.py, run on CartPole-v1) as epilogues on the DQN calls.
+ * priorities: dev f32 [slots, N] beside the replay ring; max_priority: dev f32 [1] (per.py:84, initial 1e-2); owner: dev i32 [slots*N],
+ * all -1 between calls; workspace: mi_per_workspace_bytes(slots*N).
+ * per.py:128 draws batch_inds with torch.multinomial(priorities) (O(buffer), host generator); here a keyed three-level prefix-sum descent
+ * with a fixed evaluation order (64-entry chunk sums, sums of 64 of those, total; sequential, f64; u = 53-bit Philox uniform of
+ * (seed, update_index, b, stream 7)) — the oracle implements the same contract bit for bit.  sample = 0 keeps the caller's idx
+ * (parity runs) and only computes the importance weights (count * p_i^alpha / sum p^alpha)^-beta / max (per.py:131,145-146; count = the
+ * reference's global_step = transitions stored).  mi_per_mark: priorities of the n_steps just written slots = max_priority (per.py:106),
+ * the ring's write head = 0.  mi_per_td_grad = mi_dqn_td_grad with loss = mean(weights * td^2) and td_abs[b] = |td_b| out (per.py:139,147).
+ * mi_per_update_priorities: priorities[idx] = td_abs (last duplicate wins), max_priority = max(max_priority, those) (per.py:141-142). */
+size_t mi_per_workspace_bytes(int64_t capacity);
+int mi_per_mark(float* priorities, int n_envs, int64_t slots, int64_t global_step, int n_steps, const float* max_priority, void* stream);
+int mi_per_sample(uint64_t seed, uint64_t update_index, const float* priorities, int64_t n_valid, int64_t capacity, double count, float alpha,
+                  float beta, int batch, int sample, void* workspace, int64_t* idx, float* weights, void* stream);
+int mi_per_td_grad(const float* params, const float* target_params, const float* observations, const int64_t* actions,
+                   const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                   float gamma, double inv_count, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, void* stream);
+int mi_per_update_priorities(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, void* stream);
+
 /* =====================================================================================================================
  * SAC (reference deep_rl/sac.py re-targeted to Pendulum-v1; SURVEY.md §8a s1-s8, BASELINE config 4).
  * Env kind MI_ENV_PENDULUM_V1: obs f32 [N,3] = (cos th, sin th, th_dot), action f32 [N] (one dim, clipped to +-2), reward

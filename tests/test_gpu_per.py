@@ -1,0 +1,180 @@
+"""GPU parity tests of the prioritized-replay epilogues (mi_per_* around the DQN kernels) against the CPU oracle and the golden vectors
+of the unmodified reference per.py (run on CartPole-v1).  Sampler indices, scatter and max_priority bit-exact; fp32 tolerances at each assert."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALPHA, BETA0 = 0.6, 0.4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import cpu_ref
+
+    cpu_ref.lib().ref_set_num_threads(8)
+    return cpu_ref
+
+
+@pytest.fixture(scope="module")
+def per_trace():
+    with np.load(os.path.join(ROOT, "tests", "golden", "per_ref_trace.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _engine(dev, n_envs, slots, params=None, seed=1, **kw):
+    import deep_rl_amd as D
+
+    env = D.make("CartPole-v1", num_envs=n_envs, device=dev, seed=seed)
+    torch.manual_seed(seed)
+    q = D.QNetwork(env); tgt = D.QNetwork(env)
+    if params is not None:
+        q.load_flat(params)
+    tgt.load_state_dict(q.state_dict())
+    opt = D.ClipAdam(q, lr=2.5e-4, eps=1e-8)
+    kw.setdefault("max_episodes_logged", 0)
+    return D.PERDQNEngine(env, q, tgt, opt, slots=slots, **kw)
+
+
+@pytest.mark.parametrize("n_envs,slots,frac", [(7, 1000, 0.63), (64, 4096, 1.0), (1024, 1024, 1.0)])
+def test_sampler_and_weights_bit_exact_indices(dev, R, n_envs, slots, frac):
+    """Random priorities with zeros: the device's prefix sums, sampled indices (bit-exact) and importance weights vs the oracle."""
+    eng = _engine(dev, n_envs, slots, seed=9, batch_size=1000, total_timesteps=10 * slots)
+    rng = np.random.default_rng(slots)
+    cap = slots * n_envs
+    stored_steps = int(slots * frac)
+    prio = rng.gamma(0.5, 1.0, cap).astype(np.float32)
+    prio[rng.random(cap) < 0.15] = 0.0
+    prio[stored_steps * n_envs:] = 0.0
+    eng.priorities.copy_(torch.from_numpy(prio.reshape(slots, n_envs)))
+    eng.global_step = stored_steps
+    eng.update_index = 17
+    eng.sample()
+    n = stored_steps * n_envs
+    s0, s1, total, total_alpha = R.per_sums(prio, n, ALPHA)
+    idx = R.per_sample(9, 17, prio, n, s0, s1, total, 1000)
+    got = eng.batch_inds.cpu().numpy()
+    assert np.array_equal(got, idx) and (prio[got] > 0).all()
+    w = R.per_weights(prio, idx, ALPHA, np.float32(eng.beta()), total_alpha, n)
+    assert np.allclose(eng.weights.cpu().numpy(), w, rtol=2e-5) and abs(float(eng.weights.max()) - 1.0) < 1e-6
+    # caller-supplied indices: weights only
+    mine = rng.choice(np.flatnonzero(prio[:n] > 0), 1000)
+    eng.sample(mine)
+    assert np.array_equal(eng.batch_inds.cpu().numpy(), mine)
+    assert np.allclose(eng.weights.cpu().numpy(), R.per_weights(prio, mine, ALPHA, np.float32(eng.beta()), total_alpha, n), rtol=2e-5)
+
+
+def test_scatter_last_duplicate_wins_and_max_priority(dev, R):
+    eng = _engine(dev, 5, 100, batch_size=512)
+    rng = np.random.default_rng(1)
+    prio = rng.random(500).astype(np.float32)
+    eng.priorities.copy_(torch.from_numpy(prio.reshape(100, 5)))
+    idx = rng.integers(0, 500, 512); idx[100:140] = idx[60:100]          # plenty of duplicates
+    td = rng.gamma(1.0, 2.0, 512).astype(np.float32)
+    for start in (np.float32(0.01), np.float32(50.0)):
+        eng.priorities.copy_(torch.from_numpy(prio.reshape(100, 5))); eng.max_priority.fill_(float(start))
+        eng.batch_inds.copy_(torch.from_numpy(idx).to(dev)); eng.td_abs.copy_(torch.from_numpy(td).to(dev))
+        from deep_rl_amd import _native as N
+        N.check(N.lib().mi_per_update_priorities(N.ptr(eng.priorities), N.ptr(eng.batch_inds), N.ptr(eng.td_abs), 512, N.ptr(eng._owner), N.ptr(eng.max_priority),
+                                                 N.stream_ptr(dev)), "mi_per_update_priorities")
+        want = prio.copy()
+        mp = R.per_update_priorities(want, idx, td, float(start))
+        assert np.array_equal(eng.priorities.cpu().numpy().reshape(-1), want) and float(eng.max_priority) == mp
+        assert (eng._owner == -1).all()
+
+
+def test_mark_priorities_and_ring_head(dev, R):
+    """per.py:106 for every env of every step of an acting call; the ring's write head gets priority 0 (never sampled)."""
+    eng = _engine(dev, 6, 16, learning_starts=0, total_timesteps=1000)
+    eng.reset()
+    eng.max_priority.fill_(0.75)
+    eng.act(10)
+    p = eng.priorities.cpu().numpy()
+    assert (p[:10] == 0.75).all() and (p[10:] == 0).all()
+    eng.max_priority.fill_(1.5)
+    eng.act(10)                                   # wraps: slots 10..15, 0..3 written, head = slot 4
+    p = eng.priorities.cpu().numpy()
+    assert (p[10:] == 1.5).all() and (p[:4] == 1.5).all() and (p[4] == 0).all() and (p[5:10] == 0.75).all()
+
+
+def _replay_storage(R, g, upto_steps):
+    from tests.test_oracle_per_pinned import replay_per
+
+    st, prio, gs = replay_per(g, 10**9 if upto_steps >= 100_000 else max(0, (upto_steps - 10_000) // 10 + 1), lambda *a: None)
+    return st
+
+
+def test_weighted_td_grad_vs_reference_checkpoints(dev, R, per_trace):
+    """Un-chained: the reference's pre-update priorities, parameters, target and indices at updates 1000 / 5000 / 9000 -> device
+    importance weights, |td|, loss, gradient and max_priority against the reference's own values (and the oracle's)."""
+    g = per_trace
+    st = _replay_storage(R, g, 100_000)
+    eng = _engine(dev, 1, slots=100_001, total_timesteps=100_000)
+    from tests.test_gpu_dqn import _upload
+    _upload(eng, st)
+    for i, k in enumerate(g["ck_update"]):
+        gs = int(g["ck_gs"][i]); pre = g["ck_pre_%d" % k]
+        eng.priorities.zero_(); eng.priorities[:gs + 1, 0].copy_(torch.from_numpy(pre))
+        eng.max_priority.fill_(float(pre.max()))
+        eng.global_step = gs
+        eng.q.load_flat(g["ck_params"][i]); eng.target.load_flat(g["ck_target"][i])
+        eng.sample(g["ck_inds"][i])
+        assert np.allclose(eng.weights.cpu().numpy(), g["ck_weights"][i], rtol=5e-5), k
+        eng.td_grad()
+        assert np.allclose(eng.td_abs.cpu().numpy(), np.abs(g["ck_td"][i]), rtol=2e-5, atol=2e-4)
+        scale = np.abs(g["ck_grads"][i]).max()
+        assert np.abs(eng.grads.cpu().numpy() - g["ck_grads"][i]).max() <= 2e-5 * scale, k
+        assert abs(float(eng.loss) - g["ck_loss"][i]) <= 3e-5 * g["ck_loss"][i]
+        assert abs(float(eng.max_priority) - g["ck_max_prio"][i]) <= 2e-5 * g["ck_max_prio"][i]
+
+
+def test_first_200_updates_chained_on_device(dev, R, per_trace):
+    """The reference's first 200 updates chained on the device: its batch indices, the device's own priorities / weights / weighted TD
+    gradient / Adam / scatter: loss, priority sum and max_priority track the reference."""
+    g = per_trace
+    st = _replay_storage(R, g, 12_100)
+    eng = _engine(dev, 1, slots=100_001, params=g["init_params"], total_timesteps=100_000)
+    from tests.test_gpu_dqn import _upload
+    _upload(eng, st)
+    eng.priorities[:10_000].fill_(1e-2)
+    for k in range(200):
+        gs = 10_000 + 10 * k
+        eng.global_step = gs
+        eng.train_step(g["batch_inds_chain"][k])
+        assert abs(float(eng.loss) - g["loss_all"][k]) <= 3e-4 * max(abs(g["loss_all"][k]), 1e-3), k
+        assert abs(eng.priorities.double().sum().item() - g["prio_sum_all"][k]) <= 5e-6 * g["prio_sum_all"][k], k
+        assert abs(float(eng.max_priority) - g["max_prio_all"][k]) <= 5e-6 * g["max_prio_all"][k], k
+        if k < 8:
+            assert np.abs(eng.q.flat.cpu().numpy() - g["full_params"][k]).max() < 2e-6, k
+        if gs % 500 == 0:
+            eng.sync_target()
+        eng.priorities[gs:gs + 10].copy_(eng.max_priority.expand(10, 1))      # per.py:106 for the next 10 steps
+
+
+def test_script_reference_shape_n1():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ, PYTHONPATH=ROOT, NUM_ENVS="1", TOTAL_TIMESTEPS="6000")
+    code = ("import runpy, json; g = runpy.run_module('deep_rl_amd.per', run_name='__main__');"
+            "print('GLOBALS', json.dumps({k: g[k] for k in ['env_id','total_timesteps','learning_starts','alpha','beta_0','train_frequency','batch_size','global_step','memory_size']}));"
+            "print('PRIO', tuple(g['priorities'].shape), int((g['priorities'] > 0).sum()), g['max_priority'] >= 0.01, g['optimizer'].step_count); print('LOSS', g['loss'])")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("global_step=")]
+    assert len(lines) > 100 and all(re.fullmatch(r"global_step=\d+, episodic_return=\d+\.\d\d", ln) for ln in lines)
+    assert '"alpha": 0.6' in out.stdout and '"beta_0": 0.4' in out.stdout and '"global_step": 6000' in out.stdout
+    assert "PRIO (6001, 1) 6000 True 541" in out.stdout
+    assert np.isfinite(float(out.stdout.split("LOSS")[1].split()[0]))

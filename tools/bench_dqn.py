@@ -9,13 +9,16 @@ import deep_rl_amd as D
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=4096); ap.add_argument("--slots", type=int, default=256)
 ap.add_argument("--batch", type=int, default=128); ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--variant", default="dqn", choices=["dqn", "dueling", "per"], help="dueling_dqn.py / per.py epilogues on the same kernels")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 env = D.make("CartPole-v1", num_envs=a.envs, device=dev, seed=1)
 torch.manual_seed(1)
-q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
+Net = D.DuelingQNetwork if a.variant == "dueling" else D.QNetwork
+Eng = {"dqn": D.DQNEngine, "dueling": D.DuelingDQNEngine, "per": D.PERDQNEngine}[a.variant]
+q = Net(env); t = Net(env); t.load_state_dict(q.state_dict())
 opt = D.ClipAdam(q, lr=2.5e-4, eps=1e-8)
-eng = D.DQNEngine(env, q, t, opt, slots=a.slots, batch_size=a.batch, learning_starts=100, total_timesteps=10 * (a.iters + 60))
+eng = Eng(env, q, t, opt, slots=a.slots, batch_size=a.batch, learning_starts=100, total_timesteps=10 * (a.iters + 60))
 eng.reset()
 def it():
     eng.act(10); eng.train_step()
@@ -24,6 +27,6 @@ for _ in range(50): it()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.iters): it()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(json.dumps({"workload": "dqn.py CartPole-v1, %d envs, %d-slot ring (%d transitions), batch %d, train every 10 steps" % (a.envs, a.slots, a.envs * a.slots, a.batch),
+print(json.dumps({"variant": a.variant, "workload": "dqn.py CartPole-v1, %d envs, %d-slot ring (%d transitions), batch %d, train every 10 steps" % (a.envs, a.slots, a.envs * a.slots, a.batch),
                   "env_steps_per_s": round(a.iters * 10 * a.envs / dt, 1), "updates_per_s": round(a.iters / dt, 1), "us_per_iteration": round(1e6 * dt / a.iters, 1),
                   "loss": float(eng.loss.item())}))
