@@ -112,6 +112,28 @@ extern "C" int mi_env_create(int kind, int n_envs, uint64_t seed, uint64_t env_i
     return MI_OK;
 }
 
+// ---- checkpointing (the reference has none): the whole env state is ONE slab (60 bytes per env: 4 f64 state,
+// episode / step counters u64, TimeLimit / episode-length i32, episode return f32), so export / import are one device-to-device copy.
+// With the counter-based RNG (keys = seed, global env id, these counters) a restored run continues bit for bit.
+extern "C" size_t mi_env_state_bytes(void* handle) {
+    if (!handle) return 0;
+    return (size_t)((mi_env*)handle)->n * (4 * 8 + 2 * 8 + 3 * 4);
+}
+
+extern "C" int mi_env_export_state(void* handle, void* dst, void* stream) {
+    MI_CHECK_ARG(handle && dst, "NULL pointer");
+    mi_env* e = (mi_env*)handle;
+    MI_HIP(hipMemcpyAsync(dst, e->x, mi_env_state_bytes(handle), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MI_OK;
+}
+
+extern "C" int mi_env_import_state(void* handle, const void* src, void* stream) {
+    MI_CHECK_ARG(handle && src, "NULL pointer");
+    mi_env* e = (mi_env*)handle;
+    MI_HIP(hipMemcpyAsync(e->x, src, mi_env_state_bytes(handle), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MI_OK;
+}
+
 extern "C" int mi_env_destroy(void* handle) {
     if (!handle) return MI_OK;
     mi_env* e = (mi_env*)handle;

@@ -72,6 +72,13 @@ const char* mi_last_error(void); /* thread-local, valid until the next call on t
  *      ppo.py:10-22,79-84; arithmetic of gym==0.21 cartpole.py / time_limit.py) ------------------ */
 int mi_env_create(int kind, int n_envs, uint64_t seed, uint64_t env_id_base, void** handle);
 int mi_env_destroy(void* handle);
+/* checkpoint / resume (absent in the reference): the complete env state — fp64 dynamics state, TimeLimit and
+ * episode-statistics counters, and the RNG counters (episode, step) that key the counter-based draws — as one opaque device blob of
+ * mi_env_state_bytes(handle) bytes.  Importing it into a handle created with the same (kind, n_envs, seed, env_id_base) continues the
+ * run bit for bit. */
+size_t mi_env_state_bytes(void* handle);
+int mi_env_export_state(void* handle, void* dst, void* stream);
+int mi_env_import_state(void* handle, const void* src, void* stream);
 /* env.reset() (ppo.py:21,101).  obs: dev f32 [N,4].  forced_state: dev f64 [N,4] or NULL (keyed noise). */
 int mi_env_reset(void* handle, float* obs, const double* forced_state, void* stream);
 /* env.step(action) followed by ppo.py:128-129's `if done: observation = env.reset()`.
