@@ -11,11 +11,16 @@ optimizer step one all-reduce(SUM) of the flat 9,155-float gradient (already sca
 clip + Adam then run identically on every rank.  Minibatch permutations are per-rank-local.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _native as N
 from . import dist as D
+
+
+# diagnostics: MIRL_PPO_SHARDED_SEQUENCE=1 makes a single process walk the sharded launch sequence (all-reduces are no-ops), to measure its host cost
+_FORCE_SHARDED_SEQUENCE = os.environ.get("MIRL_PPO_SHARDED_SEQUENCE", "0") == "1"
 
 
 class PPOEngine:
@@ -150,7 +155,7 @@ class PPOEngine:
         if self.observation is None:
             self.reset()
         g = self.optimizer.param_groups[0]
-        if self.world_size == 1:
+        if self.world_size == 1 and not _FORCE_SHARDED_SEQUENCE:
             o = self.optimizer
             buf = N.PPOBuffers(*[N.ptr(t) for t in (
                 self.agent.flat, o.exp_avg, o.exp_avg_sq, self.grads, self.loss_terms, o.grad_norm, self.observation,
