@@ -3,7 +3,7 @@
 One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm); "gloo" on CPU for the
 world_size-2 tests.  Envs shard embarrassingly (rank r owns global envs [r*N, (r+1)*N)), so there is no
 data-path collective besides these:
-  * advantage statistics {sum, sum of squares, count} per minibatch  -> global mean / unbiased std (ppo.py:169)
+  * advantage statistics {sum, sum of squares, count} per minibatch of every epoch, once per update  -> global mean / unbiased std (ppo.py:169)
   * the flat gradient (+ 4 loss terms), each rank's share already scaled by 1/(world*mb) (ppo.py:189-192)
 Messages are <= 36.6 KB: latency-bound, one fused buffer per collective, in-stream, no bucketing.
 """

@@ -6,7 +6,7 @@ two launches through the C ABI (include/mi_rl.h) on torch's current stream.  Not
 sequences launches and (for world_size > 1) the two tiny all-reduces.
 
 Multi-GPU: envs shard across ranks (rank r owns global envs [r*N, (r+1)*N)); parameters and
-Adam state are replicated.  Per epoch one all-reduce(SUM) of the (n_minibatch, 3) advantage statistics, per
+Adam state are replicated.  Per update one all-reduce(SUM) of the (epochs, n_minibatch, 3) advantage statistics, per
 optimizer step one all-reduce(SUM) of the flat 9,155-float gradient (already scaled by 1/(world*mb));
 clip + Adam then run identically on every rank.  Minibatch permutations are per-rank-local.
 """
@@ -49,7 +49,8 @@ class PPOEngine:
         self.dones = z(T + 1, Nn)
         self.advantages = z(T + 1, Nn)
         self.returns = z(T + 1, Nn)
-        self.perm = z(self.batch_size, dt=torch.int32)
+        self._perm_all = z(self.update_epochs, self.batch_size, dt=torch.int32)  # sharded runs keep every epoch's permutation (one stats all-reduce per update)
+        self.perm = self._perm_all[0]
         self._adv_sums_all = z(self.update_epochs, self.n_minibatch, 3, dt=torch.float64)  # mi_ppo_update: one slab per epoch
         self.adv_sums = self._adv_sums_all[0]
         # gradient + loss terms share one buffer so that ONE all-reduce carries both when sharded
@@ -169,10 +170,19 @@ class PPOEngine:
         else:
             self.rollout()
             self.compute_gae()
+            # every epoch's permutation and LOCAL advantage statistics first, then ONE all-reduce for the whole update (the statistics
+            # depend only on the advantages and the permutation keys, not on the parameters): 17 collectives per update instead of 20
+            L = N.lib()
             for epoch in range(self.update_epochs):
-                self.make_perm(epoch)
-                self.adv_stats()
+                key = L.mi_perm_key(self.env._seed, self.update_index, epoch)
+                N.check(L.mi_make_perm(self.batch_size, key, N.ptr(self._perm_all[epoch]), self._s()), "mi_make_perm")
+                N.check(L.mi_adv_stats(N.ptr(self.advantages), N.ptr(self._perm_all[epoch]), self.minibatch_size, self.n_minibatch,
+                                       N.ptr(self._adv_sums_all[epoch]), self._s()), "mi_adv_stats")
+            D.allreduce_sum_(self._adv_sums_all, self.pg)
+            for epoch in range(self.update_epochs):
+                self.perm, self.adv_sums = self._perm_all[epoch], self._adv_sums_all[epoch]
                 for k in range(self.n_minibatch):
                     self.minibatch_grad(k)
                     self.optimizer_step()
+            self.perm, self.adv_sums = self._perm_all[0], self._adv_sums_all[0]
         self.update_index += 1
