@@ -240,3 +240,69 @@ def test_td_grad_batches_and_ring(dev, R, batch):
     og, ol = R.dqn_td_grads(params, tparams, st, idx)
     assert np.abs(eng.grads.cpu().numpy() - og).max() <= 1e-5 * np.abs(og).max()
     assert abs(float(eng.loss.item()) - ol) <= 2e-5 * ol
+
+
+def test_config3_full_size_properties(dev, R):
+    """BASELINE config 3 at full size (4096 envs x 256 slots = 1,048,576 transitions; the ring wraps): size-independent properties.
+    (a) shard invariance: two 2048-env engines reproduce the 4096-env ring bit for bit (keyed RNG, MFMA acting kernel);
+    (b) physics: re-stepping a stored observation with the stored action lands on the stored successor (float32 storage of a float64
+        state: 2e-5), rewards are 1, `terminated` agrees with the thresholds of the successor the env computed;
+    (c) the TD gradient is additive over the batch (two halves at half weight sum to the whole) and bitwise reproducible."""
+    n, S, steps = 4096, 256, 300
+    rng = np.random.default_rng(11)
+    params = None
+    rings = []
+    for base, cnt in ((0, n), (0, n // 2), (n // 2, n // 2)):
+        eng = _engine(dev, cnt, slots=S, seed=2, base=base, learning_starts=100, total_timesteps=600, max_episodes_logged=0)
+        if params is None:
+            params = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
+        eng.q.load_flat(params); eng.target.load_flat(params)
+        eng.reset()
+        for _ in range(steps // 10):
+            eng.act(10)
+        rings.append(eng)
+    big = rings[0]
+    for r, sl in ((rings[1], slice(0, n // 2)), (rings[2], slice(n // 2, n))):
+        for name in ("observations", "actions", "terminated"):
+            assert torch.equal(getattr(big, name)[:, sl], getattr(r, name)), name
+    # (b) on 3,000 random (slot, env) pairs whose successor slot is valid (not the write head) and which did not end an episode
+    obs = big.observations.cpu().numpy(); act = big.actions.cpu().numpy(); term = big.terminated.cpu().numpy()
+    head = steps % S
+    checked = 0
+    for _ in range(3000):
+        s, e = int(rng.integers(0, S)), int(rng.integers(0, n))
+        if (s + 1) % S == head or s == head:
+            continue
+        nxt, _t = R.cartpole_step(obs[s, e].astype(np.float64), int(act[s, e]))
+        ended = abs(nxt[0]) > 2.4 or abs(nxt[2]) > 12 * 2 * np.pi / 360
+        if ended:      # the stored successor is the reset state; the flag must say terminated (unless float32 rounding decided the threshold)
+            if min(abs(abs(nxt[0]) - 2.4), abs(abs(nxt[2]) - 12 * 2 * np.pi / 360)) > 1e-4:
+                assert term[(s + 1) % S, e] == 1
+            continue
+        if term[(s + 1) % S, e] == 0 and np.abs(obs[(s + 1) % S, e]).max() > 0.06:      # not a reset by truncation (reset states are within +-0.05)
+            assert np.abs(nxt - obs[(s + 1) % S, e]).max() < 2e-5, (s, e)
+            checked += 1
+    assert checked > 1500 and (big.rewards.cpu().numpy()[np.arange(S) != head] == 1.0).all()
+    # (c)
+    B = 16384
+    eng = _engine(dev, n, slots=S, seed=2, batch_size=B, learning_starts=100, total_timesteps=600, max_episodes_logged=0)
+    eng.q.load_flat(params); eng.target.load_flat((params + rng.normal(0, 0.05, 10934)).astype(np.float32))
+    for name in ("observations", "actions", "rewards", "terminated"):
+        getattr(eng, name).copy_(getattr(big, name))
+    eng.global_step = steps
+    eng.sample()
+    idx = eng.batch_inds.cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < S * n
+    eng.td_grad()
+    g_all = eng.grads.clone(); l_all = float(eng.loss)
+    eng.td_grad()
+    assert torch.equal(eng.grads, g_all)
+    half = _engine(dev, n, slots=S, seed=2, batch_size=B // 2, learning_starts=100, total_timesteps=600, max_episodes_logged=0)
+    half.q.load_flat(params); half.target.flat.copy_(eng.target.flat)
+    for name in ("observations", "actions", "rewards", "terminated"):
+        getattr(half, name).copy_(getattr(big, name))
+    acc = torch.zeros_like(g_all); lsum = 0.0
+    for h in range(2):
+        half.sample(idx[h * B // 2:(h + 1) * B // 2]); half.td_grad()
+        acc += 0.5 * half.grads; lsum += 0.5 * float(half.loss)
+    assert (acc - g_all).abs().max().item() <= 5e-6 * g_all.abs().max().item() and abs(lsum - l_all) <= 1e-5 * l_all

@@ -475,3 +475,60 @@ def test_train_step_learns_pendulum(dev, R):
     assert 0.0 < float(eng.alpha) < 1.0          # entropy coefficient annealed from exp(0)
     r_rand = eng.rewards[1:200].mean().item(); r_last = eng.rewards[T - 200:T].mean().item()
     assert r_last > r_rand + 2.0, (r_rand, r_last)
+
+
+def test_config4_full_size_properties(dev, R):
+    """BASELINE config 4 at full size (2048 envs, 512-slot ring, batch 256; the ring wraps): size-independent properties.
+    (a) physics: re-stepping a stored observation with the stored action lands on the stored successor (float32 storage of the
+        float64 angle: cos / sin / speed within 2e-5) and reproduces the stored reward; nothing is ever `terminated`;
+    (b) 200 production iterations keep every parameter finite, alpha falls from 1, fused == unfused updates at this size;
+    (c) the critic / actor gradients are additive over the batch (two halves at half weight sum to the whole)."""
+    n, S = 2048, 512
+    eng = _engine(dev, n, S, seed=6, batch_size=256, learning_starts=40, max_episodes_logged=0)
+    eng.reset()
+    for _ in range(600):
+        eng.act()
+        if eng.global_step >= 400:
+            eng.train_step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.q_flat).all() and torch.isfinite(eng.actor.flat).all() and 0.0 < float(eng.alpha) < 1.0
+    obs = eng.observations.cpu().numpy(); act = eng.actions.cpu().numpy(); rew = eng.rewards.cpu().numpy()
+    assert not eng.terminated.any()
+    head = 600 % S
+    rng = np.random.default_rng(3)
+    checked = 0
+    for _ in range(3000):
+        s, e = int(rng.integers(0, S)), int(rng.integers(0, n))
+        if (s + 1) % S == head or s == head:
+            continue
+        o = obs[s, e].astype(np.float64)
+        th, thd = np.arctan2(o[1], o[0]), o[2]
+        u = float(np.clip(act[s, e], -2, 2))
+        cost = th ** 2 + 0.1 * thd ** 2 + 0.001 * u ** 2
+        nthd = np.clip(thd + (15.0 * np.sin(th) + 3.0 * u) * 0.05, -8, 8)
+        nth = th + nthd * 0.05
+        want = np.array([np.cos(nth), np.sin(nth), nthd])
+        got = obs[(s + 1) % S, e]
+        if np.abs(want - got).max() < 2e-5:            # (a reset after TimeLimit puts an unrelated state there: 1 slot in 200)
+            assert abs(-cost - rew[(s + 1) % S, e]) < 2e-4 * max(1.0, cost)
+            checked += 1
+    assert checked > 2700
+    # (b) fused == unfused, (c) additivity, on this ring
+    idx = rng.integers(0, S * n, 256); idx = idx[(idx // n + 1) % S != head]
+    idx = np.concatenate([idx, idx[:256 - idx.size]])
+    eps = torch.from_numpy(rng.standard_normal((2, 256)).astype(np.float32))
+    a0, q0, t0 = eng.actor.flat.clone(), eng.q_flat.clone(), eng.qt_flat.clone()
+    eng.sample(idx)
+    eng.critic_grad(eps[0]); gq = eng.q_grads.clone(); lq = eng.q_losses.clone()
+    eng.actor_grad(eps[1]); ga = eng.actor_grads.clone()
+    half = _engine(dev, n, S, seed=6, batch_size=128, actor=a0.cpu().numpy(), q=q0.cpu().numpy(), qt=t0.cpu().numpy(), max_episodes_logged=0)
+    for name in ("observations", "actions", "rewards", "terminated"):
+        getattr(half, name).copy_(getattr(eng, name))
+    half.alpha.copy_(eng.alpha)
+    accq = torch.zeros_like(gq); acca = torch.zeros_like(ga)
+    for h in range(2):
+        half.sample(idx[128 * h:128 * (h + 1)])
+        half.critic_grad(eps[0][128 * h:128 * (h + 1)]); accq += 0.5 * half.q_grads
+        half.actor_grad(eps[1][128 * h:128 * (h + 1)]); acca += 0.5 * half.actor_grads
+    assert (accq - gq).abs().max().item() <= 1e-5 * gq.abs().max().item()
+    assert (acca - ga).abs().max().item() <= 1e-4 * ga.abs().max().item()
