@@ -167,7 +167,7 @@ def main():
             "params_finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params0)
+            out["cpu_baseline"] = cpu_baseline(params0, float(os.environ.get("MIRL_CPU_BASELINE_SECONDS", "10")))  # bounded sample (default 10 s)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

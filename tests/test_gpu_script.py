@@ -121,3 +121,29 @@ def test_sac_script_vector_ring_runs():
         pytest.skip("needs an MI355X")
     out = _run_sac({"NUM_ENVS": "2048", "TOTAL_TIMESTEPS": "600", "MEMORY_SIZE": "128", "BATCH_SIZE": "1024", "LEARNING_STARTS": "50"})
     assert '"memory_size": 128' in out and "SHAPES [(128, 2048, 3)" in out and "STEPS 551 552 552" in out
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's keys, the roofline of the dominant kernel (duration measured live with HIP events)
+    and the CPU baseline (a bounded sample; shortened here through the same code path)."""
+    import json
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], env=dict(os.environ, PYTHONPATH=ROOT, MIRL_CPU_BASELINE_SECONDS="1"),
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 3 * 128 * 4096 / (3 * d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0 and r["launches"] == 3 * 16
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
