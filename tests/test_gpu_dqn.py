@@ -108,10 +108,12 @@ def test_act_steps_teacher_forced_vs_reference_trace(dev, R, dqn_trace):
     assert np.array_equal(eng.terminated[1:n_steps + 1, 0].cpu().numpy(), g["terminated_all"][:n_steps])
 
 
-def test_act_steps_keyed_rng_ring_wrap(dev, R):
-    """96 envs, a 16-slot ring (wraps many times), epsilon decaying to 0.05 within the test: actions follow the RNG contract
-    (random action / greedy argmax decided by the keyed draw), storage bit-exact vs the oracle with the device's actions replayed."""
-    n, S, tt, ls = 96, 16, 400, 40
+@pytest.mark.parametrize("n", [96, 37, 3])
+def test_act_steps_keyed_rng_ring_wrap(dev, R, n):
+    """96 / 37 / 3 envs (the acting kernel owns 16 envs per workgroup: ragged tails), a 16-slot ring (wraps many times), epsilon decaying to
+    0.05 within the test: actions follow the RNG contract (random action / greedy argmax decided by the keyed draw), storage bit-exact vs the
+    oracle with the device's actions replayed."""
+    S, tt, ls = 16, 400, 40
     eng = _engine(dev, n, slots=S, seed=5, base=300, learning_starts=ls, total_timesteps=tt)
     rng = np.random.default_rng(1)
     params = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
@@ -133,7 +135,7 @@ def test_act_steps_keyed_rng_ring_wrap(dev, R):
         # first step of the call: the decision must follow the contract (obs known = obs_before)
         eps = np.float32(R.dqn_epsilon(gs, total_timesteps=tt))
         qv = R.dqn_forward(params, obs_before)
-        for e in range(0, n, 7):
+        for e in range(0, n, 7 if n > 7 else 1):
             u, ra = R.dqn_explore_draw(5, 300 + e, gs)
             if gs < ls or u < eps:
                 assert fa[0, e] == ra
@@ -141,7 +143,7 @@ def test_act_steps_keyed_rng_ring_wrap(dev, R):
                 assert fa[0, e] == int(qv[e, 1] > qv[e, 0]); n_greedy += 1
             n_checked += 1
         gs += k
-    assert n_greedy > 50 and n_checked > 400
+    assert n_greedy > (50 if n > 7 else 10) and n_checked > (400 if n == 96 else 100)
 
 
 def test_sample_bit_exact(dev, R):
