@@ -83,7 +83,11 @@ def main():
     from deep_rl_amd import _native as N
     from deep_rl_amd.dist import init_from_env
 
-    rank, world, local_rank = init_from_env("nccl")
+    # production: RCCL ("nccl"), one rank per GPU.  MIRL_BENCH_BACKEND=gloo MIRL_BENCH_ONE_GPU=1 lets the N > 1 code path of this script be
+    # exercised on a single-GPU box (both ranks on cuda:0; tests/test_gpu_script.py) — RCCL itself refuses two ranks on one device.
+    rank, world, local_rank = init_from_env(os.environ.get("MIRL_BENCH_BACKEND", "nccl"))
+    if os.environ.get("MIRL_BENCH_ONE_GPU", "0") == "1":
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)

@@ -147,3 +147,27 @@ def test_bench_contract_line():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0 and r["launches"] == 3 * 16
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_two_ranks_code_path_on_one_gpu():
+    """The N > 1 path of bench.py (torch.distributed.run launch, barriers, MAX over ranks, one JSON line from rank 0, whole-job value)
+    with both ranks on cuda:0 over gloo — RCCL on 2..8 GPUs is the driver's run."""
+    import json
+    import socket
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_BENCH_BACKEND="gloo", MIRL_BENCH_ONE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["params_finite"] is True
+    assert abs(d["value"] - 2 * 2 * 128 * 4096 / (2 * d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]      # whole-job aggregate over both ranks
+    assert "x2" in d["config"]["parallelism"] and d["roofline"]["launches"] == 2 * 16
