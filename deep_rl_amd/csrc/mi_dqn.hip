@@ -444,14 +444,25 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
     }
 }
 
-// grads[p] = sum over workgroup slabs in slab order; loss = sum of the slab losses * inv_count
+// grads[p] = sum over workgroup slabs in slab order; loss = sum of the slab losses * inv_count.  With `opt.params` set the same launch applies
+// optimizer.step() (torch Adam without clipping, dqn.py:68,133) to the element it has just summed: no launch of its own in single-process runs.
+struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, bc2_sqrt, eps; };
 __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
-                                                         float* __restrict__ grads, float* __restrict__ loss) {
+                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < DQ_NP) {
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int b = 0; b < n_slabs; ++b) acc[b & 3] += workspace[(size_t)b * TD_SLAB + p];
-        grads[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        grads[p] = g;
+        if (opt.params) {   // the formula of clip_adam_kernel at coef = 1 (max_norm = inf), bit for bit
+            const float pm = opt.m[p], pv = opt.v[p];
+            const float mi = pm + opt.w1 * (g - pm);
+            const float vi = pv * opt.b2 + opt.w2 * (g * g);
+            const float denom = sqrtf(vi) / opt.bc2_sqrt + opt.eps;
+            opt.m[p] = mi; opt.v[p] = vi;
+            opt.params[p] = opt.params[p] + (-opt.step_size) * (mi / denom);
+        }
     } else if (p == DQ_NP && loss) {
         double l = 0.0;
         for (int b = 0; b < n_slabs; ++b) l += workspace[(size_t)b * TD_SLAB + DQ_NP];
@@ -463,9 +474,12 @@ extern "C" size_t mi_dqn_workspace_bytes(int batch) {
     return (size_t)((batch + TD_R - 1) / TD_R) * TD_SLAB * sizeof(float);
 }
 
+static dqn_opt_t dqn_no_opt() { dqn_opt_t o; memset(&o, 0, sizeof(o)); return o; }
+
 static int dqn_td_impl(const float* params, const float* target_params, const float* observations, const int64_t* actions,
                        const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
-                       float gamma, double inv_count, void* workspace, float* grads, float* loss, const float* weights, float* td_abs, void* stream) {
+                       float gamma, double inv_count, void* workspace, float* grads, float* loss, const float* weights, float* td_abs, const dqn_opt_t& opt,
+                       void* stream) {
     MI_CHECK_ARG(params && target_params && observations && actions && rewards && terminated && idx && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
     hipStream_t s = (hipStream_t)stream;
@@ -473,7 +487,7 @@ static int dqn_td_impl(const float* params, const float* target_params, const fl
     dqn_td_kernel<<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
                                          (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs);
     MI_LAUNCH_CHECK();
-    dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss);
+    dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -482,7 +496,21 @@ extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, c
                               const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
                               float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream) {
     return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace, grads, loss,
-                       nullptr, nullptr, stream);
+                       nullptr, nullptr, dqn_no_opt(), stream);
+}
+
+// single-process fusion: TD gradient (optionally importance-weighted, weights / td_abs nullable together) + optimizer.step() in two launches
+extern "C" int mi_dqn_td_update(float* params, const float* target_params, const float* observations, const int64_t* actions,
+                                const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                                float gamma, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, float* exp_avg, float* exp_avg_sq,
+                                int64_t step, double lr, double beta1, double beta2, double eps, void* stream) {
+    MI_CHECK_ARG(exp_avg && exp_avg_sq && step >= 1 && (!weights == !td_abs), "bad optimizer state / weights and td_abs go together");
+    dqn_opt_t o;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    o.params = params; o.m = exp_avg; o.v = exp_avg_sq; o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2);
+    o.step_size = (float)(lr / bc1); o.bc2_sqrt = (float)sqrt(bc2); o.eps = (float)eps;
+    return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / batch, workspace, grads, loss,
+                       weights, td_abs, o, stream);
 }
 
 // ---- Dueling head (reference deep_rl/dueling_dqn.py:24-40) as an epilogue on the DQN kernels -----------------
@@ -751,7 +779,7 @@ extern "C" int mi_per_td_grad(const float* params, const float* target_params, c
                               float gamma, double inv_count, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, void* stream) {
     MI_CHECK_ARG(weights && td_abs, "NULL weights / td_abs");
     return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace, grads, loss,
-                       weights, td_abs, stream);
+                       weights, td_abs, dqn_no_opt(), stream);
 }
 
 extern "C" int mi_per_update_priorities(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, void* stream) {

@@ -85,11 +85,31 @@ class DQNEngine:
             1.0 / (self.batch_size * self.world_size), N.ptr(self.workspace), N.ptr(self.grads), N.ptr(self.loss), self._s()), "mi_dqn_td_grad")
         D.allreduce_sum_(self._gradbuf, self.pg)
 
+    def _row_weights(self):
+        """(importance weights, |td| out) of the TD launch — None for plain DQN (PERDQNEngine overrides)."""
+        return None, None
+
+    def _after_td(self):
+        pass
+
     def train_step(self, indices=None):
-        """One optimisation step (dqn.py:114-133)."""
+        """One optimisation step (dqn.py:114-133).  Single process without gradient clipping: the launch that sums the gradient slabs also
+        applies Adam (mi_dqn_td_update, bit-identical to td_grad() + optimizer.step())."""
         self.sample(indices)
-        self.td_grad()
-        self.optimizer.step(self.grads)
+        g = self.optimizer.param_groups[0]
+        if self.world_size == 1 and g["max_grad_norm"] == float("inf") and type(self).td_grad in (DQNEngine.td_grad, PERDQNEngine.td_grad):
+            o = self.optimizer
+            o.step_count += 1
+            w, td = self._row_weights()
+            N.check(N.lib().mi_dqn_td_update(
+                N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
+                N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self.grads),
+                N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self._s()),
+                "mi_dqn_td_update")
+            self._after_td()
+        else:
+            self.td_grad()
+            self.optimizer.step(self.grads)
         self.update_index += 1
 
     def sync_target(self):
@@ -125,9 +145,10 @@ class DuelingDQNEngine(DQNEngine):
             N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma,
             1.0 / (self.batch_size * self.world_size), N.ptr(self.workspace), N.ptr(self.grads), N.ptr(self.loss), self._s()), "mi_dqn_td_grad")
         N.check(N.lib().mi_dueling_unpack_grads(N.ptr(self.grads), N.ptr(self.dueling_grads), self._s()), "mi_dueling_unpack_grads")
-        self._dgradbuf[N.DUELING_NPARAMS:N.DUELING_NPARAMS + 1].copy_(self.loss)
-        D.allreduce_sum_(self._dgradbuf, self.pg)
-        self.loss.copy_(self._dgradbuf[N.DUELING_NPARAMS:N.DUELING_NPARAMS + 1])
+        if self.world_size > 1:     # gradient share + loss share in one buffer, as the other engines do
+            self._dgradbuf[N.DUELING_NPARAMS:N.DUELING_NPARAMS + 1].copy_(self.loss)
+            D.allreduce_sum_(self._dgradbuf, self.pg)
+            self.loss.copy_(self._dgradbuf[N.DUELING_NPARAMS:N.DUELING_NPARAMS + 1])
 
     def train_step(self, indices=None):
         self.sample(indices)
@@ -182,6 +203,12 @@ class PERDQNEngine(DQNEngine):
             N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma,
             1.0 / (self.batch_size * self.world_size), N.ptr(self.weights), N.ptr(self.td_abs), N.ptr(self.workspace), N.ptr(self.grads),
             N.ptr(self.loss), self._s()), "mi_per_td_grad")
+        self._after_td()
+        D.allreduce_sum_(self._gradbuf, self.pg)
+
+    def _row_weights(self):
+        return self.weights, self.td_abs
+
+    def _after_td(self):
         N.check(N.lib().mi_per_update_priorities(N.ptr(self.priorities), N.ptr(self.batch_inds), N.ptr(self.td_abs), self.batch_size, N.ptr(self._owner),
                                                  N.ptr(self.max_priority), self._s()), "mi_per_update_priorities")
-        D.allreduce_sum_(self._gradbuf, self.pg)

@@ -308,3 +308,34 @@ def test_config3_full_size_properties(dev, R):
         half.sample(idx[h * B // 2:(h + 1) * B // 2]); half.td_grad()
         acc += 0.5 * half.grads; lsum += 0.5 * float(half.loss)
     assert (acc - g_all).abs().max().item() <= 5e-6 * g_all.abs().max().item() and abs(lsum - l_all) <= 1e-5 * l_all
+
+
+def test_fused_td_update_equals_grad_then_adam(dev, R):
+    """mi_dqn_td_update (TD gradient + Adam in the reduction launch) == td_grad() + optimizer.step(), bit for bit, for plain and prioritized DQN."""
+    import deep_rl_amd as D
+
+    rng = np.random.default_rng(5)
+    for kind in ("dqn", "per"):
+        engs = []
+        for fused in (True, False):
+            env = D.make("CartPole-v1", num_envs=32, device=dev, seed=3)
+            torch.manual_seed(3)
+            q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
+            Eng = D.DQNEngine if kind == "dqn" else D.PERDQNEngine
+            eng = Eng(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=64, batch_size=200, learning_starts=0, total_timesteps=1000, max_episodes_logged=0)
+            eng.reset()
+            for _ in range(5):
+                eng.act(10)
+            for it in range(3):
+                if fused:
+                    eng.train_step()
+                else:
+                    eng.sample(); eng.td_grad(); eng.optimizer.step(eng.grads); eng.update_index += 1
+            engs.append(eng)
+        f, u = engs
+        assert f.optimizer.step_count == u.optimizer.step_count == 3
+        for name in ("grads", "loss", "batch_inds"):
+            assert torch.equal(getattr(f, name), getattr(u, name)), (kind, name)
+        assert torch.equal(f.q.flat, u.q.flat) and torch.equal(f.optimizer.exp_avg_sq, u.optimizer.exp_avg_sq)
+        if kind == "per":
+            assert torch.equal(f.priorities, u.priorities) and torch.equal(f.max_priority, u.max_priority)
