@@ -201,6 +201,7 @@ rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restr
 // step, TimeLimit, auto-reset) redundantly — identical IEEE sequences, identical bits — so neither action nor observation is ever
 // exchanged; wave 0 / lane group 0 writes the storage.  36 MFMAs + 24 tanh per wave and step (was: 2 x 4,500 VALU FMAs per env-step).
 #define RM_ENVS 16
+#define RM_GAE_T 128
 typedef float rm_f32x4 __attribute__((ext_vector_type(4)));
 #define RM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 __global__ void __launch_bounds__(256)
@@ -208,8 +209,12 @@ rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __
                     float* __restrict__ values, int64_t* __restrict__ actions, float* __restrict__ log_probs,
                     float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
                     const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
-                    mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep) {
+                    mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep,
+                    float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam) {
     __shared__ float hp[2][4][RM_ENVS][2];
+    // fused GAE (adv != NULL, T <= RM_GAE_T): the workgroup keeps values / rewards / dones of its 16 envs for the whole rollout and runs the
+    // reverse scan of ppo.py:144-151 itself at the end — same expression order as gae_kernel, bit for bit, without a launch of its own
+    __shared__ float gv[RM_GAE_T + 1][RM_ENVS], gr[RM_GAE_T + 1][RM_ENVS], gd[RM_GAE_T + 1][RM_ENVS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
     const int net = w >> 1, half = w & 1;
     const int N = e.n;
@@ -341,6 +346,26 @@ rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __
             values[row] = my_val;                               // :115,:139
             if (t >= 0) { rewards[row] = rew; dones[row] = dn; }  // :140-141
         }
+        if (adv && w == 0 && lg == 0) { gv[t + 1][j] = my_val; gr[t + 1][j] = rew; gd[t + 1][j] = dn; }
+    }
+    if (adv && writer) {       // GAE over this lane's env (ppo.py:144-151; expression order of gae_kernel)
+        float last = 0.0f;
+        float vnext = gv[T][j];
+        adv[(size_t)T * N + g] = 0.0f;
+        returns[(size_t)T * N + g] = 0.0f + vnext;
+#pragma unroll 8
+        for (int t = T - 1; t >= 0; --t) {
+            const size_t c = (size_t)t * N + g;
+            const float vcur = gv[t][j];
+            const float a = gamma * (1.0f - gd[t + 1][j]);
+            const float b = vnext + lam * last;
+            float v = gr[t + 1][j] + a * b;
+            v = v - vcur;
+            adv[c] = v;
+            returns[c] = v + vcur;
+            last = v;
+            vnext = vcur;
+        }
     }
     if (w == 0 && lg == 0) {   // lanes 0..15 of wave 0: one flush per workgroup
         if (episode_stats) {
@@ -360,10 +385,10 @@ rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __
 
 __global__ void zero_i32x4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
-extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
-                              int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
-                              const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
-                              int32_t* episode_stats, int max_ep, void* stream) {
+static int rollout_impl(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                        int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
+                        const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
+                        int32_t* episode_stats, int max_ep, float* advantages, float* returns, float gamma, float lam, void* stream) {
     MI_CHECK_ARG(handle && params && obs_cur && observations && values && actions && log_probs && rewards && dones, "NULL pointer");
     MI_CHECK_ARG(T > 0, "T must be positive");
     MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
@@ -373,7 +398,8 @@ extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* o
     mi_prof_scope prof(MI_PROF_ROLLOUT, s);
 #ifndef ROLLOUT_VALU
     rollout_mfma_kernel<<<(e->n + RM_ENVS - 1) / RM_ENVS, 256, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones,
-                                                                      forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep);
+                                                                      forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep,
+                                                                      advantages, returns, gamma, lam);
     MI_LAUNCH_CHECK();
     return MI_OK;
 #endif
@@ -391,6 +417,31 @@ extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* o
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+
+extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                              int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
+                              const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
+                              int32_t* episode_stats, int max_ep, void* stream) {
+    return rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, forced_actions, forced_uniforms, forced_resets,
+                        episodes, episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, stream);
+}
+
+// rollout + GAE (ppo.py:110-151): the rollout workgroups scan their own envs at the end of the launch (T <= 128; otherwise, and in the
+// -DROLLOUT_VALU build, mi_gae runs as a launch of its own).  advantages / returns: dev f32 [T+1, N], bit-identical to mi_gae's.
+extern "C" int mi_ppo_rollout_gae(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                                  int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
+                                  int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
+    MI_CHECK_ARG(advantages && returns, "NULL advantages / returns");
+#ifndef ROLLOUT_VALU
+    if (T <= RM_GAE_T)
+        return rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
+                            episode_stats, max_ep, advantages, returns, gamma, gae_lambda, stream);
+#endif
+    const int rc = rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
+                                episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, stream);
+    if (rc) return rc;
+    return mi_gae(rewards, dones, values, T, ((mi_env*)handle)->n, gamma, gae_lambda, advantages, returns, stream);
 }
 
 // ---- ActorCritic forward on an arbitrary batch (agent.get_value / get_action_distribution, ppo.py:49-54) ------

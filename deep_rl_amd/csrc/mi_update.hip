@@ -852,10 +852,8 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
     const int N = e->n, B = hp->T * N;
     MI_CHECK_ARG(B % hp->n_minibatch == 0, "T*N must be divisible by n_minibatch");
     const int mb = B / hp->n_minibatch;
-    int rc = mi_ppo_rollout(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
-                            b->dones, nullptr, nullptr, nullptr, b->episodes, b->episode_stats, b->max_ep, stream);
-    if (rc) return rc;
-    rc = mi_gae(b->rewards, b->dones, b->values, hp->T, N, hp->gamma, hp->gae_lambda, b->advantages, b->returns, stream);
+    int rc = mi_ppo_rollout_gae(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
+                                b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns, stream);
     if (rc) return rc;
     int64_t step = hp->opt_step;
     hipStream_t s = (hipStream_t)stream;

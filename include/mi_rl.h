@@ -105,6 +105,11 @@ int mi_ppo_rollout(void* handle, const float* params, int T, float* obs_cur, flo
                    int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
                    const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
                    int32_t* episode_stats, int max_ep, void* stream);
+/* rollout + GAE in one launch (ppo.py:110-151): each rollout workgroup scans its own envs when its last step is done (T <= 128; beyond
+ * that mi_gae runs as a launch of its own).  Production RNG only.  advantages / returns as for mi_gae, bit-identical. */
+int mi_ppo_rollout_gae(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                       int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
+                       int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, void* stream);
 
 /* ---- GAE reverse scan ppo.py:144-151 (expression order preserved, no FMA contraction) */
 int mi_gae(const float* rewards, const float* dones, const float* values, int T, int N, float gamma, float lam,

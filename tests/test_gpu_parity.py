@@ -524,3 +524,30 @@ def test_learning_smoke(dev):
         if eps:
             means.append(np.mean([e[2] for e in eps]))
     assert np.mean(means[-5:]) > 2.0 * np.mean(means[:3]), (means[:3], means[-5:])
+
+
+def test_rollout_with_fused_gae_is_bit_identical(dev):
+    """mi_ppo_rollout_gae (the rollout workgroups scan their own envs) == mi_ppo_rollout + mi_gae, bit for bit; T > 128 takes the two-launch route."""
+    import deep_rl_amd as D
+    from deep_rl_amd import _native as N
+
+    for n, T in ((37, 128), (1024, 64), (8, 200)):
+        engs = []
+        for fused in (False, True):
+            env = D.make("CartPole-v1", num_envs=n, device=dev, seed=8)
+            torch.manual_seed(8)
+            agent = D.ActorCritic(env)
+            eng = D.PPOEngine(env, agent, D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5), num_steps=T)
+            eng.reset()
+            for _ in range(2):      # the second rollout starts from carried-over state
+                if fused:
+                    N.check(N.lib().mi_ppo_rollout_gae(eng.env.handle, N.ptr(eng.agent.flat), eng.T, N.ptr(eng.observation), N.ptr(eng.observations), N.ptr(eng.values),
+                                                       N.ptr(eng.actions), N.ptr(eng.log_probs), N.ptr(eng.rewards), N.ptr(eng.dones), N.ptr(eng.episodes),
+                                                       N.ptr(eng.episode_stats), eng.max_ep, eng.gamma, eng.gae_lambda, N.ptr(eng.advantages), N.ptr(eng.returns),
+                                                       N.stream_ptr(dev)), "mi_ppo_rollout_gae")
+                else:
+                    eng.rollout(); eng.compute_gae()
+            engs.append(eng)
+        a, b = engs
+        for name in ("observations", "values", "actions", "log_probs", "rewards", "dones", "advantages", "returns", "episode_stats", "observation"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (n, T, name)
