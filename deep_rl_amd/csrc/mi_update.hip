@@ -104,9 +104,14 @@ __global__ void __launch_bounds__(256) adv_stats_kernel(const float* __restrict_
 // mi_ppo_update's fused form: out[i] = Feistel(i) and, in the same pass, the advantage sums of the minibatch i belongs to
 // (mb is a multiple of 256 there, so a workgroup never straddles two minibatches).  sums must be zero on entry.
 #define PS_PER_BLOCK 4096  // elements per workgroup: few workgroups per minibatch touch the fp64 atomics (contention)
-__global__ void __launch_bounds__(256) perm_stats_kernel(uint32_t n, uint32_t a, uint32_t b, uint32_t k0, uint32_t k1, int mb,
-                                                         const float* __restrict__ adv, int32_t* __restrict__ out, double* __restrict__ sums) {
+#define PS_MAX_EPOCHS 8
+struct ps_epochs_t { uint32_t k0[PS_MAX_EPOCHS], k1[PS_MAX_EPOCHS]; int32_t* out[PS_MAX_EPOCHS]; };   // blockIdx.y = epoch: all epochs of an update in one launch
+__global__ void __launch_bounds__(256) perm_stats_kernel(uint32_t n, uint32_t a, uint32_t b, ps_epochs_t ep, int mb, int n_mb,
+                                                         const float* __restrict__ adv, double* __restrict__ sums_all) {
     const uint32_t base = blockIdx.x * PS_PER_BLOCK;
+    const uint32_t k0 = ep.k0[blockIdx.y], k1 = ep.k1[blockIdx.y];
+    int32_t* __restrict__ out = ep.out[blockIdx.y];
+    double* __restrict__ sums = sums_all + (size_t)3 * n_mb * blockIdx.y;
     double s = 0.0, q = 0.0;
 #pragma unroll 4
     for (uint32_t i = base + threadIdx.x; i < base + PS_PER_BLOCK && i < n; i += 256) {
@@ -859,16 +864,41 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
     hipStream_t s = (hipStream_t)stream;
     const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass per epoch, one memset per update
     if (fused) MI_HIP(hipMemsetAsync(b->adv_sums, 0, sizeof(double) * 3 * (size_t)hp->n_minibatch * hp->update_epochs, s));
+    // all epochs' permutations + advantage statistics in ONE launch (they depend on the advantages and the keys only): epochs 0..E-2 land in the
+    // free upper half of the workspace, the last one in b->perm
+    int32_t* perm_of[PS_MAX_EPOCHS] = {nullptr};
+    const bool all_at_once = fused && hp->update_epochs <= PS_MAX_EPOCHS &&
+                             (size_t)(hp->update_epochs - 1) * B * sizeof(int32_t) <= (size_t)(GRAD_MAX_BLOCKS / 2) * PART_STRIDE * sizeof(float);
+    if (all_at_once) {
+        ps_epochs_t pe;
+        for (int ep = 0; ep < hp->update_epochs; ++ep) {
+            const uint64_t key = mi_perm_key(e->seed, (uint64_t)hp->update_index, (uint64_t)ep);
+            pe.k0[ep] = (uint32_t)key; pe.k1[ep] = (uint32_t)(key >> 32);
+            perm_of[ep] = ep == hp->update_epochs - 1 ? b->perm
+                                                       : reinterpret_cast<int32_t*>(reinterpret_cast<float*>(b->workspace) + (size_t)(GRAD_MAX_BLOCKS / 2) * PART_STRIDE) + (size_t)ep * B;
+            pe.out[ep] = perm_of[ep];
+        }
+        uint32_t bits = 1;
+        while ((1u << bits) < (uint32_t)B) ++bits;
+        if (bits < 2) bits = 2;
+        mi_prof_scope prof(MI_PROF_STATS, s);
+        perm_stats_kernel<<<dim3((B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, hp->update_epochs), 256, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, pe, mb, hp->n_minibatch,
+                                                                                                       b->advantages, b->adv_sums);
+        MI_LAUNCH_CHECK();
+    }
     for (int ep = 0; ep < hp->update_epochs; ++ep) {
         const uint64_t key = mi_perm_key(e->seed, (uint64_t)hp->update_index, (uint64_t)ep);
         double* sums = b->adv_sums + (size_t)3 * hp->n_minibatch * ep;
-        if (fused) {
+        const int32_t* perm = all_at_once ? perm_of[ep] : b->perm;
+        if (all_at_once) {
+        } else if (fused) {
+            ps_epochs_t pe;
+            pe.k0[0] = (uint32_t)key; pe.k1[0] = (uint32_t)(key >> 32); pe.out[0] = b->perm;
             uint32_t bits = 1;
             while ((1u << bits) < (uint32_t)B) ++bits;
             if (bits < 2) bits = 2;
             mi_prof_scope prof(MI_PROF_STATS, s);
-            perm_stats_kernel<<<(B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, 256, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, (uint32_t)key, (uint32_t)(key >> 32), mb,
-                                                              b->advantages, b->perm, sums);
+            perm_stats_kernel<<<dim3((B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, 1), 256, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, pe, mb, hp->n_minibatch, b->advantages, sums);
             MI_LAUNCH_CHECK();
         } else {
             rc = mi_make_perm((uint32_t)B, key, b->perm, stream);
@@ -878,7 +908,7 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
         }
         for (int k = 0; k < hp->n_minibatch; ++k) {
             rc = mi_ppo_minibatch_grad(b->params, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
-                                       b->perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef,
+                                       perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef,
                                        1.0 / mb, b->workspace, b->grads, b->loss_terms, stream);
             if (rc) return rc;
             step += 1;
