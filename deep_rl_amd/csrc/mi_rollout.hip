@@ -210,8 +210,9 @@ rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __
                     float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
                     const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
                     mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep,
-                    float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam) {
+                    float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n) {
     __shared__ float hp[2][4][RM_ENVS][2];
+    if (zero_f64 && blockIdx.x == 0) for (int k = threadIdx.x; k < zero_n; k += 256) zero_f64[k] = 0.0;   // scratch the next launches accumulate into
     // fused GAE (adv != NULL, T <= RM_GAE_T): the workgroup keeps values / rewards / dones of its 16 envs for the whole rollout and runs the
     // reverse scan of ppo.py:144-151 itself at the end — same expression order as gae_kernel, bit for bit, without a launch of its own
     __shared__ float gv[RM_GAE_T + 1][RM_ENVS], gr[RM_GAE_T + 1][RM_ENVS], gd[RM_GAE_T + 1][RM_ENVS];
@@ -388,7 +389,8 @@ __global__ void zero_i32x4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx
 static int rollout_impl(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
                         int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
                         const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
-                        int32_t* episode_stats, int max_ep, float* advantages, float* returns, float gamma, float lam, void* stream) {
+                        int32_t* episode_stats, int max_ep, float* advantages, float* returns, float gamma, float lam, double* zero_f64, int zero_n,
+                        void* stream) {
     MI_CHECK_ARG(handle && params && obs_cur && observations && values && actions && log_probs && rewards && dones, "NULL pointer");
     MI_CHECK_ARG(T > 0, "T must be positive");
     MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
@@ -399,10 +401,11 @@ static int rollout_impl(void* handle, const float* params, int T, float* obs_cur
 #ifndef ROLLOUT_VALU
     rollout_mfma_kernel<<<(e->n + RM_ENVS - 1) / RM_ENVS, 256, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones,
                                                                       forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep,
-                                                                      advantages, returns, gamma, lam);
+                                                                      advantages, returns, gamma, lam, zero_f64, zero_n);
     MI_LAUNCH_CHECK();
     return MI_OK;
 #endif
+    if (zero_f64) MI_HIP(hipMemsetAsync(zero_f64, 0, sizeof(double) * (size_t)zero_n, s));
     // the VALU formulation (-DROLLOUT_VALU, kept for A/B): E=2 halves the wave count (2 waves/SIMD at N=4096); E=1 for tiny N keeps every env on its own wave.
     if (e->n >= 512) {
         const int waves = (e->n + 1) / 2, blocks = (waves + ROLLOUT_WAVES - 1) / ROLLOUT_WAVES;
@@ -424,24 +427,35 @@ extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* o
                               const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
                               int32_t* episode_stats, int max_ep, void* stream) {
     return rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, forced_actions, forced_uniforms, forced_resets,
-                        episodes, episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, stream);
+                        episodes, episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, stream);
 }
 
 // rollout + GAE (ppo.py:110-151): the rollout workgroups scan their own envs at the end of the launch (T <= 128; otherwise, and in the
 // -DROLLOUT_VALU build, mi_gae runs as a launch of its own).  advantages / returns: dev f32 [T+1, N], bit-identical to mi_gae's.
-extern "C" int mi_ppo_rollout_gae(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
-                                  int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
-                                  int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
+// rollout + GAE (ppo.py:110-151): the rollout workgroups scan their own envs at the end of the launch (T <= 128; otherwise, and in the
+// -DROLLOUT_VALU build, mi_gae runs as a launch of its own).  advantages / returns: dev f32 [T+1, N], bit-identical to mi_gae's.
+// internal (mi_ppo_update): additionally zero-fills an fp64 scratch the following launches accumulate into (saves the memset launch)
+int mi_rollout_gae_internal(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                            int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
+                            int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, double* zero_f64, int zero_n,
+                            void* stream) {
     MI_CHECK_ARG(advantages && returns, "NULL advantages / returns");
 #ifndef ROLLOUT_VALU
     if (T <= RM_GAE_T)
         return rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
-                            episode_stats, max_ep, advantages, returns, gamma, gae_lambda, stream);
+                            episode_stats, max_ep, advantages, returns, gamma, gae_lambda, zero_f64, zero_n, stream);
 #endif
     const int rc = rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
-                                episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, stream);
+                                episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, zero_f64, zero_n, stream);
     if (rc) return rc;
     return mi_gae(rewards, dones, values, T, ((mi_env*)handle)->n, gamma, gae_lambda, advantages, returns, stream);
+}
+
+extern "C" int mi_ppo_rollout_gae(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
+                                  int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
+                                  int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
+    return mi_rollout_gae_internal(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, episodes, episode_stats, max_ep, gamma,
+                                   gae_lambda, advantages, returns, nullptr, 0, stream);
 }
 
 // ---- ActorCritic forward on an arbitrary batch (agent.get_value / get_action_distribution, ppo.py:49-54) ------

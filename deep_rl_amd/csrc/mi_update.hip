@@ -857,13 +857,13 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
     const int N = e->n, B = hp->T * N;
     MI_CHECK_ARG(B % hp->n_minibatch == 0, "T*N must be divisible by n_minibatch");
     const int mb = B / hp->n_minibatch;
-    int rc = mi_ppo_rollout_gae(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
-                                b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns, stream);
+    const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass; their fp64 accumulators are zeroed by the rollout launch
+    int rc = mi_rollout_gae_internal(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
+                                     b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns,
+                                     fused ? b->adv_sums : nullptr, 3 * hp->n_minibatch * hp->update_epochs, stream);
     if (rc) return rc;
     int64_t step = hp->opt_step;
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass per epoch, one memset per update
-    if (fused) MI_HIP(hipMemsetAsync(b->adv_sums, 0, sizeof(double) * 3 * (size_t)hp->n_minibatch * hp->update_epochs, s));
     // all epochs' permutations + advantage statistics in ONE launch (they depend on the advantages and the keys only): epochs 0..E-2 land in the
     // free upper half of the workspace, the last one in b->perm
     int32_t* perm_of[PS_MAX_EPOCHS] = {nullptr};
