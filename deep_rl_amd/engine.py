@@ -103,6 +103,15 @@ class PPOEngine:
         (read it after the next sync point; CartPole return == length)."""
         pinned.copy_(self.episode_stats, non_blocking=True)
 
+    def rollout_gae(self):
+        """rollout() + compute_gae() in one launch (production RNG): the rollout workgroups scan their own envs (mi_ppo_rollout_gae)."""
+        if self.observation is None:
+            self.reset()
+        N.check(N.lib().mi_ppo_rollout_gae(self.env.handle, N.ptr(self.agent.flat), self.T, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.values),
+                                           N.ptr(self.actions), N.ptr(self.log_probs), N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.episodes),
+                                           N.ptr(self.episode_stats), self.max_ep, self.gamma, self.gae_lambda, N.ptr(self.advantages), N.ptr(self.returns),
+                                           self._s()), "mi_ppo_rollout_gae")
+
     def compute_gae(self):
         """ppo.py:144-151."""
         N.check(N.lib().mi_gae(N.ptr(self.rewards), N.ptr(self.dones), N.ptr(self.values), self.T, self.N, self.gamma,
@@ -168,8 +177,7 @@ class PPOEngine:
             N.check(N.lib().mi_ppo_update(self.env.handle, C.byref(buf), C.byref(hp), self._s()), "mi_ppo_update")
             o.step_count += self.update_epochs * self.n_minibatch
         else:
-            self.rollout()
-            self.compute_gae()
+            self.rollout_gae()
             # every epoch's permutation and LOCAL advantage statistics first, then ONE all-reduce for the whole update (the statistics
             # depend only on the advantages and the permutation keys, not on the parameters): 17 collectives per update instead of 20
             L = N.lib()
