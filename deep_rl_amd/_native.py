@@ -68,6 +68,7 @@ SIGNATURES = {
     "mi_dqn_sample": (_I, [_U64, _U64, _I64, _I, _VP, _VP]),
     "mi_dqn_workspace_bytes": (_SZ, [_I]),
     "mi_dqn_td_grad": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _D, _VP, _VP, _VP, _VP]),
+    "mi_ppo_perms_and_stats": (_I, [_U64, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "mi_ppo_rollout_gae": (_I, [_VP, _VP, _I] + [_VP] * 9 + [_I, _F, _F, _VP, _VP, _VP]),
     "mi_env_state_bytes": (_SZ, [_VP]),
     "mi_env_export_state": (_I, [_VP, _VP, _VP]),

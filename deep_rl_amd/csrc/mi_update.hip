@@ -850,6 +850,40 @@ extern "C" int mi_explained_var(const float* values, const float* returns, size_
 // =====================================================================================================
 // One whole outer update, enqueued back to back (single rank, production RNG)
 // =====================================================================================================
+// every epoch's permutation (ppo.py:155, keyed) and per-minibatch advantage sums (ppo.py:169) of one update: one launch (+ one memset) when the
+// minibatch size is a multiple of 4096, otherwise per epoch.  perm_all: dev i32 [epochs, n_rows]; sums_all: dev f64 [epochs, n_minibatch, 3]
+// (LOCAL sums: sharded runs all-reduce them once).
+extern "C" int mi_ppo_perms_and_stats(uint64_t seed, int update_index, int epochs, int n_rows, int n_minibatch, const float* advantages, int32_t* perm_all,
+                                      double* sums_all, void* stream) {
+    MI_CHECK_ARG(advantages && perm_all && sums_all, "NULL pointer");
+    MI_CHECK_ARG(epochs > 0 && n_rows > 0 && n_minibatch > 0 && n_rows % n_minibatch == 0, "bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int mb = n_rows / n_minibatch;
+    if (mb % PS_PER_BLOCK == 0 && epochs <= PS_MAX_EPOCHS) {
+        MI_HIP(hipMemsetAsync(sums_all, 0, sizeof(double) * 3 * (size_t)n_minibatch * epochs, s));
+        ps_epochs_t pe;
+        for (int ep = 0; ep < epochs; ++ep) {
+            const uint64_t key = mi_perm_key(seed, (uint64_t)update_index, (uint64_t)ep);
+            pe.k0[ep] = (uint32_t)key; pe.k1[ep] = (uint32_t)(key >> 32); pe.out[ep] = perm_all + (size_t)ep * n_rows;
+        }
+        uint32_t bits = 1;
+        while ((1u << bits) < (uint32_t)n_rows) ++bits;
+        if (bits < 2) bits = 2;
+        mi_prof_scope prof(MI_PROF_STATS, s);
+        perm_stats_kernel<<<dim3((n_rows + PS_PER_BLOCK - 1) / PS_PER_BLOCK, epochs), 256, 0, s>>>((uint32_t)n_rows, bits / 2, bits - bits / 2, pe, mb, n_minibatch, advantages,
+                                                                                                 sums_all);
+        MI_LAUNCH_CHECK();
+        return MI_OK;
+    }
+    for (int ep = 0; ep < epochs; ++ep) {
+        int rc = mi_make_perm((uint32_t)n_rows, mi_perm_key(seed, (uint64_t)update_index, (uint64_t)ep), perm_all + (size_t)ep * n_rows, stream);
+        if (rc) return rc;
+        rc = mi_adv_stats(advantages, perm_all + (size_t)ep * n_rows, mb, n_minibatch, sums_all + (size_t)3 * n_minibatch * ep, stream);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* stream) {
     MI_CHECK_ARG(handle && b && hp, "NULL pointer");
     MI_CHECK_ARG(hp->T > 0 && hp->n_minibatch > 0 && hp->update_epochs > 0, "bad hyper-parameters");

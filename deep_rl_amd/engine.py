@@ -180,12 +180,8 @@ class PPOEngine:
             self.rollout_gae()
             # every epoch's permutation and LOCAL advantage statistics first, then ONE all-reduce for the whole update (the statistics
             # depend only on the advantages and the permutation keys, not on the parameters): 17 collectives per update instead of 20
-            L = N.lib()
-            for epoch in range(self.update_epochs):
-                key = L.mi_perm_key(self.env._seed, self.update_index, epoch)
-                N.check(L.mi_make_perm(self.batch_size, key, N.ptr(self._perm_all[epoch]), self._s()), "mi_make_perm")
-                N.check(L.mi_adv_stats(N.ptr(self.advantages), N.ptr(self._perm_all[epoch]), self.minibatch_size, self.n_minibatch,
-                                       N.ptr(self._adv_sums_all[epoch]), self._s()), "mi_adv_stats")
+            N.check(N.lib().mi_ppo_perms_and_stats(self.env._seed, self.update_index, self.update_epochs, self.batch_size, self.n_minibatch, N.ptr(self.advantages),
+                                                   N.ptr(self._perm_all), N.ptr(self._adv_sums_all), self._s()), "mi_ppo_perms_and_stats")
             D.allreduce_sum_(self._adv_sums_all, self.pg)
             for epoch in range(self.update_epochs):
                 self.perm, self.adv_sums = self._perm_all[epoch], self._adv_sums_all[epoch]

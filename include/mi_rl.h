@@ -144,6 +144,12 @@ int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_a
 /* ---- explained variance ppo.py:194-195 over n = (T+1)*N entries: out dev f64 [1] */
 int mi_explained_var(const float* values, const float* returns, size_t n, double* out, void* stream);
 
+/* ---- every epoch's keyed permutation (ppo.py:155) and per-minibatch advantage sums (ppo.py:169) of one update at once (they depend on the
+ * advantages and the keys only): perm_all dev i32 [epochs, n_rows], sums_all dev f64 [epochs, n_minibatch, 3] (local sums; sharded runs
+ * all-reduce them once per update). */
+int mi_ppo_perms_and_stats(uint64_t seed, int update_index, int epochs, int n_rows, int n_minibatch, const float* advantages, int32_t* perm_all,
+                           double* sums_all, void* stream);
+
 /* ---- one whole outer update (ppo.py:105-192) enqueued back to back on `stream`, production RNG,
  * single rank (no collective).  All pointers dev.  perm: i32 [T*N]; adv_sums: f64 [update_epochs*n_minibatch*3]. */
 typedef struct {
