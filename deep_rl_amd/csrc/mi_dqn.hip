@@ -298,7 +298,8 @@ __global__ void __launch_bounds__(256)
 dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target_params, const float* __restrict__ observations,
               const int64_t* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
               const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, float gamma, float invn, float* __restrict__ workspace,
-              const float* __restrict__ row_w, float* __restrict__ td_abs) {
+              const float* __restrict__ row_w, float* __restrict__ td_abs, uint64_t sample_seed, uint64_t sample_update, uint64_t sample_upper,
+              int64_t* __restrict__ idx_out) {
     __shared__ td_smem sm;
     const int t = threadIdx.x;
     const int row0 = blockIdx.x * TD_R;
@@ -307,7 +308,13 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
     __shared__ long long cur[TD_R];
     if (t < TD_R) {
         const int b = row0 + t < batch ? row0 + t : batch - 1;
-        const long long i = idx[b];
+        long long i;
+        if (sample_upper) {     // batch_inds = randint(upper, size=batch) (dqn.py:116) drawn here: the contract of dqn_sample_kernel, no launch of its own
+            uint32_t r[4];
+            mi_philox(sample_seed, sample_update, (uint64_t)b, STREAM_SAMPLE, r);
+            i = (long long)((((uint64_t)r[1] << 32) | r[0]) % sample_upper);
+            if (row0 + t < batch) idx_out[b] = i;
+        } else i = idx[b];
         cur[t] = i;
         nxt[t] = ((i / n_envs + 1) % slots) * n_envs + i % n_envs;
         sm.act[t] = (int)actions[i];
@@ -479,13 +486,15 @@ static dqn_opt_t dqn_no_opt() { dqn_opt_t o; memset(&o, 0, sizeof(o)); return o;
 static int dqn_td_impl(const float* params, const float* target_params, const float* observations, const int64_t* actions,
                        const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
                        float gamma, double inv_count, void* workspace, float* grads, float* loss, const float* weights, float* td_abs, const dqn_opt_t& opt,
-                       void* stream) {
+                       uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* stream) {
     MI_CHECK_ARG(params && target_params && observations && actions && rewards && terminated && idx && workspace && grads, "NULL pointer");
+    MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (batch + TD_R - 1) / TD_R;
     dqn_td_kernel<<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
-                                         (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs);
+                                         (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update, (uint64_t)sample_upper,
+                                         (int64_t*)idx);
     MI_LAUNCH_CHECK();
     dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
     MI_LAUNCH_CHECK();
@@ -496,21 +505,23 @@ extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, c
                               const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
                               float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream) {
     return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace, grads, loss,
-                       nullptr, nullptr, dqn_no_opt(), stream);
+                       nullptr, nullptr, dqn_no_opt(), 0, 0, 0, stream);
 }
 
 // single-process fusion: TD gradient (optionally importance-weighted, weights / td_abs nullable together) + optimizer.step() in two launches
 extern "C" int mi_dqn_td_update(float* params, const float* target_params, const float* observations, const int64_t* actions,
-                                const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                                const float* rewards, const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots,
                                 float gamma, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, float* exp_avg, float* exp_avg_sq,
-                                int64_t step, double lr, double beta1, double beta2, double eps, void* stream) {
+                                int64_t step, double lr, double beta1, double beta2, double eps, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper,
+                                void* stream) {
     MI_CHECK_ARG(exp_avg && exp_avg_sq && step >= 1 && (!weights == !td_abs), "bad optimizer state / weights and td_abs go together");
+    MI_CHECK_ARG(!(sample_upper > 0 && weights), "in-kernel uniform sampling and importance weights exclude each other");
     dqn_opt_t o;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     o.params = params; o.m = exp_avg; o.v = exp_avg_sq; o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2);
     o.step_size = (float)(lr / bc1); o.bc2_sqrt = (float)sqrt(bc2); o.eps = (float)eps;
     return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / batch, workspace, grads, loss,
-                       weights, td_abs, o, stream);
+                       weights, td_abs, o, sample_seed, sample_update, sample_upper, stream);
 }
 
 // ---- Dueling head (reference deep_rl/dueling_dqn.py:24-40) as an epilogue on the DQN kernels -----------------
@@ -779,7 +790,7 @@ extern "C" int mi_per_td_grad(const float* params, const float* target_params, c
                               float gamma, double inv_count, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, void* stream) {
     MI_CHECK_ARG(weights && td_abs, "NULL weights / td_abs");
     return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace, grads, loss,
-                       weights, td_abs, dqn_no_opt(), stream);
+                       weights, td_abs, dqn_no_opt(), 0, 0, 0, stream);
 }
 
 extern "C" int mi_per_update_priorities(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, void* stream) {

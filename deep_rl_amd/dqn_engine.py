@@ -95,17 +95,21 @@ class DQNEngine:
     def train_step(self, indices=None):
         """One optimisation step (dqn.py:114-133).  Single process without gradient clipping: the launch that sums the gradient slabs also
         applies Adam (mi_dqn_td_update, bit-identical to td_grad() + optimizer.step())."""
-        self.sample(indices)
         g = self.optimizer.param_groups[0]
-        if self.world_size == 1 and g["max_grad_norm"] == float("inf") and type(self).td_grad in (DQNEngine.td_grad, PERDQNEngine.td_grad):
+        fusable = self.world_size == 1 and g["max_grad_norm"] == float("inf") and type(self).td_grad in (DQNEngine.td_grad, PERDQNEngine.td_grad)
+        in_kernel_sampling = fusable and indices is None and type(self).sample is DQNEngine.sample     # uniform randint drawn by the TD launch itself
+        if not in_kernel_sampling:
+            self.sample(indices)
+        if fusable:
             o = self.optimizer
             o.step_count += 1
             w, td = self._row_weights()
+            upper = min(self.global_step, self.slots) * self.N if in_kernel_sampling else 0
             N.check(N.lib().mi_dqn_td_update(
                 N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
                 N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self.grads),
-                N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self._s()),
-                "mi_dqn_td_update")
+                N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                self.env._seed, self.update_index, upper, self._s()), "mi_dqn_td_update")
             self._after_td()
         else:
             self.td_grad()

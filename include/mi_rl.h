@@ -198,11 +198,13 @@ int mi_dqn_td_grad(const float* params, const float* target_params, const float*
                    float gamma, double inv_count, void* workspace, float* grads, float* loss, void* stream);
 /* single-process fusion: the same two launches, the second of which also applies optimizer.step() (torch Adam, no clipping) to every
  * gradient element it has just summed — bit-identical to mi_dqn_td_grad (or mi_per_td_grad when weights / td_abs are given) followed by
- * mi_clip_adam with max_norm = +inf.  inv_count = 1 / batch. */
+ * mi_clip_adam with max_norm = +inf.  inv_count = 1 / batch.  sample_upper > 0: the TD launch draws idx itself (the mi_dqn_sample contract
+ * with (sample_seed, sample_update), bit-identical) and stores it in idx — no sampling launch either; 0: idx is an input. */
 int mi_dqn_td_update(float* params, const float* target_params, const float* observations, const int64_t* actions,
-                     const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
+                     const float* rewards, const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots,
                      float gamma, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, float* exp_avg, float* exp_avg_sq,
-                     int64_t step, double lr, double beta1, double beta2, double eps, void* stream);
+                     int64_t step, double lr, double beta1, double beta2, double eps, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper,
+                     void* stream);
 /* optimizer.step() (dqn.py:131-133) = mi_clip_adam(..., n = MI_DQN_NPARAMS, eps = 1e-8, max_norm = +inf);
  * target_network.load_state_dict (dqn.py:136-137) = a device-to-device copy of the flat vector by the caller. */
 
