@@ -587,7 +587,8 @@ __global__ void __launch_bounds__(256)
 sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, const float* __restrict__ actor, const float* __restrict__ observations,
                   const float* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
                   const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, const float* __restrict__ eps, uint64_t seed, uint64_t update,
-                  const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_) {
+                  const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_, uint64_t sample_update, uint64_t sample_upper,
+                  int64_t* __restrict__ idx_out) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
     // gridDim.y == 2: the two critics' forward + backward run in two workgroups per row group (each repeats the actor / target forwards):
@@ -601,7 +602,13 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     stream_prime<false>(actor + AC_W2, ws);
     if (t < SR) {
         const int b = row0 + t < batch ? row0 + t : batch - 1;
-        const long long i = idx[b];
+        long long i;
+        if (sample_upper) {   // batch_inds = randint(global_step, size=batch) (sac.py:162) drawn here (the mi_dqn_sample contract, stream 4): no launch of its own
+            uint32_t r[4];
+            mi_philox(seed, sample_update, (uint64_t)b, 4u, r);
+            i = (long long)((((uint64_t)r[1] << 32) | r[0]) % sample_upper);
+            if (row0 + t < batch) idx_out[b] = i;     // (both workgroups of a split row group write the same value)
+        } else i = idx[b];
         sm.cur[t] = i; sm.nxt[t] = ((i / n_envs + 1) % slots) * n_envs + i % n_envs;
     }
     float e_row = 0.0f;
@@ -972,10 +979,11 @@ static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv
 static int sac_critic_impl(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
                            const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
                            uint64_t update_index, const float* alpha, float gamma, double inv_count, void* workspace, float* grads, float* losses,
-                           const sac_opt_t& opt, hipStream_t s) {
+                           const sac_opt_t& opt, uint64_t sample_update, int64_t sample_upper, hipStream_t s) {
     const int nrg = ws_kp(batch) / SR;
     sac_critic_kernel<<<dim3(nrg, nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
-                                                       seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace);
+                                                       seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
+                                                       (int64_t*)idx);
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, opt, s);
 }
@@ -987,18 +995,20 @@ extern "C" int mi_sac_critic_grad(const float* q, const float* q_target, const f
     MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "bad sizes");
     return sac_critic_impl((float*)q, (float*)q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha,
-                           gamma, inv_count, workspace, grads, losses, sac_no_opt(), (hipStream_t)stream);
+                           gamma, inv_count, workspace, grads, losses, sac_no_opt(), 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int mi_sac_critic_update(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
-                                    const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                                    const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
                                     uint64_t update_index, const float* alpha, float gamma, void* workspace, float* grads, float* losses, float* exp_avg,
-                                    float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, void* stream) {
+                                    float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, uint64_t sample_update,
+                                    int64_t sample_upper, void* stream) {
+    MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
     MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads && exp_avg && exp_avg_sq, "NULL pointer");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2 && step >= 1, "bad sizes");
     return sac_critic_impl(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
                            1.0 / batch, workspace, grads, losses, sac_make_opt(q, exp_avg, exp_avg_sq, tau >= 0.0f ? q_target : nullptr, step, lr, beta1, beta2, adam_eps, tau),
-                           (hipStream_t)stream);
+                           sample_update, sample_upper, (hipStream_t)stream);
 }
 
 static int sac_actor_impl(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,

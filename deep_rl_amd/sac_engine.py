@@ -113,7 +113,7 @@ class SACEngine:
             N.ptr(self.q_grads), N.ptr(self.q_losses), self._s()), "mi_sac_critic_grad")
         D.allreduce_sum_(self._qbuf, self.pg)
 
-    def update_critic(self, eps=None, polyak=False):
+    def update_critic(self, eps=None, polyak=False, sample_in_launch=False):
         """sac.py:170-185 (+ the target update of :213-217 when `polyak`).  Single process: ONE fused call — the launch that assembles the
         gradient also applies Adam and the polyak step; sharded: gradient, all-reduce, Adam (, polyak)."""
         if self.world_size == 1:
@@ -126,7 +126,8 @@ class SACEngine:
                 N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
                 self._key(self.update_index), N.ptr(self.alpha), self.gamma, N.ptr(self.workspace), N.ptr(self.q_grads), N.ptr(self.q_losses),
                 N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
-                self.tau if polyak else -1.0, self._s()), "mi_sac_critic_update")
+                self.tau if polyak else -1.0, self._key(self.update_index), min(self.global_step, self.slots) * self.N if sample_in_launch else 0, self._s()),
+                "mi_sac_critic_update")
         else:
             self.critic_grad(eps)
             self.q_optimizer.step(self.q_grads)
@@ -187,8 +188,10 @@ class SACEngine:
     def train_step(self, policy_frequency=2, target_network_frequency=1, indices=None):
         """The optimisation half of one loop iteration (sac.py:161-217) at the current global_step.  The target update uses the critic
         parameters, which the actor / alpha updates do not touch, so it rides on the critic update's last launch."""
-        self.sample(indices)
-        self.update_critic(polyak=self.global_step % target_network_frequency == 0)
+        in_launch = indices is None and self.world_size == 1      # the critic launch draws the batch indices itself (same contract as sample())
+        if not in_launch:
+            self.sample(indices)
+        self.update_critic(polyak=self.global_step % target_network_frequency == 0, sample_in_launch=in_launch)
         if self.global_step % policy_frequency == 0:
             for _ in range(policy_frequency):
                 self.update_actor()

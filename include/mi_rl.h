@@ -277,11 +277,14 @@ int mi_sac_actor_grad(const float* actor, const float* q, const float* observati
                       void* stream);
 /* single-process fusions (no gradient exchange in between): the same launches as the *_grad calls, whose last kernel also applies
  * optimizer.step() (torch Adam, sac.py:185 / :197) to every gradient element it has just assembled and, for the critics, the polyak step of the
- * target copy (sac.py:213-217; tau < 0 skips it).  inv_count = 1 / batch.  grads / losses / out are still written. */
+ * target copy (sac.py:213-217; tau < 0 skips it).  inv_count = 1 / batch.  grads / losses / out are still written.  sample_upper > 0: the
+ * critic launch draws idx itself (the mi_dqn_sample contract with (seed, sample_update), bit-identical) and stores it in idx for the actor /
+ * alpha calls that follow; 0: idx is an input. */
 int mi_sac_critic_update(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
-                         const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                         const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
                          uint64_t update_index, const float* alpha, float gamma, void* workspace, float* grads, float* losses, float* exp_avg,
-                         float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, void* stream);
+                         float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, uint64_t sample_update,
+                         int64_t sample_upper, void* stream);
 int mi_sac_actor_update(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                         uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
                         int64_t step, double lr, double beta1, double beta2, double adam_eps, void* stream);

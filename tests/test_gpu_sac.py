@@ -384,6 +384,31 @@ def test_fused_updates_equal_grad_then_adam(dev, R):
     assert not torch.equal(f.qt_flat, torch.from_numpy(qt_p).to(dev))      # the polyak step happened
 
 
+def test_in_launch_sampling_equals_sample_call(dev, R):
+    """train_step() lets the critic launch draw the batch indices (keyed contract); == sample() + the same updates, bit for bit."""
+    engs = []
+    for in_launch in (True, False):
+        eng = _engine(dev, 64, 128, seed=2, batch_size=256, learning_starts=10, max_episodes_logged=0)
+        eng.reset()
+        for _ in range(60):
+            eng.act()
+        for it in range(3):
+            eng.global_step += 0
+            if in_launch:
+                eng.train_step()
+            else:
+                eng.sample(); eng.update_critic(polyak=True)
+                if eng.global_step % 2 == 0:
+                    for _ in range(2):
+                        eng.update_actor(); eng.update_alpha()
+            eng.act()
+        engs.append(eng)
+    a, b = engs
+    for name in ("batch_inds", "q_flat", "qt_flat", "q_losses", "log_alpha"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.actor.flat, b.actor.flat)
+
+
 # ---------------------------------------------------------------- against the reference --------------------------------------------
 def test_chained_first_30_steps_on_device(dev, R, sac_trace):
     """The reference run's global steps 5000..5029 on the DEVICE (30 critic, 30 actor, 30 alpha updates, 30 polyak steps chained through the
