@@ -68,22 +68,50 @@ def state_dict(engine, include_replay=True):
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in st.items()}
 
 
+def _npz_path(path):
+    """np.savez appends '.npz' to a suffix-less name; load() must open the same file."""
+    path = str(path)
+    return path if path.endswith(".npz") else path + ".npz"
+
+
 def save(path, engine, include_replay=True):
+    """Write `engine` to ``path`` ('.npz' is appended when missing, as np.savez does).  -> the path written."""
+    if engine.observation is None:
+        raise N.MiError("checkpoint: the engine was never reset (no carried-over observation to save)")
     torch.cuda.current_stream(engine.device).synchronize()
-    np.savez(path, **state_dict(engine, include_replay))
+    path = _npz_path(path)
+    with open(path, "wb") as f:
+        np.savez(f, **state_dict(engine, include_replay))
+    return path
+
+
+def _check_shape(z, name, want):
+    if tuple(z[name].shape) != tuple(want):
+        raise N.MiError("checkpoint: %s has shape %s, this engine needs %s" % (name, tuple(z[name].shape), tuple(want)))
 
 
 def load(path, engine):
     """Restore `engine` (built with the same sizes, seed and env_id_base) from a checkpoint written by save()."""
-    with np.load(path, allow_pickle=False) as zf:
+    with np.load(_npz_path(path), allow_pickle=False) as zf:
         z = {k: zf[k] for k in zf.files}
     env = engine.env
+    if "format" not in z or int(z["format"]) != FORMAT:
+        raise N.MiError("checkpoint: format %s, this build reads format %d" % (z.get("format"), FORMAT))
     if str(z["kind"]) != type(engine).__name__ or int(z["num_envs"]) != env.num_envs or int(z["seed"]) != env._seed or int(z["env_id_base"]) != env.env_id_base:
         raise N.MiError("checkpoint: written for %s with (num_envs, seed, env_id_base) = (%d, %d, %d); this engine is %s (%d, %d, %d)" % (
             z["kind"], z["num_envs"], z["seed"], z["env_id_base"], type(engine).__name__, env.num_envs, env._seed, env.env_id_base))
     dev = engine.device
     t = lambda name: torch.from_numpy(z[name]).to(dev)   # noqa: E731
     _env_restore(env, z["env_blob"])
+    if isinstance(engine, PPOEngine):
+        _check_shape(z, "params", engine.agent.flat.shape)
+    elif isinstance(engine, DQNEngine):
+        _check_shape(z, "params", engine.q.flat.shape); _check_shape(z, "target", engine.target.flat.shape)
+    else:
+        _check_shape(z, "actor", engine.actor.flat.shape); _check_shape(z, "q", engine.q_flat.shape); _check_shape(z, "q_target", engine.qt_flat.shape)
+    for name in ("observations", "actions", "rewards", "terminated", "priorities"):
+        if name in z and hasattr(engine, name):
+            _check_shape(z, name, getattr(engine, name).shape)
     engine.observation = t("observation")
     if isinstance(engine, PPOEngine):
         engine.agent.flat.copy_(t("params")); engine.update_index = int(z["update_index"]); _opt_restore(engine.optimizer, z, "opt_")

@@ -297,9 +297,9 @@ struct __attribute__((aligned(16))) td_smem {
 __global__ void __launch_bounds__(256)
 dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target_params, const float* __restrict__ observations,
               const int64_t* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
-              const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, float gamma, float invn, float* __restrict__ workspace,
-              const float* __restrict__ row_w, float* __restrict__ td_abs, uint64_t sample_seed, uint64_t sample_update, uint64_t sample_upper,
-              int64_t* __restrict__ idx_out) {
+              const int64_t* idx /* may alias idx_out: no __restrict__ */, int batch, int n_envs, long long slots, float gamma, float invn,
+              float* __restrict__ workspace, const float* __restrict__ row_w, float* __restrict__ td_abs, uint64_t sample_seed, uint64_t sample_update,
+              uint64_t sample_upper, int64_t* idx_out) {
     __shared__ td_smem sm;
     const int t = threadIdx.x;
     const int row0 = blockIdx.x * TD_R;

@@ -586,9 +586,9 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
 __global__ void __launch_bounds__(256)
 sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, const float* __restrict__ actor, const float* __restrict__ observations,
                   const float* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
-                  const int64_t* __restrict__ idx, int batch, int n_envs, long long slots, const float* __restrict__ eps, uint64_t seed, uint64_t update,
-                  const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_, uint64_t sample_update, uint64_t sample_upper,
-                  int64_t* __restrict__ idx_out) {
+                  const int64_t* idx /* may alias idx_out: no __restrict__ */, int batch, int n_envs, long long slots, const float* __restrict__ eps, uint64_t seed,
+                  uint64_t update, const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_, uint64_t sample_update, uint64_t sample_upper,
+                  int64_t* idx_out) {
     __shared__ sac_smem sm;
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
     // gridDim.y == 2: the two critics' forward + backward run in two workgroups per row group (each repeats the actor / target forwards):

@@ -34,6 +34,9 @@ batch_size = int(os.environ.get("BATCH_SIZE", "128"))
 gamma = 0.99
 learning_rate = 2.5e-4
 target_network_frequency = 500  # :53
+# the loop below looks at the train / target-sync conditions (:114, :136) at chunk boundaries only: every multiple of train_frequency and
+# nothing else, which covers every multiple of target_network_frequency only if it is itself a multiple of train_frequency
+assert target_network_frequency % train_frequency == 0, "target_network_frequency must be a multiple of train_frequency"
 
 # Env setup (:56-57)
 env = make(env_id, num_envs=num_envs, device=device, env_id_base=rank * num_envs)
@@ -43,6 +46,7 @@ seed = 1
 env.seed(seed)
 np.random.seed(seed)
 torch.manual_seed(seed)
+env.action_space.seed(seed)  # :64
 
 # Network setup (:67-70)
 q_network = QNetwork(env)

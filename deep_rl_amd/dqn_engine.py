@@ -105,6 +105,8 @@ class DQNEngine:
             o.step_count += 1
             w, td = self._row_weights()
             upper = min(self.global_step, self.slots) * self.N if in_kernel_sampling else 0
+            if in_kernel_sampling and upper == 0:   # upper == 0 means "read batch_inds" to the launch: an empty ring must not train on stale indices
+                raise N.MiError("train_step: the replay ring is empty (global_step == 0); act() before training")
             N.check(N.lib().mi_dqn_td_update(
                 N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
                 N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self.grads),

@@ -35,6 +35,7 @@ batch_size = int(os.environ.get("BATCH_SIZE", "128"))
 gamma = 0.99
 learning_rate = 2.5e-4
 target_network_frequency = 500  # :53
+assert target_network_frequency % train_frequency == 0, "target_network_frequency must be a multiple of train_frequency"  # conditions are looked at every train_frequency steps
 
 # Env setup (:56-57)
 env = make(env_id, num_envs=num_envs, device=device, env_id_base=rank * num_envs)
@@ -44,6 +45,7 @@ seed = 1
 env.seed(seed)
 np.random.seed(seed)
 torch.manual_seed(seed)
+env.action_space.seed(seed)  # dueling_dqn.py:68
 
 # Network setup (dueling_dqn.py:71-75; the reference also builds a q_network2 it never uses — kept for the same RNG consumption)
 q_network1 = QNetwork(env)

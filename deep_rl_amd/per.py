@@ -38,6 +38,7 @@ batch_size = int(os.environ.get("BATCH_SIZE", "128"))
 gamma = 0.99
 learning_rate = 2.5e-4
 target_network_frequency = 500  # :53
+assert target_network_frequency % train_frequency == 0, "target_network_frequency must be a multiple of train_frequency"  # conditions are looked at every train_frequency steps
 
 # Env setup (:56-57)
 env = make(env_id, num_envs=num_envs, device=device, env_id_base=rank * num_envs)

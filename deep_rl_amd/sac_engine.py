@@ -120,6 +120,8 @@ class SACEngine:
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.q_optimizer
             g = o.param_groups[0]
+            if sample_in_launch and min(self.global_step, self.slots) * self.N == 0:   # 0 means "read batch_inds" to the launch
+                raise N.MiError("update_critic: the replay ring is empty (global_step == 0); act() before training")
             o.step_count += 1
             N.check(N.lib().mi_sac_critic_update(
                 N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
