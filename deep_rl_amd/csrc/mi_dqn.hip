@@ -453,7 +453,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 
 // grads[p] = sum over workgroup slabs in slab order; loss = sum of the slab losses * inv_count.  With `opt.params` set the same launch applies
 // optimizer.step() (torch Adam without clipping, dqn.py:68,133) to the element it has just summed: no launch of its own in single-process runs.
-struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, bc2_sqrt, eps; };
+struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, rbc2, eps; };
 __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
                                                          float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,13 +462,10 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
         for (int b = 0; b < n_slabs; ++b) acc[b & 3] += workspace[(size_t)b * TD_SLAB + p];
         const float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         grads[p] = g;
-        if (opt.params) {   // the formula of clip_adam_kernel at coef = 1 (max_norm = inf), bit for bit
-            const float pm = opt.m[p], pv = opt.v[p];
-            const float mi = pm + opt.w1 * (g - pm);
-            const float vi = pv * opt.b2 + opt.w2 * (g * g);
-            const float denom = sqrtf(vi) / opt.bc2_sqrt + opt.eps;
+        if (opt.params) {   // the formula of clip_adam_kernel at coef = 1 (max_norm = inf), bit for bit (mi_adam_elem)
+            float mi = opt.m[p], vi = opt.v[p];
+            opt.params[p] = mi_adam_elem(opt.params[p], g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
             opt.m[p] = mi; opt.v[p] = vi;
-            opt.params[p] = opt.params[p] + (-opt.step_size) * (mi / denom);
         }
     } else if (p == DQ_NP && loss) {
         double l = 0.0;
@@ -519,7 +516,7 @@ extern "C" int mi_dqn_td_update(float* params, const float* target_params, const
     dqn_opt_t o;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     o.params = params; o.m = exp_avg; o.v = exp_avg_sq; o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2);
-    o.step_size = (float)(lr / bc1); o.bc2_sqrt = (float)sqrt(bc2); o.eps = (float)eps;
+    o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps;
     return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / batch, workspace, grads, loss,
                        weights, td_abs, o, sample_seed, sample_update, sample_upper, stream);
 }

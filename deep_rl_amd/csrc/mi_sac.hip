@@ -672,15 +672,14 @@ __device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, 
 }
 
 // alpha step riding on the log-prob launch: the LAST workgroup to finish (ticket in the workspace) sums the slabs in fixed order and does the Adam step
-struct sac_alpha_t { float* log_alpha; float* m; float* v; float* alpha; float* out; unsigned int* ticket; float target_entropy, inv_count, w1, b2, w2, step_size, bc2_sqrt, eps; };
+struct sac_alpha_t { float* log_alpha; float* m; float* v; float* alpha; float* out; unsigned int* ticket; float target_entropy, inv_count, w1, b2, w2, step_size, rbc2, eps; };
 __device__ __forceinline__ void sac_alpha_apply(const sac_alpha_t& a, float mean_lp) {
     const float la = a.log_alpha[0];
     const float g = -(mean_lp + a.target_entropy);            // d/d log_alpha of mean(-log_alpha * (logp + target_entropy)), sac.py:205
     if (a.out) { a.out[0] = -la * (mean_lp + a.target_entropy); a.out[1] = g; }
-    const float mi = a.m[0] + a.w1 * (g - a.m[0]);
-    const float vi = a.v[0] * a.b2 + a.w2 * (g * g);
+    float mi = a.m[0], vi = a.v[0];
+    const float nla = mi_adam_elem(la, g, mi, vi, a.w1, a.b2, a.w2, a.step_size, a.rbc2, a.eps);
     a.m[0] = mi; a.v[0] = vi;
-    const float nla = la + (-a.step_size) * (mi / (sqrtf(vi) / a.bc2_sqrt + a.eps));
     a.log_alpha[0] = nla;
     a.alpha[0] = expf(nla);                                    // :210
 }
@@ -906,12 +905,11 @@ __global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(float* __restrict__ w
 // fixed-order sum of the GEMM's K-split partials; (c) the two loss scalars.  With `opt.params` set, the same launch also applies the Adam
 // step to every element it has just assembled and (critics) the polyak step of the target copy: optimizer.step() and the target update
 // (sac.py:185,213-217) cost no launch of their own.
-struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, bc2_sqrt, eps, tau; };
+struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, rbc2, eps, tau; };
 __device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g) {
-    const float mi = o.m[i] + o.w1 * (g - o.m[i]);
-    const float vi = o.v[i] * o.b2 + o.w2 * (g * g);
+    float mi = o.m[i], vi = o.v[i];
+    const float p = mi_adam_elem(o.params[i], g, mi, vi, o.w1, o.b2, o.w2, o.step_size, o.rbc2, o.eps);
     o.m[i] = mi; o.v[i] = vi;
-    const float p = o.params[i] + (-o.step_size) * (mi / (sqrtf(vi) / o.bc2_sqrt + o.eps));
     o.params[i] = p;
     if (o.target) o.target[i] = o.tau * p + (1.0f - o.tau) * o.target[i];
 }
@@ -961,7 +959,7 @@ static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, 
     sac_opt_t o;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     o.params = params; o.m = m; o.v = v; o.target = target;
-    o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2); o.step_size = (float)(lr / bc1); o.bc2_sqrt = (float)sqrt(bc2); o.eps = (float)eps; o.tau = tau;
+    o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2); o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps; o.tau = tau;
     return o;
 }
 
@@ -1058,7 +1056,7 @@ static sac_alpha_t sac_make_alpha(float target_entropy, float inv_count, float* 
     sac_alpha_t a;
     const double b1 = 0.9, b2 = 0.999, bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     a.log_alpha = log_alpha; a.m = m; a.v = v; a.alpha = alpha; a.out = out; a.ticket = ticket; a.target_entropy = target_entropy; a.inv_count = inv_count;
-    a.w1 = (float)(1.0 - b1); a.b2 = (float)b2; a.w2 = (float)(1.0 - b2); a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = 1e-8f;
+    a.w1 = (float)(1.0 - b1); a.b2 = (float)b2; a.w2 = (float)(1.0 - b2); a.step_size = (float)(lr / bc1); a.rbc2 = (float)(1.0 / sqrt(bc2)); a.eps = 1e-8f;
     return a;
 }
 
@@ -1101,14 +1099,12 @@ extern "C" int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, f
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
-                                                    float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps) {
+                                                    float w1, float b2, float w2, float step_size, float rbc2, float eps) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float gi = g[i];
-    const float mi = m[i] + w1 * (gi - m[i]);
-    const float vi = v[i] * b2 + w2 * (gi * gi);
+    float mi = m[i], vi = v[i];
+    p[i] = mi_adam_elem(p[i], g[i], mi, vi, w1, b2, w2, step_size, rbc2, eps);
     m[i] = mi; v[i] = vi;
-    p[i] = p[i] + (-step_size) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
 }
 
 extern "C" int mi_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1,
@@ -1116,7 +1112,7 @@ extern "C" int mi_adam(float* params, const float* grads, float* exp_avg, float*
     MI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad arguments");
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     adam_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
-                                                                 (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps);
+                                                                 (float)(1.0 - beta2), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }

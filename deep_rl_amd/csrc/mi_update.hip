@@ -146,27 +146,44 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 // =====================================================================================================
 // Minibatch gradient on the f32 MFMA pipe.
 //
-// Work split: a workgroup (4 waves) serves ONE net — even blockIdx = actor, odd = critic; the two nets share
-// nothing but the observations (the joint grad-norm clip happens later), so each CU hosts one block of each.
+// Work split: a workgroup (4 waves) serves ONE net — the two nets share nothing but the observations (the joint
+// grad-norm clip happens later), and each CU hosts one block of each.
 // A wave processes tiles of 16 minibatch rows; per tile and net (v_mfma_f32_16x16x4_f32 unless noted):
 //     z1^T = W1 x^T            4 MFMA     (rows on the lanes, hidden units in the accumulator registers)
 //     z2^T = W2 h1^T          64 MFMA     B operand = h1's accumulator registers as they stand
 //     dh1^T = W2^T dz2^T      64 MFMA     B operand = dz2's registers as they stand
 //     dW2 += dz2^T h1         64 MFMA     both operands re-read transposed through a wave-private LDS tile
-//     dW1 += dz1^T x, dW3 += dout^T h2    16 + 16 v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1 row)
+//     dW1 += dz1^T x           16 v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1 row)
+//     dW3 += dout^T h2         16 / 32 FMAs per lane on its own row and units (summed over the rows at exit; GRAD_DW3_VALU)
 // "As they stand": a 16x16 accumulator tile mt holds, in lane (j = row = lane&15, g = lane>>4), register r, the hidden
 // unit 16mt + 4g + r.  An MFMA sums over k in ANY order as long as A and B agree, so k-step s of the next product
 // takes B from register (s&3) of tile (s>>2) and A = W[..][16(s>>2) + 4g + (s&3)] — no lane movement, no LDS
 // (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").  The sum order differs from a
 // sequential-k fp32 chain; parity is to tolerance, not bitwise.
+//
+// LDS images (round 2: every read pattern audited against the per-instruction banking table of MI355X_MICROARCH.md §LDS):
+//   W2g[(i>>2)][o][i&3]  = c W2[o][i]   layer-2 A fragments: lane (j,g) reads the float4 of k-steps 4c..4c+3 at ((4c+g)*64 + 16mt + j)*4;
+//                                       the 16 lanes of a ds_read_b128 group hold 16 different j  -> 64 different banks
+//   W2t[(o>>2)][i][o&3]  =   W2[o][i]   the same for dh1 = W2^T dz2 (A[i][k = o]): 16 ds_read_b128 per tile instead of 64 ds_read_b32
+//   bufA / bufB [row][68]               wave-private staging images; the dW2 k-step s takes rows s + 4g (NOT 4s + g: lane groups g, g+1
+//                                       must sit 16 banks apart — (s+4g)*68 = 4s + 16g mod 32 — which removed the 2-way conflict of r01)
+// c = 2 log2(e) (GRAD_PRESCALE): the tanh argument scale is folded into W1, b1, W2, b2 when they are staged, so tanh is
+// 4 instructions (v_exp, v_add, v_rcp, v_fma) on z' = c z; the backward products use the unscaled W2t.
+//
 // 16-row tiles keep an activation in 16 registers (a 32-row tile on 32x32x2 spilled 100 VGPRs at 2 waves/SIMD and
 // wrote 62 MB of scratch per launch: profiles/r01a_*).  Row inputs are prefetched two tiles ahead (index) / one tile
 // ahead (gathered row), so no dependent global load sits on a tile's critical path.
 // Everything per tile is wave-private (no workgroup barrier in the loop); the only barriers are around the
 // weight staging at entry and the deterministic cross-wave reduction at exit.  Per-block partial gradients go
 // to a workspace slab and are summed in a fixed order by grad_reduce_kernel (no float atomics: reproducible).
+//
+// The optimizer step owed from the PREVIOUS minibatch rides on the weight staging (grad_pending_t): every workgroup
+// recomputes the clip coefficient from the L2-resident summed gradient (block_grad_norm: bitwise the same everywhere)
+// and steps the parameters it stages on their way into LDS / registers; the first workgroup of each net writes the
+// stepped {params, exp_avg, exp_avg_sq} to the OTHER buffer set (ping-pong: nobody reads what this launch writes).
+// mi_ppo_update therefore runs 2 launches per optimizer step (gradient, slab sum) instead of 3.
 // =====================================================================================================
-#define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row reads / writes (nearly) conflict-free
+#define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row writes and b32 row reads conflict-free
 #define GRAD_WAVES 4
 #ifndef GRAD_OCC
 #define GRAD_OCC 2        // waves per SIMD the kernel is built for (blocks per CU = GRAD_OCC)
@@ -183,17 +200,37 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #ifndef GRAD_ALT_PRIO
 #define GRAD_ALT_PRIO 0   // 1: the two waves sharing a SIMD take turns at s_setprio 1, tile by tile
 #endif
+#ifndef GRAD_PRESCALE
+#define GRAD_PRESCALE 1   // fold tanh's 2 log2(e) into the staged W1 / b1 / W2 / b2
+#endif
+#ifndef GRAD_DW3_VALU
+#define GRAD_DW3_VALU 1   // 1: dW3 as per-lane VALU partial sums (no h2 staging image, no 4x4x1 chain); 0: the r01 form (16 4x4x1 MFMAs from an LDS image)
+#endif
 #define TROWS 16
 #define PART_STRIDE 4624
 #define PART_LOSS 4610
 #define GRAD_MAX_BLOCKS 1024
+#define GRAD_SPARE_SLABS 16                 // the workspace's last slabs hold mi_ppo_update's two spare optimizer-state sets
+#define RED_STRIDE 4640                     // per-wave slot of the exit reduction: 4096 dW2 + 544 small values
+#define STATE_STRIDE 9216                   // floats between params / exp_avg / exp_avg_sq inside a spare set
+#if defined(GRAD_STAMPS) && GRAD_OCC > 2
+#error "GRAD_STAMPS writes its timestamps behind slab 512: build it with GRAD_OCC <= 2"
+#endif
 
-struct __attribute__((aligned(16))) grad_smem {
-    float W2[HID * W2S];                  // W2[o][i] row-major, padded
-    float b1[HID], b2[HID];
+struct __attribute__((aligned(16))) grad_weights {
+    float W2g[HID * HID];                 // see the header comment
+    float W2t[HID * HID];
+    float b1[HID], b2[HID];               // scaled by c
     float W3[2 * HID];
     float bufA[GRAD_WAVES][TROWS * W2S];   // wave-private [row][unit] images for the transposed re-reads; the 4 pad
     float bufB[GRAD_WAVES][TROWS * W2S];   // columns (64..67) of a row hold x[row][0..3] (bufA) / dout[row][0..3] (bufB)
+};
+struct __attribute__((aligned(16))) grad_smem {
+    union {
+        grad_weights w;
+        float red[GRAD_WAVES][RED_STRIDE];  // exit reduction (the weights are dead by then)
+    };
+    double nrm[4];
 };
 #define XS(row, k) bufA[(row) * W2S + HID + (k)]
 #define DLS(row, k) bufB[(row) * W2S + HID + (k)]
@@ -201,6 +238,71 @@ struct __attribute__((aligned(16))) grad_smem {
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// sum over the 4 lane groups (lane ^ 16, lane ^ 32) on the VALU: v_permlane16_swap / v_permlane32_swap with both operands = v
+// give {rows 0,0,2,2} / {rows 1,1,3,3} and {lo,lo} / {hi,hi}; (r0 + r1) + (r2 + r3) in every lane (what the two
+// ds_bpermute-based __shfl_xor steps computed, without the LDS round trips).
+__device__ __forceinline__ float groups_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, s);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
+// tanh of z given z' = z * 2 log2(e) (GRAD_PRESCALE) — the same function as mi_tanhf, with the scale already applied by the weights
+__device__ __forceinline__ float tanh_prescaled(float zs) {
+    const float e = __builtin_amdgcn_exp2f(zs);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+#if GRAD_PRESCALE
+#define GRAD_TANH(x) tanh_prescaled(x)
+#define GRAD_PS 2.8853900817779268f
+#else
+#define GRAD_TANH(x) mi_tanhf(x)
+#define GRAD_PS 1.0f
+#endif
+
+// Total L2 norm of a flat gradient, recomputed identically by every 256-thread workgroup that calls it: all loads in flight at
+// once (float4, compile-time trip count; a strided scalar loop costs nine dependent L2 round trips instead of one), per-thread
+// partial sums in f64 in a fixed order, xor-butterfly, four wave sums added in wave order.  Contains ONE __syncthreads.
+__device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads, int n, int vec_ok, double* ws /* shared [4] */) {
+    constexpr int NV4 = (MI_PPO_NPARAMS + 3) / 4, PER_T = (NV4 + 255) / 256;
+    float4 gv[PER_T];
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) {
+        const int q = threadIdx.x + 256 * k;
+        gv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (vec_ok && 4 * q + 3 < n) gv[k] = reinterpret_cast<const float4*>(grads)[q];
+        else {  // ragged tail (and the generic-n path): scalar, bounds-checked
+            if (4 * q + 0 < n) gv[k].x = grads[4 * q + 0];
+            if (4 * q + 1 < n) gv[k].y = grads[4 * q + 1];
+            if (4 * q + 2 < n) gv[k].z = grads[4 * q + 2];
+            if (4 * q + 3 < n) gv[k].w = grads[4 * q + 3];
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k)
+        s += ((double)gv[k].x * gv[k].x + (double)gv[k].y * gv[k].y) + ((double)gv[k].z * gv[k].z + (double)gv[k].w * gv[k].w);
+    for (int k = 4 * 256 * PER_T + threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }  // n beyond the unrolled part
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return (float)sqrt((ws[0] + ws[1]) + (ws[2] + ws[3]));
+}
+
+// The optimizer step owed from the previous minibatch (clip_grad_norm_ + Adam, ppo.py:191-192), applied by the weight staging.
+struct grad_pending_t {
+    const float* grads;                                   // summed gradient of the previous minibatch [NPARAMS]; nullptr = nothing owed
+    const float* p_in; const float* m_in; const float* v_in;   // optimizer state before the owed step
+    float* p_out; float* m_out; float* v_out;             // ... after it (never the *_in buffers)
+    float* grad_norm;                                     // nullable: pre-clip total norm of `grads`
+    float w1, b2, w2, step_size, rbc2, eps, max_norm;
+    int vec_ok;
+};
 
 struct row_in {
     float x;          // observation component g of the row (lane (j,g))
@@ -227,46 +329,90 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 #ifdef GRAD_STAMPS
 #define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
                       stamp_acc[k] += t_ - stamp_last; stamp_last = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_BASE(part) (reinterpret_cast<unsigned long long*>((part) + (size_t)(GRAD_MAX_BLOCKS / 2) * PART_STRIDE))
 #else
 #define STAMP(k) do {} while (0)
 #endif
 
 template <bool ACTOR>
-__device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict__ params, const float* __restrict__ observations,
+__device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict__ params, const grad_pending_t& pend,
+                                          const float* __restrict__ observations,
                                           const int64_t* __restrict__ actions, const float* __restrict__ log_probs,
                                           const float* __restrict__ advantages, const float* __restrict__ returns,
                                           const float* __restrict__ values, const int32_t* __restrict__ idx, int mb,
                                           const double* __restrict__ adv_sums, float clip_coef, float ent_coef, float vf_coef,
                                           float invn, float* __restrict__ part, unsigned vb) {
     constexpr int NOUT = ACTOR ? 2 : 1;
+    constexpr int BASE = ACTOR ? 0 : C_BASE;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const float* p = params + (ACTOR ? 0 : C_BASE);
+    const bool pending = pend.grads != nullptr;
+    const float* p = (pending ? pend.p_in : params) + BASE;
+    grad_weights& W = sm.w;
 #ifdef GRAD_STAMPS
     unsigned long long rt_in, rt_ready, rt_loop;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_in) :: "memory");
 #endif
 
-    // ---- stage this net's weights in LDS (once per block): 4 float4 loads in flight per lane, then the LDS writes ----
+    // ---- stage this net's weights (once per block), stepping them first when an optimizer step is owed ----
+    // thread (q, cg) owns the 4x4 block W2[4q..4q+3][4cg..4cg+3]: one float4 per row in, four float4 per image out
+    float w1f[4], b3[NOUT];
     {
-        float4 w[4];
+        const int q = tid >> 4, cg = tid & 15;
+        const bool writer = pending && (vb >> 1) == 0;   // the first workgroup of each net writes the stepped state back
+        f32x4 w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = reinterpret_cast<const float4*>(p + N_W2)[tid + 256 * k];
+        for (int e = 0; e < 4; ++e) w[e] = reinterpret_cast<const f32x4*>(p + N_W2)[(4 * q + e) * 16 + cg];
+        float coef = 1.0f;
+        if (pending) {
+            f32x4 gg[4], mm[4], vv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int f = tid + 256 * k;  // float4 index: row = f / 16, col = 4 * (f % 16)
-            *reinterpret_cast<float4*>(&sm.W2[(f >> 4) * W2S + 4 * (f & 15)]) = w[k];
+            for (int e = 0; e < 4; ++e) {
+                gg[e] = reinterpret_cast<const f32x4*>(pend.grads + BASE + N_W2)[(4 * q + e) * 16 + cg];
+                mm[e] = reinterpret_cast<const f32x4*>(pend.m_in + BASE + N_W2)[(4 * q + e) * 16 + cg];
+                vv[e] = reinterpret_cast<const f32x4*>(pend.v_in + BASE + N_W2)[(4 * q + e) * 16 + cg];
+            }
+            const float total = block_grad_norm(pend.grads, NPARAMS, pend.vec_ok, sm.nrm);
+            coef = pend.max_norm / (total + 1e-6f);
+            coef = coef > 1.0f ? 1.0f : coef;
+            if (pend.grad_norm && vb == 0 && tid == 0) *pend.grad_norm = total;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    float m_ = mm[e][x], v_ = vv[e][x];
+                    w[e][x] = mi_adam_elem(w[e][x], gg[e][x] * coef, m_, v_, pend.w1, pend.b2, pend.w2, pend.step_size, pend.rbc2, pend.eps);
+                    mm[e][x] = m_; vv[e][x] = v_;
+                }
+                if (writer) {
+                    reinterpret_cast<f32x4*>(pend.p_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = w[e];
+                    reinterpret_cast<f32x4*>(pend.m_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = mm[e];
+                    reinterpret_cast<f32x4*>(pend.v_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = vv[e];
+                }
+            }
         }
-        if (tid < HID) { sm.b1[tid] = p[N_B1 + tid]; sm.b2[tid] = p[N_B2 + tid]; }
-        if (tid < NOUT * HID) sm.W3[tid] = p[N_W3 + tid];
+        // parameter i of this net as this launch must see it (stepped when a step is owed); `wr`: this thread writes it back
+        auto fetch = [&](int i, bool wr) -> float {
+            float pv = p[i];
+            if (pending) {
+                float m_ = pend.m_in[BASE + i], v_ = pend.v_in[BASE + i];
+                pv = mi_adam_elem(pv, pend.grads[BASE + i] * coef, m_, v_, pend.w1, pend.b2, pend.w2, pend.step_size, pend.rbc2, pend.eps);
+                if (writer && wr) { pend.p_out[BASE + i] = pv; pend.m_out[BASE + i] = m_; pend.v_out[BASE + i] = v_; }
+            }
+            return pv;
+        };
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(&W.W2g[(cg * 64 + 4 * q + e) * 4]) = w[e] * GRAD_PS;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) *reinterpret_cast<f32x4*>(&W.W2t[(q * 64 + 4 * cg + x) * 4]) = f32x4{w[0][x], w[1][x], w[2][x], w[3][x]};
+        if (tid < HID) { W.b1[tid] = GRAD_PS * fetch(N_B1 + tid, true); W.b2[tid] = GRAD_PS * fetch(N_B2 + tid, true); }
+        if (tid < NOUT * HID) W.W3[tid] = fetch(N_W3 + tid, true);
+        // layer-1 A fragments live in registers: lane (i = j, g), tile mt holds c W1[16mt + i][k = g]
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w1f[mt] = GRAD_PS * fetch(N_W1 + 4 * (16 * mt + j) + g, wib == 0);
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) b3[a] = fetch(N_W3 + NOUT * HID + a, tid == 0);
     }
-    // layer-1 A fragments live in registers: lane (i = j, g), tile mt holds W1[16mt + i][k = g]
-    float w1f[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) w1f[mt] = p[N_W1 + 4 * (16 * mt + j) + g];
-    float b3[NOUT];
-#pragma unroll
-    for (int a = 0; a < NOUT; ++a) b3[a] = p[N_W3 + NOUT * HID + a];
 
     // advantage normalisation constants (ppo.py:169) from {sum, sum sq, count}
     float adv_mean = 0.0f, adv_rden = 1.0f;
@@ -321,12 +467,21 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) dW2[mo][mi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 dW1a = {0.0f, 0.0f, 0.0f, 0.0f}, dW1b = dW1a, dW3a = dW1a, dW3b = dW1a;  // two chains each: 4x4x1 latency > issue
+    f32x4 dW1a = {0.0f, 0.0f, 0.0f, 0.0f}, dW1b = dW1a;  // two chains: the 4x4x1 dependent latency exceeds its issue time
+#if GRAD_DW3_VALU
+    f32x4 dW3v[NOUT][4];   // per-lane partial sums over this lane's rows: dW3[a][16mt + 4g + r], reduced over j at exit
+#pragma unroll
+    for (int a = 0; a < NOUT; ++a)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) dW3v[a][mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#else
+    f32x4 dW3a = dW1a, dW3b = dW1a;
+#endif
     float db1 = 0.0f, db2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, db3[2] = {0.0f, 0.0f};
     float loss_a = 0.0f, loss_b = 0.0f;  // actor: sum pg, sum entropy; critic: sum max(vl1, vl2)
 
-    float* bufA = sm.bufA[wib];
-    float* bufB = sm.bufB[wib];
+    float* bufA = W.bufA[wib];
+    float* bufB = W.bufB[wib];
 
 #ifdef GRAD_STAMPS
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_ready) :: "memory");
@@ -334,7 +489,8 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
     stamp_t0 = stamp_last;
 #endif
-    for (int it = 0; tile < tile_end; tile += stride, ++it) {
+    int it = 0;
+    for (; tile < tile_end; tile += stride, ++it) {
         const bool valid = tile * TROWS + j < mb;
 #if GRAD_ALT_PRIO
         if ((it & 1) ^ (young ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
@@ -350,42 +506,38 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         f32x4 h1[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const float4 b = *reinterpret_cast<const float4*>(&sm.b1[16 * mt + 4 * g]);
+            const float4 b = *reinterpret_cast<const float4*>(&W.b1[16 * mt + 4 * g]);
             h1[mt] = mfma16(w1f[mt], cur.x, f32x4{b.x, b.y, b.z, b.w});
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h1[mt][r] = mi_tanhf(h1[mt][r]);
+            for (int r = 0; r < 4; ++r) h1[mt][r] = GRAD_TANH(h1[mt][r]);
         STAMP(1);  // layer 1 + tanh
 
         // ---- layer 2: z2^T = W2 h1^T + b2; k-steps 4c..4c+3 <-> units 16c + 4g + {0..3} ----
         f32x4 h2[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const float4 b = *reinterpret_cast<const float4*>(&sm.b2[16 * mt + 4 * g]);
+            const float4 b = *reinterpret_cast<const float4*>(&W.b2[16 * mt + 4 * g]);
             h2[mt] = f32x4{b.x, b.y, b.z, b.w};
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float4 a[4];
+            f32x4 a[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4*>(&sm.W2[(16 * mt + j) * W2S + 16 * c + 4 * g]);
+            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(&W.W2g[((4 * c + g) * 64 + 16 * mt + j) * 4]);
             // consecutive MFMAs go to different accumulators: the 16x16x4 dependent latency (40 clk) exceeds its issue (32)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].x, h1[c][0], h2[mt]);
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].y, h1[c][1], h2[mt]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].z, h1[c][2], h2[mt]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt].w, h1[c][3], h2[mt]);
+                for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt][r], h1[c][r], h2[mt]);
         }
         STAMP(2);  // layer 2 MFMAs issued
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h2[mt][r] = mi_tanhf(h2[mt][r]);
+            for (int r = 0; r < 4; ++r) h2[mt][r] = GRAD_TANH(h2[mt][r]);
         STAMP(3);  // tanh h2 (includes waiting for the layer-2 accumulators)
 
         // ---- head: out[a] = W3[a] . h2 + b3[a]; the 4 lanes (g) of a row hold 16 units each ----
@@ -395,13 +547,11 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
             float acc = 0.0f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 16 * mt + 4 * g]);
+                const float4 w = *reinterpret_cast<const float4*>(&W.W3[a * HID + 16 * mt + 4 * g]);
                 acc = __builtin_fmaf(w.x, h2[mt][0], acc); acc = __builtin_fmaf(w.y, h2[mt][1], acc);
                 acc = __builtin_fmaf(w.z, h2[mt][2], acc); acc = __builtin_fmaf(w.w, h2[mt][3], acc);
             }
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
-            outp[a] = acc + b3[a];
+            outp[a] = groups_sum(acc) + b3[a];
         }
 
         // ---- loss and d loss / d out (ppo.py:166-187), identical in the 4 lanes of a row ----
@@ -449,11 +599,20 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
             dl[a] = valid ? dl[a] : 0.0f;
             db3[a] += (g == 0) ? dl[a] : 0.0f;
         }
-        DLS(j, g) = g == 0 ? dl[0] : ((NOUT == 2 && g == 1) ? dl[NOUT - 1] : 0.0f);
         STAMP(4);  // head + loss
 
+#if GRAD_DW3_VALU
+        // ---- dW3[a][unit] += dout[row][a] h2[row][unit]: this lane's row, this lane's 16 units (summed over rows at exit) ----
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dW3v[a][mt][r] = __builtin_fmaf(dl[a], h2[mt][r], dW3v[a][mt][r]);
+#else
         // ---- dW3 += dout^T h2: stage h2 as a [row][unit] image.
         // 4x4x1 (16 blocks, block b = lane>>2): D[b][i][jj] += A[b][i] B[b][jj]; A = dout[row][i], B = h2[row][4b+jj]
+        DLS(j, g) = g == 0 ? dl[0] : ((NOUT == 2 && g == 1) ? dl[NOUT - 1] : 0.0f);
         wave_lds_fence();
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -464,6 +623,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
             dW3a = mfma4(DLS(rr, lane & 3), bufA[rr * W2S + lane], dW3a);
             dW3b = mfma4(DLS(rr + 1, lane & 3), bufA[(rr + 1) * W2S + lane], dW3b);
         }
+#endif
 
         STAMP(5);  // stage h2 + dW3
         // ---- dz2 = (W3^T dout) * (1 - h2^2); h2 is dead afterwards ----
@@ -473,7 +633,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
             float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int a = 0; a < NOUT; ++a) {
-                const float4 w = *reinterpret_cast<const float4*>(&sm.W3[a * HID + 16 * mt + 4 * g]);
+                const float4 w = *reinterpret_cast<const float4*>(&W.W3[a * HID + 16 * mt + 4 * g]);
                 d[0] = __builtin_fmaf(w.x, dl[a], d[0]); d[1] = __builtin_fmaf(w.y, dl[a], d[1]);
                 d[2] = __builtin_fmaf(w.z, dl[a], d[2]); d[3] = __builtin_fmaf(w.w, dl[a], d[3]);
             }
@@ -482,15 +642,19 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         }
 
         STAMP(6);  // dz2
-        // ---- dh1^T = W2^T dz2^T, dz1 = dh1 * (1 - h1^2); k-step s <-> output unit o = 16(s>>2) + 4g + (s&3) ----
+        // ---- dh1^T = W2^T dz2^T, dz1 = dh1 * (1 - h1^2); k-steps 4c..4c+3 <-> output units o = 16c + 4g + {0..3} ----
         f32x4 dz1[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) dz1[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float* wrow = &sm.W2[(16 * (s >> 2) + 4 * g + (s & 3)) * W2S + j];
+        for (int c = 0; c < 4; ++c) {
+            f32x4 a[4];   // a[mt][r] = W2[16c + 4g + r][16mt + j]
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) dz1[mt] = mfma16(wrow[16 * mt], dz2[s >> 2][s & 3], dz1[mt]);
+            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(&W.W2t[((4 * c + g) * 64 + 16 * mt + j) * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) dz1[mt] = mfma16(a[mt][r], dz2[c][r], dz1[mt]);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -513,7 +677,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         }
 
         STAMP(8);  // stage dz1 + dW1
-        // ---- dW2[o][i] += sum_rows dz2[row][o] h1[row][i]: A[i=o][k=row], B[k=row][j=i], rows 4s+g per k-step ----
+        // ---- dW2[o][i] += sum_rows dz2[row][o] h1[row][i]: A[i=o][k=row], B[k=row][j=i], rows s + 4g per k-step ----
         wave_lds_fence();
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -523,7 +687,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         wave_lds_fence();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int ro = (4 * s + g) * W2S + j;
+            const int ro = (s + 4 * g) * W2S + j;
             float a[4], b[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) { a[m] = bufB[ro + 16 * m]; b[m] = bufA[ro + 16 * m]; db2[m] += a[m]; }
@@ -537,70 +701,71 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         STAMP(10);  // wait for the prefetched row
     }
 #ifdef GRAD_STAMPS
-    if (lane == 0) {  // diagnostic build: the unused upper half of the workspace (grid <= 512 blocks) receives the stamps
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(part + (size_t)512 * PART_STRIDE) + 16 * wib;
+    if (lane == 0) {  // diagnostic build: the slabs behind GRAD_MAX_BLOCKS / 2 (unused by grids of <= 512 blocks) receive the stamps
+        unsigned long long* dbg = STAMP_BASE(part) + 16 * wib;
         unsigned long long now;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
         for (int k = 0; k < 11; ++k) dbg[k] = stamp_acc[k];
         dbg[11] = now - stamp_t0;
-        dbg[12] = (unsigned long long)((tile_end - (tile - ((tile_end - tile + stride - 1) / stride) * 0) + stride - 1) / stride);
+        dbg[12] = (unsigned long long)it;   // tiles this wave processed
     }
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_loop) :: "memory");
 #endif
-    const f32x4 dW1 = dW1a + dW1b, dW3 = dW3a + dW3b;
+    const f32x4 dW1 = dW1a + dW1b;
 
     // ---- deterministic cross-wave reduction, then one partial slab per block ----
-    __syncthreads();  // every wave is done with the weights and its staging tiles -> reuse LDS for the reduction
-    // two 64x64 tiles: R0 in sm.W2 (4352 floats), R1 across bufA[0..3] (4 x 1088 floats, contiguous).  Waves 0/1 store,
-    // waves 2/3 add (fixed order: (w0 + w2) + (w1 + w3)), then all threads write R0 + R1 to the slab.
-    float* red0 = sm.W2;
-    float* red1 = &sm.bufA[0][0];
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        if ((wib >> 1) == round) {
-            float* red = (wib & 1) ? red1 : red0;
-#pragma unroll
-            for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int at = (16 * mo + 4 * g + r) * HID + 16 * mi + j;  // dW2[unit_out][unit_in]
-                        red[at] = round == 0 ? dW2[mo][mi][r] : red[at] + dW2[mo][mi][r];
-                    }
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < HID * HID / 4; i += 64 * GRAD_WAVES) {
-        const float4 a = reinterpret_cast<const float4*>(red0)[i], b = reinterpret_cast<const float4*>(red1)[i];
-        reinterpret_cast<float4*>(part + N_W2)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    }
-    __syncthreads();  // red1 overlaps the per-wave slots used next
-    // small tensors: every wave drops its values in its own bufA slot, then a fixed-order sum over the 4 waves
+    // every wave drops its partial sums into its own LDS slot (dW2 in accumulator-fragment order: 16 conflict-free b128 stores),
+    // one barrier, then 256 threads add the four slots in wave order and write the slab.  The slab keeps dW2 in fragment
+    // order (float4 F = (4mo + mi)*64 + lane, component r = dW2[16mo + 4g + r][16mi + j]); grad_reduce_kernel undoes it.
+    __syncthreads();  // every wave is done with the weights and its staging tiles -> the LDS becomes the reduction buffer
     {
-        float* slot = bufB;
+        float* slot = sm.red[wib];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) slot[(4 * (lane >> 2) + i) * 4 + (lane & 3)] = dW1[i];  // dW1[unit 4b+i][k=jj]
-        slot[256 + lane] = db1;
+        for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) *reinterpret_cast<f32x4*>(&slot[((4 * mo + mi) * 64 + lane) * 4]) = dW2[mo][mi];
+        float* sm_small = slot + HID * HID;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm_small[(4 * (lane >> 2) + i) * 4 + (lane & 3)] = dW1[i];  // dW1[unit 4b+i][k=jj]
+        sm_small[256 + lane] = db1;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            float t = db2[m];
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            if (g == 0) slot[320 + 16 * m + j] = t;
+            const float t = groups_sum(db2[m]);
+            if (g == 0) sm_small[320 + 16 * m + j] = t;
         }
+#if GRAD_DW3_VALU
 #pragma unroll
-        for (int a = 0; a < NOUT; ++a) slot[384 + a * HID + lane] = dW3[a];  // dW3[a][unit = lane]
+        for (int a = 0; a < NOUT; ++a)
 #pragma unroll
-        for (int a = 0; a < NOUT; ++a) { const float t = wave_sum(db3[a]); if (lane == 0) slot[384 + NOUT * HID + a] = t; }
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = dW3v[a][mt][r];   // sum over the 16 rows (lanes j) of this lane group
+                    t += dpp_xor1(t); t += dpp_xor2(t); t += dpp_half_mirror(t); t += dpp_mirror(t);
+                    if (j == 0) sm_small[384 + a * HID + 16 * mt + 4 * g + r] = t;
+                }
+#else
+        const f32x4 dW3 = dW3a + dW3b;
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) sm_small[384 + a * HID + lane] = dW3[a];  // dW3[a][unit = lane]
+#endif
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) { const float t = wave_sum(db3[a]); if (lane == 0) sm_small[384 + NOUT * HID + a] = t; }
         const float la = wave_sum(loss_a), lb = wave_sum(loss_b);
-        if (lane == 0) { slot[520] = la; slot[521] = lb; }
+        if (lane == 0) { sm_small[520] = la; sm_small[521] = lb; }
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HID * HID / 4 / (64 * GRAD_WAVES); ++k) {
+        const int i = tid + 64 * GRAD_WAVES * k;
+        const f32x4 a0 = reinterpret_cast<const f32x4*>(sm.red[0])[i], a1 = reinterpret_cast<const f32x4*>(sm.red[1])[i];
+        const f32x4 a2 = reinterpret_cast<const f32x4*>(sm.red[2])[i], a3 = reinterpret_cast<const f32x4*>(sm.red[3])[i];
+        reinterpret_cast<f32x4*>(part + N_W2)[i] = (a0 + a2) + (a1 + a3);
+    }
     constexpr int N_SMALL = 384 + NOUT * HID + NOUT;
     for (int i = tid; i < 522; i += 64 * GRAD_WAVES) {
         if (i >= N_SMALL && i < 520) continue;
-        const float t = (sm.bufB[0][i] + sm.bufB[1][i]) + (sm.bufB[2][i] + sm.bufB[3][i]);
+        const float t = (sm.red[0][HID * HID + i] + sm.red[1][HID * HID + i]) + (sm.red[2][HID * HID + i] + sm.red[3][HID * HID + i]);
         int dst;
         if (i < 256) dst = N_W1 + i;
         else if (i < 320) dst = N_B1 + (i - 256);
@@ -613,42 +778,41 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     if (lane == 0) {
         unsigned long long rt_out;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_out) :: "memory");
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(part + (size_t)512 * PART_STRIDE) + 16 * wib;
+        unsigned long long* dbg = STAMP_BASE(part) + 16 * wib;
         dbg[13] = rt_in; dbg[14] = rt_ready; dbg[15] = rt_loop;
-        reinterpret_cast<unsigned long long*>(part + (size_t)512 * PART_STRIDE)[64 + wib] = rt_out;
+        STAMP_BASE(part)[64 + wib] = rt_out;
         const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        reinterpret_cast<unsigned long long*>(part + (size_t)512 * PART_STRIDE)[68 + wib] = ((unsigned long long)xcc << 32) | hw_id;
+        STAMP_BASE(part)[68 + wib] = ((unsigned long long)xcc << 32) | hw_id;
     }
 #endif
 }
 
 __global__ void __launch_bounds__(64 * GRAD_WAVES, GRAD_OCC)
-grad_kernel(const float* __restrict__ params, const float* __restrict__ observations, const int64_t* __restrict__ actions,
+grad_kernel(const float* __restrict__ params, grad_pending_t pend, const float* __restrict__ observations, const int64_t* __restrict__ actions,
             const float* __restrict__ log_probs, const float* __restrict__ advantages, const float* __restrict__ returns,
             const float* __restrict__ values, const int32_t* __restrict__ idx, int mb, const double* __restrict__ adv_sums,
             float clip_coef, float ent_coef, float vf_coef, float invn, float* __restrict__ workspace) {
     __shared__ grad_smem sm;
     // Workgroups are dealt round-robin over the 8 XCDs (b % 8), so role = b & 1 would give each XCD ONE net and leave the
     // critic XCDs idle while the (heavier) actor ones finish.  Swap the two low bit fields instead: the slab index
-    // `vb` keeps role = vb & 1 for the reduce kernel, while physical blocks b, b+8 (same XCD) get different roles.
-    // slab index vb: role = vb & 1 (what grad_reduce_kernel expects); the physical block's role is bit GRAD_ROLE_BIT of
-    // blockIdx (bit 0 would pin one net per XCD since workgroups are dealt round-robin over the 8 XCDs).
+    // `vb` keeps role = vb & 1 for the reduce kernel, while the physical block's role is bit GRAD_ROLE_BIT of blockIdx.
     const unsigned rb = GRAD_ROLE_BIT;
     const unsigned lowmask = (1u << rb) - 1u;
     const unsigned vb = (gridDim.x & ((2u << rb) - 1u)) ? blockIdx.x  // grid not a multiple of 2^(rb+1): identity
                                                         : ((blockIdx.x >> rb) & 1u) | (((blockIdx.x & lowmask) | ((blockIdx.x >> (rb + 1)) << rb)) << 1);
     float* part = workspace + (size_t)vb * PART_STRIDE;
     if ((vb & 1) == 0)
-        grad_body<true>(sm, params, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
+        grad_body<true>(sm, params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
                         ent_coef, vf_coef, invn, part, vb);
     else
-        grad_body<false>(sm, params, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
+        grad_body<false>(sm, params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
                          ent_coef, vf_coef, invn, part, vb);
 }
 
 // grads[p] = sum over the partial slabs of p's net in a FIXED order (reproducible); the last block finishes the loss terms.
-// 1024 threads = 64 consecutive parameters x 16 slab groups: every wave reads 256 contiguous bytes per slab, 16 independent
-// loads per lane, then the 16 group sums are added in group order through LDS.
+// 1024 threads = 64 consecutive slab positions x 16 slab groups: every wave reads 256 contiguous bytes per slab, 16 independent
+// loads per lane, then the 16 group sums are added in group order through LDS.  Slab positions inside a net's W2 range are in
+// accumulator-fragment order (grad_body's exit reduction); the store maps them back to W2[o][i].
 #define RED_PARAMS 64
 #define RED_GROUPS 16
 __global__ void __launch_bounds__(RED_PARAMS * RED_GROUPS)
@@ -660,9 +824,10 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_
         const int pl = threadIdx.x & (RED_PARAMS - 1), sg = threadIdx.x >> 6;
         const int p = blockIdx.x * RED_PARAMS + pl;
         float acc = 0.0f;
+        const int role = p < C_BASE ? 0 : 1;
+        const int off = p - (role ? C_BASE : 0);   // slab position within the net
         if (p < NPARAMS) {
-            const int role = p < C_BASE ? 0 : 1;
-            const float* src = workspace + (p - (role ? C_BASE : 0));
+            const float* src = workspace + off;
             const int per_role = n_blocks >> 1;
 #pragma unroll 4
             for (int k = sg; k < per_role; k += RED_GROUPS) acc += src[(size_t)(2 * k + role) * PART_STRIDE];
@@ -673,7 +838,13 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_
             float t = 0.0f;
 #pragma unroll
             for (int k = 0; k < RED_GROUPS; ++k) t += part[k][pl];
-            grads[p] = t;
+            int dst = p;
+            if (off >= N_W2 && off < N_W2 + HID * HID) {
+                const int s = off - N_W2, r = s & 3, F = s >> 2, ln = F & 63, frag = F >> 6;
+                const int o = 16 * (frag >> 2) + 4 * (ln >> 4) + r, i = 16 * (frag & 3) + (ln & 15);
+                dst = (role ? C_BASE : 0) + N_W2 + o * HID + i;
+            }
+            grads[dst] = t;
         }
     } else {
         // loss terms: pg / entropy from actor blocks, value loss from critic blocks
@@ -707,23 +878,23 @@ static int grad_blocks() {
         }
         int b = GRAD_OCC * cus;  // GRAD_OCC workgroups per CU, alternating actor / critic
         b &= ~1;
-        if (b > GRAD_MAX_BLOCKS) b = GRAD_MAX_BLOCKS;
+        if (b > GRAD_MAX_BLOCKS - GRAD_SPARE_SLABS) b = GRAD_MAX_BLOCKS - GRAD_SPARE_SLABS;  // the last slabs are mi_ppo_update's spare optimizer state
         g_grad_blocks = b;
     }
     return g_grad_blocks;
 }
+static_assert((size_t)GRAD_SPARE_SLABS * PART_STRIDE >= 6 * (size_t)STATE_STRIDE, "spare optimizer-state sets must fit behind the slabs");
+static_assert(STATE_STRIDE >= NPARAMS && STATE_STRIDE % 4 == 0, "STATE_STRIDE");
 
 extern "C" size_t mi_ppo_workspace_bytes(void) { return (size_t)GRAD_MAX_BLOCKS * PART_STRIDE * sizeof(float); }
 
-extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observations, const int64_t* actions,
-                                     const float* log_probs, const float* advantages, const float* returns,
-                                     const float* values, const int32_t* idx, int mb, const double* adv_sums, float clip_coef,
-                                     float ent_coef, float vf_coef, double inv_count, void* workspace, float* grads,
-                                     float* loss_terms, void* stream) {
-    MI_CHECK_ARG(params && observations && actions && log_probs && advantages && returns && values && idx && adv_sums, "NULL input");
-    MI_CHECK_ARG(workspace && grads, "NULL workspace/grads");
-    MI_CHECK_ARG(mb > 0, "mb must be positive");
-    hipStream_t s = (hipStream_t)stream;
+static grad_pending_t no_pending() { grad_pending_t z; memset(&z, 0, sizeof(z)); return z; }
+
+// gradient launch + slab sum.  `pend.grads != nullptr`: the launch first applies the owed optimizer step (see grad_pending_t).
+static int ppo_grad_launch(const float* params, const grad_pending_t& pend, const float* observations, const int64_t* actions, const float* log_probs,
+                           const float* advantages, const float* returns, const float* values, const int32_t* idx, int mb, const double* adv_sums,
+                           float clip_coef, float ent_coef, float vf_coef, double inv_count, void* workspace, float* grads, float* loss_terms,
+                           hipStream_t s) {
     int blocks = grad_blocks();
     // small minibatches: no point launching blocks that would only write zero slabs
     const int tiles = (mb + TROWS - 1) / TROWS;
@@ -731,7 +902,7 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
     if (need < blocks) blocks = need;  // (the role swizzle falls back to identity when the grid is not a multiple of 2^(bit+1))
     {
         mi_prof_scope prof(MI_PROF_GRAD, s);
-        grad_kernel<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, observations, actions, log_probs, advantages, returns, values, idx, mb,
+        grad_kernel<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb,
                                                        adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace);
     }
     MI_LAUNCH_CHECK();
@@ -744,69 +915,68 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
     return MI_OK;
 }
 
+extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observations, const int64_t* actions,
+                                     const float* log_probs, const float* advantages, const float* returns,
+                                     const float* values, const int32_t* idx, int mb, const double* adv_sums, float clip_coef,
+                                     float ent_coef, float vf_coef, double inv_count, void* workspace, float* grads,
+                                     float* loss_terms, void* stream) {
+    MI_CHECK_ARG(params && observations && actions && log_probs && advantages && returns && values && idx && adv_sums, "NULL input");
+    MI_CHECK_ARG(workspace && grads, "NULL workspace/grads");
+    MI_CHECK_ARG(mb > 0, "mb must be positive");
+    return ppo_grad_launch(params, no_pending(), observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef, ent_coef,
+                           vf_coef, inv_count, workspace, grads, loss_terms, (hipStream_t)stream);
+}
+
 // =====================================================================================================
 // clip_grad_norm_ + Adam.  Every 256-thread workgroup recomputes the total norm of the whole (9,155-float, L2-resident)
 // gradient in the same fixed order — so all workgroups get bitwise the same clip coefficient without a grid-wide
-// hand-off — and then updates its own 256-parameter slice.
+// hand-off — and then updates its own 256-parameter slice.  Out of place when the *_out pointers differ from *_in
+// (mi_ppo_update's last step: from the spare set back into the caller's tensors).
 // =====================================================================================================
-__global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
-                                                         float* __restrict__ m, float* __restrict__ v, int n, float w1, float b2,
-                                                         float w2, float step_size, float bc2_sqrt, float eps, float max_norm,
+__global__ void __launch_bounds__(256) clip_adam_kernel(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out,
+                                                         const float* __restrict__ grads, int n, float w1, float b2,
+                                                         float w2, float step_size, float rbc2, float eps, float max_norm,
                                                          float* __restrict__ grad_norm, int vec_ok) {
+    __shared__ double ws[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n;
-    const float pm = live ? m[i] : 0.0f, pv = live ? v[i] : 0.0f, pp = live ? params[i] : 0.0f, pg = live ? grads[i] : 0.0f;
-    // total norm: every workgroup reads the whole gradient (36.6 KB, L2-resident) with ALL its loads in flight at once
-    // (float4, compile-time trip count); a strided scalar loop costs nine dependent L2 round trips instead of one.
-    constexpr int NV4 = (MI_PPO_NPARAMS + 3) / 4, PER_T = (NV4 + 255) / 256;
-    float4 gv[PER_T];
-#pragma unroll
-    for (int k = 0; k < PER_T; ++k) {
-        const int q = threadIdx.x + 256 * k;
-        gv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (vec_ok && 4 * q + 3 < n) gv[k] = reinterpret_cast<const float4*>(grads)[q];
-        else {  // ragged tail (and the generic-n path): scalar, bounds-checked
-            if (4 * q + 0 < n) gv[k].x = grads[4 * q + 0];
-            if (4 * q + 1 < n) gv[k].y = grads[4 * q + 1];
-            if (4 * q + 2 < n) gv[k].z = grads[4 * q + 2];
-            if (4 * q + 3 < n) gv[k].w = grads[4 * q + 3];
-        }
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < PER_T; ++k)
-        s += ((double)gv[k].x * gv[k].x + (double)gv[k].y * gv[k].y) + ((double)gv[k].z * gv[k].z + (double)gv[k].w * gv[k].w);
-    for (int k = 4 * 256 * PER_T + threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }  // n beyond the unrolled part
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    __shared__ double ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float total = (float)sqrt((ws[0] + ws[1]) + (ws[2] + ws[3]));
+    float pm = live ? m_in[i] : 0.0f, pv = live ? v_in[i] : 0.0f;
+    const float pp = live ? p_in[i] : 0.0f, pg = live ? grads[i] : 0.0f;
+    const float total = block_grad_norm(grads, n, vec_ok, ws);
     float coef = max_norm / (total + 1e-6f);
     coef = coef > 1.0f ? 1.0f : coef;
     if (grad_norm && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm = total;
     if (live) {
-        const float g = pg * coef;
-        const float mi = pm + w1 * (g - pm);
-        const float vi = pv * b2 + w2 * (g * g);
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        m[i] = mi; v[i] = vi;
-        params[i] = pp + (-step_size) * (mi / denom);
+        const float np = mi_adam_elem(pp, pg * coef, pm, pv, w1, b2, w2, step_size, rbc2, eps);
+        m_out[i] = pm; v_out[i] = pv;
+        p_out[i] = np;
     }
+}
+
+struct adam_consts_t { float w1, b2, w2, step_size, rbc2, eps; };
+static adam_consts_t adam_consts(int64_t step, double lr, double beta1, double beta2, double eps) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    adam_consts_t k;
+    k.w1 = (float)(1.0 - beta1); k.b2 = (float)beta2; k.w2 = (float)(1.0 - beta2);
+    k.step_size = (float)(lr / bc1); k.rbc2 = (float)(1.0 / sqrt(bc2)); k.eps = (float)eps;
+    return k;
+}
+
+static int clip_adam_launch(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out, const float* grads, int n,
+                            const adam_consts_t& k, float max_norm, float* grad_norm, hipStream_t s) {
+    mi_prof_scope prof(MI_PROF_CLIP_ADAM, s);
+    clip_adam_kernel<<<(n + 255) / 256, 256, 0, s>>>(p_in, m_in, v_in, p_out, m_out, v_out, grads, n, k.w1, k.b2, k.w2, k.step_size, k.rbc2, k.eps, max_norm,
+                                                    grad_norm, ((uintptr_t)grads & 15) == 0 ? 1 : 0);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
 }
 
 extern "C" int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr,
                             double beta1, double beta2, double eps, float max_norm, float* grad_norm, void* stream) {
     MI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "NULL pointer");
     MI_CHECK_ARG(n > 0 && step >= 1, "n must be positive and step 1-based");
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    mi_prof_scope prof(MI_PROF_CLIP_ADAM, (hipStream_t)stream);
-    clip_adam_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
-                                                          (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps,
-                                                          max_norm, grad_norm, ((uintptr_t)grads & 15) == 0 ? 1 : 0);
-    MI_LAUNCH_CHECK();
-    return MI_OK;
+    return clip_adam_launch(params, exp_avg, exp_avg_sq, params, exp_avg, exp_avg_sq, grads, n, adam_consts(step, lr, beta1, beta2, eps), max_norm, grad_norm,
+                            (hipStream_t)stream);
 }
 
 // =====================================================================================================
@@ -884,6 +1054,9 @@ extern "C" int mi_ppo_perms_and_stats(uint64_t seed, int update_index, int epoch
     return MI_OK;
 }
 
+// One optimizer-state set {params, exp_avg, exp_avg_sq}
+struct opt_set_t { float* p; float* m; float* v; };
+
 extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* stream) {
     MI_CHECK_ARG(handle && b && hp, "NULL pointer");
     MI_CHECK_ARG(hp->T > 0 && hp->n_minibatch > 0 && hp->update_epochs > 0, "bad hyper-parameters");
@@ -896,21 +1069,13 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
                                      b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns,
                                      fused ? b->adv_sums : nullptr, 3 * hp->n_minibatch * hp->update_epochs, stream);
     if (rc) return rc;
-    int64_t step = hp->opt_step;
     hipStream_t s = (hipStream_t)stream;
-    // all epochs' permutations + advantage statistics in ONE launch (they depend on the advantages and the keys only): epochs 0..E-2 land in the
-    // free upper half of the workspace, the last one in b->perm
-    int32_t* perm_of[PS_MAX_EPOCHS] = {nullptr};
-    const bool all_at_once = fused && hp->update_epochs <= PS_MAX_EPOCHS &&
-                             (size_t)(hp->update_epochs - 1) * B * sizeof(int32_t) <= (size_t)(GRAD_MAX_BLOCKS / 2) * PART_STRIDE * sizeof(float);
-    if (all_at_once) {
+    // every epoch's permutation + advantage statistics (they depend on the advantages and the keys only): b->perm is [update_epochs, T*N]
+    if (fused && hp->update_epochs <= PS_MAX_EPOCHS) {
         ps_epochs_t pe;
         for (int ep = 0; ep < hp->update_epochs; ++ep) {
             const uint64_t key = mi_perm_key(e->seed, (uint64_t)hp->update_index, (uint64_t)ep);
-            pe.k0[ep] = (uint32_t)key; pe.k1[ep] = (uint32_t)(key >> 32);
-            perm_of[ep] = ep == hp->update_epochs - 1 ? b->perm
-                                                       : reinterpret_cast<int32_t*>(reinterpret_cast<float*>(b->workspace) + (size_t)(GRAD_MAX_BLOCKS / 2) * PART_STRIDE) + (size_t)ep * B;
-            pe.out[ep] = perm_of[ep];
+            pe.k0[ep] = (uint32_t)key; pe.k1[ep] = (uint32_t)(key >> 32); pe.out[ep] = b->perm + (size_t)ep * B;
         }
         uint32_t bits = 1;
         while ((1u << bits) < (uint32_t)B) ++bits;
@@ -919,39 +1084,45 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
         perm_stats_kernel<<<dim3((B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, hp->update_epochs), 256, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, pe, mb, hp->n_minibatch,
                                                                                                        b->advantages, b->adv_sums);
         MI_LAUNCH_CHECK();
+    } else {
+        rc = mi_ppo_perms_and_stats(e->seed, hp->update_index, hp->update_epochs, B, hp->n_minibatch, b->advantages, b->perm, b->adv_sums, stream);
+        if (rc) return rc;
     }
+    // Optimizer steps.  Step k's clip + Adam is applied by the weight staging of gradient launch k+1 (grad_pending_t), reading one
+    // state set and writing another: caller's tensors -> spare X -> spare Y -> X ... ; the last step is a launch of its own that
+    // lands the state back in the caller's tensors.  2 launches per optimizer step + 1.
+    float* spare = reinterpret_cast<float*>(b->workspace) + (size_t)(GRAD_MAX_BLOCKS - GRAD_SPARE_SLABS) * PART_STRIDE;
+    const opt_set_t caller = {b->params, b->exp_avg, b->exp_avg_sq};
+    const opt_set_t sets[2] = {{spare, spare + STATE_STRIDE, spare + 2 * STATE_STRIDE},
+                               {spare + 3 * STATE_STRIDE, spare + 4 * STATE_STRIDE, spare + 5 * STATE_STRIDE}};
+    opt_set_t cur = caller;
+    int64_t step = hp->opt_step;   // steps applied or owed so far
+    bool owed = false;
+    int flip = 0;
     for (int ep = 0; ep < hp->update_epochs; ++ep) {
-        const uint64_t key = mi_perm_key(e->seed, (uint64_t)hp->update_index, (uint64_t)ep);
-        double* sums = b->adv_sums + (size_t)3 * hp->n_minibatch * ep;
-        const int32_t* perm = all_at_once ? perm_of[ep] : b->perm;
-        if (all_at_once) {
-        } else if (fused) {
-            ps_epochs_t pe;
-            pe.k0[0] = (uint32_t)key; pe.k1[0] = (uint32_t)(key >> 32); pe.out[0] = b->perm;
-            uint32_t bits = 1;
-            while ((1u << bits) < (uint32_t)B) ++bits;
-            if (bits < 2) bits = 2;
-            mi_prof_scope prof(MI_PROF_STATS, s);
-            perm_stats_kernel<<<dim3((B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, 1), 256, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, pe, mb, hp->n_minibatch, b->advantages, sums);
-            MI_LAUNCH_CHECK();
-        } else {
-            rc = mi_make_perm((uint32_t)B, key, b->perm, stream);
-            if (rc) return rc;
-            rc = mi_adv_stats(b->advantages, b->perm, mb, hp->n_minibatch, sums, stream);
-            if (rc) return rc;
-        }
+        const double* sums = b->adv_sums + (size_t)3 * hp->n_minibatch * ep;
+        const int32_t* perm = b->perm + (size_t)ep * B;
         for (int k = 0; k < hp->n_minibatch; ++k) {
-            rc = mi_ppo_minibatch_grad(b->params, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
-                                       perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef,
-                                       1.0 / mb, b->workspace, b->grads, b->loss_terms, stream);
+            grad_pending_t pend = no_pending();
+            if (owed) {
+                const adam_consts_t c = adam_consts(step, hp->lr, hp->beta1, hp->beta2, hp->eps);
+                const opt_set_t out = sets[flip];
+                flip ^= 1;
+                pend.grads = b->grads; pend.p_in = cur.p; pend.m_in = cur.m; pend.v_in = cur.v; pend.p_out = out.p; pend.m_out = out.m; pend.v_out = out.v;
+                pend.grad_norm = b->grad_norm; pend.w1 = c.w1; pend.b2 = c.b2; pend.w2 = c.w2; pend.step_size = c.step_size; pend.rbc2 = c.rbc2; pend.eps = c.eps;
+                pend.max_norm = hp->max_grad_norm; pend.vec_ok = ((uintptr_t)b->grads & 15) == 0 ? 1 : 0;
+                cur = out;   // what this launch trains on and what the next owed step starts from
+            }
+            rc = ppo_grad_launch(owed ? nullptr : cur.p, pend, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
+                                 perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef, 1.0 / mb, b->workspace, b->grads,
+                                 b->loss_terms, s);
             if (rc) return rc;
             step += 1;
-            rc = mi_clip_adam(b->params, b->grads, b->exp_avg, b->exp_avg_sq, NPARAMS, step, hp->lr, hp->beta1, hp->beta2, hp->eps,
-                              hp->max_grad_norm, b->grad_norm, stream);
-            if (rc) return rc;
+            owed = true;
         }
     }
-    return MI_OK;
+    return clip_adam_launch(cur.p, cur.m, cur.v, caller.p, caller.m, caller.v, b->grads, NPARAMS, adam_consts(step, hp->lr, hp->beta1, hp->beta2, hp->eps),
+                            hp->max_grad_norm, b->grad_norm, s);
 }
 
 // =====================================================================================================

@@ -151,7 +151,11 @@ int mi_ppo_perms_and_stats(uint64_t seed, int update_index, int epochs, int n_ro
                            double* sums_all, void* stream);
 
 /* ---- one whole outer update (ppo.py:105-192) enqueued back to back on `stream`, production RNG,
- * single rank (no collective).  All pointers dev.  perm: i32 [T*N]; adv_sums: f64 [update_epochs*n_minibatch*3]. */
+ * single rank (no collective).  All pointers dev.  perm: i32 [update_epochs, T*N] (every epoch's permutation is drawn before the first
+ * optimizer step); adv_sums: f64 [update_epochs*n_minibatch*3].  Launch sequence: rollout+GAE, permutations+statistics, then per optimizer
+ * step {gradient, slab sum} — the clip + Adam of step k rides on the weight staging of gradient launch k+1 (the stepped state ping-pongs
+ * between two spare sets kept in the last 16 slabs of `workspace`) — and one clip + Adam launch for the last step, which lands the state
+ * back in params / exp_avg / exp_avg_sq.  grads / loss_terms / grad_norm hold the LAST minibatch's values on return. */
 typedef struct {
     float* params; float* exp_avg; float* exp_avg_sq; float* grads; float* loss_terms; float* grad_norm;
     float* obs_cur; float* observations; float* values; int64_t* actions; float* log_probs; float* rewards;
