@@ -12,8 +12,11 @@ updates bracketed by barrier + torch.cuda.synchronize(); MAX over ranks; rank 0 
   roofline   = the dominant kernel (grad_kernel: f32 MFMA bound): algorithmic FLOPs per launch / its average launch
                duration, measured live over the timed region with HIP events on the launch stream (mi_prof_*).
   cpu_baseline = the CPU oracle (a C port of the reference loop, OpenMP over envs / rows) on this box's host cores,
-               rank 0 and N = 1 only, on a bounded sample of the SAME workload.
+               rank 0 and N = 1 only, on a bounded sample of the SAME workload; cpu_baseline_n1 = the same oracle at the
+               reference's own shape (1 env, 1 thread), the like-for-like stand-in for the unmodified ppo.py.
 Inputs are resident in HBM when the timed region starts (storage, parameters and env state never leave the device).
+At N = 1 the same JSON line also carries `config3_dqn` and `config4_sac`: BASELINE.json configs[2] / [3] run AFTER (outside)
+the PPO timed region, each with its own ms_per_step, dominant-kernel roofline (HIP events) and oracle CPU baseline.
 """
 import argparse
 import json
@@ -32,6 +35,7 @@ FLOPS_PER_ROW_UPDATE = 3 * 2 * MACS_FWD_BOTH_NETS  # forward + ~2x backward, per
 BYTES_PER_ENV_STEP = 292                         # rollout 40 + env state 72 + GAE 20 + 4 epochs x 40 gathered
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
+REFERENCE_PY_STEPS_PER_S = 886.0                 # the unmodified reference ppo.py, torch CPU, 1 thread, build container
 
 
 def usable_cpus():
@@ -69,12 +73,222 @@ def cpu_baseline(params, min_seconds=10.0):
             "sample": "%d outer update(s) of the same 4096-env x 128-step workload (%.1f s) in the C oracle, OpenMP over envs/rows" % (k, dt)}
 
 
+def cpu_baseline_n1(params, min_seconds=3.0):
+    """The oracle at the REFERENCE's shape: 1 env, 1 thread, 128-step rollouts, 4 x 4 minibatches of 32 rows (ppo.py:62-76)."""
+    from oracle import cpu_ref as R
+
+    base = R.PPOBaseline(params, 1, T=T, seed=1, threads=1)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        base.run_update()
+        k += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            break
+    R.lib().ref_set_num_threads(usable_cpus())
+    v = k * T / dt
+    return {"value": round(v, 1), "unit": "env-steps/s", "updates_per_s": round(k / dt, 2), "cores": 1, "kind": "port",
+            "sample": "%d outer updates of ppo.py's own shape (1 env x 128 steps, minibatches of 32) in %.1f s, C oracle, 1 thread" % (k, dt),
+            "reference_python_env_steps_per_s": REFERENCE_PY_STEPS_PER_S,
+            "ratio_to_reference_python": round(v / REFERENCE_PY_STEPS_PER_S, 1),
+            "note": "the unmodified reference ppo.py (torch CPU, 1 thread) ran 886 env-steps/s / 6.9 updates/s in the build container "
+                    "(SURVEY.md §6); it cannot travel to the GPU box, the oracle at its shape stands in for it"}
+
+
+# ---- BASELINE.json configs[2] and [3]: secondary workloads, reported as extra keys of the same line (N = 1 only) ----------------------
+DQN_MACS_FWD = 4 * 120 + 120 * 84 + 84 * 2          # 10,728 per Q-network forward
+SAC_MACS_NET = 4 * 256 + 256 * 256 + 256            # 66,816: critic (3+1 -> 256 -> 256 -> 1); the actor (3 -> 256 -> 256 -> 2 heads) has the same count
+
+
+def bench_dqn(dev, iters=300, cpu_seconds=3.0):
+    """dqn.py CartPole-v1, 4096 envs, 256-slot ring (1,048,576 transitions on HBM), batch 128, train every 10 steps (dqn.py:84-137).
+    One step = one loop iteration: 10 env steps of every env (one launch) + sample + TD update (+ target sync every 500 steps)."""
+    import torch
+
+    import deep_rl_amd as D
+    from deep_rl_amd import _native as N
+
+    envs, slots, batch = 4096, 256, 128
+    env = D.make("CartPole-v1", num_envs=envs, device=dev, seed=1)
+    torch.manual_seed(1)
+    q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
+    params0 = q.flat.cpu().numpy().copy()
+    eng = D.DQNEngine(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=slots, batch_size=batch, learning_starts=100, total_timesteps=10 * (iters + 160),
+                      max_episodes_logged=0)
+    eng.reset()
+
+    def it():
+        eng.act(10); eng.train_step()
+        if eng.global_step % 500 == 0:
+            eng.sync_target()
+    for _ in range(50):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        it()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # kernel durations from a separate, shorter pass: the event pairs around every launch would otherwise sit inside the timed loop
+    N.prof_begin(4 * 100 + 8, tags=["dqn_act", "dqn_td", "dqn_reduce"])
+    for _ in range(100):
+        it()
+    prof = N.prof_end()
+    us = {k: 1e3 * v[0] / max(v[1], 1) for k, v in prof.items() if v[1]}
+    # algorithmic FLOPs: acting = one forward per env-step (the greedy branch; exploring rows skip it, so this is an upper bound of the
+    # work and the fraction below an upper bound too); TD = target forward + online forward + ~2x backward per batch row
+    act_flops = 2 * DQN_MACS_FWD * envs * 10
+    td_flops = 2 * DQN_MACS_FWD * 4 * batch
+    out = {"workload": "dqn.py CartPole-v1, %d envs, %d-slot ring (%d transitions on HBM), batch %d, train every 10 steps" % (envs, slots, envs * slots, batch),
+           "value": round(iters * 10 * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(iters / dt, 1), "ms_per_step": round(1e3 * dt / iters, 5),
+           "step": "10 env steps of every env + 1 TD update", "dtype": "f32", "kernel_us": {k: round(v, 2) for k, v in us.items()},
+           "roofline": {"bound": "mfma", "kernel": "dqn_act_kernel", "achieved": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "flops_per_launch": act_flops, "avg_launch_us": round(us["dqn_act"], 2),
+                        "note": "10 dependent env steps per launch: 16 envs per workgroup, latency-bound chain (forward, argmax, fp64 CartPole step)"},
+           "roofline_td": {"bound": "latency (f32 VALU peak quoted)", "kernel": "dqn_td_kernel", "achieved": round(td_flops / (us["dqn_td"] * 1e-6) / 1e12, 4),
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(td_flops / (us["dqn_td"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),
+                           "flops_per_launch": td_flops, "avg_launch_us": round(us["dqn_td"], 2),
+                           "note": "the reference's batch of 128 rows is 16 workgroups on a 256-CU chip: the launch is a fixed ~15 us latency, not a throughput"},
+           "loss": float(eng.loss.item())}
+    out["cpu_baseline"] = cpu_baseline_dqn(params0, envs, slots, batch, cpu_seconds)
+    return out
+
+
+def cpu_baseline_dqn(params0, envs, slots, batch, min_seconds):
+    """The same loop iteration from the oracle's primitives (ref_dqn_act_steps, ref_dqn_sample, ref_dqn_td_grads, Adam), OpenMP over envs / rows."""
+    import numpy as np
+
+    from oracle import cpu_ref as R
+
+    cores = usable_cpus()
+    R.lib().ref_set_num_threads(cores)
+    env = R.VecCartPole(envs, seed=1)
+    st = R.ReplayStorage(slots, envs)
+    obs = env.reset()
+    p = params0.copy(); tp = params0.copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    gs, k = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        R.dqn_act_steps(env, p, st, obs, 10, gs, learning_starts=100, total_timesteps=10 ** 6)
+        gs += 10
+        idx = R.dqn_sample(1, k, min(gs, slots) * envs, batch)
+        g, _ = R.dqn_td_grads(p, tp, st, idx)
+        k += 1
+        R.adam_step(p, g, m, v, k, 2.5e-4, eps=1e-8)
+        if gs % 500 == 0:
+            tp[...] = p
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            break
+    return {"value": round(gs * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(k / dt, 2), "cores": cores, "kind": "port",
+            "sample": "%d loop iterations (10 steps x %d envs + 1 update each) in %.1f s, C oracle, OpenMP over envs / rows" % (k, envs, dt)}
+
+
+def bench_sac(dev, iters=400, cpu_seconds=3.0):
+    """sac.py on Pendulum-v1, 2048 envs, 512-slot ring, batch 256 (sac.py:137-217): one step = one env step of every env + one critic
+    update (+ polyak) + one actor + one alpha update (the reference does two of each every 2nd step)."""
+    import torch
+
+    import deep_rl_amd as D
+    from deep_rl_amd import _native as N
+
+    envs, slots, batch = 2048, 512, 256
+    env = D.make("Pendulum-v1", num_envs=envs, device=dev, seed=1)
+    torch.manual_seed(1)
+    actor = D.Actor(env)
+    qs = [D.SoftQNetwork(env) for _ in range(4)]
+    qs[2].load_state_dict(qs[0].state_dict()); qs[3].load_state_dict(qs[1].state_dict())
+    eng = D.SACEngine(env, actor, *qs, slots=slots, batch_size=batch, learning_starts=20, max_episodes_logged=0)
+    a0, q0 = actor.flat.cpu().numpy().copy(), eng.q_flat.cpu().numpy().copy()
+    eng.reset()
+
+    def it():
+        eng.act()
+        if eng.global_step >= eng.learning_starts:
+            eng.train_step()
+    for _ in range(60):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        it()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tags = ["sac_act", "sac_critic", "sac_actor", "sac_gemm", "sac_assemble", "sac_logp"]
+    N.prof_begin(12 * 100 + 16, tags=tags)   # separate pass: see bench_dqn
+    for _ in range(100):
+        it()
+    prof = N.prof_end()
+    us = {k: 1e3 * v[0] / max(v[1], 1) for k, v in prof.items() if v[1]}
+    per_it = {k: round(1e3 * v[0] / 100, 2) for k, v in prof.items() if v[1]}
+    # sac_critic_kernel per batch row: actor forward on the next observation, two target-Q forwards, two critic forwards + ~2x backward
+    critic_flops = 2 * SAC_MACS_NET * (1 + 2 + 2 * 3) * batch
+    out = {"workload": "sac.py Pendulum-v1, %d envs, %d-slot ring (%d transitions on HBM), batch %d, 1 critic + 1 actor + 1 alpha update per time step" % (
+               envs, slots, envs * slots, batch),
+           "value": round(iters * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(iters / dt, 1), "ms_per_step": round(1e3 * dt / iters, 5),
+           "step": "1 env step of every env + critic update + polyak + actor update + alpha update", "dtype": "f32",
+           "kernel_us": {k: round(v, 2) for k, v in us.items()}, "kernel_us_per_step": per_it,
+           "roofline": {"bound": "mfma", "kernel": "sac_critic_kernel", "achieved": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12, 3),
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": None, "flops_per_launch": critic_flops, "avg_launch_us": round(us["sac_critic"], 2),
+                        "note": "batch 256 = 16 row groups x 2 workgroups on a 256-CU chip: 7 dependent 256x256 passes, latency-bound (DESIGN.md §7c)"},
+           "alpha": float(eng.alpha), "q_losses": [round(float(x), 5) for x in eng.q_losses.tolist()]}
+    out["cpu_baseline"] = cpu_baseline_sac(a0, q0, envs, slots, batch, cpu_seconds)
+    return out
+
+
+def cpu_baseline_sac(actor0, q0, envs, slots, batch, min_seconds):
+    """The same loop iteration from the oracle's primitives (Pendulum step, actor sample, critic / actor / alpha gradients, Adam, polyak)."""
+    import numpy as np
+
+    from oracle import cpu_ref as R
+
+    cores = usable_cpus()
+    R.lib().ref_set_num_threads(cores)
+    rng = np.random.default_rng(1)
+    env = R.VecPendulum(envs, seed=1)
+    st = R.SacStorage(slots, envs)
+    obs = env.reset()
+    a_p = actor0.copy(); q_p = q0.copy(); qt_p = q0.copy()
+    am, av = np.zeros_like(a_p), np.zeros_like(a_p)
+    qm, qv = np.zeros_like(q_p), np.zeros_like(q_p)
+    la = np.zeros(1, np.float32); lm = np.zeros(1, np.float32); lv = np.zeros(1, np.float32)
+    gs, k = 0, 0
+    st.observations[0] = obs
+    t0 = time.perf_counter()
+    while True:
+        act, _ = R.sac_actor_sample(a_p, obs, rng.standard_normal(envs).astype(np.float32))
+        obs, rew, done, _, _ = env.step(act)
+        st.actions[gs % slots] = act
+        gs += 1
+        st.observations[gs % slots] = obs; st.rewards[gs % slots] = rew; st.terminated[gs % slots] = 0
+        if gs >= 20:
+            alpha = float(np.exp(la[0]))
+            idx = R.dqn_sample(1, k, min(gs, slots) * envs, batch)
+            g, _ = R.sac_critic_grads(q_p, qt_p, a_p, st, idx, rng.standard_normal(batch).astype(np.float32), alpha)
+            k += 1
+            R.adam_step(q_p, g, qm, qv, k, 1e-3, eps=1e-8)
+            ga, _, _ = R.sac_actor_grads(a_p, q_p, st, idx, rng.standard_normal(batch).astype(np.float32), alpha)
+            R.adam_step(a_p, ga, am, av, k, 3e-4, eps=1e-8)
+            mlp = R.sac_mean_logp(a_p, st, idx, rng.standard_normal(batch).astype(np.float32))
+            R.adam_step(la, np.array([-(mlp - 1.0)], np.float32), lm, lv, k, 1e-3, eps=1e-8)
+            R.polyak(qt_p, q_p)
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            break
+    return {"value": round(gs * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(k / dt, 2), "cores": cores, "kind": "port",
+            "sample": "%d loop iterations (1 step x %d envs + critic / actor / alpha update each) in %.1f s, C oracle, OpenMP over envs / rows" % (gs, envs, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the config-3 (DQN) / config-4 (SAC) extra keys")
     args = ap.parse_args()
 
     import torch
@@ -143,11 +357,13 @@ def main():
         g_ms, g_n = prof["grad"]
         flops_per_launch = FLOPS_PER_ROW_UPDATE * mb
         ach = flops_per_launch / (g_ms / max(g_n, 1) * 1e-3) / 1e12 if g_n else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("grad_kernel", {}).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                traffic = j.get("grad_kernel", {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/latest_pmc.json (static: separate rocprofv3 --pmc passes of this command, build %s; not measured in this run)" % j.get("build", "?")
             except Exception:
                 traffic = None
         steps_per_s = env_steps / dt
@@ -161,17 +377,23 @@ def main():
                                    "2x64-tanh actor+critic (9155 params), on-device env.step + GAE + fwd/bwd + clip + Adam" % (ENVS_PER_GPU, T, mb),
                        "envs_per_gpu": ENVS_PER_GPU, "num_steps": T, "minibatch_rows": mb, "parallelism": "env-sharded x%d, grad all-reduce" % world},
             "roofline": {"bound": "mfma", "kernel": "grad_kernel", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_launch, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "launches": g_n},
             "hbm_roofline": {"algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                              "achieved_GBps_per_gpu": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9, 2), "peak_GBps": PEAK_HBM_GBS,
                              "frac": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9 / PEAK_HBM_GBS, 6)},
-            "kernel_ms_per_update": {k: round(v[0] / 3, 4) for k, v in breakdown.items()},
+            "kernel_ms_per_update": {k: round(v[0] / 3, 4) for k, v in breakdown.items() if v[1]},
             "last_rollout": {"episodes": ep[0], "mean_return": round(ep[1] / max(ep[0], 1), 2), "max_return": ep[2]},
             "params_finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params0, float(os.environ.get("MIRL_CPU_BASELINE_SECONDS", "10")))  # bounded sample (default 10 s)
+            out["cpu_baseline_n1"] = cpu_baseline_n1(params0)
+        if world == 1 and not args.headline_only:
+            cs = 0.0 if args.no_cpu_baseline else 3.0
+            del eng, env, agent, opt
+            out["config3_dqn"] = bench_dqn(dev, cpu_seconds=cs)
+            out["config4_sac"] = bench_sac(dev, cpu_seconds=cs)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -63,6 +63,12 @@ SIGNATURES = {
     "mi_clip_adam": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _D, _D, _D, _D, _F, _VP, _VP]),
     "mi_explained_var": (_I, [_VP, _VP, _SZ, _VP, _VP]),
     "mi_ppo_update": (_I, [_VP, C.POINTER(PPOBuffers), C.POINTER(PPOHparams), _VP]),
+    "mi_ppo_update_sharded": (_I, [_VP, C.POINTER(PPOBuffers), C.POINTER(PPOHparams), _VP, _VP]),
+    "mi_comm_unique_id": (_I, [_VP]),
+    "mi_comm_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
+    "mi_comm_destroy": (_I, [_VP]),
+    "mi_comm_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "mi_comm_allreduce_sum": (_I, [_VP, _VP, _SZ, _I, _VP]),
     "mi_dqn_forward": (_I, [_VP, _VP, _I, _VP, _VP]),
     "mi_dqn_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP]),
     "mi_dqn_sample": (_I, [_U64, _U64, _I64, _I, _VP, _VP]),
@@ -145,7 +151,8 @@ def stream_ptr(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-PROF_TAGS = ("rollout", "gae", "grad", "reduce", "clip_adam", "stats")
+PROF_TAGS = ("rollout", "gae", "grad", "reduce", "clip_adam", "stats", "dqn_act", "dqn_td", "dqn_reduce", "per",
+             "sac_act", "sac_critic", "sac_actor", "sac_gemm", "sac_assemble", "sac_logp")   # == enum MI_PROF_* of include/mi_rl.h
 
 
 def prof_begin(max_launches, tags=None):

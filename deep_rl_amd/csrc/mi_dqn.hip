@@ -255,6 +255,7 @@ extern "C" int mi_dqn_act_steps(void* handle, const float* params, int n_steps, 
         const double ev = slope * (double)(global_step + k) + start_e;
         tab.v[k] = (float)(ev > end_e ? ev : end_e);
     }
+    mi_prof_scope prof(MI_PROF_DQN_ACT, s);
     dqn_act_kernel<<<(e->n + DA_ENVS - 1) / DA_ENVS, 64 * DA_WAVES, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab,
                                                   obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes,
                                                   episode_stats, max_ep);
@@ -489,11 +490,17 @@ static int dqn_td_impl(const float* params, const float* target_params, const fl
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (batch + TD_R - 1) / TD_R;
-    dqn_td_kernel<<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
-                                         (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update, (uint64_t)sample_upper,
-                                         (int64_t*)idx);
+    {
+        mi_prof_scope prof(MI_PROF_DQN_TD, s);
+        dqn_td_kernel<<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
+                                             (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update, (uint64_t)sample_upper,
+                                             (int64_t*)idx);
+    }
     MI_LAUNCH_CHECK();
-    dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
+    {
+        mi_prof_scope prof(MI_PROF_DQN_REDUCE, s);
+        dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
+    }
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -774,6 +781,7 @@ extern "C" int mi_per_sample(uint64_t seed, uint64_t update_index, const float* 
     MI_CHECK_ARG(priorities && workspace && idx && weights && n_valid > 0 && n_valid <= capacity && batch > 0, "bad arguments");
     MI_CHECK_ARG(capacity <= (int64_t)PER_MAX_L1 * PER_CHUNK * PER_CHUNK, "prioritized sampler: capacity above 4,194,304 entries needs a fourth level");
     const per_ws_t w = per_ws(workspace, capacity);
+    mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);   // the sums launches and the sampler as one bracket
     const int rc = per_launch_sums(priorities, n_valid, alpha, w, (hipStream_t)stream);
     if (rc) return rc;
     per_sample_kernel<<<1, 256, 0, (hipStream_t)stream>>>(seed, update_index, priorities, (long long)n_valid, w.s0, w.s1, w.totals, batch, (float)count, alpha, beta,

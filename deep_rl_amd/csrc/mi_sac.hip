@@ -489,6 +489,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
     MI_CHECK_ARG(slots >= 2 && global_step >= 0 && max_ep >= 0 && (max_ep == 0 || episodes), "bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (episode_stats) { sac_zero4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    mi_prof_scope prof(MI_PROF_SAC_ACT, s);
     sac_act_kernel<<<(e->n + SR - 1) / SR, 256, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations,
                                                        actions, rewards, terminated, forced_actions, forced_eps, forced_resets, episodes, episode_stats, max_ep);
     MI_LAUNCH_CHECK();
@@ -965,11 +966,17 @@ static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, 
 
 static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv_count, float* grads, float* out2, const sac_opt_t& opt, hipStream_t s) {
     const int nb = ws_kp(batch) / SR, nets = is_actor ? 1 : 2, split = gemm_split(batch);
-    sac_dw2_gemm_kernel<<<dim3(32 * nets, split), 256, 0, s>>>((float*)workspace, batch, is_actor ? 2 : 0, nets);
+    {
+        mi_prof_scope prof(MI_PROF_SAC_GEMM, s);
+        sac_dw2_gemm_kernel<<<dim3(32 * nets, split), 256, 0, s>>>((float*)workspace, batch, is_actor ? 2 : 0, nets);
+    }
     MI_LAUNCH_CHECK();
     const int n_small = (is_actor ? 1794 : 2 * 1793) + 2;
     const int nblk = (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK + nets * (SA_H * SA_H / 4) / 256;
-    sac_grad_reduce_kernel<<<nblk, 256, 0, s>>>((const float*)workspace, batch, nb, split, is_actor, inv_count, grads, out2, opt);
+    {
+        mi_prof_scope prof(MI_PROF_SAC_ASSEMBLE, s);
+        sac_grad_reduce_kernel<<<nblk, 256, 0, s>>>((const float*)workspace, batch, nb, split, is_actor, inv_count, grads, out2, opt);
+    }
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -979,9 +986,12 @@ static int sac_critic_impl(float* q, float* q_target, const float* actor, const 
                            uint64_t update_index, const float* alpha, float gamma, double inv_count, void* workspace, float* grads, float* losses,
                            const sac_opt_t& opt, uint64_t sample_update, int64_t sample_upper, hipStream_t s) {
     const int nrg = ws_kp(batch) / SR;
-    sac_critic_kernel<<<dim3(nrg, nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
-                                                       seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
-                                                       (int64_t*)idx);
+    {
+        mi_prof_scope prof(MI_PROF_SAC_CRITIC, s);
+        sac_critic_kernel<<<dim3(nrg, nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+                                                           seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
+                                                           (int64_t*)idx);
+    }
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, opt, s);
 }
@@ -1011,8 +1021,11 @@ extern "C" int mi_sac_critic_update(float* q, float* q_target, const float* acto
 
 static int sac_actor_impl(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                           uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out, const sac_opt_t& opt, hipStream_t s) {
-    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0,
-                                                      sac_alpha_t{});
+    {
+        mi_prof_scope prof(MI_PROF_SAC_ACTOR, s);
+        sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0,
+                                                          sac_alpha_t{});
+    }
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 1, inv_count, grads, out, opt, s);
 }
@@ -1062,7 +1075,10 @@ static sac_alpha_t sac_make_alpha(float target_entropy, float inv_count, float* 
 
 static int sac_launch_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                            uint64_t update_index, void* workspace, const sac_alpha_t& al, hipStream_t s) {
-    sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al);
+    {
+        mi_prof_scope prof(MI_PROF_SAC_LOGP, s);
+        sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al);
+    }
     MI_LAUNCH_CHECK();
     return MI_OK;
 }

@@ -1057,7 +1057,23 @@ extern "C" int mi_ppo_perms_and_stats(uint64_t seed, int update_index, int epoch
 // One optimizer-state set {params, exp_avg, exp_avg_sq}
 struct opt_set_t { float* p; float* m; float* v; };
 
+static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* comm, int world, void* stream);
+
 extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* stream) {
+    return ppo_update_impl(handle, b, hp, nullptr, 1, stream);
+}
+
+extern "C" int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* comm, void* stream) {
+    int world = 1;
+    if (comm) {
+        int rc = mi_comm_info(comm, &world, nullptr, nullptr);
+        if (rc) return rc;
+        MI_CHECK_ARG(b && b->loss_terms == b->grads + NPARAMS, "sharded update: loss_terms must be grads + MI_PPO_NPARAMS (one buffer, one all-reduce)");
+    }
+    return ppo_update_impl(handle, b, hp, comm, world, stream);
+}
+
+static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* comm, int world, void* stream) {
     MI_CHECK_ARG(handle && b && hp, "NULL pointer");
     MI_CHECK_ARG(hp->T > 0 && hp->n_minibatch > 0 && hp->update_epochs > 0, "bad hyper-parameters");
     mi_env* e = (mi_env*)handle;
@@ -1088,6 +1104,10 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
         rc = mi_ppo_perms_and_stats(e->seed, hp->update_index, hp->update_epochs, B, hp->n_minibatch, b->advantages, b->perm, b->adv_sums, stream);
         if (rc) return rc;
     }
+    if (comm) {   // global advantage mean / std (ppo.py:169 over the union minibatch): one SUM all-reduce of every epoch's local sums
+        rc = mi_comm_allreduce_impl(comm, b->adv_sums, (size_t)3 * hp->n_minibatch * hp->update_epochs, 1, s);
+        if (rc) return rc;
+    }
     // Optimizer steps.  Step k's clip + Adam is applied by the weight staging of gradient launch k+1 (grad_pending_t), reading one
     // state set and writing another: caller's tensors -> spare X -> spare Y -> X ... ; the last step is a launch of its own that
     // lands the state back in the caller's tensors.  2 launches per optimizer step + 1.
@@ -1114,9 +1134,13 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
                 cur = out;   // what this launch trains on and what the next owed step starts from
             }
             rc = ppo_grad_launch(owed ? nullptr : cur.p, pend, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
-                                 perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef, 1.0 / mb, b->workspace, b->grads,
+                                 perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef, 1.0 / ((double)mb * world), b->workspace, b->grads,
                                  b->loss_terms, s);
             if (rc) return rc;
+            if (comm) {   // gradient shares (already scaled by 1/(world*mb)) + the 4 loss-term shares: one SUM all-reduce (ppo.py:189 -> :191)
+                rc = mi_comm_allreduce_impl(comm, b->grads, (size_t)NPARAMS + 4, 0, s);
+                if (rc) return rc;
+            }
             step += 1;
             owed = true;
         }

@@ -6,11 +6,22 @@ data-path collective besides these:
   * advantage statistics {sum, sum of squares, count} per minibatch of every epoch, once per update  -> global mean / unbiased std (ppo.py:169)
   * the flat gradient (+ 4 loss terms), each rank's share already scaled by 1/(world*mb) (ppo.py:189-192)
 Messages are <= 36.6 KB: latency-bound, one fused buffer per collective, in-stream, no bucketing.
+
+Two carriers: (1) libmirl's own RCCL communicator (`native_comm`, csrc/mi_comm.hip, direct rccl.h) — the production path: the whole
+sharded update is ONE C call (mi_ppo_update_sharded) with the collectives enqueued between its launches; (2) `torch.distributed`
+(`allreduce_sum_`) — the host-sequenced path, kept for gloo (CPU tests, two ranks on one GPU) and as the A/B reference.
+Diagnostics on a one-GPU box: MIRL_FORCE_PG=1 makes a single process join a (world_size 1) process group so that RCCL really runs;
+MIRL_FORCE_COLLECTIVES=1 makes `allreduce_sum_` issue its collective even at world_size 1.
 """
 import os
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+_FORCE_PG = os.environ.get("MIRL_FORCE_PG", "0") == "1"
+_FORCE_COLLECTIVES = os.environ.get("MIRL_FORCE_COLLECTIVES", "0") == "1"
 
 
 def init_from_env(backend=None):
@@ -18,7 +29,7 @@ def init_from_env(backend=None):
     Returns (rank, world_size, local_rank); a single process needs no process group."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE_PG) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
@@ -39,9 +50,41 @@ def rank(group=None):
 
 def allreduce_sum_(t, group=None):
     """In-place SUM all-reduce on the tensor's device/stream; no-op for a single process."""
-    if world_size(group) > 1:
+    if world_size(group) > 1 or (_FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+_native_comms = {}
+
+
+def native_comm(group=None):
+    """libmirl's RCCL communicator for `group` (created collectively on first use) or None when there is no process group or its
+    backend is not nccl (gloo runs keep the host-sequenced path).  Rank 0 draws the ncclUniqueId, the group broadcasts it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+        return None
+    key = id(group) if group is not None else 0
+    if key not in _native_comms:
+        from . import _native as N
+
+        ident = (C.c_char * 128)()
+        if dist.get_rank(group) == 0:
+            N.check(N.lib().mi_comm_unique_id(ident), "mi_comm_unique_id")
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident.raw = box[0]
+        h = C.c_void_p()
+        N.check(N.lib().mi_comm_create(ident, dist.get_world_size(group), dist.get_rank(group), C.byref(h)), "mi_comm_create")
+        _native_comms[key] = h
+    return _native_comms[key]
+
+
+def destroy_native_comms():
+    from . import _native as N
+
+    for h in _native_comms.values():
+        N.lib().mi_comm_destroy(h)
+    _native_comms.clear()
 
 
 def global_adv_mean_std(sums):

@@ -7,8 +7,10 @@ sequences launches and (for world_size > 1) the two tiny all-reduces.
 
 Multi-GPU: envs shard across ranks (rank r owns global envs [r*N, (r+1)*N)); parameters and
 Adam state are replicated.  Per update one all-reduce(SUM) of the (epochs, n_minibatch, 3) advantage statistics, per
-optimizer step one all-reduce(SUM) of the flat 9,155-float gradient (already scaled by 1/(world*mb));
-clip + Adam then run identically on every rank.  Minibatch permutations are per-rank-local.
+optimizer step one all-reduce(SUM) of the flat 9,155-float gradient + 4 loss terms (already scaled by 1/(world*mb)):
+17 collectives per update; clip + Adam then run identically on every rank.  Minibatch permutations are per-rank-local.
+With an NCCL process group the whole sharded update is ONE C call (mi_ppo_update_sharded: RCCL all-reduces enqueued
+in-stream between the launches, no Python in between); other backends (gloo) walk the same launches from here.
 """
 import ctypes as C
 import os
@@ -21,6 +23,8 @@ from . import dist as D
 
 # diagnostics: MIRL_PPO_SHARDED_SEQUENCE=1 makes a single process walk the sharded launch sequence (all-reduces are no-ops), to measure its host cost
 _FORCE_SHARDED_SEQUENCE = os.environ.get("MIRL_PPO_SHARDED_SEQUENCE", "0") == "1"
+# MIRL_PPO_NATIVE_SHARDED=1: take the mi_ppo_update_sharded route whenever an RCCL communicator exists, even at world_size 1 (one-GPU box: RCCL really runs)
+_FORCE_NATIVE_SHARDED = os.environ.get("MIRL_PPO_NATIVE_SHARDED", "0") == "1"
 
 
 class PPOEngine:
@@ -165,16 +169,22 @@ class PPOEngine:
         if self.observation is None:
             self.reset()
         g = self.optimizer.param_groups[0]
-        if self.world_size == 1 and not _FORCE_SHARDED_SEQUENCE:
+        comm = None
+        if not _FORCE_SHARDED_SEQUENCE and (self.world_size > 1 or _FORCE_NATIVE_SHARDED):
+            comm = D.native_comm(self.pg)   # None unless the process group is NCCL (= RCCL)
+        if (self.world_size == 1 and not _FORCE_SHARDED_SEQUENCE) or comm is not None:
             o = self.optimizer
             buf = N.PPOBuffers(*[N.ptr(t) for t in (
                 self.agent.flat, o.exp_avg, o.exp_avg_sq, self.grads, self.loss_terms, o.grad_norm, self.observation,
                 self.observations, self.values, self.actions, self.log_probs, self.rewards, self.dones, self.advantages,
-                self.returns, self.perm, self._adv_sums_all, self.workspace, self.episodes, self.episode_stats)], self.max_ep)
+                self.returns, self._perm_all, self._adv_sums_all, self.workspace, self.episodes, self.episode_stats)], self.max_ep)
             hp = N.PPOHparams(self.T, self.n_minibatch, self.update_epochs, self.update_index, o.step_count, self.gamma,
                               self.gae_lambda, self.clip_coef, self.ent_coef, self.vf_coef, float(g["max_grad_norm"]),
                               float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"])
-            N.check(N.lib().mi_ppo_update(self.env.handle, C.byref(buf), C.byref(hp), self._s()), "mi_ppo_update")
+            if comm is not None:
+                N.check(N.lib().mi_ppo_update_sharded(self.env.handle, C.byref(buf), C.byref(hp), comm, self._s()), "mi_ppo_update_sharded")
+            else:
+                N.check(N.lib().mi_ppo_update(self.env.handle, C.byref(buf), C.byref(hp), self._s()), "mi_ppo_update")
             o.step_count += self.update_epochs * self.n_minibatch
         else:
             self.rollout_gae()

@@ -169,6 +169,25 @@ typedef struct {
 } mi_ppo_hparams_t;
 int mi_ppo_update(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* stream);
 
+/* ---- multi-GPU: one process per GPU, envs sharded (rank r owns global envs [r*N, (r+1)*N): env_id_base = r*N), parameters
+ * and Adam state replicated.  The exchange runs straight on RCCL (rccl.h, bound at run time), in-stream:
+ *   mi_comm_unique_id   rank 0 draws the 128-byte ncclUniqueId; the caller ships it to the other ranks (torch.distributed / file / MPI);
+ *   mi_comm_create      collective: every rank calls it with the same id (ncclCommInitRank on the CURRENT device) -> opaque handle;
+ *   mi_comm_allreduce_sum  in-place SUM all-reduce of n f32 (dtype 0) / f64 (dtype 1) elements of a device buffer on `stream`;
+ *   mi_ppo_update_sharded  mi_ppo_update with the collectives of the sharded path enqueued between its launches (replaces the host-side
+ *       sequence of ppo.py:154-192 with a gradient exchange between backward and clip_grad_norm_):  rollout+GAE, permutations + LOCAL
+ *       advantage sums, ONE all-reduce of adv_sums (f64 [update_epochs*n_minibatch*3]), then per optimizer step {gradient (share scaled by
+ *       1/(world*mb)), slab sum, ONE all-reduce of the MI_PPO_NPARAMS gradient + 4 loss terms}; clip + Adam of step k rides on gradient
+ *       launch k+1 as in mi_ppo_update and runs identically on every rank.  buf->loss_terms MUST be buf->grads + MI_PPO_NPARAMS (one
+ *       buffer, one collective).  comm == NULL or world 1: exactly mi_ppo_update. */
+#define MI_COMM_ID_BYTES 128
+int mi_comm_unique_id(void* id128);
+int mi_comm_create(const void* id128, int world_size, int rank, void** comm);
+int mi_comm_destroy(void* comm);
+int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version); /* any out pointer may be NULL */
+int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stream);
+int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* comm, void* stream);
+
 /* =====================================================================================================================
  * DQN (reference deep_rl/dqn.py; SURVEY.md §8a d1-d8, BASELINE config 3).
  * QNetwork 4 -> 120 -> 84 -> 2 ReLU; flat f32 parameters in q_network.parameters() order: W1[120,4] b1[120] W2[84,120] b2[84]
@@ -324,7 +343,11 @@ int mi_test_tanh(const float* x, float* y, int n, void* stream);
  * pool, may synchronise);
  * mi_prof_end synchronises, fills total_ms[MI_PROF_NTAGS] / count[MI_PROF_NTAGS] (host arrays) and disarms. */
 enum { MI_PROF_ROLLOUT = 0, MI_PROF_GAE = 1, MI_PROF_GRAD = 2, MI_PROF_REDUCE = 3, MI_PROF_CLIP_ADAM = 4, MI_PROF_STATS = 5,
-       MI_PROF_NTAGS = 6 };
+       /* DQN (config 3): acting launch, TD forward+backward, slab sum (+ Adam), PER sampler launches */
+       MI_PROF_DQN_ACT = 6, MI_PROF_DQN_TD = 7, MI_PROF_DQN_REDUCE = 8, MI_PROF_PER = 9,
+       /* SAC (config 4): acting launch, row-group critic / actor kernels, dW2 GEMM, assembly (+ Adam + polyak), log-prob + alpha */
+       MI_PROF_SAC_ACT = 10, MI_PROF_SAC_CRITIC = 11, MI_PROF_SAC_ACTOR = 12, MI_PROF_SAC_GEMM = 13, MI_PROF_SAC_ASSEMBLE = 14, MI_PROF_SAC_LOGP = 15,
+       MI_PROF_NTAGS = 16 };
 int mi_prof_begin(int max_launches, uint32_t tag_mask);
 int mi_prof_end(float* total_ms, int32_t* count);
 

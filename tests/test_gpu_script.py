@@ -147,6 +147,14 @@ def test_bench_contract_line():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0 and r["launches"] == 3 * 16
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert "static" in r["traffic_source"]                        # roofline.traffic comes from committed PMC passes, and the line says so
+    n1 = d["cpu_baseline_n1"]                                     # the oracle at the reference's own shape (1 env, 1 thread)
+    assert n1["cores"] == 1 and n1["value"] > 0 and n1["reference_python_env_steps_per_s"] == 886.0
+    for key, kern in (("config3_dqn", "dqn_act_kernel"), ("config4_sac", "sac_critic_kernel")):   # BASELINE configs[2] / [3] ride on the same line
+        x = d[key]
+        assert x["unit"] == "env-steps/s" and x["value"] > 0 and x["ms_per_step"] > 0 and x["dtype"] == "f32"
+        assert x["roofline"]["kernel"] == kern and 0 < x["roofline"]["frac"] < 1 and x["roofline"]["avg_launch_us"] > 0
+        assert x["cpu_baseline"]["kind"] == "port" and x["cpu_baseline"]["value"] > 0
 
 
 def test_bench_two_ranks_code_path_on_one_gpu():
