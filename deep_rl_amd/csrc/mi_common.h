@@ -317,6 +317,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 
+// sum over the 4 lane groups (lane ^ 16, lane ^ 32) on the VALU: v_permlane16_swap / v_permlane32_swap with both operands = v
+// give {rows 0,0,2,2} / {rows 1,1,3,3} and {lo,lo} / {hi,hi}; (r0 + r1) + (r2 + r3) in every lane (what the two
+// ds_bpermute-based __shfl_xor steps computed, without the LDS round trips).
+__device__ __forceinline__ float groups_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, s);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
+
 // wave-private LDS traffic: LDS executes one wave's instructions in order, so only the COMPILER must be kept
 // from moving accesses across this point.
 __device__ __forceinline__ void wave_lds_fence() {

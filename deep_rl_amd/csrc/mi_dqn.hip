@@ -96,6 +96,10 @@ struct dqn_eps_tab { float v[DQN_MAX_STEPS_PER_CALL]; };  // epsilon(global_step
 #define DA_WAVES 3
 typedef float dq_f32x4 __attribute__((ext_vector_type(4)));
 #define DQ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// FORCED (parity mode: forced_actions / forced_resets may be given) and EPLOG (per-episode list kept) are separate instantiations, not
+// run-time branches: a conditional global load or returning atomic inside the step loop makes the compiler place s_waitcnt vmcnt(0) at
+// the join, executed on EVERY step, where it waits for all of the wave's outstanding ring stores (mi_rollout.hip, rollout_q4_kernel).
+template <bool FORCED, bool EPLOG>
 __global__ void __launch_bounds__(64 * DA_WAVES)
 dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long long global_step, long long slots, long long learning_starts,
                dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
@@ -147,10 +151,12 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
     uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
     float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
     int st_cnt = 0, st_len = 0, st_max = 0, par = 0;
+    // every value loaded so far is consumed here: no load is pending when the loop starts (it would become a vmcnt wait inside the body)
+    asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr));
     for (int s = 0; s < n_steps; ++s) {
         const long long gs = global_step + s, slot = gs % slots, nslot = (gs + 1) % slots;
         int a;
-        if (forced_actions) a = (int)forced_actions[(size_t)s * N + g];
+        if (FORCED && forced_actions) a = (int)forced_actions[(size_t)s * N + g];
         else {
             uint32_t r[4];
             mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr, STREAM_EXPLORE, r);
@@ -203,14 +209,14 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
         if (d) {
             if (writer) {
                 st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
-                if (max_ep > 0 && episode_stats) {
+                if (EPLOG && max_ep > 0 && episode_stats) {
                     const int sl = atomicAdd(episode_stats + 3, 1);
                     if (sl < max_ep) episodes[sl] = mi_episode_t{g, s, epret, eplen};
                 }
             }
             epret = 0.0f; eplen = 0; elapsed = 0;
             double rs[4];
-            if (forced_resets) {
+            if (FORCED && forced_resets) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) rs[k] = forced_resets[4 * ((size_t)s * N + g) + k];
             } else {
@@ -256,9 +262,14 @@ extern "C" int mi_dqn_act_steps(void* handle, const float* params, int n_steps, 
         tab.v[k] = (float)(ev > end_e ? ev : end_e);
     }
     mi_prof_scope prof(MI_PROF_DQN_ACT, s);
-    dqn_act_kernel<<<(e->n + DA_ENVS - 1) / DA_ENVS, 64 * DA_WAVES, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab,
-                                                  obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes,
-                                                  episode_stats, max_ep);
+    const bool forced = forced_actions || forced_resets, eplog = max_ep > 0 && episode_stats;
+    const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(64 * DA_WAVES);
+#define DA_LAUNCH(F, L) dqn_act_kernel<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
+                                                                  obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes, \
+                                                                  episode_stats, max_ep)
+    if (forced) { if (eplog) DA_LAUNCH(true, true); else DA_LAUNCH(true, false); }
+    else { if (eplog) DA_LAUNCH(false, true); else DA_LAUNCH(false, false); }
+#undef DA_LAUNCH
     MI_LAUNCH_CHECK();
     return MI_OK;
 }

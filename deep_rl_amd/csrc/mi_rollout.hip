@@ -384,6 +384,322 @@ rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __
     }
 }
 
+// ---- round 2: 4 envs per actor / critic wave pair on the 16-block 4x4x1 MFMA ------------------------------------------------------
+// The 16-env workgroup above spends 2,900 of its ~4,000 cycles per step in the two nets although their MFMAs need 1,150: four waves
+// meet at a barrier every step, each evaluates half a net, and the critic sits on the critical path although nothing waits for a value
+// before the GAE scan.  This form cuts the dependency chain to what the algorithm needs:
+//   * a workgroup = 2 waves owns 4 envs: wave 0 = ACTOR (forward, draw, env step — NO global memory traffic inside its loop), wave 1 =
+//     CRITIC (forward on the observations the actor publishes through an LDS ring, ALL the storage writes, GAE scan at the end): a
+//     vector store costs its issuing wave ~100 cycles whatever its lane count, and the actor's chain is what the launch lasts.  No barrier in the loop: the actor never waits for
+//     the critic (ring depth T + 1 when T <= 128), the critic polls an LDS counter.  1024 workgroups at N = 4096: 8 waves per CU.
+//   * v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1) with the A operand BROADCAST from one block (cbsz = 4, abid = b'):
+//         D[b][i][j] += A[b'][i] * B[b][j]      i = env (4), block b / column j = output unit 4b + j = the LANE, one k per instruction
+//     so the accumulator holds out[unit = lane][env = register], the B operand of k-step k is W[unit = lane][k] — every lane keeps ITS
+//     row of W2 (64 VGPRs), W1 (4) and W3 resident for the whole launch — and a layer of 64 outputs x 64 inputs x 4 envs is 64 MFMAs of
+//     8 cycles at full utilisation (the 16x16x4 form needs 16 envs per wave for that).  The A operand of k-step k = 4b' + jj is the
+//     previous layer's activation h[k][env i] in lanes 4b' + i: a 4x4 transpose inside every quad of lanes (quad_transpose: 8 DPP moves)
+//     turns the accumulator (lane 4b' + q, register e = h[4b' + q][e]) into exactly that (register jj, abid b').
+//   * heads: per-lane products, then quad_env_reduce — a butterfly that halves the values per lane at each of its two quad stages, two
+//     row rotations and the two cross-row permlane swaps: 18 instructions per output, the total of env (lane & 3) in every lane.
+//   * every lane carries the fp64 state of env (lane & 3) and runs the scalar section (draw, CartPole step, TimeLimit, auto-reset)
+//     redundantly, as before — identical IEEE sequences, identical bits; lanes 0..3 write.  The critic wave runs no physics at all.
+// Layouts (CBSZ / ABID broadcast, D register = i) are verified on the device with exact integers: mi_selftest_mfma probe 4.
+#define RQ_ENVS 4
+#define RQ_GAE_T 128
+#define RQ_RING (RQ_GAE_T + 1)
+typedef float rq_f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef RQ_CHAINS
+#define RQ_CHAINS 4   // independent accumulator chains of layer 2 (k mod RQ_CHAINS); 8 measured no faster: the wave is issue-bound, not MFMA-latency-bound
+#endif
+template <int K>
+struct rq_layer2 {   // k-steps K..63
+    static __device__ __forceinline__ void run(const float (&w2)[HID], const rq_f32x4& tr, rq_f32x4 (&acc)[RQ_CHAINS]) {
+        acc[K % RQ_CHAINS] = __builtin_amdgcn_mfma_f32_4x4x1f32(tr[K & 3], w2[K], acc[K % RQ_CHAINS], 4, K >> 2, 0);
+        rq_layer2<K + 1>::run(w2, tr, acc);
+    }
+};
+template <>
+struct rq_layer2<HID> {
+    static __device__ __forceinline__ void run(const float (&)[HID], const rq_f32x4&, rq_f32x4 (&)[RQ_CHAINS]) {}
+};
+
+// 4x4 transpose inside every quad of lanes: in: lane 4b + q holds v[e] = M[q][e]; out: lane 4b + q holds v[e] = M[e][q]
+__device__ __forceinline__ rq_f32x4 quad_transpose(rq_f32x4 v, bool b0, bool b1) {
+    const float x0 = dpp_xor1(b0 ? v[0] : v[1]), x1 = dpp_xor1(b0 ? v[2] : v[3]);
+    if (b0) { v[0] = x0; v[2] = x1; } else { v[1] = x0; v[3] = x1; }
+    const float x2 = dpp_xor2(b1 ? v[0] : v[2]), x3 = dpp_xor2(b1 ? v[1] : v[3]);
+    if (b1) { v[0] = x2; v[1] = x3; } else { v[2] = x2; v[3] = x3; }
+    return v;
+}
+
+__device__ __forceinline__ float dpp_row_ror4(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_row_ror8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
+
+// p[e] = this lane's contribution to env e's total (e = 0..3) -> the sum over all 64 lanes for env (lane & 3), in every lane.
+// Fixed order: quad butterfly (lane ^ 1, lane ^ 2), the row's 4 quads (ror 4, ror 8), the 4 rows (permlane16 / 32 swaps).
+__device__ __forceinline__ float quad_env_reduce(const rq_f32x4& p, bool b0, bool b1) {
+    const float r01 = (b0 ? p[1] : p[0]) + dpp_xor1(b0 ? p[0] : p[1]);
+    const float r23 = (b0 ? p[3] : p[2]) + dpp_xor1(b0 ? p[2] : p[3]);
+    float r = (b1 ? r23 : r01) + dpp_xor2(b1 ? r01 : r23);
+    r += dpp_row_ror4(r);
+    r += dpp_row_ror8(r);
+    return groups_sum(r);
+}
+
+// one net's hidden layers on 4 envs: ob = this lane's env's observation (env = lane & 3); returns tanh(layer 2)[unit = lane][env = register]
+__device__ __forceinline__ rq_f32x4 rq_hidden(const float4& ob, const float (&w1)[OBS], float b1, const float (&w2)[HID], float b2, bool q0, bool q1) {
+    rq_f32x4 h = {b1, b1, b1, b1}, hb = {0.0f, 0.0f, 0.0f, 0.0f};       // two chains
+    h = __builtin_amdgcn_mfma_f32_4x4x1f32(ob.x, w1[0], h, 4, 0, 0);   // A: lanes 0..3 of block 0 = obs component k of envs 0..3
+    hb = __builtin_amdgcn_mfma_f32_4x4x1f32(ob.y, w1[1], hb, 4, 0, 0);
+    h = __builtin_amdgcn_mfma_f32_4x4x1f32(ob.z, w1[2], h, 4, 0, 0);
+    hb = __builtin_amdgcn_mfma_f32_4x4x1f32(ob.w, w1[3], hb, 4, 0, 0);
+    h = h + hb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = mi_tanhf(h[e]);
+    const rq_f32x4 tr = quad_transpose(h, q0, q1);
+    rq_f32x4 acc[RQ_CHAINS];
+#pragma unroll
+    for (int c = 0; c < RQ_CHAINS; ++c) acc[c] = rq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    acc[0] = rq_f32x4{b2, b2, b2, b2};
+    rq_layer2<0>::run(w2, tr, acc);
+#pragma unroll
+    for (int st = RQ_CHAINS / 2; st > 0; st >>= 1)
+#pragma unroll
+        for (int c = 0; c < st; ++c) acc[c] = acc[c] + acc[c + st];
+    rq_f32x4 z = acc[0];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = mi_tanhf(z[e]);
+    return z;
+}
+
+#ifdef RQ_STAMPS   // diagnostic build: where the actor wave's cycles go (s_memtime), read back by mi_debug_rollout_stamps
+__device__ unsigned long long rq_stamp_dbg[1024 * 8];
+#define RQ_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                         rq_acc[k] += t_ - rq_last; rq_last = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int mi_debug_rollout_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rq_stamp_dbg), sizeof(unsigned long long) * (size_t)(n < 8192 ? n : 8192)) == hipSuccess ? 0 : -2;
+}
+#else
+#define RQ_STAMP(k) do {} while (0)
+#endif
+
+// LDS mailbox words between the waves of a workgroup.  The accesses must be ds_read / ds_write: a `volatile int*` to __shared__ memory
+// compiles to FLAT instructions with sc0 sc1 and an s_waitcnt vmcnt(0) behind every store, i.e. each publish would wait for all of the
+// wave's outstanding GLOBAL stores (measured: 500 cycles per step).  The LDS executes one wave's accesses in program order, so data
+// written before the counter is visible before it; the empty asm statements keep the COMPILER from reordering around them.
+typedef __attribute__((address_space(3))) int rq_lds_int;
+__device__ __forceinline__ void lds_publish(int* word, int v) {
+    asm volatile("" ::: "memory");
+    *(volatile rq_lds_int*)(rq_lds_int*)word = v;
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ int lds_peek(int* word) {
+    const int v = *(volatile rq_lds_int*)(rq_lds_int*)word;
+    asm volatile("" ::: "memory");
+    return v;
+}
+
+struct __attribute__((aligned(16))) rq_slot {   // what the actor publishes per step and env: slot (t + 1) % RQ_RING
+    float4 ob;                  // obs[t+1] (the reset observation where done)
+    float rew, dn, logp;        // rewards[t+1], dones[t+1]; log_probs[t]
+    int act;                    // actions[t]
+};
+struct __attribute__((aligned(16))) rq_smem {
+    rq_slot ring[RQ_RING][RQ_ENVS];
+    float gv[RQ_GAE_T + 1][RQ_ENVS];    // fused GAE (T <= RQ_GAE_T): the critic's values (rewards / dones: the ring, which does not wrap then)
+    int produced;                       // slots published so far (actor -> critic)
+    int consumed;                       // slots the critic is done with (critic -> actor; only read when T + 1 > RQ_RING)
+};
+
+// FORCED: parity mode (forced_actions / forced_uniforms / forced_resets may be given); EPLOG: the per-episode list is kept (max_ep > 0).
+// Separate instantiations, not run-time branches: a conditional global LOAD (or returning atomic) inside the step loop makes the compiler
+// place s_waitcnt vmcnt(0) at the join, which is executed on EVERY step and drains all of the wave's outstanding stores (~500 cycles).
+template <bool FORCED, bool EPLOG>
+__global__ void __launch_bounds__(128)
+rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __restrict__ obs_cur, float* __restrict__ observations,
+                  float* __restrict__ values, int64_t* __restrict__ actions, float* __restrict__ log_probs,
+                  float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
+                  const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
+                  mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep,
+                  float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n) {
+    __shared__ rq_smem sm;
+    if (zero_f64 && blockIdx.x == 0) for (int k = threadIdx.x; k < zero_n; k += 128) zero_f64[k] = 0.0;   // scratch the next launches accumulate into
+    const int lane = threadIdx.x & 63, net = threadIdx.x >> 6, en = lane & 3;
+    const bool q0 = lane & 1, q1 = lane & 2;
+    const int N = e.n;
+    const int i = blockIdx.x * RQ_ENVS + en;
+    const bool mine = i < N, writer = mine && lane < RQ_ENVS;
+    const int g = mine ? i : N - 1;   // lanes past the end shadow the last env and never write
+    if (threadIdx.x == 0) { sm.produced = 0; sm.consumed = 0; }
+    // ---- this wave's net: lane = hidden unit; its rows of W1 / W2, its column of W3 ----
+    const float* p = params + (net ? C_BASE : 0);
+    float w1[OBS], w2[HID];
+    {
+        const float4 a = *reinterpret_cast<const float4*>(p + N_W1 + 4 * lane);
+        w1[0] = a.x; w1[1] = a.y; w1[2] = a.z; w1[3] = a.w;
+#pragma unroll
+        for (int k = 0; k < HID; k += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(p + N_W2 + HID * lane + k);
+            w2[k] = q.x; w2[k + 1] = q.y; w2[k + 2] = q.z; w2[k + 3] = q.w;
+        }
+    }
+    const float b1 = p[N_B1 + lane], b2 = p[N_B2 + lane];
+    const float w3a = p[N_W3 + lane], w3b = net == 0 ? p[N_W3 + HID + lane] : 0.0f;
+    const float b3a0 = params[A_B3], b3a1 = params[A_B3 + 1], b3c = params[C_BASE + N_W3 + HID];
+    const bool ringed = T + 1 > RQ_RING;   // long rollouts: the ring wraps and the actor must not overrun the critic
+    __syncthreads();                       // counters initialised
+
+    if (net == 0) {
+        // ================================================= ACTOR wave =================================================
+        __builtin_amdgcn_s_setprio(2);     // the dependent chain of the launch: win every issue arbitration against the critic waves
+        double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
+        int elapsed = e.elapsed[g], eplen = e.ep_len[g];
+        float epret = e.ep_ret[g];
+        uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
+        float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
+        // Categorical(logits) depends on the logits only through d = l0 - l1 (log-softmax and probabilities are shift-invariant,
+        // ppo.py:52-59): ONE head reduction over (W3[0] - W3[1]) . h2 instead of two; the distribution is evaluated at (d, 0).
+        float my_d = 0.0f;
+        const float w3d = w3a - w3b, b3d = b3a0 - b3a1;
+        int st_cnt = 0, st_len = 0, st_max = 0;
+        uint32_t urand[4] = {0, 0, 0, 0};
+        const bool keyed_actions = !FORCED || (!forced_actions && !forced_uniforms);
+        if (keyed_actions && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
+        // every value loaded so far is consumed HERE, so that no load is pending when the loop starts (a pending load at the loop head
+        // becomes an s_waitcnt vmcnt(small) inside the body, which in steady state waits for the previous step's stores instead)
+        asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr));
+#ifdef RQ_STAMPS
+        unsigned long long rq_acc[4] = {0, 0, 0, 0}, rq_last;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rq_last) :: "memory");
+#endif
+        for (int t = -1; t < T; ++t) {
+            float rew = 0.0f, dn = 0.0f, logp_t = 0.0f;
+            int act_t = 0;
+            if (t >= 0) {
+                // ---- sample from the logits of obs[t], step the env (ppo.py:120-129) ----
+                const size_t row = (size_t)t * N + g;
+                float nl0, nl1, p0, p1, ent;
+                mi_categorical2_fast(my_d, 0.0f, nl0, nl1, p0, p1, ent);
+                int a;
+                if (FORCED && forced_actions) a = (int)forced_actions[row];
+                else {
+                    float u;
+                    if (FORCED && forced_uniforms) u = forced_uniforms[row];
+                    else {
+                        const uint32_t wd = (uint32_t)stepctr & 3u;
+                        if (wd == 0) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
+                        u = mi_u32_to_uniform(wd == 0 ? urand[0] : wd == 1 ? urand[1] : wd == 2 ? urand[2] : urand[3]);
+                    }
+                    a = (u >= p0) ? 1 : 0;
+                }
+                stepctr += 1;
+                act_t = a; logp_t = a ? nl1 : nl0;   // ppo.py:123-124 (stored by the critic wave)
+                int term;
+                mi_cartpole_step(sx, sxd, sth, sthd, a, term);
+                elapsed += 1;
+                const bool d = term || elapsed >= CP_MAX_STEPS;
+                epret += 1.0f;
+                eplen += 1;
+                if (d) {
+                    if (writer) {
+                        st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
+                        if (EPLOG && max_ep > 0 && episode_stats) {
+                            const int slot = atomicAdd(episode_stats + 3, 1);
+                            if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
+                        }
+                    }
+                    epret = 0.0f; eplen = 0; elapsed = 0;
+                    double sr[4];
+                    if (FORCED && forced_resets) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sr[k] = forced_resets[4 * row + k];
+                    } else {
+                        mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, sr);
+                    }
+                    episode += 1;
+                    sx = sr[0]; sxd = sr[1]; sth = sr[2]; sthd = sr[3];
+                }
+                ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
+                rew = 1.0f; dn = d ? 1.0f : 0.0f;
+            }
+            RQ_STAMP(0);   // scalar section
+            // ---- publish obs[t+1] to the critic (LDS executes one wave's accesses in order: data first, then the counter) ----
+            if (ringed) while (lds_peek(&sm.consumed) < t + 3 - RQ_RING) __builtin_amdgcn_s_sleep(2);
+            // (the LDS executes one wave's accesses in program order, so the counter can never become visible before the data; a
+            //  workgroup-scope RELEASE store would also wait for this wave's outstanding GLOBAL stores — 400 cycles per step — for nothing)
+            if (lane < RQ_ENVS) {
+                rq_slot& sl = sm.ring[(t + 1) % RQ_RING][lane];
+                sl.ob = ob;
+                *reinterpret_cast<float4*>(&sl.rew) = make_float4(rew, dn, logp_t, __builtin_bit_cast(float, act_t));
+            }
+            if (lane == 0) lds_publish(&sm.produced, t + 2);
+            RQ_STAMP(1);   // publish + stores
+            // ---- actor(obs[t+1]) (ppo.py:120 of the next iteration) ----
+            const rq_f32x4 h2 = rq_hidden(ob, w1, b1, w2, b2, q0, q1);
+            RQ_STAMP(2);   // hidden layers
+            my_d = quad_env_reduce(h2 * w3d, q0, q1) + b3d;
+            RQ_STAMP(3);   // head
+        }
+#ifdef RQ_STAMPS
+        if (lane == 0 && blockIdx.x < 1024) { for (int k = 0; k < 4; ++k) rq_stamp_dbg[blockIdx.x * 8 + k] = rq_acc[k]; }
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        if (episode_stats) {   // lanes 0..3: one flush per workgroup
+            int c = writer ? st_cnt : 0, l = writer ? st_len : 0, m = writer ? st_max : 0;
+#pragma unroll
+            for (int sft = 1; sft < 4; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
+            if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
+        }
+        if (writer) {   // carry-over `observation` and env state for the next rollout
+            e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
+            e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen;
+            e.episode[g] = episode; e.step_ctr[g] = stepctr;
+            reinterpret_cast<float4*>(obs_cur)[g] = ob;
+        }
+    } else {
+        // ================================================= CRITIC wave ================================================
+        for (int t = -1; t < T; ++t) {
+            while (lds_peek(&sm.produced) < t + 2) __builtin_amdgcn_s_sleep(1);   // the ring read below is issued after the poll that saw the counter
+            const rq_slot& sl = sm.ring[(t + 1) % RQ_RING][en];
+            const float4 ob = sl.ob;
+            const float4 misc = *reinterpret_cast<const float4*>(&sl.rew);
+            const rq_f32x4 h2 = rq_hidden(ob, w1, b1, w2, b2, q0, q1);
+            const float val = quad_env_reduce(h2 * w3a, q0, q1) + b3c;   // ppo.py:115,:139
+            if (writer) {   // the storage of time step t (action, log-prob) and t + 1 (everything that resulted from it)
+                const size_t row = (size_t)(t + 1) * N + g;
+                reinterpret_cast<float4*>(observations)[row] = ob;      // :113,:137 (the reset obs where done)
+                values[row] = val;
+                if (t >= 0) {
+                    rewards[row] = misc.x; dones[row] = misc.y;         // :140-141
+                    log_probs[row - N] = misc.z; actions[row - N] = (int64_t)__builtin_bit_cast(int, misc.w);   // :123-124
+                }
+            }
+            if (adv && lane < RQ_ENVS) sm.gv[t + 1][lane] = val;
+            if (ringed && lane == 0) lds_publish(&sm.consumed, t + 2);
+        }
+        if (adv && writer) {       // GAE over this lane's env (ppo.py:144-151; expression order of gae_kernel): every reward / done is published
+            float last = 0.0f;
+            float vnext = sm.gv[T][lane];
+            adv[(size_t)T * N + g] = 0.0f;
+            returns[(size_t)T * N + g] = 0.0f + vnext;
+#pragma unroll 8
+            for (int t = T - 1; t >= 0; --t) {
+                const size_t c = (size_t)t * N + g;
+                const float vcur = sm.gv[t][lane];
+                const float a = gamma * (1.0f - sm.ring[t + 1][lane].dn);
+                const float b = vnext + lam * last;
+                float v = sm.ring[t + 1][lane].rew + a * b;
+                v = v - vcur;
+                adv[c] = v;
+                returns[c] = v + vcur;
+                last = v;
+                vnext = vcur;
+            }
+        }
+    }
+}
+
 __global__ void zero_i32x4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
 static int rollout_impl(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
@@ -398,7 +714,20 @@ static int rollout_impl(void* handle, const float* params, int T, float* obs_cur
     hipStream_t s = (hipStream_t)stream;
     if (episode_stats) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
     mi_prof_scope prof(MI_PROF_ROLLOUT, s);
-#ifndef ROLLOUT_VALU
+#if !defined(ROLLOUT_VALU) && !defined(ROLLOUT_MFMA16)
+    {
+        const bool forced = forced_actions || forced_uniforms || forced_resets, eplog = max_ep > 0 && episode_stats;
+        const dim3 grid((e->n + RQ_ENVS - 1) / RQ_ENVS), block(128);
+#define RQ_LAUNCH(F, L) rollout_q4_kernel<F, L><<<grid, block, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, \
+                                                                     forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep, \
+                                                                     advantages, returns, gamma, lam, zero_f64, zero_n)
+        if (forced) { if (eplog) RQ_LAUNCH(true, true); else RQ_LAUNCH(true, false); }
+        else { if (eplog) RQ_LAUNCH(false, true); else RQ_LAUNCH(false, false); }
+#undef RQ_LAUNCH
+    }
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+#elif !defined(ROLLOUT_VALU)
     rollout_mfma_kernel<<<(e->n + RM_ENVS - 1) / RM_ENVS, 256, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones,
                                                                       forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep,
                                                                       advantages, returns, gamma, lam, zero_f64, zero_n);

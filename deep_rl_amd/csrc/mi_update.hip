@@ -239,18 +239,6 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
-// sum over the 4 lane groups (lane ^ 16, lane ^ 32) on the VALU: v_permlane16_swap / v_permlane32_swap with both operands = v
-// give {rows 0,0,2,2} / {rows 1,1,3,3} and {lo,lo} / {hi,hi}; (r0 + r1) + (r2 + r3) in every lane (what the two
-// ds_bpermute-based __shfl_xor steps computed, without the LDS round trips).
-__device__ __forceinline__ float groups_sum(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float s = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
-    const unsigned w = __builtin_bit_cast(unsigned, s);
-    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
-}
-
 // tanh of z given z' = z * 2 log2(e) (GRAD_PRESCALE) — the same function as mi_tanhf, with the scale already applied by the weights
 __device__ __forceinline__ float tanh_prescaled(float zs) {
     const float e = __builtin_amdgcn_exp2f(zs);
@@ -1152,7 +1140,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
 // =====================================================================================================
 // Hardware self-test of the MFMA fragment layouts grad_kernel relies on (exact small-integer data).
 // report[0]: 32x32x2 A/B/D maps   report[1]: 4x4x1 (16 blocks) A/B/D maps   report[2]: accumulator-as-B chain (32x32x2)
-// report[3]: accumulator-as-B chain on 16x16x4 (the form grad_kernel uses)
+// report[3]: accumulator-as-B chain on 16x16x4 (the form grad_kernel uses)   report[4]: 4x4x1 with A broadcast (cbsz / abid; rollout_q4_kernel)
 // dump (nullable, f32 [3*64*16]): raw accumulators of the three probes for offline diagnosis.
 // =====================================================================================================
 __global__ void __launch_bounds__(64) selftest_kernel(int32_t* __restrict__ report, float* __restrict__ dump) {
@@ -1241,9 +1229,24 @@ __global__ void __launch_bounds__(64) selftest_kernel(int32_t* __restrict__ repo
             if (dump) dump[(2 * 64 + lane) * 16 + 8 + r] = y[r];
         }
     }
+    // probe 4: the 16-block 4x4x1 with the A operand broadcast from ONE block (cbsz = 4, abid = b'), as rollout_q4_kernel uses it:
+    //          D[b][i][j] += A[b'][i] * B[b][j], A value taken from lane 4b' + i, B from lane 4b + j, D register i in lane 4b + j.
+    //          Two chained k-steps with different source blocks (5, then 12) and asymmetric integer data.
+    int bad4 = 0;
+    {
+        const float a1 = (float)(1 + lane), a2 = (float)(200 - lane), b1 = (float)(3 + 2 * lane), b2 = (float)(7 + lane % 5);
+        f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+        d = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, d, 4, 5, 0);
+        d = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, b2, d, 4, 12, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float want = (float)(1 + 4 * 5 + i) * (float)(3 + 2 * lane) + (float)(200 - (4 * 12 + i)) * (float)(7 + lane % 5);
+            bad4 += d[i] != want;
+        }
+    }
     const int t0 = (int)wave_sum((float)bad0), t1 = (int)wave_sum((float)bad1), t2 = (int)wave_sum((float)bad2);
-    const int t3 = (int)wave_sum((float)bad3);
-    if (lane == 0) { report[0] = t0; report[1] = t1; report[2] = t2; report[3] = t3; for (int k = 4; k < 16; ++k) report[k] = 0; }
+    const int t3 = (int)wave_sum((float)bad3), t4 = (int)wave_sum((float)bad4);
+    if (lane == 0) { report[0] = t0; report[1] = t1; report[2] = t2; report[3] = t3; report[4] = t4; for (int k = 5; k < 16; ++k) report[k] = 0; }
 }
 
 extern "C" int mi_selftest_mfma(int32_t* report, float* dump, void* stream) {

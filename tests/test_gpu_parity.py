@@ -78,6 +78,7 @@ def test_mfma_layout_selftest(dev):
     assert rep[1] == 0, "4x4x1_16b A/B/D map wrong: " + msg
     assert rep[2] == 0, "accumulator-as-B-operand chain (32x32x2) wrong: " + msg
     assert rep[3] == 0, "accumulator-as-B-operand chain (16x16x4) wrong: " + msg + "\n%s" % d[2, :20, 8:12]
+    assert rep[4] == 0, "4x4x1 with the A operand broadcast from one block (cbsz = 4, abid) wrong (rollout_q4_kernel): %d mismatches" % rep[4]
 
 
 def test_device_tanh_accuracy(dev):
