@@ -700,6 +700,13 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
     }
 }
 
+// Negative result (measured, removed; profiles/r02_rollout_stamps.txt): a THIRD wave per 4 envs that computes both successors of the
+// current state while the actor evaluates the policy on it (speculation over CartPole's two actions; the positions and the termination
+// test are action-independent).  Correct and bit-identical, but 0.258 ms against 0.216: the two-action physics costs 2,050 cycles per
+// step (two IEEE fp64 divisions, ~130 fp64 operations at 3 waves per SIMD), more than the actor's whole step, and the launch is not purely
+// latency-bound — per SIMD and step the two nets' MFMAs (1,088 cycles), their VALU work (~800) and one physics step (~600) already fill
+// ~75 % of the issue slots, so work added to shorten the chain is paid in full.
+
 __global__ void zero_i32x4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
 static int rollout_impl(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
@@ -717,7 +724,8 @@ static int rollout_impl(void* handle, const float* params, int T, float* obs_cur
 #if !defined(ROLLOUT_VALU) && !defined(ROLLOUT_MFMA16)
     {
         const bool forced = forced_actions || forced_uniforms || forced_resets, eplog = max_ep > 0 && episode_stats;
-        const dim3 grid((e->n + RQ_ENVS - 1) / RQ_ENVS), block(128);
+        const dim3 grid((e->n + RQ_ENVS - 1) / RQ_ENVS);
+        const dim3 block(128);
 #define RQ_LAUNCH(F, L) rollout_q4_kernel<F, L><<<grid, block, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, \
                                                                      forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep, \
                                                                      advantages, returns, gamma, lam, zero_f64, zero_n)
