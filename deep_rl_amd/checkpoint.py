@@ -125,6 +125,7 @@ def load(path, engine):
             engine.max_priority.copy_(t("max_priority"))
             if "priorities" in z:
                 engine.priorities.copy_(t("priorities"))
+                engine.refresh_sums()   # the sampler's chunk sums follow the priorities
         for name in ("observations", "actions", "rewards", "terminated"):
             if name in z:
                 getattr(engine, name).copy_(t(name))

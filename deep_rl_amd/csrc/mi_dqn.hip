@@ -597,17 +597,20 @@ extern "C" int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_gr
 // bit for bit): s0 = sums of 64-entry chunks, s1 = sums of 64 s0's, total — all sequential, in double (-ffp-contract=off: no FMA).
 #define PER_CHUNK 64
 #define STREAM_PER 7u
-struct per_ws_t { double* s0; double* a0; double* s1; double* totals; };   // a0: chunk sums of p^alpha; totals = {sum p, sum p^alpha}
+struct per_ws_t { double* s0; double* a0; double* s1; double* a1; double* totals; };   // a0 / a1: the same sums of p^alpha; totals = {sum p, sum p^alpha}
+// p^alpha of a priority (per.py:131): 2^(alpha log2 p) on the hardware log2 / exp2 (3 instructions instead of ~150 for powf; relative
+// error ~1e-6, it only enters the importance weights, which are compared to 2e-5).  p = 0 -> 0 exactly (log2 0 = -inf, 2^-inf = 0).
+__device__ __forceinline__ float per_pow(float p, float alpha) { return __builtin_amdgcn_exp2f(alpha * __builtin_amdgcn_logf(p)); }
 __host__ __device__ inline int64_t per_n0(int64_t n) { return (n + PER_CHUNK - 1) / PER_CHUNK; }
 static per_ws_t per_ws(void* workspace, int64_t capacity) {
     per_ws_t w;
     const int64_t c0 = per_n0(capacity), c1 = per_n0(c0);
-    w.s0 = (double*)workspace; w.a0 = w.s0 + c0; w.s1 = w.a0 + c0; w.totals = w.s1 + c1;
+    w.s0 = (double*)workspace; w.a0 = w.s0 + c0; w.s1 = w.a0 + c0; w.a1 = w.s1 + c1; w.totals = w.a1 + c1;
     return w;
 }
 extern "C" size_t mi_per_workspace_bytes(int64_t capacity) {
     const int64_t c0 = per_n0(capacity), c1 = per_n0(c0);
-    return (size_t)(2 * c0 + c1 + 2) * sizeof(double);
+    return (size_t)(2 * c0 + 2 * c1 + 2) * sizeof(double);
 }
 
 // priorities[global_step .. + n_steps) = max_priority (per.py:106; max_priority only changes at an update, i.e. between acting calls);
@@ -629,7 +632,7 @@ __global__ void __launch_bounds__(256) per_sums0_kernel(const float* __restrict_
         const int e = it * 256 + threadIdx.x;                  // entry within the workgroup's 4,096
         const long long i = base + e;
         const float p = i < n ? prio[i] : 0.0f;
-        pv[e >> 6][e & 63] = p; pa[e >> 6][e & 63] = i < n ? powf(p, alpha) : 0.0f;
+        pv[e >> 6][e & 63] = p; pa[e >> 6][e & 63] = i < n ? per_pow(p, alpha) : 0.0f;
     }
     __syncthreads();
     const long long k = (long long)blockIdx.x * PER_CHUNK + threadIdx.x;
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(256) per_sums0_kernel(const float* __restrict_
 // level-1 values.  One workgroup; n1 <= PER_MAX_L1 (capacity <= 4M entries).
 #define PER_MAX_L1 1024
 __global__ void __launch_bounds__(256) per_sums1_kernel(const double* __restrict__ s0, const double* __restrict__ a0, long long n0, double* __restrict__ s1,
-                                                        double* __restrict__ totals) {
+                                                        double* __restrict__ a1out, double* __restrict__ totals) {
     __shared__ double l1[PER_MAX_L1], a1[PER_MAX_L1];
     const long long n1 = per_n0(n0);
     for (long long m = threadIdx.x; m < n1; m += 256) {
@@ -661,7 +664,7 @@ __global__ void __launch_bounds__(256) per_sums1_kernel(const double* __restrict
 #pragma unroll
             for (int j = 0; j < 32; ++j) if (32 * h + j < cnt) { sum += v[j]; sa += va[j]; }
         }
-        s1[m] = sum; l1[m] = sum; a1[m] = sa;
+        s1[m] = sum; l1[m] = sum; a1[m] = sa; a1out[m] = sa;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -674,18 +677,33 @@ __global__ void __launch_bounds__(256) per_sums1_kernel(const double* __restrict
 
 // indices (sample != 0) by the prefix-sum descent, then the importance weights of per.py:131,145-146, normalised by their maximum
 __global__ void __launch_bounds__(256)
-per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio, long long n, const double* __restrict__ s0, const double* __restrict__ s1,
-                  const double* __restrict__ totals, int batch, float count, float alpha, float beta, int sample, int64_t* __restrict__ idx,
-                  float* __restrict__ weights) {
-    __shared__ float wmax[4];
+per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio, long long n, const double* __restrict__ s0, const double* __restrict__ a0,
+                  const double* __restrict__ s1, const double* __restrict__ totals, int batch, float count, float alpha, float beta, int sample,
+                  int64_t* __restrict__ idx, float* __restrict__ weights) {
+    __shared__ float wmax[16];
     __shared__ double l1s[PER_MAX_L1];                      // the level-1 sums: walked by every draw
+    __shared__ double tot[2];
     const long long n0 = per_n0(n), n1 = per_n0(n0);
-    for (long long m = threadIdx.x; m < n1; m += 256) l1s[m] = s1[m];
+    if (a0) {   // incremental form: level 1 is kept current in memory (a0 here = the level-1 sums of p^alpha); only the totals remain (per_sums1_kernel's order)
+        __shared__ double a1s[PER_MAX_L1];
+        for (long long m = threadIdx.x; m < n1; m += blockDim.x) { l1s[m] = s1[m]; a1s[m] = a0[m]; }
+        __syncthreads();
+        if (threadIdx.x == 0 || threadIdx.x == 64) {
+            const double* src = threadIdx.x == 0 ? l1s : a1s;
+            double t = 0.0;
+#pragma unroll 16
+            for (long long m2 = 0; m2 < n1; ++m2) t += src[m2];
+            tot[threadIdx.x == 0 ? 0 : 1] = t;
+        }
+    } else {
+        for (long long m = threadIdx.x; m < n1; m += blockDim.x) l1s[m] = s1[m];
+        if (threadIdx.x == 0) { tot[0] = totals[0]; tot[1] = totals[1]; }
+    }
     __syncthreads();
-    const double total = totals[0];
-    const float total_alpha = (float)totals[1];
+    const double total = tot[0];
+    const float total_alpha = (float)tot[1];
     float mx = 0.0f;
-    for (int b = threadIdx.x; b < batch; b += 256) {
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) {
         long long i;
         if (sample) {
             uint32_t r[4];
@@ -693,45 +711,46 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
             const double u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
             double x = u * total;
             // the three walks subtract in index order (the contract); each level's 64 values are requested together, so a draw costs
-            // three memory round trips instead of up to 384 dependent ones
-            long long m = 0;
-            for (long long gq = 0; gq < n1; gq += PER_CHUNK) {        // level 2 in groups of 64 register-resident values (same subtraction order)
-                const int cnt = (int)(gq + PER_CHUNK < n1 ? PER_CHUNK : n1 - gq);
+            // three memory round trips instead of up to 384 dependent ones.  32-bit indices (capacity <= 4M entries), no guarded reads and
+            // no short-circuit conditions: every guard of this loop nest used to be a branch or a 64-bit scalar compare held in SGPRs
+            // (the kernel spilled them to VGPR lanes); now a step is compare + subtract + select on the vector unit.
+            const int n_i = (int)n, n0_i = (int)n0, n1_i = (int)n1;
+            int m = 0;
+            bool go = true;
+            for (int gq = 0; gq < n1_i; gq += PER_CHUNK) {            // level 2 in groups of 64 register-resident values (same subtraction order)
                 double v[PER_CHUNK];
 #pragma unroll
-                for (int j = 0; j < PER_CHUNK; ++j) v[j] = j < cnt ? l1s[gq + j] : 0.0;
-                int j = 0;
+                for (int j = 0; j < PER_CHUNK; ++j) v[j] = l1s[gq + j < PER_MAX_L1 ? gq + j : PER_MAX_L1 - 1];
+                const int left = n1_i - gq;                            // a step may advance only while a next level-1 entry exists
 #pragma unroll
-                for (int jj = 0; jj < PER_CHUNK; ++jj) if (j == jj && gq + jj + 1 < n1 && x >= v[jj]) { x -= v[jj]; j = jj + 1; }
-                m = gq + j;
-                if (j < PER_CHUNK) break;                              // stopped inside this group
+                for (int jj = 0; jj < PER_CHUNK; ++jj) { go = go & (jj + 1 < left) & (x >= v[jj]); x = go ? x - v[jj] : x; m += go ? 1 : 0; }
+                if (!__any(go)) break;                                 // wave-uniform exit: every draw of the wave has stopped
             }
-            long long k = m * PER_CHUNK;
+            int k = m * PER_CHUNK;
             {
-                const int cnt = (int)(k + PER_CHUNK < n0 ? PER_CHUNK : n0 - k);
+                const int cnt = k + PER_CHUNK < n0_i ? PER_CHUNK : n0_i - k;
                 double v[PER_CHUNK];
 #pragma unroll
-                for (int j = 0; j < PER_CHUNK; ++j) v[j] = j < cnt ? s0[k + j] : 0.0;
-                int j = 0;
+                for (int j = 0; j < PER_CHUNK; ++j) v[j] = s0[k + j < n0_i ? k + j : n0_i - 1];
+                go = true;
 #pragma unroll
-                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) if (j == jj && jj + 1 < cnt && x >= v[jj]) { x -= v[jj]; j = jj + 1; }
-                k += j;
+                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) { go = go & (jj + 1 < cnt) & (x >= v[jj]); x = go ? x - v[jj] : x; k += go ? 1 : 0; }
             }
-            i = k * PER_CHUNK;
+            int ii = k * PER_CHUNK;
             {
-                const int cnt = (int)(i + PER_CHUNK < n ? PER_CHUNK : n - i);
+                const int cnt = ii + PER_CHUNK < n_i ? PER_CHUNK : n_i - ii;
                 float v[PER_CHUNK];
 #pragma unroll
-                for (int j = 0; j < PER_CHUNK; ++j) v[j] = j < cnt ? prio[i + j] : 0.0f;
-                int j = 0;
+                for (int j = 0; j < PER_CHUNK; ++j) v[j] = prio[ii + j < n_i ? ii + j : n_i - 1];
+                go = true;
 #pragma unroll
-                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) if (j == jj && jj + 1 < cnt && x >= (double)v[jj]) { x -= (double)v[jj]; j = jj + 1; }
-                i += j;
+                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) { const double vd = (double)v[jj]; go = go & (jj + 1 < cnt) & (x >= vd); x = go ? x - vd : x; ii += go ? 1 : 0; }
             }
+            i = ii;
             while (i > 0 && prio[i] == 0.0f) --i;
             idx[b] = i;
         } else i = idx[b];
-        const float prob = powf(prio[i], alpha) / total_alpha;
+        const float prob = per_pow(prio[i], alpha) / total_alpha;
         const float w = powf(count * prob, -beta);
         weights[b] = w;
         mx = fmaxf(mx, w);
@@ -741,9 +760,8 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = wmax[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) mx = fmaxf(mx, wmax[k]);
-    for (int b = threadIdx.x; b < batch; b += 256) weights[b] = weights[b] / mx;
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) mx = fmaxf(mx, wmax[k]);
+    for (int b = threadIdx.x; b < batch; b += blockDim.x) weights[b] = weights[b] / mx;
 }
 
 // priorities[idx[b]] = |td_b| with the LAST occurrence of a duplicated index winning (per.py:141 on the host is sequential), and
@@ -778,11 +796,135 @@ extern "C" int mi_per_mark(float* priorities, int n_envs, int64_t slots, int64_t
     return MI_OK;
 }
 
+// ---- incremental form: the level-0 sums are kept CURRENT by the two calls that change priorities ------------------------------------
+// A full pass over 1M priorities per update (per_sums0 + per_sums1 + the sampler: three dependent launches, 65 us) is what the reference's
+// O(buffer) torch.multinomial becomes when restated naively.  But between two draws only (a) the rows an acting call has just written and
+// the write head and (b) the <= batch entries the last update re-prioritised have changed, and a chunk sum depends on its own 64 entries
+// only.  So per_mark_sums_kernel and per_scatter_sums_kernel RECOMPUTE (never adjust) the chunks they touch — same operations in the same
+// order as per_sums0_kernel, hence bit-identical sums — and per_sample_kernel takes level 1 and the totals into its own prologue.
+// Invariant used: an entry that was never written holds 0 (the priorities ring starts zero-filled) and contributes +0.0 to its chunk, so
+// chunk sums over whole chunks equal the contract's sums over prio[:n_valid].
+#define PS_ROWS 128   // batch rows whose chunks per_scatter_sums_kernel recomputes per pass (2 x 33 KB of LDS)
+struct per_mark_t { long long a[2], b[2]; int nb0; };   // the touched flat ranges [a, b) (the second one after the ring wrap) and piece 0's workgroup count
+// One workgroup of 1024 threads per LEVEL-1 GROUP (64 chunks = 4,096 entries) that the touched rows reach: it writes the marks, recomputes the
+// group's 64 chunk sums and — owning the whole group — the group's level-1 sums too, so the sampler never re-reads level 0.
+__global__ void __launch_bounds__(1024) per_mark_sums_kernel(float* __restrict__ prio, int N, long long slots, long long gs, int n_steps, const float* __restrict__ max_prio,
+                                                             per_mark_t mk, long long capacity, float alpha, double* __restrict__ s0, double* __restrict__ a0,
+                                                             double* __restrict__ s1, double* __restrict__ a1) {
+    __shared__ float pv[PER_CHUNK][PER_CHUNK + 1], pa[PER_CHUNK][PER_CHUNK + 1];
+    __shared__ double cs[PER_CHUNK], ca[PER_CHUNK];
+    const int piece = (int)blockIdx.x < mk.nb0 ? 0 : 1;
+    const long long m = mk.a[piece] / (PER_CHUNK * PER_CHUNK) + ((int)blockIdx.x - (piece ? mk.nb0 : 0));   // this workgroup's level-1 group
+    const long long base = m * PER_CHUNK * PER_CHUNK, head = gs % slots;
+    const long long row0 = base / N;                 // 64-bit divisions once per workgroup; per entry only 32-bit arithmetic
+    const int off0 = (int)(base - row0 * N);
+    const float mp = max_prio[0];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = it * 1024 + threadIdx.x;
+        const long long i = base + e;
+        float p = 0.0f;
+        if (i < capacity) {
+            long long st = row0 + (unsigned)(off0 + e) / (unsigned)N - head;   // time steps after the first one written by the acting call
+            st = st < 0 ? st + slots : st;
+            if (st < n_steps) { p = mp; prio[i] = p; }                   // per.py:106
+            else if (st == n_steps) { p = 0.0f; prio[i] = p; }           // the ring's write head: never sampled
+            else p = prio[i];
+        }
+        pv[e >> 6][e & 63] = p; pa[e >> 6][e & 63] = per_pow(p, alpha);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * PER_CHUNK) {               // threads 0..63: chunk sums of p, 64..127: of p^alpha — per_sums0_kernel's loop
+        const int r = threadIdx.x & 63;
+        const float (*src)[PER_CHUNK + 1] = threadIdx.x < PER_CHUNK ? pv : pa;
+        double sum = 0.0;
+        for (int j = 0; j < PER_CHUNK; ++j) sum += (double)src[r][j];
+        const long long k = m * PER_CHUNK + r;
+        if (threadIdx.x < PER_CHUNK) { cs[r] = sum; if (k * PER_CHUNK < capacity) s0[k] = sum; }
+        else { ca[r] = sum; if (k * PER_CHUNK < capacity) a0[k] = sum; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64) {     // the group's level-1 sums (per_sums1_kernel's order; chunks beyond the ring are +0.0)
+        const double* src = threadIdx.x == 0 ? cs : ca;
+        double sum = 0.0;
+        for (int j = 0; j < PER_CHUNK; ++j) sum += src[j];
+        (threadIdx.x == 0 ? s1 : a1)[m] = sum;
+    }
+}
+
+// per_scatter_kernel + the chunk sums of every chunk it touched
+__global__ void __launch_bounds__(1024) per_scatter_sums_kernel(float* __restrict__ prio, const int64_t* __restrict__ idx, const float* __restrict__ td_abs, int batch,
+                                                                int32_t* __restrict__ owner, float* __restrict__ max_prio, long long capacity, float alpha,
+                                                                double* __restrict__ s0, double* __restrict__ a0, double* __restrict__ s1, double* __restrict__ a1) {
+    __shared__ float wmax[16];
+    __shared__ __attribute__((aligned(16))) unsigned char raw[2 * PS_ROWS * (PER_CHUNK + 1) * sizeof(double)];   // phase 1: two float images; phase 2: two double images
+    float (*spv)[PER_CHUNK + 1] = reinterpret_cast<float (*)[PER_CHUNK + 1]>(raw);
+    float (*spa)[PER_CHUNK + 1] = spv + PS_ROWS;
+    double (*ts)[PER_CHUNK + 1] = reinterpret_cast<double (*)[PER_CHUNK + 1]>(raw);
+    double (*ta)[PER_CHUNK + 1] = ts + PS_ROWS;
+    for (int b = threadIdx.x; b < batch; b += 1024) atomicMax(&owner[idx[b]], b);
+    __syncthreads();
+    float mx = 0.0f;
+    for (int b = threadIdx.x; b < batch; b += 1024)
+        if (owner[idx[b]] == b) { prio[idx[b]] = td_abs[b]; mx = fmaxf(mx, td_abs[b]); }
+    __syncthreads();
+    for (int b = threadIdx.x; b < batch; b += 1024) owner[idx[b]] = -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();   // (also: every priority store of this workgroup is visible to its own later loads)
+    if (threadIdx.x == 0) {
+        float m = max_prio[0];
+        for (int k = 0; k < 16; ++k) m = fmaxf(m, wmax[k]);
+        max_prio[0] = m;
+    }
+    // the touched chunks, PS_ROWS batch rows at a time: all threads fill the [row][64] images (p and p^alpha, coalesced 256-byte reads), then
+    // one thread per row takes the two sums in index order from LDS — per_sums0_kernel's loop
+    for (int b0 = 0; b0 < batch; b0 += PS_ROWS) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < PS_ROWS * PER_CHUNK; e += 1024) {
+            const int r = e >> 6, j = e & 63;
+            float p = 0.0f;
+            if (b0 + r < batch) { const long long i = (idx[b0 + r] / PER_CHUNK) * PER_CHUNK + j; p = i < capacity ? prio[i] : 0.0f; }
+            spv[r][j] = p; spa[r][j] = per_pow(p, alpha);
+        }
+        __syncthreads();
+        if (threadIdx.x < PS_ROWS && b0 + (int)threadIdx.x < batch) {
+            double sum = 0.0, sa = 0.0;
+            for (int j = 0; j < PER_CHUNK; ++j) { sum += (double)spv[threadIdx.x][j]; sa += (double)spa[threadIdx.x][j]; }
+            const long long k = idx[b0 + threadIdx.x] / PER_CHUNK;
+            s0[k] = sum; a0[k] = sa;   // (a chunk hit by several batch rows is recomputed by several threads: same inputs, same value)
+        }
+    }
+    // phase 2: the level-1 sums of every group one of those chunks belongs to, from the (now current) level-0 sums: coalesced 512-byte reads
+    // into [row][64] images, then one thread per row and array adds in index order (per_sums1_kernel's sums)
+    const long long n0c = per_n0(capacity);
+    for (int b0 = 0; b0 < batch; b0 += PS_ROWS) {
+        __syncthreads();   // (first pass: also orders this workgroup's level-0 stores before the loads below)
+        for (int e = threadIdx.x; e < PS_ROWS * PER_CHUNK; e += 1024) {
+            const int r = e >> 6, j = e & 63;
+            double vs = 0.0, va = 0.0;
+            if (b0 + r < batch) { const long long k = (idx[b0 + r] / (PER_CHUNK * PER_CHUNK)) * PER_CHUNK + j; if (k < n0c) { vs = s0[k]; va = a0[k]; } }
+            ts[r][j] = vs; ta[r][j] = va;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * PS_ROWS) {
+            const int r = threadIdx.x % PS_ROWS;
+            if (b0 + r < batch) {
+                const double (*src)[PER_CHUNK + 1] = threadIdx.x < PS_ROWS ? ts : ta;
+                double sum = 0.0;
+                for (int j = 0; j < PER_CHUNK; ++j) sum += src[r][j];
+                (threadIdx.x < PS_ROWS ? s1 : a1)[idx[b0 + r] / (PER_CHUNK * PER_CHUNK)] = sum;
+            }
+        }
+    }
+}
+
 static int per_launch_sums(const float* priorities, int64_t n_valid, float alpha, const per_ws_t& w, hipStream_t s) {
     const int64_t n0 = per_n0(n_valid);
     per_sums0_kernel<<<(unsigned)((n0 + PER_CHUNK - 1) / PER_CHUNK), 256, 0, s>>>(priorities, (long long)n_valid, alpha, w.s0, w.a0);
     MI_LAUNCH_CHECK();
-    per_sums1_kernel<<<1, 256, 0, s>>>(w.s0, w.a0, (long long)n0, w.s1, w.totals);
+    per_sums1_kernel<<<1, 256, 0, s>>>(w.s0, w.a0, (long long)n0, w.s1, w.a1, w.totals);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -795,8 +937,67 @@ extern "C" int mi_per_sample(uint64_t seed, uint64_t update_index, const float* 
     mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);   // the sums launches and the sampler as one bracket
     const int rc = per_launch_sums(priorities, n_valid, alpha, w, (hipStream_t)stream);
     if (rc) return rc;
-    per_sample_kernel<<<1, 256, 0, (hipStream_t)stream>>>(seed, update_index, priorities, (long long)n_valid, w.s0, w.s1, w.totals, batch, (float)count, alpha, beta,
+    per_sample_kernel<<<1, 256, 0, (hipStream_t)stream>>>(seed, update_index, priorities, (long long)n_valid, w.s0, nullptr, w.s1, w.totals, batch, (float)count, alpha,
+                                                          beta, sample, idx, weights);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// ---- the incremental entry points (see per_mark_sums_kernel) ----
+extern "C" int mi_per_sums_refresh(const float* priorities, int64_t capacity, float alpha, void* workspace, void* stream) {
+    MI_CHECK_ARG(priorities && workspace && capacity > 0, "bad arguments");
+    const per_ws_t w = per_ws(workspace, capacity);
+    const int64_t n0 = per_n0(capacity);
+    per_sums0_kernel<<<(unsigned)((n0 + PER_CHUNK - 1) / PER_CHUNK), 256, 0, (hipStream_t)stream>>>(priorities, (long long)capacity, alpha, w.s0, w.a0);
+    MI_LAUNCH_CHECK();
+    per_sums1_kernel<<<1, 256, 0, (hipStream_t)stream>>>(w.s0, w.a0, (long long)n0, w.s1, w.a1, w.totals);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" int mi_per_mark_sums(float* priorities, int n_envs, int64_t slots, int64_t global_step, int n_steps, const float* max_priority, float alpha, void* workspace,
+                                void* stream) {
+    MI_CHECK_ARG(priorities && max_priority && workspace && n_envs > 0 && slots >= 2 && n_steps > 0 && n_steps < slots && global_step >= 0, "bad arguments");
+    const int64_t capacity = slots * n_envs, touched = (int64_t)(n_steps + 1) * n_envs;
+    const per_ws_t w = per_ws(workspace, capacity);
+    if (touched + 2 * (int64_t)PER_CHUNK * PER_CHUNK > capacity) {   // the touched rows (nearly) cover the ring: mark, then one full pass
+        int rc = mi_per_mark(priorities, n_envs, slots, global_step, n_steps, max_priority, stream);
+        if (rc) return rc;
+        return mi_per_sums_refresh(priorities, capacity, alpha, workspace, stream);
+    }
+    per_mark_t mk;
+    const int64_t lo = (global_step % slots) * n_envs, hi = lo + touched;
+    mk.a[0] = lo; mk.b[0] = hi < capacity ? hi : capacity;
+    mk.a[1] = 0; mk.b[1] = hi > capacity ? hi - capacity : 0;
+    constexpr int64_t G = (int64_t)PER_CHUNK * PER_CHUNK;   // entries per level-1 group = per workgroup
+    auto nblocks = [](int64_t a, int64_t b) -> int { return b <= a ? 0 : (int)((b - 1) / G - a / G + 1); };
+    mk.nb0 = nblocks(mk.a[0], mk.b[0]);
+    const int nb1 = nblocks(mk.a[1], mk.b[1]);
+    mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);
+    per_mark_sums_kernel<<<mk.nb0 + nb1, 1024, 0, (hipStream_t)stream>>>(priorities, n_envs, (long long)slots, (long long)global_step, n_steps, max_priority, mk,
+                                                                        (long long)capacity, alpha, w.s0, w.a0, w.s1, w.a1);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" int mi_per_sample_current(uint64_t seed, uint64_t update_index, const float* priorities, int64_t n_valid, int64_t capacity, double count, float alpha,
+                                     float beta, int batch, int sample, void* workspace, int64_t* idx, float* weights, void* stream) {
+    MI_CHECK_ARG(priorities && workspace && idx && weights && n_valid > 0 && n_valid <= capacity && batch > 0, "bad arguments");
+    MI_CHECK_ARG(capacity <= (int64_t)PER_MAX_L1 * PER_CHUNK * PER_CHUNK, "prioritized sampler: capacity above 4,194,304 entries needs a fourth level");
+    const per_ws_t w = per_ws(workspace, capacity);
+    mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);
+    per_sample_kernel<<<1, 256, 0, (hipStream_t)stream>>>(seed, update_index, priorities, (long long)n_valid, w.s0, w.a1, w.s1, nullptr, batch, (float)count, alpha, beta,
                                                           sample, idx, weights);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" int mi_per_update_priorities_sums(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, int64_t capacity,
+                                             float alpha, void* workspace, void* stream) {
+    MI_CHECK_ARG(priorities && idx && td_abs && owner && max_priority && workspace && batch > 0 && capacity > 0, "bad arguments");
+    const per_ws_t w = per_ws(workspace, capacity);
+    mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);
+    per_scatter_sums_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(priorities, idx, td_abs, batch, owner, max_priority, (long long)capacity, alpha, w.s0, w.a0, w.s1, w.a1);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }

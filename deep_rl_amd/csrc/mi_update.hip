@@ -479,6 +479,9 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #endif
     int it = 0;
     for (; tile < tile_end; tile += stride, ++it) {
+#ifdef GRAD_IGLP
+        __builtin_amdgcn_iglp_opt(GRAD_IGLP);   // experiment: LLVM's MFMA / DS interleaving strategies on the tile body
+#endif
         const bool valid = tile * TROWS + j < mb;
 #if GRAD_ALT_PRIO
         if ((it & 1) ^ (young ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);

@@ -182,12 +182,18 @@ class PERDQNEngine(DQNEngine):
         self.weights = torch.zeros(self.batch_size, dtype=torch.float32, device=dev)
         self.td_abs = torch.zeros(self.batch_size, dtype=torch.float32, device=dev)
         self._owner = torch.full((S * Nn,), -1, dtype=torch.int32, device=dev)
-        self._per_ws = torch.empty(N.lib().mi_per_workspace_bytes(S * Nn), dtype=torch.uint8, device=dev)
+        # the sampler's chunk sums, kept current by mark / update_priorities (zero-filled = current for the zero-filled ring)
+        self._per_ws = torch.zeros(N.lib().mi_per_workspace_bytes(S * Nn), dtype=torch.uint8, device=dev)
+
+    def refresh_sums(self):
+        """Rebuild the sampler's chunk sums from `priorities` (after anything but act / train_step wrote them: checkpoint load, tests)."""
+        N.check(N.lib().mi_per_sums_refresh(N.ptr(self.priorities), self.slots * self.N, self.alpha, N.ptr(self._per_ws), self._s()), "mi_per_sums_refresh")
 
     def act(self, n_steps, forced_actions=None, forced_resets=None):
         gs = self.global_step
         super().act(n_steps, forced_actions, forced_resets)
-        N.check(N.lib().mi_per_mark(N.ptr(self.priorities), self.N, self.slots, gs, int(n_steps), N.ptr(self.max_priority), self._s()), "mi_per_mark")   # :106
+        N.check(N.lib().mi_per_mark_sums(N.ptr(self.priorities), self.N, self.slots, gs, int(n_steps), N.ptr(self.max_priority), self.alpha, N.ptr(self._per_ws),
+                                         self._s()), "mi_per_mark_sums")   # :106
 
     def beta(self):
         """per.py:126: beta starts at beta_0 and increases linearly to 1."""
@@ -198,9 +204,9 @@ class PERDQNEngine(DQNEngine):
         stored = min(self.global_step, self.slots) * self.N
         if indices is not None:
             self.batch_inds.copy_(torch.as_tensor(indices, dtype=torch.int64).reshape(-1).to(self.device))
-        N.check(N.lib().mi_per_sample(self.env._seed, self.update_index, N.ptr(self.priorities), stored, self.slots * self.N, float(stored), self.alpha,
-                                      self.beta(), self.batch_size, 0 if indices is not None else 1, N.ptr(self._per_ws), N.ptr(self.batch_inds),
-                                      N.ptr(self.weights), self._s()), "mi_per_sample")
+        N.check(N.lib().mi_per_sample_current(self.env._seed, self.update_index, N.ptr(self.priorities), stored, self.slots * self.N, float(stored), self.alpha,
+                                              self.beta(), self.batch_size, 0 if indices is not None else 1, N.ptr(self._per_ws), N.ptr(self.batch_inds),
+                                              N.ptr(self.weights), self._s()), "mi_per_sample_current")
 
     def td_grad(self):
         """weighted loss + gradient (per.py:133-147), |td| per row; then priorities[batch_inds] = |td| and max_priority (:141-142)."""
@@ -216,5 +222,6 @@ class PERDQNEngine(DQNEngine):
         return self.weights, self.td_abs
 
     def _after_td(self):
-        N.check(N.lib().mi_per_update_priorities(N.ptr(self.priorities), N.ptr(self.batch_inds), N.ptr(self.td_abs), self.batch_size, N.ptr(self._owner),
-                                                 N.ptr(self.max_priority), self._s()), "mi_per_update_priorities")
+        N.check(N.lib().mi_per_update_priorities_sums(N.ptr(self.priorities), N.ptr(self.batch_inds), N.ptr(self.td_abs), self.batch_size, N.ptr(self._owner),
+                                                      N.ptr(self.max_priority), self.slots * self.N, self.alpha, N.ptr(self._per_ws), self._s()),
+                "mi_per_update_priorities_sums")

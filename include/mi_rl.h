@@ -258,6 +258,22 @@ int mi_per_td_grad(const float* params, const float* target_params, const float*
                    const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
                    float gamma, double inv_count, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, void* stream);
 int mi_per_update_priorities(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, void* stream);
+/* Incremental form of the same sampler (what PERDQNEngine runs): the level-0 chunk sums in `workspace` are kept CURRENT by the calls that
+ * change priorities — each RECOMPUTES the chunks it touches with mi_per_sample's own operations, so the sums, the indices drawn and the
+ * weights are bit-identical to the calls above — and the draw takes level 1 + totals into its own launch: per update 3 launches that touch
+ * O(new rows + batch) priorities instead of 5 that scan the whole ring (per.py:128 is an O(buffer) torch.multinomial).
+ *   mi_per_sums_refresh            full level-0 pass (after priorities were written by anything else, e.g. a checkpoint load); a zero-filled
+ *                                  workspace is current for a zero-filled ring
+ *   mi_per_mark_sums               = mi_per_mark + the sums of the touched chunks
+ *   mi_per_sample_current          = mi_per_sample, trusting the level-0 sums
+ *   mi_per_update_priorities_sums  = mi_per_update_priorities + the sums of the touched chunks (capacity = slots * N) */
+int mi_per_sums_refresh(const float* priorities, int64_t capacity, float alpha, void* workspace, void* stream);
+int mi_per_mark_sums(float* priorities, int n_envs, int64_t slots, int64_t global_step, int n_steps, const float* max_priority, float alpha, void* workspace,
+                     void* stream);
+int mi_per_sample_current(uint64_t seed, uint64_t update_index, const float* priorities, int64_t n_valid, int64_t capacity, double count, float alpha,
+                          float beta, int batch, int sample, void* workspace, int64_t* idx, float* weights, void* stream);
+int mi_per_update_priorities_sums(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, int64_t capacity,
+                                  float alpha, void* workspace, void* stream);
 
 /* =====================================================================================================================
  * SAC (reference deep_rl/sac.py re-targeted to Pendulum-v1; SURVEY.md §8a s1-s8, BASELINE config 4).

@@ -60,6 +60,7 @@ def test_sampler_and_weights_bit_exact_indices(dev, R, n_envs, slots, frac):
     prio[rng.random(cap) < 0.15] = 0.0
     prio[stored_steps * n_envs:] = 0.0
     eng.priorities.copy_(torch.from_numpy(prio.reshape(slots, n_envs)))
+    eng.refresh_sums()   # priorities written behind the engine's back: rebuild the sampler's chunk sums
     eng.global_step = stored_steps
     eng.update_index = 17
     eng.sample()
@@ -110,6 +111,39 @@ def test_mark_priorities_and_ring_head(dev, R):
     assert (p[10:] == 1.5).all() and (p[:4] == 1.5).all() and (p[4] == 0).all() and (p[5:10] == 0.75).all()
 
 
+@pytest.mark.parametrize("n_envs,slots", [(64, 37), (4096, 256)])
+def test_incremental_sums_equal_full_pass_and_oracle(dev, R, n_envs, slots):
+    """What PERDQNEngine runs (mi_per_mark_sums / mi_per_sample_current / mi_per_update_priorities_sums: only the touched chunks are
+    recomputed) against the full-pass form and the oracle, on a ring that fills and wraps under production acting and training:
+    the chunk sums are bit-identical to a full level-0 pass, the indices drawn bit-identical to mi_per_sample's and the oracle's."""
+    from deep_rl_amd import _native as N
+
+    eng = _engine(dev, n_envs, slots, seed=4, batch_size=128, learning_starts=0, total_timesteps=100 * slots)
+    eng.reset()
+    cap = slots * n_envs
+    n0 = (cap + 63) // 64
+    n1 = (n0 + 63) // 64
+    for it in range(slots // 10 + 12):          # fills the ring and wraps it
+        eng.act(10)
+        eng.train_step()
+        if it % 7 == 3 or it == slots // 10 + 11:
+            inc = eng._per_ws.clone()
+            eng.refresh_sums()
+            assert torch.equal(inc.view(torch.float64)[:2 * n0 + 2 * n1], eng._per_ws.view(torch.float64)[:2 * n0 + 2 * n1]), it   # level-0 and level-1 sums of p and p^alpha
+            prio = eng.priorities.cpu().numpy().reshape(-1)
+            stored = min(eng.global_step, slots) * n_envs
+            eng.sample()
+            got = eng.batch_inds.cpu().numpy().copy()
+            s0, s1, total, total_alpha = R.per_sums(prio, stored, ALPHA)
+            assert np.array_equal(got, R.per_sample(4, eng.update_index, prio, stored, s0, s1, total, 128)), it
+            full_idx = torch.zeros_like(eng.batch_inds); full_w = torch.zeros_like(eng.weights)
+            ws2 = torch.empty_like(eng._per_ws)
+            N.check(N.lib().mi_per_sample(4, eng.update_index, N.ptr(eng.priorities), stored, cap, float(stored), ALPHA, eng.beta(), 128, 1, N.ptr(ws2),
+                                          N.ptr(full_idx), N.ptr(full_w), N.stream_ptr(dev)), "mi_per_sample")
+            assert torch.equal(full_idx, eng.batch_inds) and torch.equal(full_w, eng.weights), it
+    assert (eng.priorities > 0).sum().item() > 0.9 * cap
+
+
 def _replay_storage(R, g, upto_steps):
     from tests.test_oracle_per_pinned import replay_per
 
@@ -128,6 +162,7 @@ def test_weighted_td_grad_vs_reference_checkpoints(dev, R, per_trace):
     for i, k in enumerate(g["ck_update"]):
         gs = int(g["ck_gs"][i]); pre = g["ck_pre_%d" % k]
         eng.priorities.zero_(); eng.priorities[:gs + 1, 0].copy_(torch.from_numpy(pre))
+        eng.refresh_sums()
         eng.max_priority.fill_(float(pre.max()))
         eng.global_step = gs
         eng.q.load_flat(g["ck_params"][i]); eng.target.load_flat(g["ck_target"][i])
@@ -153,6 +188,7 @@ def test_first_200_updates_chained_on_device(dev, R, per_trace):
     for k in range(200):
         gs = 10_000 + 10 * k
         eng.global_step = gs
+        eng.refresh_sums()   # (this loop writes the new rows' priorities itself instead of acting)
         eng.train_step(g["batch_inds_chain"][k])
         assert abs(float(eng.loss) - g["loss_all"][k]) <= 3e-4 * max(abs(g["loss_all"][k]), 1e-3), k
         assert abs(eng.priorities.double().sum().item() - g["prio_sum_all"][k]) <= 5e-6 * g["prio_sum_all"][k], k
