@@ -184,10 +184,12 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 // mi_ppo_update therefore runs 2 launches per optimizer step (gradient, slab sum) instead of 3.
 // =====================================================================================================
 #define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row writes and b32 row reads conflict-free
-#define GRAD_WAVES 4
-#ifndef GRAD_OCC
-#define GRAD_OCC 2        // waves per SIMD the kernel is built for (blocks per CU = GRAD_OCC)
+#ifndef GRAD_WAVES
+#define GRAD_WAVES 8      // waves per workgroup: 8 = ONE 512-thread workgroup per CU (two waves per SIMD share one staged copy of the weights, half as
+                          // many slabs to write and to sum, half the prologue traffic); 4 = the r01 form, two workgroups per CU (A/B switch)
 #endif
+#define GRAD_WPS 2        // waves per SIMD the kernel is built for
+#define GRAD_OCC (GRAD_WPS * 4 / GRAD_WAVES)   // workgroups per CU
 #ifndef GRAD_STAGGER
 #define GRAD_STAGGER 0    // diagnostic: s_sleep(127) count the second-round workgroups wait before their first tile
 #endif
@@ -213,9 +215,7 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #define GRAD_SPARE_SLABS 16                 // the workspace's last slabs hold mi_ppo_update's two spare optimizer-state sets
 #define RED_STRIDE 4640                     // per-wave slot of the exit reduction: 4096 dW2 + 544 small values
 #define STATE_STRIDE 9216                   // floats between params / exp_avg / exp_avg_sq inside a spare set
-#if defined(GRAD_STAMPS) && GRAD_OCC > 2
-#error "GRAD_STAMPS writes its timestamps behind slab 512: build it with GRAD_OCC <= 2"
-#endif
+static_assert(GRAD_WAVES == 4 || GRAD_WAVES == 8, "GRAD_WAVES");
 
 struct __attribute__((aligned(16))) grad_weights {
     float W2g[HID * HID];                 // see the header comment
@@ -257,11 +257,13 @@ __device__ __forceinline__ float tanh_prescaled(float zs) {
 // partial sums in f64 in a fixed order, xor-butterfly, four wave sums added in wave order.  Contains ONE __syncthreads.
 __device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads, int n, int vec_ok, double* ws /* shared [4] */) {
     constexpr int NV4 = (MI_PPO_NPARAMS + 3) / 4, PER_T = (NV4 + 255) / 256;
+    const bool act = threadIdx.x < 256;   // the first 256 threads of the workgroup carry the sum (the same thread -> element map in every caller); the rest only meet the barrier
     float4 gv[PER_T];
 #pragma unroll
     for (int k = 0; k < PER_T; ++k) {
         const int q = threadIdx.x + 256 * k;
         gv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!act) continue;
         if (vec_ok && 4 * q + 3 < n) gv[k] = reinterpret_cast<const float4*>(grads)[q];
         else {  // ragged tail (and the generic-n path): scalar, bounds-checked
             if (4 * q + 0 < n) gv[k].x = grads[4 * q + 0];
@@ -274,10 +276,10 @@ __device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads
 #pragma unroll
     for (int k = 0; k < PER_T; ++k)
         s += ((double)gv[k].x * gv[k].x + (double)gv[k].y * gv[k].y) + ((double)gv[k].z * gv[k].z + (double)gv[k].w * gv[k].w);
-    for (int k = 4 * 256 * PER_T + threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }  // n beyond the unrolled part
+    if (act) for (int k = 4 * 256 * PER_T + threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }  // n beyond the unrolled part
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    if (act && (threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
     return (float)sqrt((ws[0] + ws[1]) + (ws[2] + ws[3]));
 }
@@ -342,25 +344,55 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_in) :: "memory");
 #endif
 
+#ifdef GRAD_STAMPS
+    unsigned long long pro_t[6] = {0, 0, 0, 0, 0, 0};
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[0]) :: "memory");
+#endif
     // ---- stage this net's weights (once per block), stepping them first when an optimizer step is owed ----
     // thread (q, cg) owns the 4x4 block W2[4q..4q+3][4cg..4cg+3]: one float4 per row in, four float4 per image out
     float w1f[4], b3[NOUT];
     {
-        const int q = tid >> 4, cg = tid & 15;
+        const int q = (tid >> 4) & 15, cg = tid & 15;
         const bool writer = pending && (vb >> 1) == 0;   // the first workgroup of each net writes the stepped state back
+        const bool w2t = tid < 256;   // the W2 block map covers 256 threads; with 8 waves the upper half stages only its thin parameters
         f32x4 w[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = reinterpret_cast<const f32x4*>(p + N_W2)[(4 * q + e) * 16 + cg];
+        for (int e = 0; e < 4; ++e) w[e] = w2t ? reinterpret_cast<const f32x4*>(p + N_W2)[(4 * q + e) * 16 + cg] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // the thin parameters this thread stages: W1 fragments (4), b1 / b2 (threads < 64), W3 (threads < NOUT * 64), b3 (NOUT).
+        // ALL loads of the prologue — these, the W2 block and the whole gradient for the norm — are issued before the first one is waited
+        // for: one memory round trip instead of one per parameter group (measured: 5 us of the 6.9 us prologue were dependent round trips)
+        constexpr int NS = 7 + NOUT;
+        int sidx[NS];
+        bool sval[NS], swr[NS];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { sidx[mt] = N_W1 + 4 * (16 * mt + j) + g; sval[mt] = true; swr[mt] = wib == 0; }
+        sidx[4] = N_B1 + (tid & (HID - 1)); sval[4] = tid < HID; swr[4] = sval[4];
+        sidx[5] = N_B2 + (tid & (HID - 1)); sval[5] = tid < HID; swr[5] = sval[5];
+        sidx[6] = N_W3 + (tid < NOUT * HID ? tid : 0); sval[6] = tid < NOUT * HID; swr[6] = sval[6];
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) { sidx[7 + a] = N_W3 + NOUT * HID + a; sval[7 + a] = true; swr[7 + a] = tid == 0; }
+        float sp[NS], sg[NS], sm1[NS], sv1[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sp[k] = p[sidx[k]];
         float coef = 1.0f;
         if (pending) {
             f32x4 gg[4], mm[4], vv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                gg[e] = reinterpret_cast<const f32x4*>(pend.grads + BASE + N_W2)[(4 * q + e) * 16 + cg];
-                mm[e] = reinterpret_cast<const f32x4*>(pend.m_in + BASE + N_W2)[(4 * q + e) * 16 + cg];
-                vv[e] = reinterpret_cast<const f32x4*>(pend.v_in + BASE + N_W2)[(4 * q + e) * 16 + cg];
+                const int at = w2t ? (4 * q + e) * 16 + cg : 0;
+                gg[e] = reinterpret_cast<const f32x4*>(pend.grads + BASE + N_W2)[at];
+                mm[e] = reinterpret_cast<const f32x4*>(pend.m_in + BASE + N_W2)[at];
+                vv[e] = reinterpret_cast<const f32x4*>(pend.v_in + BASE + N_W2)[at];
             }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { sg[k] = pend.grads[BASE + sidx[k]]; sm1[k] = pend.m_in[BASE + sidx[k]]; sv1[k] = pend.v_in[BASE + sidx[k]]; }
+#ifdef GRAD_STAMPS
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[1]) :: "memory");
+#endif
             const float total = block_grad_norm(pend.grads, NPARAMS, pend.vec_ok, sm.nrm);
+#ifdef GRAD_STAMPS
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[2]) :: "memory");
+#endif
             coef = pend.max_norm / (total + 1e-6f);
             coef = coef > 1.0f ? 1.0f : coef;
             if (pend.grad_norm && vb == 0 && tid == 0) *pend.grad_norm = total;
@@ -372,34 +404,34 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
                     w[e][x] = mi_adam_elem(w[e][x], gg[e][x] * coef, m_, v_, pend.w1, pend.b2, pend.w2, pend.step_size, pend.rbc2, pend.eps);
                     mm[e][x] = m_; vv[e][x] = v_;
                 }
-                if (writer) {
+                if (writer && w2t) {
                     reinterpret_cast<f32x4*>(pend.p_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = w[e];
                     reinterpret_cast<f32x4*>(pend.m_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = mm[e];
                     reinterpret_cast<f32x4*>(pend.v_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = vv[e];
                 }
             }
-        }
-        // parameter i of this net as this launch must see it (stepped when a step is owed); `wr`: this thread writes it back
-        auto fetch = [&](int i, bool wr) -> float {
-            float pv = p[i];
-            if (pending) {
-                float m_ = pend.m_in[BASE + i], v_ = pend.v_in[BASE + i];
-                pv = mi_adam_elem(pv, pend.grads[BASE + i] * coef, m_, v_, pend.w1, pend.b2, pend.w2, pend.step_size, pend.rbc2, pend.eps);
-                if (writer && wr) { pend.p_out[BASE + i] = pv; pend.m_out[BASE + i] = m_; pend.v_out[BASE + i] = v_; }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                sp[k] = mi_adam_elem(sp[k], sg[k] * coef, sm1[k], sv1[k], pend.w1, pend.b2, pend.w2, pend.step_size, pend.rbc2, pend.eps);
+                if (writer && sval[k] && swr[k]) { pend.p_out[BASE + sidx[k]] = sp[k]; pend.m_out[BASE + sidx[k]] = sm1[k]; pend.v_out[BASE + sidx[k]] = sv1[k]; }
             }
-            return pv;
-        };
+        }
+#ifdef GRAD_STAMPS
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[3]) :: "memory");
+#endif
+        if (w2t) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(&W.W2g[(cg * 64 + 4 * q + e) * 4]) = w[e] * GRAD_PS;
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(&W.W2g[(cg * 64 + 4 * q + e) * 4]) = w[e] * GRAD_PS;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) *reinterpret_cast<f32x4*>(&W.W2t[(q * 64 + 4 * cg + x) * 4]) = f32x4{w[0][x], w[1][x], w[2][x], w[3][x]};
-        if (tid < HID) { W.b1[tid] = GRAD_PS * fetch(N_B1 + tid, true); W.b2[tid] = GRAD_PS * fetch(N_B2 + tid, true); }
-        if (tid < NOUT * HID) W.W3[tid] = fetch(N_W3 + tid, true);
+            for (int x = 0; x < 4; ++x) *reinterpret_cast<f32x4*>(&W.W2t[(q * 64 + 4 * cg + x) * 4]) = f32x4{w[0][x], w[1][x], w[2][x], w[3][x]};
+        }
+        if (tid < HID) { W.b1[tid] = GRAD_PS * sp[4]; W.b2[tid] = GRAD_PS * sp[5]; }
+        if (tid < NOUT * HID) W.W3[tid] = sp[6];
         // layer-1 A fragments live in registers: lane (i = j, g), tile mt holds c W1[16mt + i][k = g]
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) w1f[mt] = GRAD_PS * fetch(N_W1 + 4 * (16 * mt + j) + g, wib == 0);
+        for (int mt = 0; mt < 4; ++mt) w1f[mt] = GRAD_PS * sp[mt];
 #pragma unroll
-        for (int a = 0; a < NOUT; ++a) b3[a] = fetch(N_W3 + NOUT * HID + a, tid == 0);
+        for (int a = 0; a < NOUT; ++a) b3[a] = sp[7 + a];
     }
 
     // advantage normalisation constants (ppo.py:169) from {sum, sum sq, count}
@@ -418,16 +450,25 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     // workgroup of a CU (blockIdx < grid/2) wins every conflict and runs ~1.3x faster than the second one (measured with
     // s_memrealtime stamps: 60 vs 80 us for equal work).  So the older half of a role's waves takes GRAD_OLD_SHARE of every
     // 16 tile rounds and the younger half the rest; a fixed function of the indices, so results stay reproducible.
+#if GRAD_WAVES == 8
+    // one workgroup per CU: its waves 0-3 are the older wave of their SIMD, waves 4-7 the younger one
+    const int half = (int)(gridDim.x >> 1) * 4;                   // older (or younger) waves of this role
+    const bool split_ok = (gridDim.x % (2u << GRAD_ROLE_BIT)) == 0;
+    const bool young = split_ok && wib >= 4;
+    const int wi_half = (int)(vb >> 1) * 4 + (wib & 3);           // index within its half
+#else
     const int half = (int)(gridDim.x >> 2) * GRAD_WAVES;          // waves of this role in one dispatch round
     // valid only when both dispatch rounds hold half of each role's workgroups: grid a multiple of 4 * 2^GRAD_ROLE_BIT
     const bool split_ok = (gridDim.x % (4u << GRAD_ROLE_BIT)) == 0;
     const bool young = split_ok && blockIdx.x >= (gridDim.x >> 1);
+    const int wi_half = (int)((vb >> 1) % (unsigned)(gridDim.x >> 2)) * GRAD_WAVES + wib;
+#endif
     int tile, stride, tile_end;
     if (split_ok) {
         const int rounds = (n_tiles + half - 1) / half;            // tile rounds over one half
         const int old_rounds = (rounds * GRAD_OLD_SHARE + 8) / 16; // rounds taken by the older half
         const int split = old_rounds * half < n_tiles ? old_rounds * half : n_tiles;
-        const int wi = (int)((vb >> 1) % (unsigned)(gridDim.x >> 2)) * GRAD_WAVES + wib;  // index within its half
+        const int wi = wi_half;
         stride = half;
         tile = young ? split + wi : wi;
         tile_end = young ? n_tiles : split;
@@ -440,7 +481,13 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     auto tile_rid = [&](int t) { const int row = t * TROWS + j; return idx[row < mb ? row : mb - 1]; };
     int rid_next = tile_rid(tile + stride);
     row_in cur = gather_row<ACTOR>(tile_rid(tile), g, observations, actions, log_probs, advantages, returns, values);
+#ifdef GRAD_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[4]) :: "memory");
+#endif
     __syncthreads();  // weights staged
+#ifdef GRAD_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[5]) :: "memory");
+#endif
 #if GRAD_STAGGER > 0
     // de-phase the two workgroups that share a CU (dispatch order: blocks b and b + grid/2 land on the same CU)
     if (blockIdx.x >= (gridDim.x >> 1)) {
@@ -699,6 +746,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         for (int k = 0; k < 11; ++k) dbg[k] = stamp_acc[k];
         dbg[11] = now - stamp_t0;
         dbg[12] = (unsigned long long)it;   // tiles this wave processed
+        for (int k = 0; k < 6; ++k) STAMP_BASE(part)[72 + 6 * wib + k] = pro_t[k];
     }
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_loop) :: "memory");
 #endif
@@ -751,12 +799,21 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         const int i = tid + 64 * GRAD_WAVES * k;
         const f32x4 a0 = reinterpret_cast<const f32x4*>(sm.red[0])[i], a1 = reinterpret_cast<const f32x4*>(sm.red[1])[i];
         const f32x4 a2 = reinterpret_cast<const f32x4*>(sm.red[2])[i], a3 = reinterpret_cast<const f32x4*>(sm.red[3])[i];
+#if GRAD_WAVES == 8
+        const f32x4 a4 = reinterpret_cast<const f32x4*>(sm.red[4])[i], a5 = reinterpret_cast<const f32x4*>(sm.red[5])[i];
+        const f32x4 a6 = reinterpret_cast<const f32x4*>(sm.red[6])[i], a7 = reinterpret_cast<const f32x4*>(sm.red[7])[i];
+        reinterpret_cast<f32x4*>(part + N_W2)[i] = ((a0 + a2) + (a1 + a3)) + ((a4 + a6) + (a5 + a7));
+#else
         reinterpret_cast<f32x4*>(part + N_W2)[i] = (a0 + a2) + (a1 + a3);
+#endif
     }
     constexpr int N_SMALL = 384 + NOUT * HID + NOUT;
     for (int i = tid; i < 522; i += 64 * GRAD_WAVES) {
         if (i >= N_SMALL && i < 520) continue;
-        const float t = (sm.red[0][HID * HID + i] + sm.red[1][HID * HID + i]) + (sm.red[2][HID * HID + i] + sm.red[3][HID * HID + i]);
+        float t = (sm.red[0][HID * HID + i] + sm.red[1][HID * HID + i]) + (sm.red[2][HID * HID + i] + sm.red[3][HID * HID + i]);
+#if GRAD_WAVES == 8
+        t += (sm.red[4][HID * HID + i] + sm.red[5][HID * HID + i]) + (sm.red[6][HID * HID + i] + sm.red[7][HID * HID + i]);
+#endif
         int dst;
         if (i < 256) dst = N_W1 + i;
         else if (i < 320) dst = N_B1 + (i - 256);
@@ -778,7 +835,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
 #endif
 }
 
-__global__ void __launch_bounds__(64 * GRAD_WAVES, GRAD_OCC)
+__global__ void __launch_bounds__(64 * GRAD_WAVES, GRAD_WPS)
 grad_kernel(const float* __restrict__ params, grad_pending_t pend, const float* __restrict__ observations, const int64_t* __restrict__ actions,
             const float* __restrict__ log_probs, const float* __restrict__ advantages, const float* __restrict__ returns,
             const float* __restrict__ values, const int32_t* __restrict__ idx, int mb, const double* __restrict__ adv_sums,
@@ -820,8 +877,16 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_
         if (p < NPARAMS) {
             const float* src = workspace + off;
             const int per_role = n_blocks >> 1;
+            if (per_role == 8 * RED_GROUPS) {   // the full grid (128 slabs per net): all 8 loads of the thread in flight at once, same summation order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(2 * (sg + RED_GROUPS * u) + role) * PART_STRIDE];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            } else {
 #pragma unroll 4
-            for (int k = sg; k < per_role; k += RED_GROUPS) acc += src[(size_t)(2 * k + role) * PART_STRIDE];
+                for (int k = sg; k < per_role; k += RED_GROUPS) acc += src[(size_t)(2 * k + role) * PART_STRIDE];
+            }
         }
         part[sg][pl] = acc;
         __syncthreads();

@@ -13,8 +13,12 @@ torch.manual_seed(1)
 agent = D.ActorCritic(env); opt = D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
 eng = D.PPOEngine(env, agent, opt)
 eng.reset(); eng.rollout(); eng.compute_gae(); eng.make_perm(0); eng.adv_stats()
-for _ in range(3):
-    eng.minibatch_grad(0)
+if os.environ.get("STAMP_UPDATE", "0") == "1":   # the stamps of the LAST gradient launch of a whole update (owed clip + Adam step on its weight staging)
+    for _ in range(3):
+        eng.update()
+else:
+    for _ in range(3):
+        eng.minibatch_grad(0)
 torch.cuda.synchronize()
 ws = eng.workspace.view(torch.float32).cpu().numpy()
 names = ["issue gathers", "L1 + tanh", "L2 mfma", "tanh h2 (+L2 drain)", "head + loss", "stage h2 + dW3", "dz2", "dh1 mfma + dz1",
@@ -112,3 +116,14 @@ for pat, t in rows:
     agg[pat].append(t)
 for pat, ts in sorted(agg.items()):
     print("  SIMD occupancy pattern %s: %d CUs, mean loop %.1f us" % (pat, len(ts), np.mean(ts)))
+
+# prologue sub-phases (s_memtime): entry | loads issued | norm done (loads landed, barrier) | Adam done | LDS stores issued + gathers | barrier
+pro = []
+for b in range(512):
+    base = (512 + b) * 4624
+    raw = ws[base + 2 * 72: base + 2 * 72 + 2 * 24].view(np.uint64).reshape(4, 6).astype(np.float64)
+    if raw[0, 0]: pro.append(raw)
+if pro:
+    pro = np.concatenate(pro)
+    d = np.diff(pro, axis=1)
+    print("  prologue cycles (mean over waves): issue loads %.0f | norm (land + reduce + barrier) %.0f | Adam %.0f | LDS stores + first gathers %.0f | barrier %.0f" % tuple(d.mean(0)))
