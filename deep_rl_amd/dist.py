@@ -59,23 +59,38 @@ _native_comms = {}
 
 
 def native_comm(group=None):
-    """libmirl's RCCL communicator for `group` (created collectively on first use) or None when there is no process group or its
-    backend is not nccl (gloo runs keep the host-sequenced path).  Rank 0 draws the ncclUniqueId, the group broadcasts it."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+    """libmirl's RCCL communicator for `group` (created collectively on first use) or None when there is no process group, its backend
+    is not nccl (gloo runs keep the host-sequenced path), MIRL_NATIVE_COMM=0, or the creation failed on ANY rank (the ranks agree on
+    that through the process group, so either all of them take the one-call path or all of them fall back).
+    Rank 0 draws the ncclUniqueId, the group broadcasts it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl" or os.environ.get("MIRL_NATIVE_COMM", "1") == "0":
         return None
     key = id(group) if group is not None else 0
     if key not in _native_comms:
+        import sys
+
         from . import _native as N
 
         ident = (C.c_char * 128)()
+        ok = 1
         if dist.get_rank(group) == 0:
-            N.check(N.lib().mi_comm_unique_id(ident), "mi_comm_unique_id")
-        box = [bytes(ident.raw)]
+            ok = 1 if N.lib().mi_comm_unique_id(ident) == 0 else 0
+        box = [bytes(ident.raw), ok]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident.raw = box[0]
+        ident.raw, ok = box[0], box[1]
         h = C.c_void_p()
-        N.check(N.lib().mi_comm_create(ident, dist.get_world_size(group), dist.get_rank(group), C.byref(h)), "mi_comm_create")
-        _native_comms[key] = h
+        if ok and N.lib().mi_comm_create(ident, dist.get_world_size(group), dist.get_rank(group), C.byref(h)) != 0:
+            ok, err = 0, N.lib().mi_last_error().decode()
+            print("deep_rl_amd: mi_comm_create failed on rank %d (%s): falling back to torch.distributed collectives" % (dist.get_rank(group), err), file=sys.stderr)
+        import torch as _t
+        flag = _t.tensor([ok], dtype=_t.int32, device=_t.device("cuda", _t.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            if h.value:
+                N.lib().mi_comm_destroy(h)
+            _native_comms[key] = None
+        else:
+            _native_comms[key] = h
     return _native_comms[key]
 
 
@@ -83,7 +98,8 @@ def destroy_native_comms():
     from . import _native as N
 
     for h in _native_comms.values():
-        N.lib().mi_comm_destroy(h)
+        if h is not None:
+            N.lib().mi_comm_destroy(h)
     _native_comms.clear()
 
 

@@ -11,7 +11,7 @@ CMD="python3 $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $CMD > $OUT/stats_run.log 2>&1
 find /tmp/rp_stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 find /tmp/rp_stats -name '*kernel_trace.csv' -exec cp {} /tmp/kernel_trace.csv \;
-PCMD="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+PCMD="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only"
 i=0
 for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
