@@ -71,6 +71,7 @@ SIGNATURES = {
     "mi_comm_allreduce_sum": (_I, [_VP, _VP, _SZ, _I, _VP]),
     "mi_dqn_forward": (_I, [_VP, _VP, _I, _VP, _VP]),
     "mi_dqn_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP]),
+    "mi_dqn_act_steps2": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP, _VP]),
     "mi_dqn_sample": (_I, [_U64, _U64, _I64, _I, _VP, _VP]),
     "mi_dqn_workspace_bytes": (_SZ, [_I]),
     "mi_dqn_td_grad": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _D, _VP, _VP, _VP, _VP]),

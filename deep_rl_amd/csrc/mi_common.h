@@ -330,6 +330,31 @@ __device__ __forceinline__ float groups_sum(float v) {
 }
 
 
+// ---- lane = unit / register = env building blocks of the 16-block 4x4x1 MFMA kernels (rollout_q4_kernel, dqn_act_q4_kernel) ----
+typedef float rq_f32x4 __attribute__((ext_vector_type(4)));
+// 4x4 transpose inside every quad of lanes: in: lane 4b + q holds v[e] = M[q][e]; out: lane 4b + q holds v[e] = M[e][q]
+__device__ __forceinline__ rq_f32x4 quad_transpose(rq_f32x4 v, bool b0, bool b1) {
+    const float x0 = dpp_xor1(b0 ? v[0] : v[1]), x1 = dpp_xor1(b0 ? v[2] : v[3]);
+    if (b0) { v[0] = x0; v[2] = x1; } else { v[1] = x0; v[3] = x1; }
+    const float x2 = dpp_xor2(b1 ? v[0] : v[2]), x3 = dpp_xor2(b1 ? v[1] : v[3]);
+    if (b1) { v[0] = x2; v[1] = x3; } else { v[2] = x2; v[3] = x3; }
+    return v;
+}
+
+__device__ __forceinline__ float dpp_row_ror4(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_row_ror8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
+
+// p[e] = this lane's contribution to env e's total (e = 0..3) -> the sum over all 64 lanes for env (lane & 3), in every lane.
+// Fixed order: quad butterfly (lane ^ 1, lane ^ 2), the row's 4 quads (ror 4, ror 8), the 4 rows (permlane16 / 32 swaps).
+__device__ __forceinline__ float quad_env_reduce(const rq_f32x4& p, bool b0, bool b1) {
+    const float r01 = (b0 ? p[1] : p[0]) + dpp_xor1(b0 ? p[0] : p[1]);
+    const float r23 = (b0 ? p[3] : p[2]) + dpp_xor1(b0 ? p[2] : p[3]);
+    float r = (b1 ? r23 : r01) + dpp_xor2(b1 ? r01 : r23);
+    r += dpp_row_ror4(r);
+    r += dpp_row_ror8(r);
+    return groups_sum(r);
+}
+
 // wave-private LDS traffic: LDS executes one wave's instructions in order, so only the COMPILER must be kept
 // from moving accesses across this point.
 __device__ __forceinline__ void wave_lds_fence() {

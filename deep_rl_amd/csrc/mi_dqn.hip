@@ -105,8 +105,9 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
                dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
                int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
                const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
-               int32_t* __restrict__ episode_stats, int max_ep) {
+               int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next) {
     __shared__ float qp[2][DA_WAVES][DA_ENVS][2];
+    if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;   // the NEXT acting call's statistics (nobody else touches them during this launch)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
     const int N = e.n;
     const int i = blockIdx.x * DA_ENVS + j;
@@ -240,19 +241,24 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
     }
 }
 
+// Negative result (round 2, measured, removed): the PPO rollout's lane = unit formulation on the 16-block 4x4x1 MFMA (4 envs per 2-wave workgroup,
+// weights as register-resident B operands) for THIS net: correct and parity-green, but 55 us per 10-step launch against 35 — 84 output units on
+// 64-lane waves leave a third of every layer-2 MFMA empty (the 16x16x4 form pads 84 to 96), each wave needs 120 + 8 resident weights (255 VGPRs,
+// spills), and the two waves still meet at a barrier per step for the head.
+
 __global__ void dqn_zero_stats_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
-extern "C" int mi_dqn_act_steps(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
-                                double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
-                                float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
-                                const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, void* stream) {
+static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
+                        double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
+                        float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
+                        const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, int32_t* zero_next, bool zero_now, void* stream) {
     MI_CHECK_ARG(handle && params && obs_cur && observations && actions && rewards && terminated, "NULL pointer");
     MI_CHECK_ARG(n_steps > 0 && n_steps <= DQN_MAX_STEPS_PER_CALL, "n_steps must be in [1, 64]");
     MI_CHECK_ARG(slots >= 2 && global_step >= 0, "slots must be >= 2 and global_step >= 0");
     MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
     mi_env* e = (mi_env*)handle;
     hipStream_t s = (hipStream_t)stream;
-    if (episode_stats) { dqn_zero_stats_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    if (episode_stats && zero_now) { dqn_zero_stats_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
     // epsilon = max(slope * global_step + start_e, end_e) in the reference's double arithmetic (dqn.py:47,86), evaluated on
     // the host for the n_steps of this call and handed over by value (no allocation, no copy to enqueue)
     dqn_eps_tab tab;
@@ -266,12 +272,31 @@ extern "C" int mi_dqn_act_steps(void* handle, const float* params, int n_steps, 
     const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(64 * DA_WAVES);
 #define DA_LAUNCH(F, L) dqn_act_kernel<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
                                                                   obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes, \
-                                                                  episode_stats, max_ep)
+                                                                  episode_stats, max_ep, zero_next)
     if (forced) { if (eplog) DA_LAUNCH(true, true); else DA_LAUNCH(true, false); }
     else { if (eplog) DA_LAUNCH(false, true); else DA_LAUNCH(false, false); }
 #undef DA_LAUNCH
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+
+extern "C" int mi_dqn_act_steps(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
+                                double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
+                                float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
+                                const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, void* stream) {
+    return dqn_act_impl(handle, params, n_steps, global_step, slots, learning_starts, start_e, end_e, exploration_fraction, total_timesteps, obs_cur, observations,
+                        actions, rewards, terminated, forced_actions, forced_resets, episodes, episode_stats, max_ep, nullptr, true, stream);
+}
+
+// the same with the statistics double-buffered by the caller: `episode_stats` must be zero on entry (it is NOT reset by a launch of its own);
+// `zero_next` (dev i32 [4], a different buffer) is zeroed by this launch for the next acting call
+extern "C" int mi_dqn_act_steps2(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
+                                 double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
+                                 float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
+                                 const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, int32_t* zero_next, void* stream) {
+    MI_CHECK_ARG(zero_next && zero_next != episode_stats, "zero_next must be a second statistics buffer");
+    return dqn_act_impl(handle, params, n_steps, global_step, slots, learning_starts, start_e, end_e, exploration_fraction, total_timesteps, obs_cur, observations,
+                        actions, rewards, terminated, forced_actions, forced_resets, episodes, episode_stats, max_ep, zero_next, false, stream);
 }
 
 // ---- sampling: idx[b] = (w0 | w1 << 32) mod upper of Philox(seed, env := update, idx := b, stream 4) -----------------------

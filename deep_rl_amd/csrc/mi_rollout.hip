@@ -407,7 +407,6 @@ rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __
 #define RQ_ENVS 4
 #define RQ_GAE_T 128
 #define RQ_RING (RQ_GAE_T + 1)
-typedef float rq_f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef RQ_CHAINS
 #define RQ_CHAINS 4   // independent accumulator chains of layer 2 (k mod RQ_CHAINS); 8 measured no faster: the wave is issue-bound, not MFMA-latency-bound
@@ -423,29 +422,6 @@ template <>
 struct rq_layer2<HID> {
     static __device__ __forceinline__ void run(const float (&)[HID], const rq_f32x4&, rq_f32x4 (&)[RQ_CHAINS]) {}
 };
-
-// 4x4 transpose inside every quad of lanes: in: lane 4b + q holds v[e] = M[q][e]; out: lane 4b + q holds v[e] = M[e][q]
-__device__ __forceinline__ rq_f32x4 quad_transpose(rq_f32x4 v, bool b0, bool b1) {
-    const float x0 = dpp_xor1(b0 ? v[0] : v[1]), x1 = dpp_xor1(b0 ? v[2] : v[3]);
-    if (b0) { v[0] = x0; v[2] = x1; } else { v[1] = x0; v[3] = x1; }
-    const float x2 = dpp_xor2(b1 ? v[0] : v[2]), x3 = dpp_xor2(b1 ? v[1] : v[3]);
-    if (b1) { v[0] = x2; v[1] = x3; } else { v[2] = x2; v[3] = x3; }
-    return v;
-}
-
-__device__ __forceinline__ float dpp_row_ror4(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)); }
-__device__ __forceinline__ float dpp_row_ror8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
-
-// p[e] = this lane's contribution to env e's total (e = 0..3) -> the sum over all 64 lanes for env (lane & 3), in every lane.
-// Fixed order: quad butterfly (lane ^ 1, lane ^ 2), the row's 4 quads (ror 4, ror 8), the 4 rows (permlane16 / 32 swaps).
-__device__ __forceinline__ float quad_env_reduce(const rq_f32x4& p, bool b0, bool b1) {
-    const float r01 = (b0 ? p[1] : p[0]) + dpp_xor1(b0 ? p[0] : p[1]);
-    const float r23 = (b0 ? p[3] : p[2]) + dpp_xor1(b0 ? p[2] : p[3]);
-    float r = (b1 ? r23 : r01) + dpp_xor2(b1 ? r01 : r23);
-    r += dpp_row_ror4(r);
-    r += dpp_row_ror8(r);
-    return groups_sum(r);
-}
 
 // one net's hidden layers on 4 envs: ob = this lane's env's observation (env = lane & 3); returns tanh(layer 2)[unit = lane][env = register]
 __device__ __forceinline__ rq_f32x4 rq_hidden(const float4& ob, const float (&w1)[OBS], float b1, const float (&w2)[HID], float b2, bool q0, bool q1) {

@@ -32,7 +32,9 @@ class DQNEngine:
         self.workspace = torch.empty(N.lib().mi_dqn_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)
         self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (1024 if Nn <= 8 else 0))
         self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
-        self.episode_stats = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._stats2 = torch.zeros((2, 4), dtype=torch.int32, device=dev)   # double-buffered: an acting launch zeroes the NEXT call's statistics
+        self._stats_i = 0
+        self.episode_stats = self._stats2[0]
         self.observation = None
         self.global_step = 0      # time steps taken (each advances every env once)
         self.update_index = 0
@@ -51,11 +53,17 @@ class DQNEngine:
         dev = self.device
         fa = None if forced_actions is None else forced_actions.to(dev, torch.int64).contiguous()
         fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
-        N.check(N.lib().mi_dqn_act_steps(
-            self.env.handle, N.ptr(self.q.flat), int(n_steps), self.global_step, self.slots, self.learning_starts, self.start_e, self.end_e,
+        self._act_launch(self.q.flat, n_steps, fa, fr)
+
+    def _act_launch(self, flat, n_steps, fa, fr):
+        cur, nxt = self._stats2[self._stats_i], self._stats2[self._stats_i ^ 1]
+        self.episode_stats = cur
+        N.check(N.lib().mi_dqn_act_steps2(
+            self.env.handle, N.ptr(flat), int(n_steps), self.global_step, self.slots, self.learning_starts, self.start_e, self.end_e,
             self.exploration_fraction, self.total_timesteps, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.actions),
-            N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fr), N.ptr(self.episodes), N.ptr(self.episode_stats), self.max_ep,
-            self._s()), "mi_dqn_act_steps")
+            N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fr), N.ptr(self.episodes), N.ptr(cur), self.max_ep, N.ptr(nxt),
+            self._s()), "mi_dqn_act_steps2")
+        self._stats_i ^= 1
         self.global_step += int(n_steps)
 
     def drain_episodes(self):
@@ -138,12 +146,7 @@ class DuelingDQNEngine(DQNEngine):
         dev = self.device
         fa = None if forced_actions is None else forced_actions.to(dev, torch.int64).contiguous()
         fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
-        N.check(N.lib().mi_dqn_act_steps(
-            self.env.handle, N.ptr(self.q.eff), int(n_steps), self.global_step, self.slots, self.learning_starts, self.start_e, self.end_e,
-            self.exploration_fraction, self.total_timesteps, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.actions),
-            N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fr), N.ptr(self.episodes), N.ptr(self.episode_stats), self.max_ep,
-            self._s()), "mi_dqn_act_steps")
-        self.global_step += int(n_steps)
+        self._act_launch(self.q.eff, n_steps, fa, fr)
 
     def td_grad(self):
         N.check(N.lib().mi_dqn_td_grad(

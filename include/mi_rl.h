@@ -211,6 +211,12 @@ int mi_dqn_act_steps(void* handle, const float* params, int n_steps, int64_t glo
                      double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
                      float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
                      const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, void* stream);
+/* the same with the statistics double-buffered by the caller (saves the tiny launch that resets them): episode_stats must be ZERO on entry;
+ * zero_next (dev i32 [4], another buffer) is zeroed by this launch for the next acting call, which passes it as its episode_stats */
+int mi_dqn_act_steps2(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
+                      double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
+                      float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
+                      const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, int32_t* zero_next, void* stream);
 /* batch_inds = randint(upper, size=batch) (dqn.py:116 / iqn.py:225-226): idx dev i64 [batch], uniform in [0, upper_flat) */
 int mi_dqn_sample(uint64_t seed, uint64_t update_index, int64_t upper_flat, int batch, int64_t* idx, void* stream);
 /* TD loss + gradient of one batch (dqn.py:118-128): grads dev f32 [MI_DQN_NPARAMS] = d loss/d params scaled by inv_count
