@@ -205,6 +205,9 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #ifndef GRAD_PRESCALE
 #define GRAD_PRESCALE 1   // fold tanh's 2 log2(e) into the staged W1 / b1 / W2 / b2
 #endif
+#ifndef GRAD_ACTOR_EXTRA
+#define GRAD_ACTOR_EXTRA 2   // per 128 workgroups: how many more serve the actor than the critic (0 = even split)
+#endif
 #ifndef GRAD_DW3_VALU
 #define GRAD_DW3_VALU 1   // 1: dW3 as per-lane VALU partial sums (no h2 staging image, no 4x4x1 chain); 0: the r01 form (16 4x4x1 MFMAs from an LDS image)
 #endif
@@ -294,6 +297,21 @@ struct grad_pending_t {
     int vec_ok;
 };
 
+// Which net a slab / workgroup serves.  Slab index vb: even = actor, odd = critic, except that the first `extra` critic slabs serve the actor too: an
+// actor tile costs ~3.5 % more than a critic tile (the policy loss), and with one workgroup per CU that is a per-CU imbalance, so the actor gets
+// `extra` more CUs (130 : 126 at 256).  ri = index within the role (the order grad_reduce_kernel sums in), nr = workgroups of that role.
+struct grad_role_t { int role, ri, nr; };
+__host__ __device__ inline grad_role_t grad_role(unsigned vb, int n_blocks, int extra) {
+    const int half = n_blocks >> 1, k = (int)(vb >> 1);
+    if ((vb & 1u) == 0) return grad_role_t{0, k, half + extra};
+    if (k < extra) return grad_role_t{0, half + k, half + extra};
+    return grad_role_t{1, k - extra, half - extra};
+}
+__host__ __device__ inline int grad_slab(int role, int ri, int n_blocks, int extra) {   // inverse: the slab of workgroup ri of a role
+    const int half = n_blocks >> 1;
+    return role == 0 ? (ri < half ? 2 * ri : 2 * (ri - half) + 1) : 2 * (ri + extra) + 1;
+}
+
 struct row_in {
     float x;          // observation component g of the row (lane (j,g))
     int act;
@@ -331,7 +349,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
                                           const float* __restrict__ advantages, const float* __restrict__ returns,
                                           const float* __restrict__ values, const int32_t* __restrict__ idx, int mb,
                                           const double* __restrict__ adv_sums, float clip_coef, float ent_coef, float vf_coef,
-                                          float invn, float* __restrict__ part, unsigned vb) {
+                                          float invn, float* __restrict__ part, unsigned vb, grad_role_t rl) {
     constexpr int NOUT = ACTOR ? 2 : 1;
     constexpr int BASE = ACTOR ? 0 : C_BASE;
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -353,7 +371,7 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     float w1f[4], b3[NOUT];
     {
         const int q = (tid >> 4) & 15, cg = tid & 15;
-        const bool writer = pending && (vb >> 1) == 0;   // the first workgroup of each net writes the stepped state back
+        const bool writer = pending && rl.ri == 0;   // the first workgroup of each net writes the stepped state back
         const bool w2t = tid < 256;   // the W2 block map covers 256 threads; with 8 waves the upper half stages only its thin parameters
         f32x4 w[4];
 #pragma unroll
@@ -452,10 +470,10 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     // 16 tile rounds and the younger half the rest; a fixed function of the indices, so results stay reproducible.
 #if GRAD_WAVES == 8
     // one workgroup per CU: its waves 0-3 are the older wave of their SIMD, waves 4-7 the younger one
-    const int half = (int)(gridDim.x >> 1) * 4;                   // older (or younger) waves of this role
+    const int half = rl.nr * 4;                                   // older (or younger) waves of this role
     const bool split_ok = (gridDim.x % (2u << GRAD_ROLE_BIT)) == 0;
     const bool young = split_ok && wib >= 4;
-    const int wi_half = (int)(vb >> 1) * 4 + (wib & 3);           // index within its half
+    const int wi_half = rl.ri * 4 + (wib & 3);                    // index within its half
 #else
     const int half = (int)(gridDim.x >> 2) * GRAD_WAVES;          // waves of this role in one dispatch round
     // valid only when both dispatch rounds hold half of each role's workgroups: grid a multiple of 4 * 2^GRAD_ROLE_BIT
@@ -473,8 +491,8 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
         tile = young ? split + wi : wi;
         tile_end = young ? n_tiles : split;
     } else {  // small grids: plain striding
-        stride = (int)(gridDim.x >> 1) * GRAD_WAVES;
-        tile = (int)(vb >> 1) * GRAD_WAVES + wib;
+        stride = rl.nr * GRAD_WAVES;
+        tile = rl.ri * GRAD_WAVES + wib;
         tile_end = n_tiles;
     }
     // ---- input prefetch pipeline: row index two tiles ahead, gathered row one tile ahead ----
@@ -740,13 +758,13 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     }
 #ifdef GRAD_STAMPS
     if (lane == 0) {  // diagnostic build: the slabs behind GRAD_MAX_BLOCKS / 2 (unused by grids of <= 512 blocks) receive the stamps
-        unsigned long long* dbg = STAMP_BASE(part) + 16 * wib;
+        unsigned long long* dbg = STAMP_BASE(part) + 32 * wib;   // 32 words per wave: 0-10 phases, 11 loop cycles, 12 tiles, 13-16 realtime marks, 17 hw id, 20-25 prologue
         unsigned long long now;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
         for (int k = 0; k < 11; ++k) dbg[k] = stamp_acc[k];
         dbg[11] = now - stamp_t0;
         dbg[12] = (unsigned long long)it;   // tiles this wave processed
-        for (int k = 0; k < 6; ++k) STAMP_BASE(part)[72 + 6 * wib + k] = pro_t[k];
+        for (int k = 0; k < 6; ++k) dbg[20 + k] = pro_t[k];
     }
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_loop) :: "memory");
 #endif
@@ -826,11 +844,10 @@ __device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict
     if (lane == 0) {
         unsigned long long rt_out;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_out) :: "memory");
-        unsigned long long* dbg = STAMP_BASE(part) + 16 * wib;
-        dbg[13] = rt_in; dbg[14] = rt_ready; dbg[15] = rt_loop;
-        STAMP_BASE(part)[64 + wib] = rt_out;
+        unsigned long long* dbg = STAMP_BASE(part) + 32 * wib;
+        dbg[13] = rt_in; dbg[14] = rt_ready; dbg[15] = rt_loop; dbg[16] = rt_out;
         const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        STAMP_BASE(part)[68 + wib] = ((unsigned long long)xcc << 32) | hw_id;
+        dbg[17] = ((unsigned long long)xcc << 32) | hw_id;
     }
 #endif
 }
@@ -839,7 +856,7 @@ __global__ void __launch_bounds__(64 * GRAD_WAVES, GRAD_WPS)
 grad_kernel(const float* __restrict__ params, grad_pending_t pend, const float* __restrict__ observations, const int64_t* __restrict__ actions,
             const float* __restrict__ log_probs, const float* __restrict__ advantages, const float* __restrict__ returns,
             const float* __restrict__ values, const int32_t* __restrict__ idx, int mb, const double* __restrict__ adv_sums,
-            float clip_coef, float ent_coef, float vf_coef, float invn, float* __restrict__ workspace) {
+            float clip_coef, float ent_coef, float vf_coef, float invn, float* __restrict__ workspace, int extra) {
     __shared__ grad_smem sm;
     // Workgroups are dealt round-robin over the 8 XCDs (b % 8), so role = b & 1 would give each XCD ONE net and leave the
     // critic XCDs idle while the (heavier) actor ones finish.  Swap the two low bit fields instead: the slab index
@@ -849,12 +866,13 @@ grad_kernel(const float* __restrict__ params, grad_pending_t pend, const float* 
     const unsigned vb = (gridDim.x & ((2u << rb) - 1u)) ? blockIdx.x  // grid not a multiple of 2^(rb+1): identity
                                                         : ((blockIdx.x >> rb) & 1u) | (((blockIdx.x & lowmask) | ((blockIdx.x >> (rb + 1)) << rb)) << 1);
     float* part = workspace + (size_t)vb * PART_STRIDE;
-    if ((vb & 1) == 0)
+    const grad_role_t rl = grad_role(vb, (int)gridDim.x, extra);
+    if (rl.role == 0)
         grad_body<true>(sm, params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
-                        ent_coef, vf_coef, invn, part, vb);
+                        ent_coef, vf_coef, invn, part, vb, rl);
     else
         grad_body<false>(sm, params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
-                         ent_coef, vf_coef, invn, part, vb);
+                         ent_coef, vf_coef, invn, part, vb, rl);
 }
 
 // grads[p] = sum over the partial slabs of p's net in a FIXED order (reproducible); the last block finishes the loss terms.
@@ -864,7 +882,7 @@ grad_kernel(const float* __restrict__ params, grad_pending_t pend, const float* 
 #define RED_PARAMS 64
 #define RED_GROUPS 16
 __global__ void __launch_bounds__(RED_PARAMS * RED_GROUPS)
-grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_coef, float vf_coef, double inv_count,
+grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra, float ent_coef, float vf_coef, double inv_count,
                    float* __restrict__ grads, float* __restrict__ loss_terms) {
     const int pblocks = (NPARAMS + RED_PARAMS - 1) / RED_PARAMS;
     if ((int)blockIdx.x < pblocks) {
@@ -876,16 +894,16 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_
         const int off = p - (role ? C_BASE : 0);   // slab position within the net
         if (p < NPARAMS) {
             const float* src = workspace + off;
-            const int per_role = n_blocks >> 1;
-            if (per_role == 8 * RED_GROUPS) {   // the full grid (128 slabs per net): all 8 loads of the thread in flight at once, same summation order
-                float v[8];
+            const int nr = role == 0 ? (n_blocks >> 1) + extra : (n_blocks >> 1) - extra;
+            if (nr <= 9 * RED_GROUPS) {   // the full grid (130 / 126 slabs per net): every load of the thread in flight at once, summed in workgroup order
+                float v[9];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(2 * (sg + RED_GROUPS * u) + role) * PART_STRIDE];
+                for (int u = 0; u < 9; ++u) { const int k = sg + RED_GROUPS * u; v[u] = k < nr ? src[(size_t)grad_slab(role, k, n_blocks, extra) * PART_STRIDE] : 0.0f; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
+                for (int u = 0; u < 9; ++u) if (sg + RED_GROUPS * u < nr) acc += v[u];
             } else {
 #pragma unroll 4
-                for (int k = sg; k < per_role; k += RED_GROUPS) acc += src[(size_t)(2 * k + role) * PART_STRIDE];
+                for (int k = sg; k < nr; k += RED_GROUPS) acc += src[(size_t)grad_slab(role, k, n_blocks, extra) * PART_STRIDE];
             }
         }
         part[sg][pl] = acc;
@@ -907,7 +925,7 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_
         double pg = 0.0, en = 0.0, vl = 0.0;
         for (int b = threadIdx.x; b < n_blocks; b += RED_PARAMS * RED_GROUPS) {
             const float* s = workspace + (size_t)b * PART_STRIDE + PART_LOSS;
-            if ((b & 1) == 0) { pg += s[0]; en += s[1]; } else { vl += s[0]; }
+            if (grad_role((unsigned)b, n_blocks, extra).role == 0) { pg += s[0]; en += s[1]; } else { vl += s[0]; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { pg += __shfl_xor(pg, o); en += __shfl_xor(en, o); vl += __shfl_xor(vl, o); }
@@ -956,15 +974,17 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
     const int tiles = (mb + TROWS - 1) / TROWS;
     const int need = 2 * ((tiles + GRAD_WAVES - 1) / GRAD_WAVES);
     if (need < blocks) blocks = need;  // (the role swizzle falls back to identity when the grid is not a multiple of 2^(bit+1))
+    // full grids: the actor gets GRAD_ACTOR_EXTRA of every 128 workgroups more than the critic (see grad_role)
+    const int extra = (GRAD_WAVES == 8 && blocks == grad_blocks() && blocks >= 128) ? GRAD_ACTOR_EXTRA * (blocks / 128) / 2 : 0;
     {
         mi_prof_scope prof(MI_PROF_GRAD, s);
         grad_kernel<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb,
-                                                       adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace);
+                                                       adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace, extra);
     }
     MI_LAUNCH_CHECK();
     {
         mi_prof_scope prof(MI_PROF_REDUCE, s);
-        grad_reduce_kernel<<<(NPARAMS + RED_PARAMS - 1) / RED_PARAMS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>((const float*)workspace, blocks, ent_coef, vf_coef, inv_count,
+        grad_reduce_kernel<<<(NPARAMS + RED_PARAMS - 1) / RED_PARAMS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>((const float*)workspace, blocks, extra, ent_coef, vf_coef, inv_count,
                                                                      grads, loss_terms);
     }
     MI_LAUNCH_CHECK();
