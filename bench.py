@@ -322,26 +322,41 @@ def main():
         eng.update()
         eng.episode_summary_async(stats_host)  # what a training loop reads per update; no host sync
 
+    def timed_updates(u0, n):
+        """n updates bracketed by barrier + synchronize on both sides; -> (seconds, MAX over ranks; grad_kernel's in-library HIP-event profile)"""
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        N.prof_begin(n * 16 + 16, tags=["grad"])  # only the dominant kernel is bracketed inside the timed region
+        t0 = time.perf_counter()
+        for u in range(u0, u0 + n):
+            one_update(min(u, num_updates - 1))
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = N.prof_end()
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, prof
+
     for u in range(args.warmup):
         one_update(u)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    N.prof_begin(args.steps * 16 + 16, tags=["grad"])  # only the dominant kernel is bracketed inside the timed region
-    t0 = time.perf_counter()
-    for u in range(args.warmup, num_updates):
-        one_update(u)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = N.prof_end()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, prof = timed_updates(args.warmup, args.steps)   # THE measurement: f32 contractions
+
+    # beside it, never instead of it: the same K updates with the split-bf16 experiment switched on (include/mi_rl.h, mi_ppo_set_contraction)
+    variant = None
+    if not args.headline_only:
+        D.set_contraction("bf16x3")
+        for u in range(2):
+            one_update(num_updates - 1)
+        v_dt, v_prof = timed_updates(num_updates, args.steps)
+        D.set_contraction("f32")
+        variant = (v_dt, v_prof)
 
     # untimed: per-kernel breakdown of 3 more updates (all tags)
     N.prof_begin(3 * 64 + 64)
@@ -389,6 +404,14 @@ def main():
             "last_rollout": {"episodes": ep[0], "mean_return": round(ep[1] / max(ep[0], 1), 2), "max_return": ep[2]},
             "params_finite": finite,
         }
+        if variant is not None:
+            v_dt, v_prof = variant
+            vg_ms, vg_n = v_prof["grad"]
+            out["variant_bf16x3"] = {
+                "dtype": "f32 operands split into 3 bf16 parts, 6 products, f32 accumulate (bf16 MFMA)", "switch": "mi_ppo_set_contraction(MI_CONTRACTION_BF16X3) / MIRL_PPO_CONTRACTION=bf16x3",
+                "status": "experiment; every f32 parity tolerance holds unchanged (tests/test_gpu_contraction.py); not the headline",
+                "value": round(env_steps / v_dt, 1), "unit": "env-steps/s", "ms_per_step": round(1e3 * v_dt / args.steps, 4), "steps": args.steps,
+                "grad_kernel_avg_launch_us": round(1e3 * vg_ms / max(vg_n, 1), 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params0, float(os.environ.get("MIRL_CPU_BASELINE_SECONDS", "10")))  # bounded sample (default 10 s)
             out["cpu_baseline_n1"] = cpu_baseline_n1(params0)

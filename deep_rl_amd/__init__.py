@@ -7,6 +7,7 @@ for gfx950 in ``csrc/`` behind the C ABI of ``include/mi_rl.h``.  There is no CP
 ``deep_rl_amd._native`` without the built ``libmirl.so`` raises.
 """
 from . import _native  # noqa: F401
+from ._native import set_contraction, get_contraction  # noqa: F401
 from .envs import make, CartPoleVecEnv, PendulumVecEnv  # noqa: F401
 from .agent import ActorCritic, QNetwork, DuelingQNetwork, SoftQNetwork, Actor, layer_init, pack  # noqa: F401
 from .optim import ClipAdam, Adam  # noqa: F401
@@ -15,4 +16,4 @@ from .dqn_engine import DQNEngine, DuelingDQNEngine, PERDQNEngine  # noqa: F401
 from .sac_engine import SACEngine  # noqa: F401
 
 __all__ = ["make", "CartPoleVecEnv", "ActorCritic", "QNetwork", "layer_init", "ClipAdam", "PPOEngine", "DQNEngine",
-           "DuelingQNetwork", "DuelingDQNEngine", "PERDQNEngine", "PendulumVecEnv", "SoftQNetwork", "Actor", "Adam", "SACEngine", "pack"]
+           "DuelingQNetwork", "DuelingDQNEngine", "PERDQNEngine", "PendulumVecEnv", "SoftQNetwork", "Actor", "Adam", "SACEngine", "pack", "set_contraction", "get_contraction"]

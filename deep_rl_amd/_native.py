@@ -59,6 +59,8 @@ SIGNATURES = {
     "mi_perm_key": (_U64, [_U64, _U64, _U64]),
     "mi_adv_stats": (_I, [_VP, _VP, _I, _I, _VP, _VP]),
     "mi_ppo_workspace_bytes": (_SZ, []),
+    "mi_ppo_set_contraction": (_I, [_I]),
+    "mi_ppo_get_contraction": (_I, []),
     "mi_ppo_minibatch_grad": (_I, [_VP] * 8 + [_I, _VP, _F, _F, _F, _D, _VP, _VP, _VP, _VP]),
     "mi_clip_adam": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _D, _D, _D, _D, _F, _VP, _VP]),
     "mi_explained_var": (_I, [_VP, _VP, _SZ, _VP, _VP]),
@@ -132,7 +134,26 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype, fn.argtypes = res, args
         _lib = L
+        mode = os.environ.get("MIRL_PPO_CONTRACTION", "f32")   # experiment switch, see set_contraction
+        if mode != "f32":
+            set_contraction(mode)
     return _lib
+
+
+CONTRACTIONS = ("f32", "bf16x3")   # == enum MI_CONTRACTION_* of include/mi_rl.h
+
+
+def set_contraction(mode):
+    """Which matrix pipe the PPO gradient kernel's 64 x 64 contractions run on, process-wide: "f32" (default, exact f32 MFMA) or "bf16x3"
+    (experiment: three-part bf16 split of both operands, six products, f32 accumulate — f32-grade, not bit-identical).  Also settable with
+    the environment variable MIRL_PPO_CONTRACTION."""
+    if mode not in CONTRACTIONS:
+        raise MiError("unknown contraction %r (known: %s)" % (mode, ", ".join(CONTRACTIONS)))
+    check(lib().mi_ppo_set_contraction(CONTRACTIONS.index(mode)), "mi_ppo_set_contraction")
+
+
+def get_contraction():
+    return CONTRACTIONS[lib().mi_ppo_get_contraction()]
 
 
 def check(rc, what=""):

@@ -220,24 +220,8 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #define STATE_STRIDE 9216                   // floats between params / exp_avg / exp_avg_sq inside a spare set
 static_assert(GRAD_WAVES == 4 || GRAD_WAVES == 8, "GRAD_WAVES");
 
-struct __attribute__((aligned(16))) grad_weights {
-    float W2g[HID * HID];                 // see the header comment
-    float W2t[HID * HID];
-    float b1[HID], b2[HID];               // scaled by c
-    float W3[2 * HID];
-    float bufA[GRAD_WAVES][TROWS * W2S];   // wave-private [row][unit] images for the transposed re-reads; the 4 pad
-    float bufB[GRAD_WAVES][TROWS * W2S];   // columns (64..67) of a row hold x[row][0..3] (bufA) / dout[row][0..3] (bufB)
-};
-struct __attribute__((aligned(16))) grad_smem {
-    union {
-        grad_weights w;
-        float red[GRAD_WAVES][RED_STRIDE];  // exit reduction (the weights are dead by then)
-    };
-    double nrm[4];
-};
-#define XS(row, k) bufA[(row) * W2S + HID + (k)]
-#define DLS(row, k) bufB[(row) * W2S + HID + (k)]
-
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
@@ -254,6 +238,70 @@ __device__ __forceinline__ float tanh_prescaled(float zs) {
 #define GRAD_TANH(x) mi_tanhf(x)
 #define GRAD_PS 1.0f
 #endif
+
+// ---- GRAD_BX (experiment): the two contractions whose B operand is an activation in accumulator registers (layer 2 forward,
+// dh1 backward) on v_mfma_f32_16x16x32_bf16 with BOTH operands split into three bf16 parts (x = hi + mid + lo exactly up to 2^-27 |x|) and six products
+// per k-half (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; the dropped ones are < 2^-24 relative): f32-grade results from the bf16 matrix pipe.
+// The accumulator-as-B trick carries over: lane (row j, g) supplies k-slot e of k-half s as unit 16 (2s + (e >> 2)) + 4g + (e & 3), i.e. the registers
+// of tiles 2s and 2s + 1 as they stand; the A images hold W2 in exactly that slot order, pre-split when the weights are staged.
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: {bf16(a) in the low half, bf16(b) in the high half}, round to nearest even
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
+}
+// (a, b) -> packed hi / mid / lo parts: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); both subtractions are exact in f32
+__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = pk_bf16(ra, rb);
+    const float qa = ra - __builtin_bit_cast(float, mid << 16), qb = rb - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = pk_bf16(qa, qb);
+}
+struct bx_parts { bf16x8 p[3]; };   // [0] hi, [1] mid, [2] lo of 8 k-slots
+__device__ __forceinline__ bx_parts split8(const f32x4& t0, const f32x4& t1) {   // k-slots 0..3 = t0[0..3], 4..7 = t1[0..3]
+    unsigned h[4], m[4], l[4];
+    split3(t0[0], t0[1], h[0], m[0], l[0]); split3(t0[2], t0[3], h[1], m[1], l[1]);
+    split3(t1[0], t1[1], h[2], m[2], l[2]); split3(t1[2], t1[3], h[3], m[3], l[3]);
+    bx_parts r;
+    r.p[0] = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+    r.p[1] = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+    r.p[2] = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+    return r;
+}
+// acc += A . B over one k-half (32 k-slots), six products, small terms first
+__device__ __forceinline__ f32x4 bx_mac(const bf16x8 (&a)[3], const bx_parts& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b.p[0], acc, 0, 0, 0);   // lo . hi
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b.p[2], acc, 0, 0, 0);   // hi . lo
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b.p[1], acc, 0, 0, 0);   // mid . mid
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b.p[0], acc, 0, 0, 0);   // mid . hi
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b.p[1], acc, 0, 0, 0);   // hi . mid
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b.p[0], acc, 0, 0, 0);   // hi . hi
+    return acc;
+}
+
+// the lane's 8 split k-slots (units 16 (2 sh) + 4g + {0..3}, 16 (2 sh + 1) + 4g + {0..3} of row j) into a [part][unit][row] image
+__device__ __forceinline__ void bx_store_image(unsigned short* img, const bx_parts& q, int sh, int g, int j) {
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+        const u32x4 w = __builtin_bit_cast(u32x4, q.p[pp]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned short* at = img + pp * (HID * TROWS) + (16 * (2 * sh + (e >> 1)) + 4 * g + 2 * (e & 1)) * TROWS + j;
+            at[0] = (unsigned short)(w[e] & 0xffffu);
+            at[TROWS] = (unsigned short)(w[e] >> 16);
+        }
+    }
+}
+// acc[o][i] += sum over the tile's 16 rows of A[o][row] B[row][i] on v_mfma_f32_32x32x16_bf16, six products, small terms first
+__device__ __forceinline__ f32x16 bx_mac32(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
 
 // Total L2 norm of a flat gradient, recomputed identically by every 256-thread workgroup that calls it: all loads in flight at
 // once (float4, compile-time trip count; a strided scalar loop costs nine dependent L2 round trips instead of one), per-thread
@@ -342,538 +390,17 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 #define STAMP(k) do {} while (0)
 #endif
 
-template <bool ACTOR>
-__device__ __forceinline__ void grad_body(grad_smem& sm, const float* __restrict__ params, const grad_pending_t& pend,
-                                          const float* __restrict__ observations,
-                                          const int64_t* __restrict__ actions, const float* __restrict__ log_probs,
-                                          const float* __restrict__ advantages, const float* __restrict__ returns,
-                                          const float* __restrict__ values, const int32_t* __restrict__ idx, int mb,
-                                          const double* __restrict__ adv_sums, float clip_coef, float ent_coef, float vf_coef,
-                                          float invn, float* __restrict__ part, unsigned vb, grad_role_t rl) {
-    constexpr int NOUT = ACTOR ? 2 : 1;
-    constexpr int BASE = ACTOR ? 0 : C_BASE;
-    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
-    const int j = lane & 15, g = lane >> 4;
-    const bool pending = pend.grads != nullptr;
-    const float* p = (pending ? pend.p_in : params) + BASE;
-    grad_weights& W = sm.w;
-#ifdef GRAD_STAMPS
-    unsigned long long rt_in, rt_ready, rt_loop;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_in) :: "memory");
-#endif
-
-#ifdef GRAD_STAMPS
-    unsigned long long pro_t[6] = {0, 0, 0, 0, 0, 0};
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[0]) :: "memory");
-#endif
-    // ---- stage this net's weights (once per block), stepping them first when an optimizer step is owed ----
-    // thread (q, cg) owns the 4x4 block W2[4q..4q+3][4cg..4cg+3]: one float4 per row in, four float4 per image out
-    float w1f[4], b3[NOUT];
-    {
-        const int q = (tid >> 4) & 15, cg = tid & 15;
-        const bool writer = pending && rl.ri == 0;   // the first workgroup of each net writes the stepped state back
-        const bool w2t = tid < 256;   // the W2 block map covers 256 threads; with 8 waves the upper half stages only its thin parameters
-        f32x4 w[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = w2t ? reinterpret_cast<const f32x4*>(p + N_W2)[(4 * q + e) * 16 + cg] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // the thin parameters this thread stages: W1 fragments (4), b1 / b2 (threads < 64), W3 (threads < NOUT * 64), b3 (NOUT).
-        // ALL loads of the prologue — these, the W2 block and the whole gradient for the norm — are issued before the first one is waited
-        // for: one memory round trip instead of one per parameter group (measured: 5 us of the 6.9 us prologue were dependent round trips)
-        constexpr int NS = 7 + NOUT;
-        int sidx[NS];
-        bool sval[NS], swr[NS];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { sidx[mt] = N_W1 + 4 * (16 * mt + j) + g; sval[mt] = true; swr[mt] = wib == 0; }
-        sidx[4] = N_B1 + (tid & (HID - 1)); sval[4] = tid < HID; swr[4] = sval[4];
-        sidx[5] = N_B2 + (tid & (HID - 1)); sval[5] = tid < HID; swr[5] = sval[5];
-        sidx[6] = N_W3 + (tid < NOUT * HID ? tid : 0); sval[6] = tid < NOUT * HID; swr[6] = sval[6];
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a) { sidx[7 + a] = N_W3 + NOUT * HID + a; sval[7 + a] = true; swr[7 + a] = tid == 0; }
-        float sp[NS], sg[NS], sm1[NS], sv1[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) sp[k] = p[sidx[k]];
-        float coef = 1.0f;
-        if (pending) {
-            f32x4 gg[4], mm[4], vv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int at = w2t ? (4 * q + e) * 16 + cg : 0;
-                gg[e] = reinterpret_cast<const f32x4*>(pend.grads + BASE + N_W2)[at];
-                mm[e] = reinterpret_cast<const f32x4*>(pend.m_in + BASE + N_W2)[at];
-                vv[e] = reinterpret_cast<const f32x4*>(pend.v_in + BASE + N_W2)[at];
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) { sg[k] = pend.grads[BASE + sidx[k]]; sm1[k] = pend.m_in[BASE + sidx[k]]; sv1[k] = pend.v_in[BASE + sidx[k]]; }
-#ifdef GRAD_STAMPS
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[1]) :: "memory");
-#endif
-            const float total = block_grad_norm(pend.grads, NPARAMS, pend.vec_ok, sm.nrm);
-#ifdef GRAD_STAMPS
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[2]) :: "memory");
-#endif
-            coef = pend.max_norm / (total + 1e-6f);
-            coef = coef > 1.0f ? 1.0f : coef;
-            if (pend.grad_norm && vb == 0 && tid == 0) *pend.grad_norm = total;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    float m_ = mm[e][x], v_ = vv[e][x];
-                    w[e][x] = mi_adam_elem(w[e][x], gg[e][x] * coef, m_, v_, pend.w1, pend.b2, pend.w2, pend.step_size, pend.rbc2, pend.eps);
-                    mm[e][x] = m_; vv[e][x] = v_;
-                }
-                if (writer && w2t) {
-                    reinterpret_cast<f32x4*>(pend.p_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = w[e];
-                    reinterpret_cast<f32x4*>(pend.m_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = mm[e];
-                    reinterpret_cast<f32x4*>(pend.v_out + BASE + N_W2)[(4 * q + e) * 16 + cg] = vv[e];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                sp[k] = mi_adam_elem(sp[k], sg[k] * coef, sm1[k], sv1[k], pend.w1, pend.b2, pend.w2, pend.step_size, pend.rbc2, pend.eps);
-                if (writer && sval[k] && swr[k]) { pend.p_out[BASE + sidx[k]] = sp[k]; pend.m_out[BASE + sidx[k]] = sm1[k]; pend.v_out[BASE + sidx[k]] = sv1[k]; }
-            }
-        }
-#ifdef GRAD_STAMPS
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[3]) :: "memory");
-#endif
-        if (w2t) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(&W.W2g[(cg * 64 + 4 * q + e) * 4]) = w[e] * GRAD_PS;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) *reinterpret_cast<f32x4*>(&W.W2t[(q * 64 + 4 * cg + x) * 4]) = f32x4{w[0][x], w[1][x], w[2][x], w[3][x]};
-        }
-        if (tid < HID) { W.b1[tid] = GRAD_PS * sp[4]; W.b2[tid] = GRAD_PS * sp[5]; }
-        if (tid < NOUT * HID) W.W3[tid] = sp[6];
-        // layer-1 A fragments live in registers: lane (i = j, g), tile mt holds c W1[16mt + i][k = g]
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) w1f[mt] = GRAD_PS * sp[mt];
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a) b3[a] = sp[7 + a];
-    }
-
-    // advantage normalisation constants (ppo.py:169) from {sum, sum sq, count}
-    float adv_mean = 0.0f, adv_rden = 1.0f;
-    if constexpr (ACTOR) {
-        const double s1 = adv_sums[0], s2 = adv_sums[1], cnt = adv_sums[2];
-        const double mean = s1 / cnt;
-        double var = (s2 - s1 * mean) / (cnt - 1.0);
-        var = var > 0.0 ? var : 0.0;
-        adv_mean = (float)mean;
-        adv_rden = 1.0f / ((float)sqrt(var) + 1e-8f);
-    }
-
-    const int n_tiles = (mb + TROWS - 1) / TROWS;
-    // Tile assignment.  The SIMD arbitrates VALU issue between its two waves by priority, then AGE: the first-dispatched
-    // workgroup of a CU (blockIdx < grid/2) wins every conflict and runs ~1.3x faster than the second one (measured with
-    // s_memrealtime stamps: 60 vs 80 us for equal work).  So the older half of a role's waves takes GRAD_OLD_SHARE of every
-    // 16 tile rounds and the younger half the rest; a fixed function of the indices, so results stay reproducible.
-#if GRAD_WAVES == 8
-    // one workgroup per CU: its waves 0-3 are the older wave of their SIMD, waves 4-7 the younger one
-    const int half = rl.nr * 4;                                   // older (or younger) waves of this role
-    const bool split_ok = (gridDim.x % (2u << GRAD_ROLE_BIT)) == 0;
-    const bool young = split_ok && wib >= 4;
-    const int wi_half = rl.ri * 4 + (wib & 3);                    // index within its half
-#else
-    const int half = (int)(gridDim.x >> 2) * GRAD_WAVES;          // waves of this role in one dispatch round
-    // valid only when both dispatch rounds hold half of each role's workgroups: grid a multiple of 4 * 2^GRAD_ROLE_BIT
-    const bool split_ok = (gridDim.x % (4u << GRAD_ROLE_BIT)) == 0;
-    const bool young = split_ok && blockIdx.x >= (gridDim.x >> 1);
-    const int wi_half = (int)((vb >> 1) % (unsigned)(gridDim.x >> 2)) * GRAD_WAVES + wib;
-#endif
-    int tile, stride, tile_end;
-    if (split_ok) {
-        const int rounds = (n_tiles + half - 1) / half;            // tile rounds over one half
-        const int old_rounds = (rounds * GRAD_OLD_SHARE + 8) / 16; // rounds taken by the older half
-        const int split = old_rounds * half < n_tiles ? old_rounds * half : n_tiles;
-        const int wi = wi_half;
-        stride = half;
-        tile = young ? split + wi : wi;
-        tile_end = young ? n_tiles : split;
-    } else {  // small grids: plain striding
-        stride = rl.nr * GRAD_WAVES;
-        tile = rl.ri * GRAD_WAVES + wib;
-        tile_end = n_tiles;
-    }
-    // ---- input prefetch pipeline: row index two tiles ahead, gathered row one tile ahead ----
-    auto tile_rid = [&](int t) { const int row = t * TROWS + j; return idx[row < mb ? row : mb - 1]; };
-    int rid_next = tile_rid(tile + stride);
-    row_in cur = gather_row<ACTOR>(tile_rid(tile), g, observations, actions, log_probs, advantages, returns, values);
-#ifdef GRAD_STAMPS
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[4]) :: "memory");
-#endif
-    __syncthreads();  // weights staged
-#ifdef GRAD_STAMPS
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pro_t[5]) :: "memory");
-#endif
-#if GRAD_STAGGER > 0
-    // de-phase the two workgroups that share a CU (dispatch order: blocks b and b + grid/2 land on the same CU)
-    if (blockIdx.x >= (gridDim.x >> 1)) {
-#pragma unroll
-        for (int k = 0; k < GRAD_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-
-    // ---- accumulators that live across tiles ----
-    f32x4 dW2[4][4];
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) dW2[mo][mi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 dW1a = {0.0f, 0.0f, 0.0f, 0.0f}, dW1b = dW1a;  // two chains: the 4x4x1 dependent latency exceeds its issue time
-#if GRAD_DW3_VALU
-    f32x4 dW3v[NOUT][4];   // per-lane partial sums over this lane's rows: dW3[a][16mt + 4g + r], reduced over j at exit
-#pragma unroll
-    for (int a = 0; a < NOUT; ++a)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) dW3v[a][mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#else
-    f32x4 dW3a = dW1a, dW3b = dW1a;
-#endif
-    float db1 = 0.0f, db2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, db3[2] = {0.0f, 0.0f};
-    float loss_a = 0.0f, loss_b = 0.0f;  // actor: sum pg, sum entropy; critic: sum max(vl1, vl2)
-
-    float* bufA = W.bufA[wib];
-    float* bufB = W.bufB[wib];
-
-#ifdef GRAD_STAMPS
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_ready) :: "memory");
-    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last, stamp_t0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
-    stamp_t0 = stamp_last;
-#endif
-    int it = 0;
-    for (; tile < tile_end; tile += stride, ++it) {
-#ifdef GRAD_IGLP
-        __builtin_amdgcn_iglp_opt(GRAD_IGLP);   // experiment: LLVM's MFMA / DS interleaving strategies on the tile body
-#endif
-        const bool valid = tile * TROWS + j < mb;
-#if GRAD_ALT_PRIO
-        if ((it & 1) ^ (young ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-        // issue the next tile's gathers and the index after that; they land while this tile computes
-        const row_in nxt = gather_row<ACTOR>(rid_next, g, observations, actions, log_probs, advantages, returns, values);
-        rid_next = tile_rid(tile + 2 * stride);
-
-        XS(j, g) = cur.x;
-        STAMP(0);  // gathers issued
-
-        // ---- layer 1: z1^T = W1 x^T + b1 (K = 4 = obs dim: one MFMA per 16-unit tile) ----
-        f32x4 h1[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const float4 b = *reinterpret_cast<const float4*>(&W.b1[16 * mt + 4 * g]);
-            h1[mt] = mfma16(w1f[mt], cur.x, f32x4{b.x, b.y, b.z, b.w});
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h1[mt][r] = GRAD_TANH(h1[mt][r]);
-        STAMP(1);  // layer 1 + tanh
-
-        // ---- layer 2: z2^T = W2 h1^T + b2; k-steps 4c..4c+3 <-> units 16c + 4g + {0..3} ----
-        f32x4 h2[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const float4 b = *reinterpret_cast<const float4*>(&W.b2[16 * mt + 4 * g]);
-            h2[mt] = f32x4{b.x, b.y, b.z, b.w};
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x4 a[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(&W.W2g[((4 * c + g) * 64 + 16 * mt + j) * 4]);
-            // consecutive MFMAs go to different accumulators: the 16x16x4 dependent latency (40 clk) exceeds its issue (32)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma16(a[mt][r], h1[c][r], h2[mt]);
-        }
-        STAMP(2);  // layer 2 MFMAs issued
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h2[mt][r] = GRAD_TANH(h2[mt][r]);
-        STAMP(3);  // tanh h2 (includes waiting for the layer-2 accumulators)
-
-        // ---- head: out[a] = W3[a] . h2 + b3[a]; the 4 lanes (g) of a row hold 16 units each ----
-        float outp[NOUT];
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float4 w = *reinterpret_cast<const float4*>(&W.W3[a * HID + 16 * mt + 4 * g]);
-                acc = __builtin_fmaf(w.x, h2[mt][0], acc); acc = __builtin_fmaf(w.y, h2[mt][1], acc);
-                acc = __builtin_fmaf(w.z, h2[mt][2], acc); acc = __builtin_fmaf(w.w, h2[mt][3], acc);
-            }
-            outp[a] = groups_sum(acc) + b3[a];
-        }
-
-        // ---- loss and d loss / d out (ppo.py:166-187), identical in the 4 lanes of a row ----
-        float dl[NOUT];
-        const float count_me = (valid && g == 0) ? 1.0f : 0.0f;
-        if constexpr (ACTOR) {
-            float nl0, nl1, p0, p1, H;
-            mi_categorical2_fast(outp[0], outp[NOUT - 1], nl0, nl1, p0, p1, H);
-            const float A = (cur.f1 - adv_mean) * adv_rden;
-            const float ratio = mi_fast_exp((cur.act ? nl1 : nl0) - cur.f0);
-            const float lo = 1.0f - clip_coef, hi = 1.0f + clip_coef;
-            const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
-            const float pg1 = -A * ratio, pg2 = -A * rc;
-            loss_a += count_me * (pg1 > pg2 ? pg1 : pg2);
-            loss_b += count_me * H;
-            const bool inrange = (ratio >= lo) && (ratio <= hi);
-            float dpg;
-            if (pg1 > pg2) dpg = -A;
-            else if (pg1 < pg2) dpg = inrange ? -A : 0.0f;
-            else dpg = -0.5f * A + (inrange ? -0.5f * A : 0.0f);
-            const float g_lp = invn * dpg * ratio;
-            const float ec = ent_coef * invn;
-            dl[0] = g_lp * ((cur.act == 0 ? 1.0f : 0.0f) - p0) + ec * (p0 * (nl0 + H));
-            dl[NOUT - 1] = g_lp * ((cur.act == 1 ? 1.0f : 0.0f) - p1) + ec * (p1 * (nl1 + H));
-        } else {
-            const float ret = cur.f0, v_old = cur.f1;
-            const float v = outp[0];
-            const float d1 = v - ret;
-            const float vl1 = d1 * d1;
-            const float dv = v - v_old;
-            const float dvc = dv < -clip_coef ? -clip_coef : (dv > clip_coef ? clip_coef : dv);
-            const float vc = v_old + dvc;
-            const float d2 = vc - ret;
-            const float vl2 = d2 * d2;
-            loss_a += count_me * (vl1 > vl2 ? vl1 : vl2);
-            const bool vin = (dv >= -clip_coef) && (dv <= clip_coef);
-            float dmax;
-            if (vl1 > vl2) dmax = 2.0f * d1;
-            else if (vl1 < vl2) dmax = vin ? 2.0f * d2 : 0.0f;
-            else dmax = d1 + (vin ? d2 : 0.0f);
-            dl[0] = (vf_coef * 0.5f * invn) * dmax;
-        }
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a) {
-            dl[a] = valid ? dl[a] : 0.0f;
-            db3[a] += (g == 0) ? dl[a] : 0.0f;
-        }
-        STAMP(4);  // head + loss
-
-#if GRAD_DW3_VALU
-        // ---- dW3[a][unit] += dout[row][a] h2[row][unit]: this lane's row, this lane's 16 units (summed over rows at exit) ----
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dW3v[a][mt][r] = __builtin_fmaf(dl[a], h2[mt][r], dW3v[a][mt][r]);
-#else
-        // ---- dW3 += dout^T h2: stage h2 as a [row][unit] image.
-        // 4x4x1 (16 blocks, block b = lane>>2): D[b][i][jj] += A[b][i] B[b][jj]; A = dout[row][i], B = h2[row][4b+jj]
-        DLS(j, g) = g == 0 ? dl[0] : ((NOUT == 2 && g == 1) ? dl[NOUT - 1] : 0.0f);
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            *reinterpret_cast<float4*>(bufA + j * W2S + 16 * mt + 4 * g) = make_float4(h2[mt][0], h2[mt][1], h2[mt][2], h2[mt][3]);
-        wave_lds_fence();
-#pragma unroll
-        for (int rr = 0; rr < TROWS; rr += 2) {
-            dW3a = mfma4(DLS(rr, lane & 3), bufA[rr * W2S + lane], dW3a);
-            dW3b = mfma4(DLS(rr + 1, lane & 3), bufA[(rr + 1) * W2S + lane], dW3b);
-        }
-#endif
-
-        STAMP(5);  // stage h2 + dW3
-        // ---- dz2 = (W3^T dout) * (1 - h2^2); h2 is dead afterwards ----
-        f32x4 dz2[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int a = 0; a < NOUT; ++a) {
-                const float4 w = *reinterpret_cast<const float4*>(&W.W3[a * HID + 16 * mt + 4 * g]);
-                d[0] = __builtin_fmaf(w.x, dl[a], d[0]); d[1] = __builtin_fmaf(w.y, dl[a], d[1]);
-                d[2] = __builtin_fmaf(w.z, dl[a], d[2]); d[3] = __builtin_fmaf(w.w, dl[a], d[3]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float t = h2[mt][r]; dz2[mt][r] = d[r] * __builtin_fmaf(-t, t, 1.0f); }
-        }
-
-        STAMP(6);  // dz2
-        // ---- dh1^T = W2^T dz2^T, dz1 = dh1 * (1 - h1^2); k-steps 4c..4c+3 <-> output units o = 16c + 4g + {0..3} ----
-        f32x4 dz1[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) dz1[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x4 a[4];   // a[mt][r] = W2[16c + 4g + r][16mt + j]
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(&W.W2t[((4 * c + g) * 64 + 16 * mt + j) * 4]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) dz1[mt] = mfma16(a[mt][r], dz2[c][r], dz1[mt]);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float t = h1[mt][r]; dz1[mt][r] = dz1[mt][r] * __builtin_fmaf(-t, t, 1.0f); }
-
-        STAMP(7);  // dh1 MFMAs + dz1
-        // ---- dW1 += dz1^T x (4x4x1: A = dz1[row][4b+i], B = x[row][jj]) and db1; dz1 is dead afterwards ----
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            *reinterpret_cast<float4*>(bufB + j * W2S + 16 * mt + 4 * g) = make_float4(dz1[mt][0], dz1[mt][1], dz1[mt][2], dz1[mt][3]);
-        wave_lds_fence();
-#pragma unroll
-        for (int rr = 0; rr < TROWS; rr += 2) {
-            const float z0 = bufB[rr * W2S + lane], z1v = bufB[(rr + 1) * W2S + lane];
-            db1 += z0 + z1v;
-            dW1a = mfma4(z0, XS(rr, lane & 3), dW1a);
-            dW1b = mfma4(z1v, XS(rr + 1, lane & 3), dW1b);
-        }
-
-        STAMP(8);  // stage dz1 + dW1
-        // ---- dW2[o][i] += sum_rows dz2[row][o] h1[row][i]: A[i=o][k=row], B[k=row][j=i], rows s + 4g per k-step ----
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            *reinterpret_cast<float4*>(bufA + j * W2S + 16 * mt + 4 * g) = make_float4(h1[mt][0], h1[mt][1], h1[mt][2], h1[mt][3]);
-            *reinterpret_cast<float4*>(bufB + j * W2S + 16 * mt + 4 * g) = make_float4(dz2[mt][0], dz2[mt][1], dz2[mt][2], dz2[mt][3]);
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ro = (s + 4 * g) * W2S + j;
-            float a[4], b[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { a[m] = bufB[ro + 16 * m]; b[m] = bufA[ro + 16 * m]; db2[m] += a[m]; }
-#pragma unroll
-            for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) dW2[mo][mi] = mfma16(a[mo], b[mi], dW2[mo][mi]);
-        }
-        STAMP(9);  // stage h1, dz2 + dW2
-        cur = nxt;
-        STAMP(10);  // wait for the prefetched row
-    }
-#ifdef GRAD_STAMPS
-    if (lane == 0) {  // diagnostic build: the slabs behind GRAD_MAX_BLOCKS / 2 (unused by grids of <= 512 blocks) receive the stamps
-        unsigned long long* dbg = STAMP_BASE(part) + 32 * wib;   // 32 words per wave: 0-10 phases, 11 loop cycles, 12 tiles, 13-16 realtime marks, 17 hw id, 20-25 prologue
-        unsigned long long now;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
-        for (int k = 0; k < 11; ++k) dbg[k] = stamp_acc[k];
-        dbg[11] = now - stamp_t0;
-        dbg[12] = (unsigned long long)it;   // tiles this wave processed
-        for (int k = 0; k < 6; ++k) dbg[20 + k] = pro_t[k];
-    }
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_loop) :: "memory");
-#endif
-    const f32x4 dW1 = dW1a + dW1b;
-
-    // ---- deterministic cross-wave reduction, then one partial slab per block ----
-    // every wave drops its partial sums into its own LDS slot (dW2 in accumulator-fragment order: 16 conflict-free b128 stores),
-    // one barrier, then 256 threads add the four slots in wave order and write the slab.  The slab keeps dW2 in fragment
-    // order (float4 F = (4mo + mi)*64 + lane, component r = dW2[16mo + 4g + r][16mi + j]); grad_reduce_kernel undoes it.
-    __syncthreads();  // every wave is done with the weights and its staging tiles -> the LDS becomes the reduction buffer
-    {
-        float* slot = sm.red[wib];
-#pragma unroll
-        for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) *reinterpret_cast<f32x4*>(&slot[((4 * mo + mi) * 64 + lane) * 4]) = dW2[mo][mi];
-        float* sm_small = slot + HID * HID;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sm_small[(4 * (lane >> 2) + i) * 4 + (lane & 3)] = dW1[i];  // dW1[unit 4b+i][k=jj]
-        sm_small[256 + lane] = db1;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float t = groups_sum(db2[m]);
-            if (g == 0) sm_small[320 + 16 * m + j] = t;
-        }
-#if GRAD_DW3_VALU
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = dW3v[a][mt][r];   // sum over the 16 rows (lanes j) of this lane group
-                    t += dpp_xor1(t); t += dpp_xor2(t); t += dpp_half_mirror(t); t += dpp_mirror(t);
-                    if (j == 0) sm_small[384 + a * HID + 16 * mt + 4 * g + r] = t;
-                }
-#else
-        const f32x4 dW3 = dW3a + dW3b;
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a) sm_small[384 + a * HID + lane] = dW3[a];  // dW3[a][unit = lane]
-#endif
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a) { const float t = wave_sum(db3[a]); if (lane == 0) sm_small[384 + NOUT * HID + a] = t; }
-        const float la = wave_sum(loss_a), lb = wave_sum(loss_b);
-        if (lane == 0) { sm_small[520] = la; sm_small[521] = lb; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < HID * HID / 4 / (64 * GRAD_WAVES); ++k) {
-        const int i = tid + 64 * GRAD_WAVES * k;
-        const f32x4 a0 = reinterpret_cast<const f32x4*>(sm.red[0])[i], a1 = reinterpret_cast<const f32x4*>(sm.red[1])[i];
-        const f32x4 a2 = reinterpret_cast<const f32x4*>(sm.red[2])[i], a3 = reinterpret_cast<const f32x4*>(sm.red[3])[i];
-#if GRAD_WAVES == 8
-        const f32x4 a4 = reinterpret_cast<const f32x4*>(sm.red[4])[i], a5 = reinterpret_cast<const f32x4*>(sm.red[5])[i];
-        const f32x4 a6 = reinterpret_cast<const f32x4*>(sm.red[6])[i], a7 = reinterpret_cast<const f32x4*>(sm.red[7])[i];
-        reinterpret_cast<f32x4*>(part + N_W2)[i] = ((a0 + a2) + (a1 + a3)) + ((a4 + a6) + (a5 + a7));
-#else
-        reinterpret_cast<f32x4*>(part + N_W2)[i] = (a0 + a2) + (a1 + a3);
-#endif
-    }
-    constexpr int N_SMALL = 384 + NOUT * HID + NOUT;
-    for (int i = tid; i < 522; i += 64 * GRAD_WAVES) {
-        if (i >= N_SMALL && i < 520) continue;
-        float t = (sm.red[0][HID * HID + i] + sm.red[1][HID * HID + i]) + (sm.red[2][HID * HID + i] + sm.red[3][HID * HID + i]);
-#if GRAD_WAVES == 8
-        t += (sm.red[4][HID * HID + i] + sm.red[5][HID * HID + i]) + (sm.red[6][HID * HID + i] + sm.red[7][HID * HID + i]);
-#endif
-        int dst;
-        if (i < 256) dst = N_W1 + i;
-        else if (i < 320) dst = N_B1 + (i - 256);
-        else if (i < 384) dst = N_B2 + (i - 320);
-        else if (i < N_SMALL) dst = N_W3 + (i - 384);
-        else dst = PART_LOSS + (i - 520);
-        part[dst] = t;
-    }
-#ifdef GRAD_STAMPS
-    if (lane == 0) {
-        unsigned long long rt_out;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_out) :: "memory");
-        unsigned long long* dbg = STAMP_BASE(part) + 32 * wib;
-        dbg[13] = rt_in; dbg[14] = rt_ready; dbg[15] = rt_loop; dbg[16] = rt_out;
-        const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        dbg[17] = ((unsigned long long)xcc << 32) | hw_id;
-    }
-#endif
-}
-
-__global__ void __launch_bounds__(64 * GRAD_WAVES, GRAD_WPS)
-grad_kernel(const float* __restrict__ params, grad_pending_t pend, const float* __restrict__ observations, const int64_t* __restrict__ actions,
-            const float* __restrict__ log_probs, const float* __restrict__ advantages, const float* __restrict__ returns,
-            const float* __restrict__ values, const int32_t* __restrict__ idx, int mb, const double* __restrict__ adv_sums,
-            float clip_coef, float ent_coef, float vf_coef, float invn, float* __restrict__ workspace, int extra) {
-    __shared__ grad_smem sm;
-    // Workgroups are dealt round-robin over the 8 XCDs (b % 8), so role = b & 1 would give each XCD ONE net and leave the
-    // critic XCDs idle while the (heavier) actor ones finish.  Swap the two low bit fields instead: the slab index
-    // `vb` keeps role = vb & 1 for the reduce kernel, while the physical block's role is bit GRAD_ROLE_BIT of blockIdx.
-    const unsigned rb = GRAD_ROLE_BIT;
-    const unsigned lowmask = (1u << rb) - 1u;
-    const unsigned vb = (gridDim.x & ((2u << rb) - 1u)) ? blockIdx.x  // grid not a multiple of 2^(rb+1): identity
-                                                        : ((blockIdx.x >> rb) & 1u) | (((blockIdx.x & lowmask) | ((blockIdx.x >> (rb + 1)) << rb)) << 1);
-    float* part = workspace + (size_t)vb * PART_STRIDE;
-    const grad_role_t rl = grad_role(vb, (int)gridDim.x, extra);
-    if (rl.role == 0)
-        grad_body<true>(sm, params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
-                        ent_coef, vf_coef, invn, part, vb, rl);
-    else
-        grad_body<false>(sm, params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb, adv_sums, clip_coef,
-                         ent_coef, vf_coef, invn, part, vb, rl);
-}
+// ---- the two instantiations of grad_kernel (mi_grad_kernel.inc) ----
+#define GRAD_BX 0
+#define GV(x) x##_f32
+#include "mi_grad_kernel.inc"
+#undef GRAD_BX
+#undef GV
+#define GRAD_BX 1
+#define GV(x) x##_bx
+#include "mi_grad_kernel.inc"
+#undef GRAD_BX
+#undef GV
 
 // grads[p] = sum over the partial slabs of p's net in a FIXED order (reproducible); the last block finishes the loss terms.
 // 1024 threads = 64 consecutive slab positions x 16 slab groups: every wave reads 256 contiguous bytes per slab, 16 independent
@@ -962,6 +489,15 @@ static_assert(STATE_STRIDE >= NPARAMS && STATE_STRIDE % 4 == 0, "STATE_STRIDE");
 
 extern "C" size_t mi_ppo_workspace_bytes(void) { return (size_t)GRAD_MAX_BLOCKS * PART_STRIDE * sizeof(float); }
 
+// Which matrix pipe grad_kernel's three 64 x 64 contractions run on (process-wide; every later gradient launch of this process uses it).
+static int g_contraction = MI_CONTRACTION_F32;
+extern "C" int mi_ppo_set_contraction(int mode) {
+    MI_CHECK_ARG(mode == MI_CONTRACTION_F32 || mode == MI_CONTRACTION_BF16X3, "mode must be MI_CONTRACTION_F32 or MI_CONTRACTION_BF16X3");
+    g_contraction = mode;
+    return MI_OK;
+}
+extern "C" int mi_ppo_get_contraction(void) { return g_contraction; }
+
 static grad_pending_t no_pending() { grad_pending_t z; memset(&z, 0, sizeof(z)); return z; }
 
 // gradient launch + slab sum.  `pend.grads != nullptr`: the launch first applies the owed optimizer step (see grad_pending_t).
@@ -978,8 +514,12 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
     const int extra = (GRAD_WAVES == 8 && blocks == grad_blocks() && blocks >= 128) ? GRAD_ACTOR_EXTRA * (blocks / 128) / 2 : 0;
     {
         mi_prof_scope prof(MI_PROF_GRAD, s);
-        grad_kernel<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb,
-                                                       adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace, extra);
+        if (g_contraction == MI_CONTRACTION_BF16X3)
+            grad_kernel_bx<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb,
+                                                              adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace, extra);
+        else
+            grad_kernel_f32<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb,
+                                                               adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace, extra);
     }
     MI_LAUNCH_CHECK();
     {
@@ -1229,6 +769,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
 // Hardware self-test of the MFMA fragment layouts grad_kernel relies on (exact small-integer data).
 // report[0]: 32x32x2 A/B/D maps   report[1]: 4x4x1 (16 blocks) A/B/D maps   report[2]: accumulator-as-B chain (32x32x2)
 // report[3]: accumulator-as-B chain on 16x16x4 (the form grad_kernel uses)   report[4]: 4x4x1 with A broadcast (cbsz / abid; rollout_q4_kernel)
+// report[5]: 16x16x32 bf16 maps   report[6]: 32x32x16 bf16 maps (the split-bf16 gradient variant)
 // dump (nullable, f32 [3*64*16]): raw accumulators of the three probes for offline diagnosis.
 // =====================================================================================================
 __global__ void __launch_bounds__(64) selftest_kernel(int32_t* __restrict__ report, float* __restrict__ dump) {
@@ -1332,9 +873,54 @@ __global__ void __launch_bounds__(64) selftest_kernel(int32_t* __restrict__ repo
             bad4 += d[i] != want;
         }
     }
+    // probes 5 / 6: the bf16 forms of the split-bf16 variant (small integers, exact in bf16): A[i][k] = 1 + ((i + 3k) % 7), B[k][j] = 1 + ((2j + k) % 5).
+    //   5: 16x16x32 — lane l holds A[l & 15][8 (l >> 4) + e], B[8 (l >> 4) + e][l & 15], e = 0..7; D register r = D[4 (l >> 4) + r][l & 15]
+    //   6: 32x32x16 — lane l holds A[l & 31][8 (l >> 5) + e], B[8 (l >> 5) + e][l & 31];        D register q = D[8 (q >> 2) + 4 (l >> 5) + (q & 3)][l & 31]
+    int bad5 = 0, bad6 = 0;
+    {
+        bf16x8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * (lane >> 4) + e;
+            a[e] = (__bf16)(float)(1 + (((lane & 15) + 3 * k) % 7));
+            b[e] = (__bf16)(float)(1 + ((2 * (lane & 15) + k) % 5));
+        }
+        f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * (lane >> 4) + r, jj = lane & 15;
+            int want = 0;
+            for (int k = 0; k < 32; ++k) want += (1 + ((i + 3 * k) % 7)) * (1 + ((2 * jj + k) % 5));
+            bad5 += d[r] != (float)want;
+        }
+    }
+    {
+        bf16x8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * h + e;
+            a[e] = (__bf16)(float)(1 + ((li + 3 * k) % 7));
+            b[e] = (__bf16)(float)(1 + ((2 * li + k) % 5));
+        }
+        f32x16 d;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = 0.0f;
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, d, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = 8 * (q >> 2) + 4 * h + (q & 3);
+            int want = 0;
+            for (int k = 0; k < 16; ++k) want += (1 + ((i + 3 * k) % 7)) * (1 + ((2 * li + k) % 5));
+            bad6 += d[q] != (float)want;
+        }
+    }
     const int t0 = (int)wave_sum((float)bad0), t1 = (int)wave_sum((float)bad1), t2 = (int)wave_sum((float)bad2);
-    const int t3 = (int)wave_sum((float)bad3), t4 = (int)wave_sum((float)bad4);
-    if (lane == 0) { report[0] = t0; report[1] = t1; report[2] = t2; report[3] = t3; report[4] = t4; for (int k = 5; k < 16; ++k) report[k] = 0; }
+    const int t3 = (int)wave_sum((float)bad3), t4 = (int)wave_sum((float)bad4), t5 = (int)wave_sum((float)bad5), t6 = (int)wave_sum((float)bad6);
+    if (lane == 0) {
+        report[0] = t0; report[1] = t1; report[2] = t2; report[3] = t3; report[4] = t4; report[5] = t5; report[6] = t6;
+        for (int k = 7; k < 16; ++k) report[k] = 0;
+    }
 }
 
 extern "C" int mi_selftest_mfma(int32_t* report, float* dump, void* stream) {

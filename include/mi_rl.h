@@ -136,6 +136,17 @@ int mi_ppo_minibatch_grad(const float* params, const float* observations, const 
                           float vf_coef, double inv_count, void* workspace, float* grads, float* loss_terms,
                           void* stream);
 
+/* ---- EXPERIMENT, off by default: which matrix pipe the gradient kernel's three 64 x 64 contractions (layer 2 forward, its input gradient, its
+ * weight gradient; the nn.Linear(64, 64) of ppo.py:56-57 / :62-63 under loss.backward(), ppo.py:190) run on.  Process-wide; applies to every later
+ * mi_ppo_minibatch_grad / mi_ppo_update / mi_ppo_update_sharded launch.
+ *   MI_CONTRACTION_F32     exact f32 products and sums on v_mfma_f32_16x16x4_f32 (default; what every headline number is measured on)
+ *   MI_CONTRACTION_BF16X3  both operands split into three bf16 parts (x = hi + mid + lo to 2^-27 |x|), the six products above 2^-24 accumulated in
+ *                          f32 on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16: f32-grade results (every parity tolerance of the f32 path holds
+ *                          unchanged, tests/test_gpu_contraction.py), not bit-identical to the f32 path. */
+enum { MI_CONTRACTION_F32 = 0, MI_CONTRACTION_BF16X3 = 1 };
+int mi_ppo_set_contraction(int mode);
+int mi_ppo_get_contraction(void);
+
 /* ---- clip_grad_norm_(max_norm) + Adam step (ppo.py:191-192, torch single-tensor Adam).
  * step is 1-based.  grad_norm dev f32 [1] nullable: receives the pre-clip total norm. */
 int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr,

@@ -79,6 +79,8 @@ def test_mfma_layout_selftest(dev):
     assert rep[2] == 0, "accumulator-as-B-operand chain (32x32x2) wrong: " + msg
     assert rep[3] == 0, "accumulator-as-B-operand chain (16x16x4) wrong: " + msg + "\n%s" % d[2, :20, 8:12]
     assert rep[4] == 0, "4x4x1 with the A operand broadcast from one block (cbsz = 4, abid) wrong (rollout_q4_kernel): %d mismatches" % rep[4]
+    assert rep[5] == 0, "16x16x32 bf16 A/B/D map wrong (split-bf16 gradient variant): %d mismatches" % rep[5]
+    assert rep[6] == 0, "32x32x16 bf16 A/B/D map wrong (split-bf16 gradient variant): %d mismatches" % rep[6]
 
 
 def test_device_tanh_accuracy(dev):
