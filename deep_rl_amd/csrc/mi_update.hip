@@ -281,16 +281,23 @@ __device__ __forceinline__ f32x4 bx_mac(const bf16x8 (&a)[3], const bx_parts& b,
     return acc;
 }
 
-// the lane's 8 split k-slots (units 16 (2 sh) + 4g + {0..3}, 16 (2 sh + 1) + 4g + {0..3} of row j) into a [part][unit][row] image
+// Transposed bf16 images for dW2, [part][row half][unit][8 rows]: BX_HALF ushorts per row half (1,040 B: the 16 extra bytes put rows 8-15 four banks
+// behind rows 0-7, so one ds_write_b16 of the wave — lanes (row j, group g), units 4 apart per g — touches 32 different dwords), read back as one
+// ds_read_b128 per lane = the 8 rows of half (lane >> 5) of unit (lane & 31): 16-byte chunks at a 16-byte stride, conflict-free in the b128 lane groups
+// (a [unit][16 rows] image reads 32-byte-strided chunks: 2-way conflicts, 31 % of the variant's LDS cycles in its first PMC pass).
+#define BX_HALF 520
+#define BX_PART (2 * BX_HALF)
+#define BX_IMG (3 * BX_PART)
+// the lane's 8 split k-slots (units 16 (2 sh) + 4g + {0..3}, 16 (2 sh + 1) + 4g + {0..3} of row j) into the image
 __device__ __forceinline__ void bx_store_image(unsigned short* img, const bx_parts& q, int sh, int g, int j) {
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) {
         const u32x4 w = __builtin_bit_cast(u32x4, q.p[pp]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            unsigned short* at = img + pp * (HID * TROWS) + (16 * (2 * sh + (e >> 1)) + 4 * g + 2 * (e & 1)) * TROWS + j;
+            unsigned short* at = img + pp * BX_PART + (j >> 3) * BX_HALF + (16 * (2 * sh + (e >> 1)) + 4 * g + 2 * (e & 1)) * 8 + (j & 7);
             at[0] = (unsigned short)(w[e] & 0xffffu);
-            at[TROWS] = (unsigned short)(w[e] >> 16);
+            at[8] = (unsigned short)(w[e] >> 16);
         }
     }
 }

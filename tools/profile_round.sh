@@ -19,4 +19,15 @@ for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   find /tmp/rp_pmc$i -name '*counter_collection.csv' -exec cp {} /tmp/pmc$i.csv \;
 done
 python3 $REPO/tools/summarize_pmc.py /tmp/kernel_trace.csv /tmp/pmc*.csv > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
+# the same counter passes with the split-bf16 gradient variant switched on (grad_kernel_bx; experiment)
+export MIRL_PPO_CONTRACTION=bf16x3
+i=0
+for CTRS in "FETCH_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/rp_bx$i -o pmc -- $PCMD > $OUT/bx_pmc${i}_run.log 2>&1
+  find /tmp/rp_bx$i -name '*counter_collection.csv' -exec cp {} /tmp/bx_pmc$i.csv \;
+  find /tmp/rp_bx$i -name '*kernel_trace.csv' -exec cp {} /tmp/bx_trace.csv \;
+done
+unset MIRL_PPO_CONTRACTION
+python3 $REPO/tools/summarize_pmc.py /tmp/bx_trace.csv /tmp/bx_pmc*.csv > $OUT/pmc_summary_bf16x3.json 2>> $OUT/pmc_summary.err
 ls -la $OUT
