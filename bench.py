@@ -394,7 +394,7 @@ def main():
                                    "2x64-tanh actor+critic (9155 params), on-device env.step + GAE + fwd/bwd + clip + Adam" % (ENVS_PER_GPU, T, mb),
                        "envs_per_gpu": ENVS_PER_GPU, "num_steps": T, "minibatch_rows": mb, "parallelism": "env-sharded x%d, grad all-reduce" % world,
                        "collectives": "none (single process)" if world == 1 else ("RCCL direct (mi_ppo_update_sharded: one C call per update, 17 in-stream all-reduces)" if eng_native else "torch.distributed (host-sequenced, 17 all-reduces per update)")},
-            "roofline": {"bound": "mfma", "kernel": "grad_kernel", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "grad_kernel_f32", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_launch, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "launches": g_n},
             "hbm_roofline": {"algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
