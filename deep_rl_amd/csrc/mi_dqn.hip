@@ -495,13 +495,24 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
                                                          float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < DQ_NP) {
+        // the optimizer state is requested before the slabs, and the slabs 16 at a time with every load in flight at once (the kernel is one memory
+        // latency deep instead of one per group of four); the sum keeps its order: accumulator b & 3 takes slab b, then (0 + 1) + (2 + 3)
+        float pi = 0.0f, mi = 0.0f, vi = 0.0f;
+        if (opt.params) { pi = opt.params[p]; mi = opt.m[p]; vi = opt.v[p]; }
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int b = 0; b < n_slabs; ++b) acc[b & 3] += workspace[(size_t)b * TD_SLAB + p];
+        int b = 0;
+        for (; b + 16 <= n_slabs; b += 16) {
+            float x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = workspace[(size_t)(b + k) * TD_SLAB + p];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k & 3] += x[k];
+        }
+        for (; b < n_slabs; ++b) acc[b & 3] += workspace[(size_t)b * TD_SLAB + p];
         const float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         grads[p] = g;
         if (opt.params) {   // the formula of clip_adam_kernel at coef = 1 (max_norm = inf), bit for bit (mi_adam_elem)
-            float mi = opt.m[p], vi = opt.v[p];
-            opt.params[p] = mi_adam_elem(opt.params[p], g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
+            opt.params[p] = mi_adam_elem(pi, g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
             opt.m[p] = mi; opt.v[p] = vi;
         }
     } else if (p == DQ_NP && loss) {
