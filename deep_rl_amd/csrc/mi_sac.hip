@@ -907,12 +907,18 @@ __global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(float* __restrict__ w
 // step to every element it has just assembled and (critics) the polyak step of the target copy: optimizer.step() and the target update
 // (sac.py:185,213-217) cost no launch of their own.
 struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, rbc2, eps, tau; };
-__device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g) {
-    float mi = o.m[i], vi = o.v[i];
-    const float p = mi_adam_elem(o.params[i], g, mi, vi, o.w1, o.b2, o.w2, o.step_size, o.rbc2, o.eps);
-    o.m[i] = mi; o.v[i] = vi;
+// the element's optimizer state is requested BEFORE its gradient is summed (sac_state_load), so the launch is one memory latency deep, not two
+struct sac_state_t { float p, m, v, t; };
+__device__ __forceinline__ sac_state_t sac_state_load(const sac_opt_t& o, int i) {
+    sac_state_t s = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (o.params) { s.p = o.params[i]; s.m = o.m[i]; s.v = o.v[i]; if (o.target) s.t = o.target[i]; }
+    return s;
+}
+__device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g, sac_state_t s) {
+    const float p = mi_adam_elem(s.p, g, s.m, s.v, o.w1, o.b2, o.w2, o.step_size, o.rbc2, o.eps);
+    o.m[i] = s.m; o.v[i] = s.v;
     o.params[i] = p;
-    if (o.target) o.target[i] = o.tau * p + (1.0f - o.tau) * o.target[i];
+    if (o.target) o.target[i] = o.tau * p + (1.0f - o.tau) * s.t;
 }
 #define RED_SMALL_PER_BLOCK 64
 __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __restrict__ ws, int batch, int n_slabs, int n_split, int is_actor, double inv_count,
@@ -926,20 +932,41 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
         int off = -1;
         if (e < per * nets) off = (e / per) * 1793 + e % per;
         else if (e < n_small) off = (is_actor ? 1794 : 3586) + (e - per * nets);
+        int dst = -1;
+        if (e < per * nets) {
+            const int net = e / per, l = e % per;
+            if (is_actor) dst = l < 768 ? AC_W1 + l : l < 1024 ? AC_B1 + (l - 768) : l < 1280 ? AC_B2 + (l - 1024) : l < 1536 ? AC_WM + (l - 1280)
+                              : l == 1536 ? AC_BM : l < 1793 ? AC_WL + (l - 1537) : AC_BL;
+            else dst = net * SQ_NP + (l < 1024 ? SQ_W1 + l : l < 1280 ? SQ_B1 + (l - 1024) : l < 1536 ? SQ_B2 + (l - 1280) : l < 1792 ? SQ_W3 + (l - 1536) : SQ_B3);
+        }
+        sac_state_t st = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (grp == 0 && dst >= 0) st = sac_state_load(opt, dst);
         float acc = 0.0f;
-        if (off >= 0) for (int b = grp; b < n_slabs; b += 4) acc += slabs[(size_t)b * SLAB + off];
+        if (off >= 0) {   // this group's slabs grp, grp + 4, ...: eight loads in flight at a time, summed in slab order
+            int b = grp;
+            for (; b + 28 < n_slabs; b += 32) {
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = slabs[(size_t)(b + 4 * k) * SLAB + off];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += x[k];
+            }
+            for (; b + 12 < n_slabs; b += 16) {
+                float x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = slabs[(size_t)(b + 4 * k) * SLAB + off];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += x[k];
+            }
+            for (; b < n_slabs; b += 4) acc += slabs[(size_t)b * SLAB + off];
+        }
         part[grp][threadIdx.x & 63] = acc;
         __syncthreads();
         if (grp == 0 && off >= 0) {
             const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-            if (e < per * nets) {
-                const int net = e / per, l = e % per;
-                int dst;
-                if (is_actor) dst = l < 768 ? AC_W1 + l : l < 1024 ? AC_B1 + (l - 768) : l < 1280 ? AC_B2 + (l - 1024) : l < 1536 ? AC_WM + (l - 1280)
-                                  : l == 1536 ? AC_BM : l < 1793 ? AC_WL + (l - 1537) : AC_BL;
-                else dst = net * SQ_NP + (l < 1024 ? SQ_W1 + l : l < 1280 ? SQ_B1 + (l - 1024) : l < 1536 ? SQ_B2 + (l - 1280) : l < 1792 ? SQ_W3 + (l - 1536) : SQ_B3);
+            if (dst >= 0) {
                 grads[dst] = v;
-                if (opt.params) sac_apply(opt, dst, v);
+                if (opt.params) sac_apply(opt, dst, v, st);
             } else if (out2) out2[e - per * nets] = (float)((double)v * inv_count);
         }
     } else {
@@ -947,11 +974,19 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
         if (e4 >= nets * (SA_H * SA_H / 4)) return;
         const int net = e4 / (SA_H * SA_H / 4), l4 = e4 % (SA_H * SA_H / 4);
         const float* part0 = ws + ws_part_off(batch) + (size_t)net * SA_H * SA_H + 4 * (size_t)l4;
-        f32x4 acc = *reinterpret_cast<const f32x4*>(part0);
-        for (int y = 1; y < n_split; ++y) acc += *reinterpret_cast<const f32x4*>(part0 + (size_t)y * 3 * SA_H * SA_H);
-        const int d0 = (is_actor ? AC_W2 : net * SQ_NP + SQ_W2) + 4 * l4;    // the second critic's block is only 4-byte aligned: scalar stores
+        const int d0 = (is_actor ? AC_W2 : net * SQ_NP + SQ_W2) + 4 * l4;    // the second critic's block is only 4-byte aligned: scalar accesses
+        sac_state_t st[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { grads[d0 + c] = acc[c]; if (opt.params) sac_apply(opt, d0 + c, acc[c]); }
+        for (int c = 0; c < 4; ++c) st[c] = sac_state_load(opt, d0 + c);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(part0);
+        if (n_split == 2) acc += *reinterpret_cast<const f32x4*>(part0 + (size_t)3 * SA_H * SA_H);
+        else if (n_split == 4) {   // all partials in flight, summed in split order
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(part0 + (size_t)1 * 3 * SA_H * SA_H), a2 = *reinterpret_cast<const f32x4*>(part0 + (size_t)2 * 3 * SA_H * SA_H);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(part0 + (size_t)3 * 3 * SA_H * SA_H);
+            acc += a1; acc += a2; acc += a3;
+        } else for (int y = 1; y < n_split; ++y) acc += *reinterpret_cast<const f32x4*>(part0 + (size_t)y * 3 * SA_H * SA_H);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { grads[d0 + c] = acc[c]; if (opt.params) sac_apply(opt, d0 + c, acc[c], st[c]); }
     }
 }
 
