@@ -95,6 +95,7 @@ struct dqn_eps_tab { float v[DQN_MAX_STEPS_PER_CALL]; };  // epsilon(global_step
 #define DA_ENVS 16
 #define DA_WAVES 3
 typedef float dq_f32x4 __attribute__((ext_vector_type(4)));
+typedef dq_f32x4 f32x4_t;
 #define DQ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // FORCED (parity mode: forced_actions / forced_resets may be given) and EPLOG (per-episode list kept) are separate instantiations, not
 // run-time branches: a conditional global load or returning atomic inside the step loop makes the compiler place s_waitcnt vmcnt(0) at
@@ -154,8 +155,9 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
     int st_cnt = 0, st_len = 0, st_max = 0, par = 0;
     // every value loaded so far is consumed here: no load is pending when the loop starts (it would become a vmcnt wait inside the body)
     asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr));
+    long long slot = global_step % slots;
     for (int s = 0; s < n_steps; ++s) {
-        const long long gs = global_step + s, slot = gs % slots, nslot = (gs + 1) % slots;
+        const long long gs = global_step + s, nslot = slot + 1 == slots ? 0 : slot + 1;   // (no 64-bit modulo per step)
         int a;
         if (FORCED && forced_actions) a = (int)forced_actions[(size_t)s * N + g];
         else {
@@ -232,12 +234,225 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
             rewards[nslot * N + g] = 1.0f;                                     // :107
             terminated[nslot * N + g] = (uint8_t)(term ? 1 : 0);               // :108: done and not TimeLimit.truncated
         }
+        slot = nslot;
     }
     if (writer) {
         e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
         e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr;
         reinterpret_cast<float4*>(obs_cur)[g] = ob;
         if (episode_stats && st_cnt > 0) { atomicAdd(episode_stats, st_cnt); atomicAdd(episode_stats + 1, st_len); atomicMax(episode_stats + 2, st_max); }
+    }
+}
+
+// ---- the same contract with a FOURTH wave: acting at 3 waves per 16 envs leaves one SIMD of every CU idle and spends 1.07 us of every 3.5 us step on the fp64
+// dynamics, carried redundantly by all three forward waves (timing-only ablations: no dynamics 57.6 -> 46.9 us per 10-step iteration, no forward -> 41.5).
+// CartPole has two actions, so the dynamics wave computes BOTH successors of the current state (lane groups 0 / 1 take action 0 / 1, groups 2 / 3 idle
+// replicas) while the three forward waves evaluate the Q-network on it, and publishes them as records in LDS; after the step's one barrier every wave
+// derives the action from the partial sums and picks the chosen record — the forward waves only its observation.  The dynamics wave also draws the
+// exploration words one step ahead, keeps the episode bookkeeping and writes the ring.  Same keyed draws, same IEEE sequence per env: bit-identical
+// trajectories (tests/test_gpu_dqn.py runs unchanged).
+struct __attribute__((aligned(16))) da4_rec {
+    float4 ob;                      // successor observation (the reset observation where the step ends the episode)
+    double x, xd, th, thd;          // successor state (after the reset where done)
+    int elapsed, eplen; float epret; int flags;   // flags: bit 0 terminated, bit 1 done
+    int fin_len; float fin_ret; unsigned ep_lo, ep_hi;
+};
+struct __attribute__((aligned(16))) da4_smem {
+    da4_rec rec[2][2][DA_ENVS];     // [step parity][action][env]
+    float qp[2][3][DA_ENVS][2];     // [step parity][forward wave][env][action]: partial head sums
+    int expl[4][DA_ENVS];           // [step & 3][env]: bit 0 explore, bit 1 the random action
+};
+template <bool FORCED, bool EPLOG>
+__global__ void __launch_bounds__(256)
+dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long long global_step, long long slots, long long learning_starts,
+                dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
+                int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
+                const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
+                int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next) {
+    __shared__ da4_smem sm;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
+    const bool phys = w == 3;
+    const int N = e.n;
+    const int i = blockIdx.x * DA_ENVS + j;
+    const bool mine = i < N;
+    const int g = mine ? i : N - 1;
+    const int la = lg & 1;                                  // dynamics wave: the action this lane group speculates on
+    const bool writer = phys && mine && lg == 0;
+    // ---- forward waves: resident operands (as in dqn_act_kernel) ----
+    float w1a[8];
+    dq_f32x4 b1v[8];
+    float w2a[2][8][4];
+    dq_f32x4 b2v[2], w3v[2][2];
+    float b30 = params[DQ_B3], b31 = params[DQ_B3 + 1];   // every wave derives the action
+    if (!phys) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int ua = 16 * t + j;
+            w1a[t] = ua < DQ_H1 ? params[DQ_W1 + 4 * ua + lg] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int u = 16 * t + 4 * lg + r; b1v[t][r] = u < DQ_H1 ? params[DQ_B1 + u] : 0.0f; }
+        }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int row = 16 * (2 * w + T) + j;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int col = 16 * t + 4 * lg;
+                if (row < DQ_H2 && col < DQ_H1) {
+                    const float4 v = *reinterpret_cast<const float4*>(params + DQ_W2 + DQ_H1 * row + col);
+                    w2a[T][t][0] = v.x; w2a[T][t][1] = v.y; w2a[T][t][2] = v.z; w2a[T][t][3] = v.w;
+                } else { w2a[T][t][0] = w2a[T][t][1] = w2a[T][t][2] = w2a[T][t][3] = 0.0f; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * (2 * w + T) + 4 * lg + r;
+                b2v[T][r] = o < DQ_H2 ? params[DQ_B2 + o] : 0.0f;
+                w3v[T][0][r] = o < DQ_H2 ? params[DQ_W3 + o] : 0.0f;
+                w3v[T][1][r] = o < DQ_H2 ? params[DQ_W3 + DQ_H2 + o] : 0.0f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { w1a[t] = 0.0f; b1v[t] = dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            b2v[T] = dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; w3v[T][0] = b2v[T]; w3v[T][1] = b2v[T];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) w2a[T][t][0] = w2a[T][t][1] = w2a[T][t][2] = w2a[T][t][3] = 0.0f;
+        }
+    }
+    // ---- env state: the dynamics wave owns it (every lane group holds a copy) ----
+    double sx = 0.0, sxd = 0.0, sth = 0.0, sthd = 0.0;
+    int elapsed = 0, eplen = 0;
+    float epret = 0.0f;
+    uint64_t episode = 0, stepctr0 = 0;
+    if (phys) {
+        sx = e.x[g]; sxd = e.x_dot[g]; sth = e.theta[g]; sthd = e.theta_dot[g];
+        elapsed = e.elapsed[g]; eplen = e.ep_len[g]; epret = e.ep_ret[g]; episode = e.episode[g]; stepctr0 = e.step_ctr[g];
+    }
+    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
+    int st_cnt = 0, st_len = 0, st_max = 0;
+    auto draw = [&](int s) {   // exploration words of step s -> bit 0 explore, bit 1 random action (dqn.py:86-90)
+        uint32_t r[4];
+        mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr0 + (uint64_t)s, STREAM_EXPLORE, r);
+        const float u = mi_u32_to_uniform(r[0]);
+        const bool explore = global_step + s < learning_starts || u < eps.v[s];
+        return (explore ? 1 : 0) | (int)((r[1] & 1u) << 1);
+    };
+    if (phys && lg == 0) sm.expl[0][j] = draw(0);
+    asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr0), "+v"(b30), "+v"(b31));
+    __syncthreads();
+    int a = 0;
+    // bookkeeping of one committed step (dynamics wave, lane group 0): dqn.py:95, :106-108 and the episode statistics
+    long long slot = global_step % slots;   // ring slot of the step being committed; advanced by compare-and-wrap (a 64-bit modulo per step is ~150 scalar instructions)
+    auto commit = [&](int s, int act, const da4_rec& rc) {
+        const long long nslot = slot + 1 == slots ? 0 : slot + 1;
+        sx = rc.x; sxd = rc.xd; sth = rc.th; sthd = rc.thd; elapsed = rc.elapsed; eplen = rc.eplen; epret = rc.epret;
+        episode = ((uint64_t)rc.ep_hi << 32) | rc.ep_lo;
+        if (writer) {
+            actions[slot * N + g] = act;
+            reinterpret_cast<float4*>(observations)[nslot * N + g] = rc.ob;
+            rewards[nslot * N + g] = 1.0f;
+            terminated[nslot * N + g] = (uint8_t)(rc.flags & 1);
+            if (rc.flags & 2) {
+                st_cnt += 1; st_len += rc.fin_len; st_max = rc.fin_len > st_max ? rc.fin_len : st_max;
+                if (EPLOG && max_ep > 0 && episode_stats) {
+                    const int sl = atomicAdd(episode_stats + 3, 1);
+                    if (sl < max_ep) episodes[sl] = mi_episode_t{g, s, rc.fin_ret, rc.fin_len};
+                }
+            }
+        }
+        slot = nslot;
+    };
+    for (int s = 0; s < n_steps; ++s) {
+        const int par = s & 1;
+        if (!phys) {
+            const bool explore = (FORCED && forced_actions) ? true : ((sm.expl[s & 3][j] & 1) != 0);
+            if (__any(!explore)) {  // skip the forward while every env of the group explores (the same envs in all three waves)
+                const float b0 = lg == 0 ? ob.x : lg == 1 ? ob.y : lg == 2 ? ob.z : ob.w;
+                dq_f32x4 h1[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    h1[t] = DQ_MFMA(w1a[t], b0, b1v[t]);
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) h1[t][r2] = fmaxf(h1[t][r2], 0.0f);
+                }
+                dq_f32x4 h2[2] = {b2v[0], b2v[1]};
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) {
+                        h2[0] = DQ_MFMA(w2a[0][t][r2], h1[t][r2], h2[0]);
+                        h2[1] = DQ_MFMA(w2a[1][t][r2], h1[t][r2], h2[1]);
+                    }
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) {
+                        const float hv = fmaxf(h2[T][r2], 0.0f);
+                        p0 = __builtin_fmaf(w3v[T][0][r2], hv, p0); p1 = __builtin_fmaf(w3v[T][1][r2], hv, p1);
+                    }
+                p0 += __shfl_xor(p0, 16); p0 += __shfl_xor(p0, 32);   // (measured: the VALU-only groups_sum and reading both candidates in the
+                p1 += __shfl_xor(p1, 16); p1 += __shfl_xor(p1, 32);   //  post-barrier round trip are each ~1.5 us per launch SLOWER here)
+                if (lg == 0) { sm.qp[par][w][j][0] = p0; sm.qp[par][w][j][1] = p1; }
+            }
+        } else {
+            if (s > 0) commit(s - 1, a, sm.rec[par ^ 1][a][j]);
+            // both successors of the committed state: this lane group's action
+            double nx = sx, nxd = sxd, nth = sth, nthd = sthd;
+            int term;
+            mi_cartpole_step(nx, nxd, nth, nthd, la, term);
+            int nel = elapsed + 1, nlen = eplen + 1;
+            float nret = epret + 1.0f;
+            uint64_t nep = episode;
+            const bool trunc = !term && nel >= CP_MAX_STEPS;
+            const bool d = term || trunc;
+            const int fin_len = nlen; const float fin_ret = nret;
+            if (d) {
+                nret = 0.0f; nlen = 0; nel = 0;
+                double rs[4];
+                if (FORCED && forced_resets) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rs[k] = forced_resets[4 * ((size_t)s * N + g) + k];
+                } else {
+                    mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, rs);
+                }
+                nep += 1;
+                nx = rs[0]; nxd = rs[1]; nth = rs[2]; nthd = rs[3];
+            }
+            if (lg < 2) {
+                da4_rec& rc = sm.rec[par][la][j];
+                rc.ob = make_float4((float)nx, (float)nxd, (float)nth, (float)nthd);
+                rc.x = nx; rc.xd = nxd; rc.th = nth; rc.thd = nthd;
+                rc.elapsed = nel; rc.eplen = nlen; rc.epret = nret; rc.flags = (term ? 1 : 0) | (d ? 2 : 0);
+                rc.fin_len = fin_len; rc.fin_ret = fin_ret; rc.ep_lo = (unsigned)nep; rc.ep_hi = (unsigned)(nep >> 32);
+            }
+            if (lg == 0 && s + 1 < n_steps) sm.expl[(s + 1) & 3][j] = draw(s + 1);
+        }
+        __syncthreads();
+        // every wave: the action of step s (dqn.py:86-92)
+        if (FORCED && forced_actions) a = (int)forced_actions[(size_t)s * N + g];
+        else {
+            const int ex = sm.expl[s & 3][j];
+            a = (ex >> 1) & 1;
+            if (!(ex & 1)) {
+                const float q0 = ((sm.qp[par][0][j][0] + sm.qp[par][1][j][0]) + sm.qp[par][2][j][0]) + b30;
+                const float q1 = ((sm.qp[par][0][j][1] + sm.qp[par][1][j][1]) + sm.qp[par][2][j][1]) + b31;
+                a = q1 > q0 ? 1 : 0;                               // torch.argmax: first index on ties (dqn.py:92)
+            }
+        }
+        if (!phys) ob = sm.rec[par][a][j].ob;
+    }
+    if (phys) {
+        commit(n_steps - 1, a, sm.rec[(n_steps - 1) & 1][a][j]);
+        if (writer) {
+            e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
+            e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr0 + (uint64_t)n_steps;
+            reinterpret_cast<float4*>(obs_cur)[g] = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
+            if (episode_stats && st_cnt > 0) { atomicAdd(episode_stats, st_cnt); atomicAdd(episode_stats + 1, st_len); atomicMax(episode_stats + 2, st_max); }
+        }
     }
 }
 
@@ -269,8 +484,14 @@ static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t 
     }
     mi_prof_scope prof(MI_PROF_DQN_ACT, s);
     const bool forced = forced_actions || forced_resets, eplog = max_ep > 0 && episode_stats;
+#ifdef DQN_ACT3   // A/B: the 3-wave form (every forward wave carries the dynamics)
     const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(64 * DA_WAVES);
-#define DA_LAUNCH(F, L) dqn_act_kernel<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
+#define DA_KERNEL dqn_act_kernel
+#else
+    const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(256);
+#define DA_KERNEL dqn_act4_kernel
+#endif
+#define DA_LAUNCH(F, L) DA_KERNEL<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
                                                                   obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes, \
                                                                   episode_stats, max_ep, zero_next)
     if (forced) { if (eplog) DA_LAUNCH(true, true); else DA_LAUNCH(true, false); }
@@ -319,6 +540,7 @@ extern "C" int mi_dqn_sample(uint64_t seed, uint64_t update_index, int64_t upper
 //      in LDS (post-ReLU: relu(z) > 0 <=> z > 0, so the mask for the backward pass needs no second copy) --------------------
 #define TD_R 8
 #define TD_SLAB (DQ_NP + 2)   // + loss
+static_assert(TD_R == 8, "the MFMA passes of dqn_td_kernel take the rows as 2 k-steps of 4 (dW2) and as half of a 16-column B operand");
 struct __attribute__((aligned(16))) td_smem {
     float x[2][TD_R][4];          // [0] obs, [1] next obs
     float h1[2][TD_R][DQ_H1];     // [0] online on obs, [1] target on next obs
@@ -343,6 +565,23 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
     float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
     __shared__ long long nxt[TD_R];
     __shared__ long long cur[TD_R];
+    // MFMA roles (layer 2, dh1, dW2): wave mw, lane (mj, mlg).  The layer-2 A operands do not depend on the batch: requested now, they land while the
+    // indices, the gathers and layer 1 run (24 float4 + 12 dwords per lane)
+    const int mw = t >> 6, mj = t & 15, mlg = (t >> 4) & 3;
+    const int mnet = mw >> 1;
+    const float* mp = mnet ? target_params : params;
+    f32x4_t wA[3][8], acc2[3];
+#pragma unroll
+    for (int T3 = 0; T3 < 3; ++T3) {
+        const int T = 3 * (mw & 1) + T3, u2 = 16 * T + mj;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = 16 * c + 4 * mlg;
+            wA[T3][c] = (u2 < DQ_H2 && k < DQ_H1) ? *reinterpret_cast<const f32x4_t*>(mp + DQ_W2 + DQ_H1 * u2 + k) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int o = 16 * T + 4 * mlg + r; acc2[T3][r] = o < DQ_H2 ? mp[DQ_B2 + o] : 0.0f; }
+    }
     if (t < TD_R) {
         const int b = row0 + t < batch ? row0 + t : batch - 1;
         long long i;
@@ -353,7 +592,13 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             if (row0 + t < batch) idx_out[b] = i;
         } else i = idx[b];
         cur[t] = i;
-        nxt[t] = ((i / n_envs + 1) % slots) * n_envs + i % n_envs;
+        // next-slot row of the same env: ((i / N + 1) % slots) * N + i % N.  Flat indices below 2^32 (every ring this side of 4 G transitions) take the
+        // 32-bit divider; the wrap is a compare (slot < slots always), not a second modulo.
+        long long sl, en;
+        if ((unsigned long long)i >> 32) { sl = i / n_envs; en = i % n_envs; }
+        else { const unsigned q = (unsigned)i / (unsigned)n_envs; sl = q; en = (unsigned)i - q * (unsigned)n_envs; }
+        sl = sl + 1 == slots ? 0 : sl + 1;
+        nxt[t] = sl * n_envs + en;
         sm.act[t] = (int)actions[i];
     }
     __syncthreads();
@@ -377,26 +622,37 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         }
     }
     __syncthreads();
-    // ---- layer 2: unit u < 84; W2 row u streamed from L2 (float4), h1 of all rows broadcast from LDS ----
-    if (u < DQ_H2) {
-        float acc[TD_R];
-        const float b = p[DQ_B2 + u];
+    // ---- layer 2 on v_mfma_f32_16x16x4_f32, D[unit][row] = W2[unit][k] h1[k][row]: 2 nets x 6 unit tiles over the 4 waves (wave w: net w >> 1, tiles
+    //      3 (w & 1) ..+2).  Lane (j, lg) supplies k = 16c + 4lg + r in k-step (c, r): A = W2[16T + j][k] (8 float4 loads per tile, issued together;
+    //      each wave-load touches whole 64-byte segments of 16 rows), B = h1[row j][k] (one LDS float4 per c; rows >= TD_R are zero columns).
+    //      (r01 form: thread per unit, its W2 row streamed as 30 dependent float4 loads from 64 different lines each — 12,100 of the kernel's 34,500 cycles.) ----
+    {
+        const int j = mj, lg = mlg;
+        f32x4_t hB[8];
 #pragma unroll
-        for (int r = 0; r < TD_R; ++r) acc[r] = 0.0f;
-        const float4* wrow = reinterpret_cast<const float4*>(p + DQ_W2 + DQ_H1 * u);
-#pragma unroll 5
-        for (int k4 = 0; k4 < DQ_H1 / 4; ++k4) {
-            const float4 w = wrow[k4];
-#pragma unroll
-            for (int r = 0; r < TD_R; ++r) {
-                const float4 h = *reinterpret_cast<const float4*>(&sm.h1[net][r][4 * k4]);
-                acc[r] = __builtin_fmaf(w.x, h.x, acc[r]); acc[r] = __builtin_fmaf(w.y, h.y, acc[r]);
-                acc[r] = __builtin_fmaf(w.z, h.z, acc[r]); acc[r] = __builtin_fmaf(w.w, h.w, acc[r]);
-            }
+        for (int c = 0; c < 8; ++c) {
+            const int k = 16 * c + 4 * lg;
+            hB[c] = (j < TD_R && k < DQ_H1) ? *reinterpret_cast<const f32x4_t*>(&sm.h1[mnet][j][k]) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
-        for (int r = 0; r < TD_R; ++r) sm.h2[net][r][u] = fmaxf(acc[r] + b, 0.0f);
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int T3 = 0; T3 < 3; ++T3) acc2[T3] = DQ_MFMA(wA[T3][c][r], hB[c][r], acc2[T3]);
+#pragma unroll
+        for (int T3 = 0; T3 < 3; ++T3) {
+            const int o = 16 * (3 * (mw & 1) + T3) + 4 * lg;
+            if (j < TD_R && o < DQ_H2)
+                *reinterpret_cast<f32x4_t*>(&sm.h2[mnet][j][o]) = f32x4_t{fmaxf(acc2[T3][0], 0.0f), fmaxf(acc2[T3][1], 0.0f), fmaxf(acc2[T3][2], 0.0f), fmaxf(acc2[T3][3], 0.0f)};
+        }
     }
+    // the dh1 pass's A operands (W2 read column-wise: 42 dwords per lane), requested now: they land during layer 3 and the loss
+    float wa1[2][21];
+#pragma unroll
+    for (int s2 = 0; s2 < 21; ++s2)
+#pragma unroll
+        for (int U2 = 0; U2 < 2; ++U2) { const int k = 16 * (2 * mw + U2) + mj; wa1[U2][s2] = k < DQ_H1 ? params[DQ_W2 + DQ_H1 * (4 * s2 + mlg) + k] : 0.0f; }
     __syncthreads();
     // ---- layer 3: 2 nets x TD_R rows x 2 actions = 32 dot products of length 84 ----
     if (t < 2 * TD_R * 2) {
@@ -447,44 +703,67 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         part[DQ_NP] = l;
     }
     __syncthreads();
-    // ---- dh1 = W2^T dz2 (thread k < 120; W2 columns: consecutive threads read consecutive addresses), dz1, db1, dW1 ----
-    if (t < DQ_H1) {
-        float dh[TD_R];
+    // ---- dh1[k][row] = sum_j W2[j][k] dz2[j][row] on the MFMA: 8 k-tiles over the 4 waves (wave w: tiles 2w, 2w + 1), 21 k-steps over j = 4s + lg.
+    //      A = W2[j][16U + kk] (one dword per lane and k-step: 16 consecutive floats of 4 rows), B = dz2[j][row] from LDS; D: lane (row, lg), register r <-> k = 16U + 4lg + r ----
+    {
+        const int w = mw, j = mj, lg = mlg;
+        f32x4_t dh[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
+        float db[21];
 #pragma unroll
-        for (int r = 0; r < TD_R; ++r) dh[r] = 0.0f;
-        for (int j = 0; j < DQ_H2; ++j) {
-            const float w = params[DQ_W2 + DQ_H1 * j + t];
-            const float4 da = *reinterpret_cast<const float4*>(&sm.dz2[j][0]), db = *reinterpret_cast<const float4*>(&sm.dz2[j][4]);
-            dh[0] = __builtin_fmaf(w, da.x, dh[0]); dh[1] = __builtin_fmaf(w, da.y, dh[1]); dh[2] = __builtin_fmaf(w, da.z, dh[2]); dh[3] = __builtin_fmaf(w, da.w, dh[3]);
-            dh[4] = __builtin_fmaf(w, db.x, dh[4]); dh[5] = __builtin_fmaf(w, db.y, dh[5]); dh[6] = __builtin_fmaf(w, db.z, dh[6]); dh[7] = __builtin_fmaf(w, db.w, dh[7]);
+        for (int s2 = 0; s2 < 21; ++s2) db[s2] = j < TD_R ? sm.dz2[4 * s2 + lg][j] : 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < 21; ++s2)
+#pragma unroll
+            for (int U2 = 0; U2 < 2; ++U2) dh[U2] = DQ_MFMA(wa1[U2][s2], db[s2], dh[U2]);
+#pragma unroll
+        for (int U2 = 0; U2 < 2; ++U2) {
+            const int k = 16 * (2 * w + U2) + 4 * lg;
+            if (j < TD_R && k < DQ_H1) {
+                const f32x4_t h = *reinterpret_cast<const f32x4_t*>(&sm.h1[0][j][k]);
+                *reinterpret_cast<f32x4_t*>(&sm.dz1[j][k]) = f32x4_t{h[0] > 0.0f ? dh[U2][0] : 0.0f, h[1] > 0.0f ? dh[U2][1] : 0.0f, h[2] > 0.0f ? dh[U2][2] : 0.0f, h[3] > 0.0f ? dh[U2][3] : 0.0f};
+            }
         }
+    }
+    // ---- dW2 on the MFMA, computed transposed so that a lane ends up with 4 consecutive k of one row: D[k][j] = sum_r h1[r][k] dz2[j][r] (K = the TD_R rows =
+    //      2 k-steps); 8 x 6 output tiles, 12 per wave (k tiles 2w, 2w + 1).  A = h1[r = 4s + lg][16U + kk], B = dz2[16T + jj][r = 4s + lg];
+    //      D: lane (jj, lg), register r <-> k = 16U + 4lg + r: one float4 store per lane and tile, into row 16T + jj of the slab ----
+    {
+        const int w = mw, kk = mj, lg = mlg;
+        float b2[6][2];
+#pragma unroll
+        for (int T = 0; T < 6; ++T)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { const int jj = 16 * T + kk; b2[T][s2] = jj < DQ_H2 ? sm.dz2[jj][4 * s2 + lg] : 0.0f; }
+#pragma unroll
+        for (int U2 = 0; U2 < 2; ++U2) {
+            const int ka = 16 * (2 * w + U2) + kk;
+            float a2[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) a2[s2] = ka < DQ_H1 ? sm.h1[0][4 * s2 + lg][ka] : 0.0f;
+            const int k0 = 16 * (2 * w + U2) + 4 * lg;
+#pragma unroll
+            for (int T = 0; T < 6; ++T) {
+                f32x4_t d = {0.0f, 0.0f, 0.0f, 0.0f};
+                d = DQ_MFMA(a2[0], b2[T][0], d);
+                d = DQ_MFMA(a2[1], b2[T][1], d);
+                const int jj = 16 * T + kk;
+                if (jj < DQ_H2 && k0 < DQ_H1) *reinterpret_cast<f32x4_t*>(part + DQ_W2 + DQ_H1 * jj + k0) = d;
+            }
+        }
+    }
+    __syncthreads();   // dz1 complete
+    // ---- db1, dW1: thread k < 120 ----
+    if (t < DQ_H1) {
         float gb = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < TD_R; ++r) {
-            const float d = sm.h1[0][r][t] > 0.0f ? dh[r] : 0.0f;
-            sm.dz1[r][t] = d;
+            const float d = sm.dz1[r][t];
             gb += d;
 #pragma unroll
             for (int c = 0; c < 4; ++c) gw[c] = __builtin_fmaf(d, sm.x[0][r][c], gw[c]);
         }
         part[DQ_B1 + t] = gb;
         *reinterpret_cast<float4*>(part + DQ_W1 + 4 * t) = make_float4(gw[0], gw[1], gw[2], gw[3]);
-    }
-    // ---- dW2[j][k] = sum_r dz2[r][j] h1[r][k]: thread (k = t & 127, half = t >> 7) covers 42 rows j of W2 ----
-    {
-        const int k = t & 127, half = t >> 7;
-        if (k < DQ_H1) {
-            float h[TD_R];
-#pragma unroll
-            for (int r = 0; r < TD_R; ++r) h[r] = sm.h1[0][r][k];
-            for (int j = 42 * half; j < 42 * half + 42; ++j) {
-                const float4 da = *reinterpret_cast<const float4*>(&sm.dz2[j][0]), db = *reinterpret_cast<const float4*>(&sm.dz2[j][4]);
-                float gsum = da.x * h[0];
-                gsum = __builtin_fmaf(da.y, h[1], gsum); gsum = __builtin_fmaf(da.z, h[2], gsum); gsum = __builtin_fmaf(da.w, h[3], gsum);
-                gsum = __builtin_fmaf(db.x, h[4], gsum); gsum = __builtin_fmaf(db.y, h[5], gsum); gsum = __builtin_fmaf(db.z, h[6], gsum); gsum = __builtin_fmaf(db.w, h[7], gsum);
-                part[DQ_W2 + DQ_H1 * j + k] = gsum;
-            }
-        }
     }
 }
 
