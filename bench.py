@@ -143,14 +143,14 @@ def bench_dqn(dev, iters=300, cpu_seconds=3.0):
     out = {"workload": "dqn.py CartPole-v1, %d envs, %d-slot ring (%d transitions on HBM), batch %d, train every 10 steps" % (envs, slots, envs * slots, batch),
            "value": round(iters * 10 * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(iters / dt, 1), "ms_per_step": round(1e3 * dt / iters, 5),
            "step": "10 env steps of every env + 1 TD update", "dtype": "f32", "kernel_us": {k: round(v, 2) for k, v in us.items()},
-           "roofline": {"bound": "mfma", "kernel": "dqn_act_kernel", "achieved": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+           "roofline": {"bound": "mfma", "kernel": "dqn_act4_kernel", "achieved": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                         "flops_per_launch": act_flops, "avg_launch_us": round(us["dqn_act"], 2),
-                        "note": "10 dependent env steps per launch: 16 envs per workgroup, latency-bound chain (forward, argmax, fp64 CartPole step)"},
+                        "note": "10 dependent env steps per launch: 16 envs per workgroup (3 forward waves + 1 wave computing both CartPole successors), latency-bound chain (forward, barrier, argmax)"},
            "roofline_td": {"bound": "latency (f32 VALU peak quoted)", "kernel": "dqn_td_kernel", "achieved": round(td_flops / (us["dqn_td"] * 1e-6) / 1e12, 4),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(td_flops / (us["dqn_td"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),
                            "flops_per_launch": td_flops, "avg_launch_us": round(us["dqn_td"], 2),
-                           "note": "the reference's batch of 128 rows is 16 workgroups on a 256-CU chip: the launch is a fixed ~15 us latency, not a throughput"},
+                           "note": "the reference's batch of 128 rows is 16 workgroups on a 256-CU chip: the launch is a fixed ~12 us latency, not a throughput"},
            "loss": float(eng.loss.item())}
     out["cpu_baseline"] = cpu_baseline_dqn(params0, envs, slots, batch, cpu_seconds)
     return out
