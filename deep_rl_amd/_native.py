@@ -31,7 +31,7 @@ class PPOBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "params", "exp_avg", "exp_avg_sq", "grads", "loss_terms", "grad_norm", "obs_cur", "observations", "values",
         "actions", "log_probs", "rewards", "dones", "advantages", "returns", "perm", "adv_sums", "workspace",
-        "episodes", "episode_stats")] + [("max_ep", C.c_int32)]
+        "episodes", "episode_stats")] + [("max_ep", C.c_int32), ("episode_stats_next", C.c_void_p)]
 
 
 class PPOHparams(C.Structure):

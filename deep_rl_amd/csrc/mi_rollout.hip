@@ -498,9 +498,11 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                   float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
                   const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
                   mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep,
-                  float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n) {
+                  float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n,
+                  int32_t* __restrict__ zero_i32) {
     __shared__ rq_smem sm;
     if (zero_f64 && blockIdx.x == 0) for (int k = threadIdx.x; k < zero_n; k += 128) zero_f64[k] = 0.0;   // scratch the next launches accumulate into
+    if (zero_i32 && blockIdx.x == 0 && threadIdx.x < 4) zero_i32[threadIdx.x] = 0;                        // the NEXT rollout's episode statistics (double-buffered by the caller)
     const int lane = threadIdx.x & 63, net = threadIdx.x >> 6, en = lane & 3;
     const bool q0 = lane & 1, q1 = lane & 2;
     const int N = e.n;
@@ -689,13 +691,20 @@ static int rollout_impl(void* handle, const float* params, int T, float* obs_cur
                         int64_t* actions, float* log_probs, float* rewards, float* dones, const int64_t* forced_actions,
                         const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
                         int32_t* episode_stats, int max_ep, float* advantages, float* returns, float gamma, float lam, double* zero_f64, int zero_n,
-                        void* stream) {
+                        int32_t* stats_next, void* stream) {
     MI_CHECK_ARG(handle && params && obs_cur && observations && values && actions && log_probs && rewards && dones, "NULL pointer");
+    MI_CHECK_ARG(!stats_next || (episode_stats && stats_next != episode_stats), "episode_stats_next must be a second statistics buffer");
     MI_CHECK_ARG(T > 0, "T must be positive");
     MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
     mi_env* e = (mi_env*)handle;
     hipStream_t s = (hipStream_t)stream;
+    // statistics double-buffered by the caller (stats_next): episode_stats is zero on entry and this launch zeroes the other buffer — no reset launch
+#if !defined(ROLLOUT_VALU) && !defined(ROLLOUT_MFMA16)
+    if (episode_stats && !stats_next) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+#else
     if (episode_stats) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    if (stats_next) { zero_i32x4_kernel<<<1, 64, 0, s>>>(stats_next); MI_LAUNCH_CHECK(); }
+#endif
     mi_prof_scope prof(MI_PROF_ROLLOUT, s);
 #if !defined(ROLLOUT_VALU) && !defined(ROLLOUT_MFMA16)
     {
@@ -704,7 +713,7 @@ static int rollout_impl(void* handle, const float* params, int T, float* obs_cur
         const dim3 block(128);
 #define RQ_LAUNCH(F, L) rollout_q4_kernel<F, L><<<grid, block, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, \
                                                                      forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep, \
-                                                                     advantages, returns, gamma, lam, zero_f64, zero_n)
+                                                                     advantages, returns, gamma, lam, zero_f64, zero_n, stats_next)
         if (forced) { if (eplog) RQ_LAUNCH(true, true); else RQ_LAUNCH(true, false); }
         else { if (eplog) RQ_LAUNCH(false, true); else RQ_LAUNCH(false, false); }
 #undef RQ_LAUNCH
@@ -740,7 +749,7 @@ extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* o
                               const float* forced_uniforms, const double* forced_resets, mi_episode_t* episodes,
                               int32_t* episode_stats, int max_ep, void* stream) {
     return rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, forced_actions, forced_uniforms, forced_resets,
-                        episodes, episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, stream);
+                        episodes, episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, nullptr, stream);
 }
 
 // rollout + GAE (ppo.py:110-151): the rollout workgroups scan their own envs at the end of the launch (T <= 128; otherwise, and in the
@@ -751,15 +760,15 @@ extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* o
 int mi_rollout_gae_internal(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
                             int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
                             int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, double* zero_f64, int zero_n,
-                            void* stream) {
+                            int32_t* stats_next, void* stream) {
     MI_CHECK_ARG(advantages && returns, "NULL advantages / returns");
 #ifndef ROLLOUT_VALU
     if (T <= RM_GAE_T)
         return rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
-                            episode_stats, max_ep, advantages, returns, gamma, gae_lambda, zero_f64, zero_n, stream);
+                            episode_stats, max_ep, advantages, returns, gamma, gae_lambda, zero_f64, zero_n, stats_next, stream);
 #endif
     const int rc = rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
-                                episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, zero_f64, zero_n, stream);
+                                episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, zero_f64, zero_n, stats_next, stream);
     if (rc) return rc;
     return mi_gae(rewards, dones, values, T, ((mi_env*)handle)->n, gamma, gae_lambda, advantages, returns, stream);
 }
@@ -768,7 +777,7 @@ extern "C" int mi_ppo_rollout_gae(void* handle, const float* params, int T, floa
                                   int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
                                   int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
     return mi_rollout_gae_internal(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, episodes, episode_stats, max_ep, gamma,
-                                   gae_lambda, advantages, returns, nullptr, 0, stream);
+                                   gae_lambda, advantages, returns, nullptr, 0, nullptr, stream);
 }
 
 // ---- ActorCritic forward on an arbitrary batch (agent.get_value / get_action_distribution, ppo.py:49-54) ------

@@ -708,7 +708,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
     const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass; their fp64 accumulators are zeroed by the rollout launch
     int rc = mi_rollout_gae_internal(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
                                      b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns,
-                                     fused ? b->adv_sums : nullptr, 3 * hp->n_minibatch * hp->update_epochs, stream);
+                                     fused ? b->adv_sums : nullptr, 3 * hp->n_minibatch * hp->update_epochs, b->episode_stats_next, stream);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     // every epoch's permutation + advantage statistics (they depend on the advantages and the keys only): b->perm is [update_epochs, T*N]

@@ -65,11 +65,18 @@ class PPOEngine:
         self.workspace = torch.empty(N.lib().mi_ppo_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (1024 if Nn <= 8 else 0))
         self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)  # mi_episode_t = 4 x 32 bit
-        self.episode_stats = z(4, dt=torch.int32)  # {finished episodes, sum of lengths, longest, -} of the last rollout
+        # {finished episodes, sum of lengths, longest, -} of the last rollout, double-buffered: the fused update's rollout launch zeroes the OTHER buffer for the
+        # next update instead of spending a launch on the reset (`episode_stats` is the buffer of the last rollout)
+        self._stats2 = z(2, 4, dt=torch.int32)
+        self._stats_cur = 0
         self.observation = None  # the carried-over `observation` of the reference loop (ppo.py:101,127-129)
         self.update_index = 0
 
     # ---- pieces of one outer update ----------------------------------------------------------------
+    @property
+    def episode_stats(self):
+        return self._stats2[self._stats_cur]
+
     def _s(self):
         return N.stream_ptr(self.device)
 
@@ -174,10 +181,12 @@ class PPOEngine:
             comm = D.native_comm(self.pg)   # None unless the process group is NCCL (= RCCL)
         if (self.world_size == 1 and not _FORCE_SHARDED_SEQUENCE) or comm is not None:
             o = self.optimizer
+            self._stats_cur ^= 1   # the buffer the previous update's rollout launch zeroed
             buf = N.PPOBuffers(*[N.ptr(t) for t in (
                 self.agent.flat, o.exp_avg, o.exp_avg_sq, self.grads, self.loss_terms, o.grad_norm, self.observation,
                 self.observations, self.values, self.actions, self.log_probs, self.rewards, self.dones, self.advantages,
-                self.returns, self._perm_all, self._adv_sums_all, self.workspace, self.episodes, self.episode_stats)], self.max_ep)
+                self.returns, self._perm_all, self._adv_sums_all, self.workspace, self.episodes, self.episode_stats)], self.max_ep,
+                N.ptr(self._stats2[self._stats_cur ^ 1]))
             hp = N.PPOHparams(self.T, self.n_minibatch, self.update_epochs, self.update_index, o.step_count, self.gamma,
                               self.gae_lambda, self.clip_coef, self.ent_coef, self.vf_coef, float(g["max_grad_norm"]),
                               float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"])

@@ -172,6 +172,8 @@ typedef struct {
     float* obs_cur; float* observations; float* values; int64_t* actions; float* log_probs; float* rewards;
     float* dones; float* advantages; float* returns; int32_t* perm; double* adv_sums; void* workspace;
     mi_episode_t* episodes; int32_t* episode_stats; int32_t max_ep;
+    int32_t* episode_stats_next;   /* nullable.  Given (a SECOND dev i32 [4]): episode_stats must be ZERO on entry and is not reset by a launch of its own; the
+                                    * rollout launch zeroes episode_stats_next for the next update, which passes the two swapped (saves one launch per update) */
 } mi_ppo_buffers_t;
 typedef struct {
     int32_t T, n_minibatch, update_epochs, update_index; int64_t opt_step; /* optimizer steps done so far */

@@ -150,7 +150,7 @@ def test_bench_contract_line():
     assert "static" in r["traffic_source"]                        # roofline.traffic comes from committed PMC passes, and the line says so
     n1 = d["cpu_baseline_n1"]                                     # the oracle at the reference's own shape (1 env, 1 thread)
     assert n1["cores"] == 1 and n1["value"] > 0 and n1["reference_python_env_steps_per_s"] == 886.0
-    for key, kern in (("config3_dqn", "dqn_act_kernel"), ("config4_sac", "sac_critic_kernel")):   # BASELINE configs[2] / [3] ride on the same line
+    for key, kern in (("config3_dqn", "dqn_act4_kernel"), ("config4_sac", "sac_critic_kernel")):   # BASELINE configs[2] / [3] ride on the same line
         x = d[key]
         assert x["unit"] == "env-steps/s" and x["value"] > 0 and x["ms_per_step"] > 0 and x["dtype"] == "f32"
         assert x["roofline"]["kernel"] == kern and 0 < x["roofline"]["frac"] < 1 and x["roofline"]["avg_launch_us"] > 0
