@@ -450,11 +450,11 @@ __device__ __forceinline__ rq_f32x4 rq_hidden(const float4& ob, const float (&w1
 }
 
 #ifdef RQ_STAMPS   // diagnostic build: where the actor wave's cycles go (s_memtime), read back by mi_debug_rollout_stamps
-__device__ unsigned long long rq_stamp_dbg[1024 * 8];
+__device__ unsigned long long rq_stamp_dbg[1024 * 8 + 1024];   // [8192 ..): per-step wall-clock marks of workgroup 517 (tools/rollout_timeline.py)
 #define RQ_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
                          rq_acc[k] += t_ - rq_last; rq_last = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
 extern "C" int mi_debug_rollout_stamps(unsigned long long* out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rq_stamp_dbg), sizeof(unsigned long long) * (size_t)(n < 8192 ? n : 8192)) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rq_stamp_dbg), sizeof(unsigned long long) * (size_t)(n < 9216 ? n : 9216)) == hipSuccess ? 0 : -2;
 }
 #else
 #define RQ_STAMP(k) do {} while (0)
@@ -501,8 +501,13 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                   float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n,
                   int32_t* __restrict__ zero_i32) {
     __shared__ rq_smem sm;
+#ifdef RQ_STAMPS
+    if (blockIdx.x == 517 && threadIdx.x == 0) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + 600] = rt_; }
+#endif
     if (zero_f64 && blockIdx.x == 0) for (int k = threadIdx.x; k < zero_n; k += 128) zero_f64[k] = 0.0;   // scratch the next launches accumulate into
     if (zero_i32 && blockIdx.x == 0 && threadIdx.x < 4) zero_i32[threadIdx.x] = 0;                        // the NEXT rollout's episode statistics (double-buffered by the caller)
+    // (wave 0 = actor, wave 1 = critic in EVERY workgroup: the dispatcher already places the 2,048 waves of the headline launch so that each SIMD hosts exactly one
+    //  actor and one critic — tools/rollout_placement.py; swapping the roles by a block-index bit breaks that: 226 - 256 us against 230)
     const int lane = threadIdx.x & 63, net = threadIdx.x >> 6, en = lane & 3;
     const bool q0 = lane & 1, q1 = lane & 2;
     const int N = e.n;
@@ -510,6 +515,9 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
     const bool mine = i < N, writer = mine && lane < RQ_ENVS;
     const int g = mine ? i : N - 1;   // lanes past the end shadow the last env and never write
     if (threadIdx.x == 0) { sm.produced = 0; sm.consumed = 0; }
+#ifdef RQ_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) rq_stamp_dbg[blockIdx.x * 8 + 4 + (threadIdx.x >> 6)] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     // ---- this wave's net: lane = hidden unit; its rows of W1 / W2, its column of W3 ----
     const float* p = params + (net ? C_BASE : 0);
     float w1[OBS], w2[HID];
@@ -618,6 +626,9 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
             RQ_STAMP(2);   // hidden layers
             my_d = quad_env_reduce(h2 * w3d, q0, q1) + b3d;
             RQ_STAMP(3);   // head
+#ifdef RQ_STAMPS
+            if (blockIdx.x == 517 && lane == 0 && t + 1 < 200) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + t + 1] = rt_; }
+#endif
         }
 #ifdef RQ_STAMPS
         if (lane == 0 && blockIdx.x < 1024) { for (int k = 0; k < 4; ++k) rq_stamp_dbg[blockIdx.x * 8 + k] = rq_acc[k]; }
@@ -655,6 +666,9 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
             }
             if (adv && lane < RQ_ENVS) sm.gv[t + 1][lane] = val;
             if (ringed && lane == 0) lds_publish(&sm.consumed, t + 2);
+#ifdef RQ_STAMPS
+            if (blockIdx.x == 517 && lane == 0 && t + 1 < 200) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + 256 + t + 1] = rt_; }
+#endif
         }
         if (adv && writer) {       // GAE over this lane's env (ppo.py:144-151; expression order of gae_kernel): every reward / done is published
             float last = 0.0f;
