@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcpu_ref.so")
+_SO = os.environ.get("MIRL_ORACLE_SO", os.path.join(_HERE, "libcpu_ref.so"))   # MIRL_ORACLE_SO: the sanitizer build (tests/test_oracle_sanitized.py)
 NPARAMS = 9155
 T_DEFAULT = 128
 
@@ -18,7 +18,7 @@ T_DEFAULT = 128
 def build(force=False):
     src = os.path.join(_HERE, "cpu_ref.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libcpu_ref.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_SO)], stdout=subprocess.DEVNULL)
     return _SO
 
 
