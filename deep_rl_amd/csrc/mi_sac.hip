@@ -497,7 +497,8 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 }
 
 // ================================================ workspace layout ==============================================================
-// Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536][ticket]
+// Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536][ticket 4]
+// [hand-off of the split actor update: Kp x 2 floats (q2, d q2 / d action per row) + one flag per row group]
 // The caller zero-fills the workspace once (the ticket word resets itself after every use).
 // (mats 0,1: critics; 2: actor)
 #define SLAB 3600
@@ -506,9 +507,10 @@ __host__ __device__ inline int ws_kp(int batch) { return (batch + SR - 1) / SR *
 __host__ __device__ inline size_t ws_mat_floats(int batch) { return (size_t)ws_kp(batch) * SA_H; }
 __host__ __device__ inline size_t ws_slab_off(int batch) { return 6 * ws_mat_floats(batch); }
 __host__ __device__ inline size_t ws_part_off(int batch) { return ws_slab_off(batch) + (size_t)(ws_kp(batch) / SR) * SLAB; }
+__host__ __device__ inline size_t ws_xch_off(int batch) { return ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4; }
 extern "C" size_t mi_sac_workspace_bytes(int batch) {
     if (batch <= 0) return 0;
-    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */) * sizeof(float);
+    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 2 * (size_t)ws_kp(batch) + (size_t)(ws_kp(batch) / SR)) * sizeof(float);
 }
 static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >= 32 batch rows, the grid covers the rest
     int s = ws_kp(batch) / 128;
@@ -721,13 +723,70 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         if (t == 0) { sac_alpha_apply(al, mean_lp); *al.ticket = 0u; }
         return;
     }
-    issue_thin_q(q, th);
+    // gridDim.y == 2 (while the row groups do not fill the chip): critic 1's forward + backward run in this row group's workgroup y = 0, critic 2's in its sibling
+    // y = 1 (which repeats the actor forward: same bits); the sibling hands (q2, d q2 / d action) per row over through the workspace and exits, workgroup 0 goes
+    // on with the actor's backward: 4 matrix passes + one hand-off on the critical path instead of 6.  The backward runs with unit weight per row; torch.min's
+    // routing (1 / 0 / one half on ties) scales the result afterwards — exact, so both forms give the same bits.
+    const bool split = gridDim.y == 2, second = split && blockIdx.y == 1;
+    const float* qn = q + (second ? SQ_NP : 0);
+    issue_thin_q(qn, th);
     __syncthreads();
-    actor_forward2<false>(sm, actor, q + SQ_W2, sm.b0, ws, acc, e_row);
+    actor_forward2<false>(sm, actor, qn + SQ_W2, sm.b0, ws, acc, e_row);
     store_acc(acc, sm.b1);                                       // actor h2 image, kept until the actor's backward
     const float alpha = alpha_p[0];
     if (t < SR) sm.x[t][3] = sm.rv[t][6];   // the action enters the critics
     __syncthreads();
+    if (split) {
+        const int net = second ? 1 : 0;
+        float* xch = ws_ + ws_xch_off(batch);
+        int* flag = reinterpret_cast<int*>(xch + 2 * (size_t)ws_kp(batch)) + blockIdx.x;
+        const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
+        sm.qmask[net][t] = mk; sm.qw13[net][t] = th.w1[3]; sm.qw3[net][t] = th.h0;
+        __syncthreads();
+        q_forward2<true>(sm, qn, qn + SQ_W2, sm.b2, ws, acc, 8);                // q_net(obs, pi(obs)) -> rv[8]; next pass: the same matrix, column-wise
+        uint32_t hm = 0;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hm |= (acc[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
+        if (t < SR) sm.rv[t][10] = sm.rv[t][8];                                  // this critic's q
+        const float dq = row0 + li < batch ? -invn : 0.0f;                       // unit routing weight
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.qw3[net][64 * wv + 16 * tt + 4 * lg]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tt][r] = (hm >> (4 * tt + r)) & 1u ? w3[r] * dq : 0.0f;
+        }
+        __syncthreads();                                                         // the forward pass is done reading b2
+        store_acc(acc, sm.b2);
+        __syncthreads();
+        if (second) mfma_pass<true, false>(qn + SQ_W2, nullptr, sm.b2, ws, acc);
+        else mfma_pass<true, true>(qn + SQ_W2, actor + AC_W2, sm.b2, ws, acc);
+        rows_combine2(sm, q_daction_partial(sm, net, acc), 0.0f, 11, 15);        // d q_net / d action (unit weight) -> rv[11]
+        if (second) {
+            if (t < SR) { xch[2 * (row0 + t)] = sm.rv[t][10]; xch[2 * (row0 + t) + 1] = sm.rv[t][11]; }
+            __threadfence();
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (t == 0) {
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // self-resetting: the next launch finds 0
+        }
+        __syncthreads();
+        if (t < SR) {
+            const float q1 = sm.rv[t][10], da1 = sm.rv[t][11];
+            const float q2 = __hip_atomic_load(xch + 2 * (row0 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float da2 = __hip_atomic_load(xch + 2 * (row0 + t) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool valid = row0 + t < batch;
+            sm.rv[t][9] = valid ? alpha * sm.rv[t][5] - fminf(q1, q2) : 0.0f;                    // loss term (:197)
+            const float w1 = !valid ? 0.0f : q1 < q2 ? 1.0f : (q2 < q1 ? 0.0f : 0.5f);             // torch.min routes the gradient to the smaller input, half / half on ties
+            const float w2 = !valid ? 0.0f : q2 < q1 ? 1.0f : (q1 < q2 ? 0.0f : 0.5f);
+            sm.rv[t][8] = w1 * da1; sm.rv[t][11] = w2 * da2;
+        }
+        __syncthreads();
+    } else {
     // ---- min(Q1, Q2)(obs, pi(obs)) (:194-196) ----
     {
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
@@ -782,6 +841,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         da_part[net] = q_daction_partial(sm, net, acc);
     }
     rows_combine2(sm, da_part[0], da_part[1], 8, 11);
+    }
     // ---- d loss / d mean, d loss / d sraw per row ----
     if (t < SR) {
         const float u = sm.rv[t][4], sd = sm.rv[t][3], ls = sm.rv[t][2];
@@ -1058,8 +1118,9 @@ static int sac_actor_impl(float* actor, const float* q, const float* observation
                           uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out, const sac_opt_t& opt, hipStream_t s) {
     {
         mi_prof_scope prof(MI_PROF_SAC_ACTOR, s);
-        sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0,
-                                                          sac_alpha_t{});
+        const int nrg = ws_kp(batch) / SR;
+        sac_actor_kernel<<<dim3(nrg, nrg <= 128 ? 2 : 1), 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0,
+                                                                       sac_alpha_t{});
     }
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 1, inv_count, grads, out, opt, s);
