@@ -498,7 +498,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 
 // ================================================ workspace layout ==============================================================
 // Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536][ticket 4]
-// [hand-off of the split actor update: Kp x 2 floats (q2, d q2 / d action per row) + one flag per row group]
+// [hand-off between the two workgroups of a split row group: Kp x 2 floats + two flags per row group (self-resetting; both kernels use the same words)]
 // The caller zero-fills the workspace once (the ticket word resets itself after every use).
 // (mats 0,1: critics; 2: actor)
 #define SLAB 3600
@@ -510,7 +510,7 @@ __host__ __device__ inline size_t ws_part_off(int batch) { return ws_slab_off(ba
 __host__ __device__ inline size_t ws_xch_off(int batch) { return ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4; }
 extern "C" size_t mi_sac_workspace_bytes(int batch) {
     if (batch <= 0) return 0;
-    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 2 * (size_t)ws_kp(batch) + (size_t)(ws_kp(batch) / SR)) * sizeof(float);
+    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 2 * (size_t)ws_kp(batch) + 2 * (size_t)(ws_kp(batch) / SR)) * sizeof(float);
 }
 static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >= 32 batch rows, the grid covers the rest
     int s = ws_kp(batch) / 128;
@@ -624,13 +624,39 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     }
     __syncthreads();
     // ---- next action + log-prob under the current actor (no grad; sac.py:172) ----
+    // split row groups: workgroup y evaluates target critic y only and the two exchange their values through the workspace (one hand-off instead of a pass)
+    const float* qt_mine = qt + (second ? SQ_NP : 0);
     layer1<3>(sm, th, sm.xn, sm.b0);
-    issue_thin_q(qt, th);
+    issue_thin_q(split ? qt_mine : qt, th);
     __syncthreads();
-    actor_forward2<false>(sm, actor, qt + SQ_W2, sm.b0, ws, acc, e_row);
+    actor_forward2<false>(sm, actor, (split ? qt_mine : qt) + SQ_W2, sm.b0, ws, acc, e_row);
     if (t < SR) { sm.xn[t][3] = sm.rv[t][6]; sm.rv[t][9] = sm.rv[t][5]; }   // a', log pi(a'|s')
     __syncthreads();
     // ---- target critics (:173-174) ----
+    if (split) {
+        layer1<4>(sm, th, sm.xn, sm.b0);
+        issue_thin_q(q, th);
+        issue_thin_q(q + SQ_NP, th2);
+        __syncthreads();
+        q_forward2<false>(sm, qt_mine, q + (second ? SQ_NP : 0) + SQ_W2, sm.b0, ws, acc, 8);
+        float* xch = ws_ + ws_xch_off(batch);
+        int* flags = reinterpret_cast<int*>(xch + 2 * (size_t)ws_kp(batch)) + 2 * blockIdx.x;
+        const int me = second ? 1 : 0;
+        if (t < SR) xch[2 * (row0 + t) + me] = sm.rv[t][8];
+        __threadfence();
+        __syncthreads();
+        if (t == 0) {
+            __hip_atomic_store(flags + me, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(flags + (me ^ 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(flags + (me ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the reader resets the word it waited on: the next launch finds 0
+        }
+        __syncthreads();
+        if (t < SR) {
+            const float other = __hip_atomic_load(xch + 2 * (row0 + t) + (me ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm.rv[t][10] = second ? other : sm.rv[t][8];     // target 1
+            sm.rv[t][8] = second ? sm.rv[t][8] : other;      // target 2
+        }
+    } else {
     layer1<4>(sm, th, sm.xn, sm.b0);
     issue_thin_q(qt + SQ_NP, th);
     __syncthreads();
@@ -642,6 +668,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     issue_thin_q(q + SQ_NP, th2);
     __syncthreads();
     q_forward2<false>(sm, qt + SQ_NP, q + (second ? SQ_NP : 0) + SQ_W2, sm.b0, ws, acc, 8);
+    }
     if (t < SR) {
         const float alpha = alpha_p[0];
         const float mq = fminf(sm.rv[t][10], sm.rv[t][8]) - alpha * sm.rv[t][9];                                   // :176
@@ -739,7 +766,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     if (split) {
         const int net = second ? 1 : 0;
         float* xch = ws_ + ws_xch_off(batch);
-        int* flag = reinterpret_cast<int*>(xch + 2 * (size_t)ws_kp(batch)) + blockIdx.x;
+        int* flag = reinterpret_cast<int*>(xch + 2 * (size_t)ws_kp(batch)) + 2 * blockIdx.x;
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
         sm.qmask[net][t] = mk; sm.qw13[net][t] = th.w1[3]; sm.qw3[net][t] = th.h0;
         __syncthreads();
