@@ -34,6 +34,11 @@ class PPOBuffers(C.Structure):
         "episodes", "episode_stats")] + [("max_ep", C.c_int32), ("episode_stats_next", C.c_void_p)]
 
 
+class SacOwedAlpha(C.Structure):   # mi_sac_owed_alpha_t
+    _fields_ = [("log_alpha", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("alpha", C.c_void_p), ("out", C.c_void_p),
+                ("target_entropy", C.c_float), ("step", C.c_int64), ("lr", C.c_double), ("update_index", C.c_uint64)]
+
+
 class PPOHparams(C.Structure):
     _fields_ = [("T", C.c_int32), ("n_minibatch", C.c_int32), ("update_epochs", C.c_int32), ("update_index", C.c_int32),
                 ("opt_step", C.c_int64),
@@ -103,6 +108,9 @@ SIGNATURES = {
     "mi_sac_actor_grad": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _D, _VP, _VP, _VP, _VP]),
     "mi_sac_critic_update": (_I, [_VP] * 8 + [_I, _I, _I64, _VP, _U64, _U64, _VP, _F, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _F, _U64, _I64, _VP]),
     "mi_sac_actor_update": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _VP]),
+    "mi_sac_critic_update_owed": (_I, [_VP] * 8 + [_I, _I, _I64, _VP, _U64, _U64, _VP, _F, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _F, _U64, _I64, _VP, _VP]),
+    "mi_sac_actor_update_owed": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _VP, _VP]),
+    "mi_sac_alpha_step_owed": (_I, [_VP, _I, _U64, _VP, _VP, _VP]),
     "mi_sac_alpha_step": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP, _VP]),
     "mi_sac_mean_logp": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _D, _VP, _VP, _VP]),
     "mi_sac_alpha_adam": (_I, [_VP, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),

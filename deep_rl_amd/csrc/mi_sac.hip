@@ -508,13 +508,74 @@ __host__ __device__ inline size_t ws_mat_floats(int batch) { return (size_t)ws_k
 __host__ __device__ inline size_t ws_slab_off(int batch) { return 6 * ws_mat_floats(batch); }
 __host__ __device__ inline size_t ws_part_off(int batch) { return ws_slab_off(batch) + (size_t)(ws_kp(batch) / SR) * SLAB; }
 __host__ __device__ inline size_t ws_xch_off(int batch) { return ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4; }
+__host__ __device__ inline size_t ws_stash_off(int batch) { return ws_xch_off(batch) + 2 * (size_t)ws_kp(batch) + 2 * (size_t)(ws_kp(batch) / SR); }   // [Kp x 3 obs][Kp / SR partials][epoch]
 extern "C" size_t mi_sac_workspace_bytes(int batch) {
     if (batch <= 0) return 0;
-    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 2 * (size_t)ws_kp(batch) + 2 * (size_t)(ws_kp(batch) / SR)) * sizeof(float);
+    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 2 * (size_t)ws_kp(batch) + 2 * (size_t)(ws_kp(batch) / SR)
+            + 3 * (size_t)ws_kp(batch) + (size_t)(ws_kp(batch) / SR) + 4 /* owed alpha step: observation stash, log-prob partials, epoch word */) * sizeof(float);
 }
 static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >= 32 batch rows, the grid covers the rest
     int s = ws_kp(batch) / 128;
     return s < 1 ? 1 : (s > GEMM_MAX_SPLIT ? GEMM_MAX_SPLIT : s);
+}
+
+// alpha step riding on the log-prob launch: the LAST workgroup to finish (ticket in the workspace) sums the slabs in fixed order and does the Adam step
+struct sac_alpha_t { float* log_alpha; float* m; float* v; float* alpha; float* out; unsigned int* ticket; float target_entropy, inv_count, w1, b2, w2, step_size, rbc2, eps; };
+__device__ __forceinline__ void sac_alpha_apply(const sac_alpha_t& a, float mean_lp) {
+    const float la = a.log_alpha[0];
+    const float g = -(mean_lp + a.target_entropy);            // d/d log_alpha of mean(-log_alpha * (logp + target_entropy)), sac.py:205
+    if (a.out) { a.out[0] = -la * (mean_lp + a.target_entropy); a.out[1] = g; }
+    float mi = a.m[0], vi = a.v[0];
+    const float nla = mi_adam_elem(la, g, mi, vi, a.w1, a.b2, a.w2, a.step_size, a.rbc2, a.eps);
+    a.m[0] = mi; a.v[0] = vi;
+    a.log_alpha[0] = nla;
+    a.alpha[0] = expf(nla);                                    // :210
+}
+
+// ---- the owed alpha step (sac.py:199-210).  Its log-prob pass depends only on the actor (after the last actor update) and on that update's batch observations;
+// as a launch of its own it costs 12.6 us for 16 workgroups' worth of one matrix pass.  Instead the NEXT row-group launch of the stream (the following actor update,
+// or the next iteration's critic update) carries n_lp extra workgroups that evaluate it from the observations the actor update stashed in the workspace; the last
+// of them to finish does the Adam step on log_alpha and publishes the step number in the epoch word; the host launch's own workgroups read alpha only after the
+// epoch word has reached that step (they need it late: after their forward passes).  step numbers only grow, so the word never needs a reset.
+struct sac_owed_t { int n_lp, step; uint64_t seed, update; sac_alpha_t al; };
+__device__ __forceinline__ int* ws_epoch(float* ws_, int batch) { return reinterpret_cast<int*>(ws_ + ws_stash_off(batch) + 3 * (size_t)ws_kp(batch) + (size_t)(ws_kp(batch) / SR)); }
+__device__ __forceinline__ float wait_owed_alpha(const sac_owed_t& ow, float* ws_, int batch, const float* alpha_p, sac_smem& sm) {
+    if (ow.n_lp) {   // block-uniform
+        if (threadIdx.x == 0) { int* ep = ws_epoch(ws_, batch); while (__hip_atomic_load(ep, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < ow.step) __builtin_amdgcn_s_sleep(8); }
+        __syncthreads();
+        return __hip_atomic_load(alpha_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return alpha_p[0];
+}
+__device__ void sac_owed_alpha_role(sac_smem& sm, const float* __restrict__ actor, int batch, float* __restrict__ ws_, const sac_owed_t& ow, int rg) {
+    const int t = threadIdx.x, row0 = rg * SR;
+    const float* stash = ws_ + ws_stash_off(batch);
+    float* part = ws_ + ws_stash_off(batch) + 3 * (size_t)ws_kp(batch);
+    wstream ws; thin_t th; f32x4 acc[4];
+    issue_thin_actor(actor, th);
+    stream_prime<false>(actor + AC_W2, ws);
+    if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; sm.x[r][k] = stash[3 * (size_t)b + k]; }
+    float e_row = 0.0f;
+    if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = keyed_normal(ow.seed, (4ull << 40) + ow.update, (uint64_t)b); }
+    __syncthreads();
+    layer1<3>(sm, th, sm.x, sm.b0);
+    __syncthreads();
+    actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e_row);
+    if (t == 0) { float s = 0.0f; for (int r = 0; r < SR; ++r) s += row0 + r < batch ? sm.rv[r][5] : 0.0f; part[rg] = s; }
+    if (t == 0) { __threadfence(); sm.cur[0] = atomicAdd(ow.al.ticket, 1u) == (unsigned)ow.n_lp - 1 ? 1 : 0; }
+    __syncthreads();
+    if (!sm.cur[0] || t >= 64) return;
+    __threadfence();
+    const volatile float* vp = part;
+    float s = 0.0f;
+    for (int b = t; b < ow.n_lp; b += 64) s += vp[b];
+    const float mean_lp = wave_sum(s) * ow.al.inv_count;
+    if (t == 0) {
+        sac_alpha_apply(ow.al, mean_lp);
+        *ow.al.ticket = 0u;
+        __threadfence();
+        __hip_atomic_store(ws_epoch(ws_, batch), ow.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ================================================ critic update =================================================================
@@ -591,8 +652,12 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
                   const float* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
                   const int64_t* idx /* may alias idx_out: no __restrict__ */, int batch, int n_envs, long long slots, const float* __restrict__ eps, uint64_t seed,
                   uint64_t update, const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_, uint64_t sample_update, uint64_t sample_upper,
-                  int64_t* idx_out) {
+                  int64_t* idx_out, sac_owed_t ow) {
     __shared__ sac_smem sm;
+    if ((int)blockIdx.x >= (int)gridDim.x - ow.n_lp) {   // the owed alpha step's workgroups (y = 0 only)
+        if (blockIdx.y == 0) sac_owed_alpha_role(sm, actor, batch, ws_, ow, (int)blockIdx.x - ((int)gridDim.x - ow.n_lp));
+        return;
+    }
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
     // gridDim.y == 2: the two critics' forward + backward run in two workgroups per row group (each repeats the actor / target forwards):
     // 5 passes on the critical path instead of 7, used while the row groups do not fill the chip anyway
@@ -669,8 +734,9 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     __syncthreads();
     q_forward2<false>(sm, qt + SQ_NP, q + (second ? SQ_NP : 0) + SQ_W2, sm.b0, ws, acc, 8);
     }
+    const float alpha_now = wait_owed_alpha(ow, ws_, batch, alpha_p, sm);
     if (t < SR) {
-        const float alpha = alpha_p[0];
+        const float alpha = alpha_now;
         const float mq = fminf(sm.rv[t][10], sm.rv[t][8]) - alpha * sm.rv[t][9];                                   // :176
         sm.rv[t][10] = rewards[sm.nxt[t]] + (terminated[sm.nxt[t]] ? 0.0f : 1.0f) * gamma * mq;                     // :177  (y)
     }
@@ -701,24 +767,15 @@ __device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, 
     return v;
 }
 
-// alpha step riding on the log-prob launch: the LAST workgroup to finish (ticket in the workspace) sums the slabs in fixed order and does the Adam step
-struct sac_alpha_t { float* log_alpha; float* m; float* v; float* alpha; float* out; unsigned int* ticket; float target_entropy, inv_count, w1, b2, w2, step_size, rbc2, eps; };
-__device__ __forceinline__ void sac_alpha_apply(const sac_alpha_t& a, float mean_lp) {
-    const float la = a.log_alpha[0];
-    const float g = -(mean_lp + a.target_entropy);            // d/d log_alpha of mean(-log_alpha * (logp + target_entropy)), sac.py:205
-    if (a.out) { a.out[0] = -la * (mean_lp + a.target_entropy); a.out[1] = g; }
-    float mi = a.m[0], vi = a.v[0];
-    const float nla = mi_adam_elem(la, g, mi, vi, a.w1, a.b2, a.w2, a.step_size, a.rbc2, a.eps);
-    a.m[0] = mi; a.v[0] = vi;
-    a.log_alpha[0] = nla;
-    a.alpha[0] = expf(nla);                                    // :210
-}
-
 __global__ void __launch_bounds__(256)
 sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, const float* __restrict__ observations, const int64_t* __restrict__ idx,
                  int batch, const float* __restrict__ eps, uint64_t seed, uint64_t update, const float* __restrict__ alpha_p, float invn,
-                 float* __restrict__ ws_, int logp_only, sac_alpha_t al) {
+                 float* __restrict__ ws_, int logp_only, sac_alpha_t al, sac_owed_t ow) {
     __shared__ sac_smem sm;
+    if ((int)blockIdx.x >= (int)gridDim.x - ow.n_lp) {   // the owed alpha step's workgroups (y = 0 only)
+        if (blockIdx.y == 0) sac_owed_alpha_role(sm, actor, batch, ws_, ow, (int)blockIdx.x - ((int)gridDim.x - ow.n_lp));
+        return;
+    }
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
     const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
     const size_t matf = ws_mat_floats(batch);
@@ -728,7 +785,12 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     uint32_t h2mask[2];                                           // the critics' layer-2 ReLU masks in the D layout (bit 4 t + r), kept for the backward
     issue_thin_actor(actor, th);
     stream_prime<false>(actor + AC_W2, ws);
-    if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; sm.x[r][k] = observations[3 * idx[b] + k]; }
+    if (t < SR * 3) {
+        const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1;
+        const float v = observations[3 * idx[b] + k];
+        sm.x[r][k] = v;
+        if (!logp_only && blockIdx.y == 0 && row0 + r < batch) ws_[ws_stash_off(batch) + 3 * (size_t)b + k] = v;   // kept for an alpha step that rides on a later launch
+    }
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, ((logp_only ? 4ull : 3ull) << 40) + update, (uint64_t)b); }
     __syncthreads();
@@ -760,7 +822,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     __syncthreads();
     actor_forward2<false>(sm, actor, qn + SQ_W2, sm.b0, ws, acc, e_row);
     store_acc(acc, sm.b1);                                       // actor h2 image, kept until the actor's backward
-    const float alpha = alpha_p[0];
+    float alpha = 0.0f;                                          // read where it is first needed (an owed alpha step of this launch may still be producing it)
     if (t < SR) sm.x[t][3] = sm.rv[t][6];   // the action enters the critics
     __syncthreads();
     if (split) {
@@ -801,6 +863,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
             while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
             __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // self-resetting: the next launch finds 0
         }
+        alpha = wait_owed_alpha(ow, ws_, batch, alpha_p, sm);   // (contains the barrier when a step is owed)
         __syncthreads();
         if (t < SR) {
             const float q1 = sm.rv[t][10], da1 = sm.rv[t][11];
@@ -840,6 +903,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) h2mask[1] |= (acc[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
     }
+    alpha = wait_owed_alpha(ow, ws_, batch, alpha_p, sm);
     if (t < SR) {
         const float q1 = sm.rv[t][10], q2 = sm.rv[t][8];
         const bool valid = row0 + t < batch;
@@ -1103,16 +1167,33 @@ static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv
     return MI_OK;
 }
 
+static sac_alpha_t sac_make_alpha(float target_entropy, float inv_count, float* log_alpha, float* m, float* v, int64_t step, double lr, float* alpha, float* out,
+                                  unsigned int* ticket);
+static sac_owed_t sac_make_owed(const mi_sac_owed_alpha_t* o, int batch, uint64_t seed, void* workspace) {
+    sac_owed_t w; memset(&w, 0, sizeof(w));
+    if (!o) return w;
+    unsigned int* ticket = (unsigned int*)((float*)workspace + ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H);
+    w.n_lp = ws_kp(batch) / SR; w.step = (int)o->step; w.seed = seed; w.update = o->update_index;
+    w.al = sac_make_alpha(o->target_entropy, 1.0f / (float)batch, o->log_alpha, o->exp_avg, o->exp_avg_sq, o->step, o->lr, o->alpha, o->out, ticket);
+    return w;
+}
+static int sac_check_owed(const mi_sac_owed_alpha_t* o, int batch) {
+    if (!o) return MI_OK;
+    MI_CHECK_ARG(o->log_alpha && o->exp_avg && o->exp_avg_sq && o->alpha && o->step >= 1 && o->step < (1ll << 31), "owed alpha step: NULL state or bad step");
+    MI_CHECK_ARG(ws_kp(batch) / SR <= 128, "an owed alpha step rides only on launches that leave CUs idle (batch <= 2048)");
+    return MI_OK;
+}
+
 static int sac_critic_impl(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
                            const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
                            uint64_t update_index, const float* alpha, float gamma, double inv_count, void* workspace, float* grads, float* losses,
-                           const sac_opt_t& opt, uint64_t sample_update, int64_t sample_upper, hipStream_t s) {
+                           const sac_opt_t& opt, uint64_t sample_update, int64_t sample_upper, const sac_owed_t& ow, hipStream_t s) {
     const int nrg = ws_kp(batch) / SR;
     {
         mi_prof_scope prof(MI_PROF_SAC_CRITIC, s);
-        sac_critic_kernel<<<dim3(nrg, nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+        sac_critic_kernel<<<dim3(nrg + ow.n_lp, nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
                                                            seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
-                                                           (int64_t*)idx);
+                                                           (int64_t*)idx, ow);
     }
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, opt, s);
@@ -1125,29 +1206,39 @@ extern "C" int mi_sac_critic_grad(const float* q, const float* q_target, const f
     MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "bad sizes");
     return sac_critic_impl((float*)q, (float*)q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha,
-                           gamma, inv_count, workspace, grads, losses, sac_no_opt(), 0, 0, (hipStream_t)stream);
+                           gamma, inv_count, workspace, grads, losses, sac_no_opt(), 0, 0, sac_owed_t{}, (hipStream_t)stream);
 }
 
+extern "C" int mi_sac_critic_update_owed(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                                         const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                                         uint64_t update_index, const float* alpha, float gamma, void* workspace, float* grads, float* losses, float* exp_avg,
+                                         float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, uint64_t sample_update,
+                                         int64_t sample_upper, const mi_sac_owed_alpha_t* owed, void* stream) {
+    MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
+    MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads && exp_avg && exp_avg_sq, "NULL pointer");
+    MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2 && step >= 1, "bad sizes");
+    if (const int rc = sac_check_owed(owed, batch)) return rc;
+    return sac_critic_impl(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
+                           1.0 / batch, workspace, grads, losses, sac_make_opt(q, exp_avg, exp_avg_sq, tau >= 0.0f ? q_target : nullptr, step, lr, beta1, beta2, adam_eps, tau),
+                           sample_update, sample_upper, sac_make_owed(owed, batch, seed, workspace), (hipStream_t)stream);
+}
 extern "C" int mi_sac_critic_update(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
                                     const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
                                     uint64_t update_index, const float* alpha, float gamma, void* workspace, float* grads, float* losses, float* exp_avg,
                                     float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, uint64_t sample_update,
                                     int64_t sample_upper, void* stream) {
-    MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
-    MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace && grads && exp_avg && exp_avg_sq, "NULL pointer");
-    MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2 && step >= 1, "bad sizes");
-    return sac_critic_impl(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
-                           1.0 / batch, workspace, grads, losses, sac_make_opt(q, exp_avg, exp_avg_sq, tau >= 0.0f ? q_target : nullptr, step, lr, beta1, beta2, adam_eps, tau),
-                           sample_update, sample_upper, (hipStream_t)stream);
+    return mi_sac_critic_update_owed(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
+                                     workspace, grads, losses, exp_avg, exp_avg_sq, step, lr, beta1, beta2, adam_eps, tau, sample_update, sample_upper, nullptr, stream);
 }
 
 static int sac_actor_impl(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
-                          uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out, const sac_opt_t& opt, hipStream_t s) {
+                          uint64_t update_index, const float* alpha, double inv_count, void* workspace, float* grads, float* out, const sac_opt_t& opt, const sac_owed_t& ow,
+                          hipStream_t s) {
     {
         mi_prof_scope prof(MI_PROF_SAC_ACTOR, s);
         const int nrg = ws_kp(batch) / SR;
-        sac_actor_kernel<<<dim3(nrg, nrg <= 128 ? 2 : 1), 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0,
-                                                                       sac_alpha_t{});
+        sac_actor_kernel<<<dim3(nrg + ow.n_lp, nrg <= 128 ? 2 : 1), 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count,
+                                                                                 (float*)workspace, 0, sac_alpha_t{}, ow);
     }
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 1, inv_count, grads, out, opt, s);
@@ -1158,16 +1249,24 @@ extern "C" int mi_sac_actor_grad(const float* actor, const float* q, const float
                                  void* stream) {
     MI_CHECK_ARG(actor && q && observations && idx && alpha && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(batch > 0, "bad sizes");
-    return sac_actor_impl((float*)actor, q, observations, idx, batch, eps, seed, update_index, alpha, inv_count, workspace, grads, out, sac_no_opt(), (hipStream_t)stream);
+    return sac_actor_impl((float*)actor, q, observations, idx, batch, eps, seed, update_index, alpha, inv_count, workspace, grads, out, sac_no_opt(), sac_owed_t{}, (hipStream_t)stream);
 }
 
+extern "C" int mi_sac_actor_update_owed(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                                        uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
+                                        int64_t step, double lr, double beta1, double beta2, double adam_eps, const mi_sac_owed_alpha_t* owed, void* stream) {
+    MI_CHECK_ARG(actor && q && observations && idx && alpha && workspace && grads && exp_avg && exp_avg_sq, "NULL pointer");
+    MI_CHECK_ARG(batch > 0 && step >= 1, "bad sizes");
+    if (const int rc = sac_check_owed(owed, batch)) return rc;
+    return sac_actor_impl(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / batch, workspace, grads, out,
+                          sac_make_opt(actor, exp_avg, exp_avg_sq, nullptr, step, lr, beta1, beta2, adam_eps, 0.0f), sac_make_owed(owed, batch, seed, workspace),
+                          (hipStream_t)stream);
+}
 extern "C" int mi_sac_actor_update(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                                    uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
                                    int64_t step, double lr, double beta1, double beta2, double adam_eps, void* stream) {
-    MI_CHECK_ARG(actor && q && observations && idx && alpha && workspace && grads && exp_avg && exp_avg_sq, "NULL pointer");
-    MI_CHECK_ARG(batch > 0 && step >= 1, "bad sizes");
-    return sac_actor_impl(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / batch, workspace, grads, out,
-                          sac_make_opt(actor, exp_avg, exp_avg_sq, nullptr, step, lr, beta1, beta2, adam_eps, 0.0f), (hipStream_t)stream);
+    return mi_sac_actor_update_owed(actor, q, observations, idx, batch, eps, seed, update_index, alpha, workspace, grads, out, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
+                                    adam_eps, nullptr, stream);
 }
 
 // ================================================ alpha, Adam, polyak ============================================================
@@ -1200,7 +1299,7 @@ static int sac_launch_logp(const float* actor, const float* observations, const 
                            uint64_t update_index, void* workspace, const sac_alpha_t& al, hipStream_t s) {
     {
         mi_prof_scope prof(MI_PROF_SAC_LOGP, s);
-        sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al);
+        sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al, sac_owed_t{});
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -1215,6 +1314,21 @@ extern "C" int mi_sac_alpha_step(const float* actor, const float* observations, 
     unsigned int* ticket = (unsigned int*)((float*)workspace + ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H);
     return sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace,
                            sac_make_alpha(target_entropy, 1.0f / (float)batch, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, ticket), (hipStream_t)stream);
+}
+
+// an owed alpha step that found no launch to ride on (the state is read, the run ends, ...): its workgroups alone
+__global__ void __launch_bounds__(256) sac_owed_alpha_kernel(const float* __restrict__ actor, int batch, float* __restrict__ ws_, sac_owed_t ow) {
+    __shared__ sac_smem sm;
+    sac_owed_alpha_role(sm, actor, batch, ws_, ow, (int)blockIdx.x);
+}
+extern "C" int mi_sac_alpha_step_owed(const float* actor, int batch, uint64_t seed, const mi_sac_owed_alpha_t* owed, void* workspace, void* stream) {
+    MI_CHECK_ARG(actor && owed && workspace && batch > 0, "NULL pointer");
+    if (const int rc = sac_check_owed(owed, batch)) return rc;
+    const sac_owed_t ow = sac_make_owed(owed, batch, seed, workspace);
+    mi_prof_scope prof(MI_PROF_SAC_LOGP, (hipStream_t)stream);
+    sac_owed_alpha_kernel<<<ow.n_lp, 256, 0, (hipStream_t)stream>>>(actor, batch, (float*)workspace, ow);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
 }
 
 extern "C" int mi_sac_mean_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,

@@ -6,12 +6,17 @@ back in one flat buffer each, and the entropy coefficient as DEVICE scalars (log
 (sac.py:210) is the reference's one host round trip per actor update and it disappears here.  Methods are thin launch
 wrappers over the C ABI (include/mi_rl.h "SAC"); nothing is computed in Python.
 """
+import ctypes as C
+import os
+
 import torch
 
 from . import _native as N
 from . import dist as D
 from .agent import pack
 from .optim import Adam
+
+_OWE_ALPHA = os.environ.get("MIRL_SAC_OWE_ALPHA", "1") != "0"   # 0: every alpha step is a launch of its own (A/B, debugging)
 
 
 class SACEngine:
@@ -32,11 +37,14 @@ class SACEngine:
         self.q_optimizer = Adam(self.q_flat, lr=q_lr)                                          # :117
         self.alpha_lr = float(q_lr if alpha_lr is None else alpha_lr)                          # :92
         self.target_entropy = float(-1.0 if target_entropy is None else target_entropy)        # :119 (-prod(action shape))
-        self.log_alpha = torch.zeros(1, dtype=torch.float32, device=dev)                       # :120
-        self.alpha = torch.ones(1, dtype=torch.float32, device=dev)                            # :121 exp(0)
-        self._alpha_m = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._alpha_v = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.alpha_steps = 0
+        # the entropy coefficient's state; an alpha step may be OWED (see update_alpha): every reader goes through the properties below, which settle it first
+        self._log_alpha = torch.zeros(1, dtype=torch.float32, device=dev)                      # :120
+        self._alpha = torch.ones(1, dtype=torch.float32, device=dev)                           # :121 exp(0)
+        self._alpha_m_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._alpha_v_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._alpha_steps = 0
+        self._owed = None            # (update key of the owed step's log-prob draw)
+        self._stash_fresh = False
         self.observations = torch.zeros((S, Nn, 3), dtype=torch.float32, device=dev)           # :126
         self.actions = torch.zeros((S, Nn), dtype=torch.float32, device=dev)                   # :127 (one action dim)
         self.rewards = torch.zeros((S, Nn), dtype=torch.float32, device=dev)                   # :128
@@ -46,7 +54,7 @@ class SACEngine:
         self.q_grads, self.q_losses = self._qbuf[:2 * N.SAC_Q_NPARAMS], self._qbuf[2 * N.SAC_Q_NPARAMS:]
         self._abuf = torch.zeros(N.SAC_ACTOR_NPARAMS + 2, dtype=torch.float32, device=dev)
         self.actor_grads, self.actor_out = self._abuf[:N.SAC_ACTOR_NPARAMS], self._abuf[N.SAC_ACTOR_NPARAMS:]   # out = {actor_loss, mean logp}
-        self.alpha_out = torch.zeros(2, dtype=torch.float32, device=dev)                       # {alpha_loss, d/d log_alpha}
+        self._alpha_out = torch.zeros(2, dtype=torch.float32, device=dev)                      # {alpha_loss, d/d log_alpha}
         self._mean_logp = torch.zeros(1, dtype=torch.float32, device=dev)
         self.workspace = torch.zeros(N.lib().mi_sac_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)   # zero-filled once (ticket word)
         self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (64 if Nn <= 8 else 0))
@@ -59,6 +67,43 @@ class SACEngine:
 
     def _s(self):
         return N.stream_ptr(self.device)
+
+    # ---- the entropy coefficient's state: reading it settles an owed alpha step first ----
+    def _owed_struct(self):
+        """-> (ctypes struct of the owed alpha step | None); marks it as handed over."""
+        if self._owed is None:
+            return None
+        self._alpha_steps += 1
+        o = N.SacOwedAlpha(N.ptr(self._log_alpha), N.ptr(self._alpha_m_t), N.ptr(self._alpha_v_t), N.ptr(self._alpha), N.ptr(self._alpha_out),
+                           self.target_entropy, self._alpha_steps, self.alpha_lr, self._owed)
+        self._owed = None
+        return o
+
+    def flush_alpha(self):
+        """Run an owed alpha step now (a launch of its own)."""
+        o = self._owed_struct()
+        if o is not None:
+            N.check(N.lib().mi_sac_alpha_step_owed(N.ptr(self.actor.flat), self.batch_size, self.env._seed, C.byref(o), N.ptr(self.workspace), self._s()),
+                    "mi_sac_alpha_step_owed")
+
+    def _settled(self, t):
+        self.flush_alpha()
+        return t
+
+    log_alpha = property(lambda self: self._settled(self._log_alpha))
+    alpha = property(lambda self: self._settled(self._alpha))
+    alpha_out = property(lambda self: self._settled(self._alpha_out))
+    _alpha_m = property(lambda self: self._settled(self._alpha_m_t))
+    _alpha_v = property(lambda self: self._settled(self._alpha_v_t))
+
+    @property
+    def alpha_steps(self):
+        return self._alpha_steps + (1 if self._owed is not None else 0)
+
+    @alpha_steps.setter
+    def alpha_steps(self, v):
+        self.flush_alpha()
+        self._alpha_steps = int(v)
 
     def _key(self, counter):
         """per-call key of the in-kernel normal draws, distinct per rank"""
@@ -123,13 +168,14 @@ class SACEngine:
             if sample_in_launch and min(self.global_step, self.slots) * self.N == 0:   # 0 means "read batch_inds" to the launch
                 raise N.MiError("update_critic: the replay ring is empty (global_step == 0); act() before training")
             o.step_count += 1
-            N.check(N.lib().mi_sac_critic_update(
+            owed = self._owed_struct()       # an alpha step owed from the last actor update rides on this launch
+            N.check(N.lib().mi_sac_critic_update_owed(
                 N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
                 N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
-                self._key(self.update_index), N.ptr(self.alpha), self.gamma, N.ptr(self.workspace), N.ptr(self.q_grads), N.ptr(self.q_losses),
+                self._key(self.update_index), N.ptr(self._alpha), self.gamma, N.ptr(self.workspace), N.ptr(self.q_grads), N.ptr(self.q_losses),
                 N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
-                self.tau if polyak else -1.0, self._key(self.update_index), min(self.global_step, self.slots) * self.N if sample_in_launch else 0, self._s()),
-                "mi_sac_critic_update")
+                self.tau if polyak else -1.0, self._key(self.update_index), min(self.global_step, self.slots) * self.N if sample_in_launch else 0,
+                C.byref(owed) if owed is not None else None, self._s()), "mi_sac_critic_update_owed")
         else:
             self.critic_grad(eps)
             self.q_optimizer.step(self.q_grads)
@@ -153,19 +199,31 @@ class SACEngine:
             o = self.actor_optimizer
             g = o.param_groups[0]
             o.step_count += 1
-            N.check(N.lib().mi_sac_actor_update(
+            owed = self._owed_struct()
+            N.check(N.lib().mi_sac_actor_update_owed(
                 N.ptr(self.actor.flat), N.ptr(self.q_flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e),
-                self.env._seed, self._key(self.actor_updates), N.ptr(self.alpha), N.ptr(self.workspace), N.ptr(self.actor_grads),
+                self.env._seed, self._key(self.actor_updates), N.ptr(self._alpha), N.ptr(self.workspace), N.ptr(self.actor_grads),
                 N.ptr(self.actor_out), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
-                self._s()), "mi_sac_actor_update")
+                C.byref(owed) if owed is not None else None, self._s()), "mi_sac_actor_update_owed")
+            self._stash_fresh = True     # this launch stashed its batch observations: an alpha step may be owed on them
         else:
             self.actor_grad(eps)
             self.actor_optimizer.step(self.actor_grads)
 
     def update_alpha(self, eps=None):
         """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
+        if eps is None and self.world_size == 1 and self._stash_fresh and self.batch_size <= 2048 and _OWE_ALPHA:
+            # keyed draws, single process, right after a fused actor update: the step is OWED — the next row-group launch (actor or critic update) carries its
+            # log-prob pass on workgroups of its own and hands alpha to its consumers in the launch; reading the state (or flush_alpha()) settles it alone
+            self.flush_alpha()
+            self._owed = self._key(self.actor_updates)
+            self._stash_fresh = False
+            self.actor_updates += 1
+            return
+        self.flush_alpha()
+        self._stash_fresh = False
         e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
-        self.alpha_steps += 1
+        self._alpha_steps += 1
         L = N.lib()
         if self.world_size == 1:
             N.check(L.mi_sac_alpha_step(

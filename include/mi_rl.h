@@ -352,6 +352,25 @@ int mi_sac_actor_update(float* actor, const float* q, const float* observations,
 int mi_sac_alpha_step(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                       uint64_t update_index, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, float* alpha, float* out, void* workspace, void* stream);
+
+/* ---- the alpha step OWED from the last actor update, carried by the next launch instead of a launch of its own.  Its log-prob pass (sac.py:203-204) depends only
+ * on the actor and on the batch observations of that actor update (mi_sac_actor_update* stashes them in the workspace).  mi_sac_actor_update_owed /
+ * mi_sac_critic_update_owed run it on workgroups of their own launch (idle CUs at batch <= 2048), apply Adam to log_alpha (:205-210) and hand alpha to the
+ * launch's own workgroups, which read it only where the reference does (after their forward passes); mi_sac_alpha_step_owed runs it alone (flush).  Identical
+ * results to mi_sac_alpha_step called right after the actor update, with eps == NULL (keyed draws).  step: 1-based Adam step of log_alpha, strictly increasing. */
+typedef struct {
+    float* log_alpha; float* exp_avg; float* exp_avg_sq; float* alpha; float* out /* nullable, [2] = {alpha_loss, d / d log_alpha} */;
+    float target_entropy; int64_t step; double lr; uint64_t update_index /* key of the log-prob draw: the actor update's update_index */;
+} mi_sac_owed_alpha_t;
+int mi_sac_critic_update_owed(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                              const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                              uint64_t update_index, const float* alpha, float gamma, void* workspace, float* grads, float* losses, float* exp_avg,
+                              float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau, uint64_t sample_update,
+                              int64_t sample_upper, const mi_sac_owed_alpha_t* owed, void* stream);
+int mi_sac_actor_update_owed(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                             uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
+                             int64_t step, double lr, double beta1, double beta2, double adam_eps, const mi_sac_owed_alpha_t* owed, void* stream);
+int mi_sac_alpha_step_owed(const float* actor, int batch, uint64_t seed, const mi_sac_owed_alpha_t* owed, void* workspace, void* stream);
 /* the same in two halves for sharded runs (all-reduce *mean_logp between them): mean_logp dev f32 [1] = inv_count * sum of this rank's
  * fresh log-probs; then the Adam step on log_alpha from the global mean. */
 int mi_sac_mean_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
