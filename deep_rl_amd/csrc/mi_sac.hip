@@ -498,7 +498,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 
 // ================================================ workspace layout ==============================================================
 // Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536][ticket 4]
-// [hand-off between the two workgroups of a split row group: Kp x 2 floats + two flags per row group (self-resetting; both kernels use the same words)]
+// [hand-off between the two workgroups of a split row group: Kp x 2 tagged 64-bit words (xw_put / xw_take; self-resetting; both kernels use the same words)]
 // The caller zero-fills the workspace once (the ticket word resets itself after every use).
 // (mats 0,1: critics; 2: actor)
 #define SLAB 3600
@@ -508,15 +508,27 @@ __host__ __device__ inline size_t ws_mat_floats(int batch) { return (size_t)ws_k
 __host__ __device__ inline size_t ws_slab_off(int batch) { return 6 * ws_mat_floats(batch); }
 __host__ __device__ inline size_t ws_part_off(int batch) { return ws_slab_off(batch) + (size_t)(ws_kp(batch) / SR) * SLAB; }
 __host__ __device__ inline size_t ws_xch_off(int batch) { return ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4; }
-__host__ __device__ inline size_t ws_stash_off(int batch) { return ws_xch_off(batch) + 2 * (size_t)ws_kp(batch) + 2 * (size_t)(ws_kp(batch) / SR); }   // [Kp x 3 obs][Kp / SR partials][epoch]
+__host__ __device__ inline size_t ws_stash_off(int batch) { return ws_xch_off(batch) + 4 * (size_t)ws_kp(batch); }   // [Kp x 3 obs][Kp / SR partials][epoch]
 extern "C" size_t mi_sac_workspace_bytes(int batch) {
     if (batch <= 0) return 0;
-    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 2 * (size_t)ws_kp(batch) + 2 * (size_t)(ws_kp(batch) / SR)
+    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 4 * (size_t)ws_kp(batch)
             + 3 * (size_t)ws_kp(batch) + (size_t)(ws_kp(batch) / SR) + 4 /* owed alpha step: observation stash, log-prob partials, epoch word */) * sizeof(float);
 }
 static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >= 32 batch rows, the grid covers the rest
     int s = ws_kp(batch) / 128;
     return s < 1 ? 1 : (s > GEMM_MAX_SPLIT ? GEMM_MAX_SPLIT : s);
+}
+
+// hand-off of one float per row between sibling workgroups: a 64-bit word = (tag 1 << 32) | value bits, written and read with device-scope atomics, so the
+// value travels WITH its "ready" mark (no flag -> fence -> payload sequence: one round trip less); the reader zeroes the word, the next launch finds 0.
+__device__ __forceinline__ void xw_put(unsigned long long* w, float v) {
+    __hip_atomic_store(w, (1ull << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float xw_take(unsigned long long* w) {
+    unsigned long long v;
+    while (((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != 1ull) __builtin_amdgcn_s_sleep(2);
+    __hip_atomic_store(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(float, (unsigned)v);
 }
 
 // alpha step riding on the log-prob launch: the LAST workgroup to finish (ticket in the workspace) sums the slabs in fixed order and does the Adam step
@@ -704,20 +716,11 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         issue_thin_q(q + SQ_NP, th2);
         __syncthreads();
         q_forward2<false>(sm, qt_mine, q + (second ? SQ_NP : 0) + SQ_W2, sm.b0, ws, acc, 8);
-        float* xch = ws_ + ws_xch_off(batch);
-        int* flags = reinterpret_cast<int*>(xch + 2 * (size_t)ws_kp(batch)) + 2 * blockIdx.x;
+        unsigned long long* xw = reinterpret_cast<unsigned long long*>(ws_ + ws_xch_off(batch)) + 2 * (size_t)row0;
         const int me = second ? 1 : 0;
-        if (t < SR) xch[2 * (row0 + t) + me] = sm.rv[t][8];
-        __threadfence();
-        __syncthreads();
-        if (t == 0) {
-            __hip_atomic_store(flags + me, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(flags + (me ^ 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
-            __hip_atomic_store(flags + (me ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the reader resets the word it waited on: the next launch finds 0
-        }
-        __syncthreads();
         if (t < SR) {
-            const float other = __hip_atomic_load(xch + 2 * (row0 + t) + (me ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xw_put(xw + 2 * t + me, sm.rv[t][8]);
+            const float other = xw_take(xw + 2 * t + (me ^ 1));
             sm.rv[t][10] = second ? other : sm.rv[t][8];     // target 1
             sm.rv[t][8] = second ? sm.rv[t][8] : other;      // target 2
         }
@@ -827,8 +830,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     __syncthreads();
     if (split) {
         const int net = second ? 1 : 0;
-        float* xch = ws_ + ws_xch_off(batch);
-        int* flag = reinterpret_cast<int*>(xch + 2 * (size_t)ws_kp(batch)) + 2 * blockIdx.x;
+        unsigned long long* xw = reinterpret_cast<unsigned long long*>(ws_ + ws_xch_off(batch)) + 2 * (size_t)row0;
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
         sm.qmask[net][t] = mk; sm.qw13[net][t] = th.w1[3]; sm.qw3[net][t] = th.h0;
         __syncthreads();
@@ -853,22 +855,13 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         else mfma_pass<true, true>(qn + SQ_W2, actor + AC_W2, sm.b2, ws, acc);
         rows_combine2(sm, q_daction_partial(sm, net, acc), 0.0f, 11, 15);        // d q_net / d action (unit weight) -> rv[11]
         if (second) {
-            if (t < SR) { xch[2 * (row0 + t)] = sm.rv[t][10]; xch[2 * (row0 + t) + 1] = sm.rv[t][11]; }
-            __threadfence();
-            __syncthreads();
-            if (t == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < SR) { xw_put(xw + 2 * t, sm.rv[t][10]); xw_put(xw + 2 * t + 1, sm.rv[t][11]); }
             return;
         }
-        if (t == 0) {
-            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
-            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // self-resetting: the next launch finds 0
-        }
-        alpha = wait_owed_alpha(ow, ws_, batch, alpha_p, sm);   // (contains the barrier when a step is owed)
-        __syncthreads();
+        alpha = wait_owed_alpha(ow, ws_, batch, alpha_p, sm);   // (contains a barrier when a step is owed)
         if (t < SR) {
             const float q1 = sm.rv[t][10], da1 = sm.rv[t][11];
-            const float q2 = __hip_atomic_load(xch + 2 * (row0 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float da2 = __hip_atomic_load(xch + 2 * (row0 + t) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float q2 = xw_take(xw + 2 * t), da2 = xw_take(xw + 2 * t + 1);
             const bool valid = row0 + t < batch;
             sm.rv[t][9] = valid ? alpha * sm.rv[t][5] - fminf(q1, q2) : 0.0f;                    // loss term (:197)
             const float w1 = !valid ? 0.0f : q1 < q2 ? 1.0f : (q2 < q1 ? 0.0f : 0.5f);             // torch.min routes the gradient to the smaller input, half / half on ties
