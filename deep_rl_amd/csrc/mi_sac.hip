@@ -679,26 +679,32 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     float* slab = ws_ + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
     wstream ws; thin_t th, th2; f32x4 acc[4];
     issue_thin_actor(actor, th);
-    stream_prime<false>(actor + AC_W2, ws);
-    if (t < SR) {
-        const int b = row0 + t < batch ? row0 + t : batch - 1;
+    // the batch rows: thread (r = t / 4, k = t & 3) derives row r's index itself (four threads repeat the draw: no LDS hand-over, no barrier) and requests its
+    // element; the weight stream is started AFTER these requests (loads return in order: the first pass cannot start before layer 1 has the rows anyway)
+    float gx = 0.0f, gxn = 0.0f;
+    if (t < SR * 4) {
+        const int r = t >> 2, k = t & 3;
+        const int b = row0 + r < batch ? row0 + r : batch - 1;
         long long i;
         if (sample_upper) {   // batch_inds = randint(global_step, size=batch) (sac.py:162) drawn here (the mi_dqn_sample contract, stream 4): no launch of its own
-            uint32_t r[4];
-            mi_philox(seed, sample_update, (uint64_t)b, 4u, r);
-            i = (long long)((((uint64_t)r[1] << 32) | r[0]) % sample_upper);
-            if (row0 + t < batch) idx_out[b] = i;     // (both workgroups of a split row group write the same value)
+            uint32_t rr[4];
+            mi_philox(seed, sample_update, (uint64_t)b, 4u, rr);
+            i = (long long)((((uint64_t)rr[1] << 32) | rr[0]) % sample_upper);
+            if (k == 0 && row0 + r < batch) idx_out[b] = i;     // (both workgroups of a split row group write the same value)
         } else i = idx[b];
-        sm.cur[t] = i; sm.nxt[t] = ((i / n_envs + 1) % slots) * n_envs + i % n_envs;
+        long long sl, en;   // next-slot row of the same env; flat indices below 2^32 take the 32-bit divider, the wrap is a compare
+        if ((unsigned long long)i >> 32) { sl = i / n_envs; en = i % n_envs; }
+        else { const unsigned qd = (unsigned)i / (unsigned)n_envs; sl = qd; en = (unsigned)i - qd * (unsigned)n_envs; }
+        sl = sl + 1 == slots ? 0 : sl + 1;
+        const long long nx = sl * n_envs + en;
+        gx = k < 3 ? observations[3 * i + k] : actions[i];
+        gxn = k < 3 ? observations[3 * nx + k] : 0.0f;
+        if (k == 0) { sm.cur[r] = i; sm.nxt[r] = nx; }
     }
+    stream_prime<false>(actor + AC_W2, ws);
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
-    __syncthreads();
-    if (t < SR * 4) {
-        const int r = t / 4, k = t & 3;
-        sm.x[r][k] = k < 3 ? observations[3 * sm.cur[r] + k] : actions[sm.cur[r]];
-        sm.xn[r][k] = k < 3 ? observations[3 * sm.nxt[r] + k] : 0.0f;
-    }
+    if (t < SR * 4) { sm.x[t >> 2][t & 3] = gx; sm.xn[t >> 2][t & 3] = gxn; }
     __syncthreads();
     // ---- next action + log-prob under the current actor (no grad; sac.py:172) ----
     // split row groups: workgroup y evaluates target critic y only and the two exchange their values through the workspace (one hand-off instead of a pass)
@@ -787,12 +793,13 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     wstream ws; thin_t th; f32x4 acc[4];
     uint32_t h2mask[2];                                           // the critics' layer-2 ReLU masks in the D layout (bit 4 t + r), kept for the backward
     issue_thin_actor(actor, th);
-    stream_prime<false>(actor + AC_W2, ws);
+    float gv = 0.0f;
+    if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; gv = observations[3 * idx[b] + k]; }
+    stream_prime<false>(actor + AC_W2, ws);   // (after the row requests: loads return in order)
     if (t < SR * 3) {
         const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1;
-        const float v = observations[3 * idx[b] + k];
-        sm.x[r][k] = v;
-        if (!logp_only && blockIdx.y == 0 && row0 + r < batch) ws_[ws_stash_off(batch) + 3 * (size_t)b + k] = v;   // kept for an alpha step that rides on a later launch
+        sm.x[r][k] = gv;
+        if (!logp_only && blockIdx.y == 0 && row0 + r < batch) ws_[ws_stash_off(batch) + 3 * (size_t)b + k] = gv;   // kept for an alpha step that rides on a later launch
     }
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, ((logp_only ? 4ull : 3ull) << 40) + update, (uint64_t)b); }
