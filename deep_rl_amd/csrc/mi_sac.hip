@@ -498,7 +498,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 
 // ================================================ workspace layout ==============================================================
 // Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536][ticket 4]
-// [hand-off between the two workgroups of a split row group: Kp x 2 tagged 64-bit words (xw_put / xw_take; self-resetting; both kernels use the same words)]
+// [hand-off between the sibling workgroups of a row group: Kp x 6 tagged 64-bit words (xw_put / xw_take; self-resetting; both kernels use the same words)]
 // The caller zero-fills the workspace once (the ticket word resets itself after every use).
 // (mats 0,1: critics; 2: actor)
 #define SLAB 3600
@@ -508,10 +508,10 @@ __host__ __device__ inline size_t ws_mat_floats(int batch) { return (size_t)ws_k
 __host__ __device__ inline size_t ws_slab_off(int batch) { return 6 * ws_mat_floats(batch); }
 __host__ __device__ inline size_t ws_part_off(int batch) { return ws_slab_off(batch) + (size_t)(ws_kp(batch) / SR) * SLAB; }
 __host__ __device__ inline size_t ws_xch_off(int batch) { return ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4; }
-__host__ __device__ inline size_t ws_stash_off(int batch) { return ws_xch_off(batch) + 4 * (size_t)ws_kp(batch); }   // [Kp x 3 obs][Kp / SR partials][epoch]
+__host__ __device__ inline size_t ws_stash_off(int batch) { return ws_xch_off(batch) + 12 * (size_t)ws_kp(batch); }   // [Kp x 3 obs][Kp / SR partials][epoch]
 extern "C" size_t mi_sac_workspace_bytes(int batch) {
     if (batch <= 0) return 0;
-    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 4 * (size_t)ws_kp(batch)
+    return (ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H + 4 /* ticket */ + 12 * (size_t)ws_kp(batch)
             + 3 * (size_t)ws_kp(batch) + (size_t)(ws_kp(batch) / SR) + 4 /* owed alpha step: observation stash, log-prob partials, epoch word */) * sizeof(float);
 }
 static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >= 32 batch rows, the grid covers the rest
@@ -593,9 +593,12 @@ __device__ void sac_owed_alpha_role(sac_smem& sm, const float* __restrict__ acto
 // ================================================ critic update =================================================================
 // slab layout (critic): net n at n*1793: W1 1024 | b1 256 | b2 256 | W3 256 | b3 1;  then [3586] = sum (q1-y)^2, [3587] = sum (q2-y)^2
 // passes: actor fwd -> target 1 fwd -> target 2 fwd -> critic 1 fwd, bwd -> critic 2 fwd, bwd
+// the TD target's ingredients arriving from the target workgroups of a four-workgroup row group (see sac_critic_kernel)
+struct quad_wait_t { unsigned long long* xw; const float* rewards; const uint8_t* terminated; const float* alpha_p; float* ws_; float gamma; const sac_owed_t* ow; };
 template <int NET>
 __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __restrict__ q, const float* __restrict__ Wnext, wstream& ws, const thin_t& th,
-                                                  int batch, int row0, float invn, float* __restrict__ H1, float* __restrict__ DZ2, float* __restrict__ slab) {
+                                                  int batch, int row0, float invn, float* __restrict__ H1, float* __restrict__ DZ2, float* __restrict__ slab,
+                                                  const quad_wait_t* qw = nullptr) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
     const float* p = q + (size_t)NET * SQ_NP;
     float* sl = slab + NET * 1793;
@@ -603,6 +606,16 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
     layer1<4>(sm, th, sm.x, sm.b0);
     __syncthreads();
     q_forward2<true>(sm, p, p + SQ_W2, sm.b0, ws, acc, 8);          // h1 in b0, relu(h2) in acc; the stream continues with this net's backward
+    if (qw) {   // y = r + gamma (1 - d) (min(Q1', Q2') - alpha log pi(a'|s')) (sac.py:176-177) from the target workgroups' words
+        float rw = 0.0f, nd = 0.0f;
+        if (t < SR) { rw = qw->rewards[sm.nxt[t]]; nd = qw->terminated[sm.nxt[t]] ? 0.0f : 1.0f; }
+        const float alpha = wait_owed_alpha(*qw->ow, qw->ws_, batch, qw->alpha_p, sm);
+        if (t < SR) {
+            const float t1 = xw_take(qw->xw + 6 * t + NET), t2 = xw_take(qw->xw + 6 * t + 2 + NET), lp = xw_take(qw->xw + 6 * t + 4 + NET);
+            sm.rv[t][10] = rw + nd * qw->gamma * (fminf(t1, t2) - alpha * lp);
+        }
+        __syncthreads();
+    }
     if (t < SR) {
         const bool valid = row0 + t < batch;
         const float d = valid ? sm.rv[t][8] - sm.rv[t][10] : 0.0f;
@@ -673,11 +686,17 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     const int t = threadIdx.x, row0 = blockIdx.x * SR;
     // gridDim.y == 2: the two critics' forward + backward run in two workgroups per row group (each repeats the actor / target forwards):
     // 5 passes on the critical path instead of 7, used while the row groups do not fill the chip anyway
-    const bool split = gridDim.y == 2, second = split && blockIdx.y == 1;
+    // gridDim.y == 4 (row groups <= 32): FOUR workgroups per row group.  y = 0 / 1 evaluate the next action and target critic 1 / 2 on the next observations and
+    // publish (Q_y', and y = 0 also log pi(a'|s')) once per reader; y = 2 / 3 own critic 1 / 2: they run its forward on (obs, action) — which needs nothing from the
+    // targets — at the same time, then take the targets' words, form the TD target and do loss + backward.  Critical path: max(actor fwd + target fwd, critic fwd)
+    // + hand-off + backward instead of actor fwd + target fwd + hand-off + critic fwd + backward.
+    const bool quad = gridDim.y == 4, split = gridDim.y == 2, second = split && blockIdx.y == 1;
+    const int role = quad ? (int)blockIdx.y : 0;
     const size_t matf = ws_mat_floats(batch);
     float* H1 = ws_; float* DZ2 = ws_ + 3 * matf;
     float* slab = ws_ + ws_slab_off(batch) + (size_t)blockIdx.x * SLAB;
     wstream ws; thin_t th, th2; f32x4 acc[4];
+    if (quad && role >= 2) issue_thin_q(q + (role - 2) * SQ_NP, th); else
     issue_thin_actor(actor, th);
     // the batch rows: thread (r = t / 4, k = t & 3) derives row r's index itself (four threads repeat the draw: no LDS hand-over, no barrier) and requests its
     // element; the weight stream is started AFTER these requests (loads return in order: the first pass cannot start before layer 1 has the rows anyway)
@@ -701,11 +720,35 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         gxn = k < 3 ? observations[3 * nx + k] : 0.0f;
         if (k == 0) { sm.cur[r] = i; sm.nxt[r] = nx; }
     }
-    stream_prime<false>(actor + AC_W2, ws);
+    stream_prime<false>(quad && role >= 2 ? q + (role - 2) * SQ_NP + SQ_W2 : actor + AC_W2, ws);
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
     if (t < SR * 4) { sm.x[t >> 2][t & 3] = gx; sm.xn[t >> 2][t & 3] = gxn; }
     __syncthreads();
+    if (quad) {
+        unsigned long long* xw = reinterpret_cast<unsigned long long*>(ws_ + ws_xch_off(batch)) + 6 * (size_t)row0;
+        if (role >= 2) {   // critic role - 2
+            const quad_wait_t qw = {xw, rewards, terminated, alpha_p, ws_, gamma, &ow};
+            if (role == 2) critic_net_update<0>(sm, q, nullptr, ws, th, batch, row0, invn, H1, DZ2, slab, &qw);
+            else critic_net_update<1>(sm, q, nullptr, ws, th, batch, row0, invn, H1, DZ2, slab, &qw);
+            return;
+        }
+        const float* qtn = qt + role * SQ_NP;   // target role
+        layer1<3>(sm, th, sm.xn, sm.b0);
+        issue_thin_q(qtn, th);
+        __syncthreads();
+        actor_forward2<false>(sm, actor, qtn + SQ_W2, sm.b0, ws, acc, e_row);
+        if (t < SR) { sm.xn[t][3] = sm.rv[t][6]; sm.rv[t][9] = sm.rv[t][5]; }   // a', log pi(a'|s')
+        __syncthreads();
+        layer1<4>(sm, th, sm.xn, sm.b0);
+        __syncthreads();
+        q_forward2<false>(sm, qtn, nullptr, sm.b0, ws, acc, 8);
+        if (t < SR) {
+            xw_put(xw + 6 * t + 2 * role, sm.rv[t][8]); xw_put(xw + 6 * t + 2 * role + 1, sm.rv[t][8]);
+            if (role == 0) { xw_put(xw + 6 * t + 4, sm.rv[t][9]); xw_put(xw + 6 * t + 5, sm.rv[t][9]); }
+        }
+        return;
+    }
     // ---- next action + log-prob under the current actor (no grad; sac.py:172) ----
     // split row groups: workgroup y evaluates target critic y only and the two exchange their values through the workspace (one hand-off instead of a pass)
     const float* qt_mine = qt + (second ? SQ_NP : 0);
@@ -1191,7 +1234,7 @@ static int sac_critic_impl(float* q, float* q_target, const float* actor, const 
     const int nrg = ws_kp(batch) / SR;
     {
         mi_prof_scope prof(MI_PROF_SAC_CRITIC, s);
-        sac_critic_kernel<<<dim3(nrg + ow.n_lp, nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+        sac_critic_kernel<<<dim3(nrg + ow.n_lp, nrg <= 32 ? 4 : nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
                                                            seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
                                                            (int64_t*)idx, ow);
     }
