@@ -233,7 +233,7 @@ def bench_sac(dev, iters=400, cpu_seconds=3.0):
            "roofline": {"bound": "mfma", "kernel": "sac_critic_kernel", "achieved": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12, 3),
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                         "traffic": None, "flops_per_launch": critic_flops, "avg_launch_us": round(us["sac_critic"], 2),
-                        "note": "batch 256 = 16 row groups x 2 workgroups on a 256-CU chip: 7 dependent 256x256 passes, latency-bound (DESIGN.md §7c)"},
+                        "note": "batch 256 = 16 row groups x 4 workgroups (two target roles, two critic roles) on a 256-CU chip: 3 dependent 256x256 passes + one hand-off on the critical path, latency-bound (DESIGN.md §7c)"},
            "alpha": float(eng.alpha), "q_losses": [round(float(x), 5) for x in eng.q_losses.tolist()]}
     out["cpu_baseline"] = cpu_baseline_sac(a0, q0, envs, slots, batch, cpu_seconds)
     return out
