@@ -1210,6 +1210,24 @@ static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv
     return MI_OK;
 }
 
+// How many sibling workgroups a row group gets.  Siblings WAIT for each other inside the launch, so every workgroup of the launch must be resident at once: these
+// kernels run one workgroup per CU (256 + 68..128 registers per lane), and the launch is kept to half the chip (row groups x roles + the owed-alpha workgroups
+// <= CUs / 2), which leaves room even when something else holds part of the device.  Beyond that the single-workgroup form (no waits) runs.
+static int sac_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+static int sac_roles(int nrg, int n_lp, int max_roles) {
+    for (int r = max_roles; r > 1; r >>= 1) if (nrg * r + n_lp <= sac_cus() / 2) return r;
+    return 1;
+}
+static bool sac_owed_fits(int nrg) { return 2 * nrg <= sac_cus() / 2; }   // row groups (single role at least... with one sibling) + as many owed workgroups
+
 static sac_alpha_t sac_make_alpha(float target_entropy, float inv_count, float* log_alpha, float* m, float* v, int64_t step, double lr, float* alpha, float* out,
                                   unsigned int* ticket);
 static sac_owed_t sac_make_owed(const mi_sac_owed_alpha_t* o, int batch, uint64_t seed, void* workspace) {
@@ -1223,7 +1241,7 @@ static sac_owed_t sac_make_owed(const mi_sac_owed_alpha_t* o, int batch, uint64_
 static int sac_check_owed(const mi_sac_owed_alpha_t* o, int batch) {
     if (!o) return MI_OK;
     MI_CHECK_ARG(o->log_alpha && o->exp_avg && o->exp_avg_sq && o->alpha && o->step >= 1 && o->step < (1ll << 31), "owed alpha step: NULL state or bad step");
-    MI_CHECK_ARG(ws_kp(batch) / SR <= 128, "an owed alpha step rides only on launches that leave CUs idle (batch <= 2048)");
+    MI_CHECK_ARG(sac_owed_fits(ws_kp(batch) / SR), "an owed alpha step rides only on launches that leave at least half of the CUs idle (batch <= 1024 on 256 CUs)");
     return MI_OK;
 }
 
@@ -1234,7 +1252,7 @@ static int sac_critic_impl(float* q, float* q_target, const float* actor, const 
     const int nrg = ws_kp(batch) / SR;
     {
         mi_prof_scope prof(MI_PROF_SAC_CRITIC, s);
-        sac_critic_kernel<<<dim3(nrg + ow.n_lp, nrg <= 32 ? 4 : nrg <= 128 ? 2 : 1), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+        sac_critic_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 4)), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
                                                            seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
                                                            (int64_t*)idx, ow);
     }
@@ -1280,7 +1298,7 @@ static int sac_actor_impl(float* actor, const float* q, const float* observation
     {
         mi_prof_scope prof(MI_PROF_SAC_ACTOR, s);
         const int nrg = ws_kp(batch) / SR;
-        sac_actor_kernel<<<dim3(nrg + ow.n_lp, nrg <= 128 ? 2 : 1), 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count,
+        sac_actor_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 2)), 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count,
                                                                                  (float*)workspace, 0, sac_alpha_t{}, ow);
     }
     MI_LAUNCH_CHECK();

@@ -212,7 +212,7 @@ class SACEngine:
 
     def update_alpha(self, eps=None):
         """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
-        if eps is None and self.world_size == 1 and self._stash_fresh and self.batch_size <= 2048 and _OWE_ALPHA:
+        if eps is None and self.world_size == 1 and self._stash_fresh and self.batch_size <= 1024 and _OWE_ALPHA:
             # keyed draws, single process, right after a fused actor update: the step is OWED — the next row-group launch (actor or critic update) carries its
             # log-prob pass on workgroups of its own and hands alpha to its consumers in the launch; reading the state (or flush_alpha()) settles it alone
             self.flush_alpha()

@@ -355,7 +355,7 @@ int mi_sac_alpha_step(const float* actor, const float* observations, const int64
 
 /* ---- the alpha step OWED from the last actor update, carried by the next launch instead of a launch of its own.  Its log-prob pass (sac.py:203-204) depends only
  * on the actor and on the batch observations of that actor update (mi_sac_actor_update* stashes them in the workspace).  mi_sac_actor_update_owed /
- * mi_sac_critic_update_owed run it on workgroups of their own launch (idle CUs at batch <= 2048), apply Adam to log_alpha (:205-210) and hand alpha to the
+ * mi_sac_critic_update_owed run it on workgroups of their own launch (accepted while the launch stays within half of the CUs: batch <= 1024 on an MI355X), apply Adam to log_alpha (:205-210) and hand alpha to the
  * launch's own workgroups, which read it only where the reference does (after their forward passes); mi_sac_alpha_step_owed runs it alone (flush).  Identical
  * results to mi_sac_alpha_step called right after the actor update, with eps == NULL (keyed draws).  step: 1-based Adam step of log_alpha, strictly increasing. */
 typedef struct {
