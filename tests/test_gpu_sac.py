@@ -557,3 +557,39 @@ def test_config4_full_size_properties(dev, R):
         half.actor_grad(eps[1][128 * h:128 * (h + 1)]); acca += 0.5 * half.actor_grads
     assert (accq - gq).abs().max().item() <= 1e-5 * gq.abs().max().item()
     assert (acca - ga).abs().max().item() <= 1e-4 * ga.abs().max().item()
+
+
+@pytest.mark.parametrize("batch", [40, 256, 600])
+def test_owed_alpha_step_is_bit_identical_to_a_launch_of_its_own(dev, batch, monkeypatch):
+    """The alpha step carried by the next row-group launch (mi_sac_*_update_owed: its log-prob pass on workgroups of the actor / critic update that follows,
+    alpha handed to that launch's consumers through the epoch word) against the same training with every alpha step as its own launch: every parameter, the
+    optimizer moments, log alpha and its Adam state agree BIT FOR BIT after 30 iterations (policy_frequency 2: both carriers occur), at a batch inside the
+    four-workgroup form (40, 256) and one beyond it (600: two-workgroup actor form, single-workgroup critic form)."""
+    import deep_rl_amd as D
+    import deep_rl_amd.sac_engine as SE
+
+    def run(owe):
+        monkeypatch.setattr(SE, "_OWE_ALPHA", owe)
+        env = D.make("Pendulum-v1", num_envs=48, device=dev, seed=9)
+        torch.manual_seed(9)
+        actor = D.Actor(env); q1 = D.SoftQNetwork(env); q2 = D.SoftQNetwork(env); q1t = D.SoftQNetwork(env); q2t = D.SoftQNetwork(env)
+        q1t.load_state_dict(q1.state_dict()); q2t.load_state_dict(q2.state_dict())
+        eng = D.SACEngine(env, actor, q1, q2, q1t, q2t, slots=40, batch_size=batch, learning_starts=4)
+        eng.reset()
+        owed_seen = 0
+        for _ in range(30):
+            eng.act()
+            if eng.global_step > 6:
+                eng.train_step()
+                owed_seen += eng._owed is not None
+        return eng, owed_seen
+
+    a, seen_a = run(True)
+    b, seen_b = run(False)
+    assert seen_a > 5 and seen_b == 0, "the owed path was not exercised"
+    assert a.alpha_steps == b.alpha_steps
+    for name in ("log_alpha", "alpha", "_alpha_m", "_alpha_v", "alpha_out"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.actor.flat, b.actor.flat) and torch.equal(a.q_flat, b.q_flat) and torch.equal(a.qt_flat, b.qt_flat)
+    assert torch.equal(a.actor_optimizer.exp_avg, b.actor_optimizer.exp_avg) and torch.equal(a.q_optimizer.exp_avg_sq, b.q_optimizer.exp_avg_sq)
+    assert torch.equal(a.observations, b.observations) and torch.equal(a.actions, b.actions)
