@@ -111,6 +111,7 @@ SIGNATURES = {
     "mi_sac_critic_update_owed": (_I, [_VP] * 8 + [_I, _I, _I64, _VP, _U64, _U64, _VP, _F, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _F, _U64, _I64, _VP, _VP]),
     "mi_sac_actor_update_owed": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _VP, _VP]),
     "mi_sac_alpha_step_owed": (_I, [_VP, _I, _U64, _VP, _VP, _VP]),
+    "mi_sac_owed_alpha_fits": (_I, [_I]),
     "mi_sac_alpha_step": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP, _VP]),
     "mi_sac_mean_logp": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _D, _VP, _VP, _VP]),
     "mi_sac_alpha_adam": (_I, [_VP, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),

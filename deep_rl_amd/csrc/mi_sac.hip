@@ -1226,7 +1226,8 @@ static int sac_roles(int nrg, int n_lp, int max_roles) {
     for (int r = max_roles; r > 1; r >>= 1) if (nrg * r + n_lp <= sac_cus() / 2) return r;
     return 1;
 }
-static bool sac_owed_fits(int nrg) { return 2 * nrg <= sac_cus() / 2; }   // row groups (single role at least... with one sibling) + as many owed workgroups
+static bool sac_owed_fits(int nrg) { return 2 * nrg <= sac_cus() / 2; }
+extern "C" int mi_sac_owed_alpha_fits(int batch) { return batch > 0 && sac_owed_fits(ws_kp(batch) / SR) ? 1 : 0; }   // row groups (single role at least... with one sibling) + as many owed workgroups
 
 static sac_alpha_t sac_make_alpha(float target_entropy, float inv_count, float* log_alpha, float* m, float* v, int64_t step, double lr, float* alpha, float* out,
                                   unsigned int* ticket);

@@ -45,6 +45,7 @@ class SACEngine:
         self._alpha_steps = 0
         self._owed = None            # (update key of the owed step's log-prob draw)
         self._stash_fresh = False
+        self._owed_fits = bool(N.lib().mi_sac_owed_alpha_fits(self.batch_size))   # the carrying launch must leave half of the device's CUs free
         self.observations = torch.zeros((S, Nn, 3), dtype=torch.float32, device=dev)           # :126
         self.actions = torch.zeros((S, Nn), dtype=torch.float32, device=dev)                   # :127 (one action dim)
         self.rewards = torch.zeros((S, Nn), dtype=torch.float32, device=dev)                   # :128
@@ -212,7 +213,7 @@ class SACEngine:
 
     def update_alpha(self, eps=None):
         """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
-        if eps is None and self.world_size == 1 and self._stash_fresh and self.batch_size <= 1024 and _OWE_ALPHA:
+        if eps is None and self.world_size == 1 and self._stash_fresh and self._owed_fits and _OWE_ALPHA:
             # keyed draws, single process, right after a fused actor update: the step is OWED — the next row-group launch (actor or critic update) carries its
             # log-prob pass on workgroups of its own and hands alpha to its consumers in the launch; reading the state (or flush_alpha()) settles it alone
             self.flush_alpha()

@@ -371,6 +371,7 @@ int mi_sac_actor_update_owed(float* actor, const float* q, const float* observat
                              uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
                              int64_t step, double lr, double beta1, double beta2, double adam_eps, const mi_sac_owed_alpha_t* owed, void* stream);
 int mi_sac_alpha_step_owed(const float* actor, int batch, uint64_t seed, const mi_sac_owed_alpha_t* owed, void* workspace, void* stream);
+int mi_sac_owed_alpha_fits(int batch);   /* 1 when a launch at this batch may carry an owed alpha step on the current device (half of its CUs stay free) */
 /* the same in two halves for sharded runs (all-reduce *mean_logp between them): mean_logp dev f32 [1] = inv_count * sum of this rank's
  * fresh log-probs; then the Adam step on log_alpha from the global mean. */
 int mi_sac_mean_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
