@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
+ABI_VERSION = 101   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
@@ -142,6 +143,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        got = L.mi_version()
+        if got != ABI_VERSION:   # a stale libmirl.so would read structs of another layout: refuse instead of corrupting memory
+            raise MiError("deep_rl_amd: %s reports ABI version %d, this binding is written against %d — rebuild it (make -C deep_rl_amd/csrc)" % (SO_PATH, got, ABI_VERSION))
         _lib = L
         mode = os.environ.get("MIRL_PPO_CONTRACTION", "f32")   # experiment switch, see set_contraction
         if mode != "f32":

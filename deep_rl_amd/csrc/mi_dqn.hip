@@ -914,8 +914,11 @@ extern "C" int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_gr
 #define STREAM_PER 7u
 struct per_ws_t { double* s0; double* a0; double* s1; double* a1; double* totals; };   // a0 / a1: the same sums of p^alpha; totals = {sum p, sum p^alpha}
 // p^alpha of a priority (per.py:131): 2^(alpha log2 p) on the hardware log2 / exp2 (3 instructions instead of ~150 for powf; relative
-// error ~1e-6, it only enters the importance weights, which are compared to 2e-5).  p = 0 -> 0 exactly (log2 0 = -inf, 2^-inf = 0).
-__device__ __forceinline__ float per_pow(float p, float alpha) { return __builtin_amdgcn_exp2f(alpha * __builtin_amdgcn_logf(p)); }
+// error ~1e-6, it only enters the importance weights, which are compared to 2e-5).  p = 0 -> 0 for EVERY alpha, explicitly: never-written entries and
+// the ring's write head must contribute +0 to the incremental sums, and alpha = 0 (uniform PER, legitimate in per.py) would otherwise give 0 * -inf = NaN.
+// (torch's 0 ** 0 = 1 would add the count of never-written entries to sum p^alpha at alpha = 0; the weights of per.py:145-146 are normalised by their
+// maximum and every sampled entry has p > 0, so they are exactly 1 either way.  the CPU oracle makes the same choice.)
+__device__ __forceinline__ float per_pow(float p, float alpha) { return p == 0.0f ? 0.0f : __builtin_amdgcn_exp2f(alpha * __builtin_amdgcn_logf(p)); }
 __host__ __device__ inline int64_t per_n0(int64_t n) { return (n + PER_CHUNK - 1) / PER_CHUNK; }
 static per_ws_t per_ws(void* workspace, int64_t capacity) {
     per_ws_t w;

@@ -1,392 +1,20 @@
-// mi_rollout.hip — the whole rollout loop of reference ppo.py:110-141 in ONE launch.
+// mi_rollout.hip — the whole rollout loop of reference ppo.py:110-141 in ONE launch (rollout_q4_kernel), plus the batch forward that backs
+// the nn.Module-style API (forward_kernel).
 //
-// Two formulations share the step logic: rollout_mfma_kernel (default; further down) and the original VALU one below
-// (-DROLLOUT_VALU, kept for A/B).  Mapping of the VALU form (SURVEY §7 hard part 1: 4096 envs is small for 256 CUs, the chain is 128 deep):
-//   * envs are independent for the whole rollout (weights are frozen), so there is no inter-workgroup
-//     communication at all: one WAVE owns E envs for all T steps; lane j owns hidden unit j of both nets.
-//   * W1/W2/W3 rows of unit j live in that lane's VGPRs for the whole kernel (36.6 KB of weights are read from
-//     HBM/L2 once per wave); the 64-wide hidden vector is broadcast through a wave-private LDS row
-//     (one ds_write_b32 + 16 broadcast ds_read_b128 per layer), no workgroup barrier anywhere.
-//   * the 64->{2,1} heads are DPP wave reductions; the Categorical draw, log-prob, fp64 CartPole step,
-//     TimeLimit, episode statistics and auto-reset are wave-uniform scalar work done redundantly per lane.
-//   * critic(obs[t+1]) and actor(obs[t+1]) see the same observation, so both nets are evaluated together
-//     once per step (ppo.py:139 and :120 of the next iteration).
-//   * E = 2 envs per wave gives two independent dependency chains per wave (ILP) at 2 waves/SIMD for N=4096.
-// Storage index convention (ppo.py:113-141): actions/log_probs at t, obs/values/rewards/dones at t+1; on
-// done the stored obs/value are those of the RESET state.
+// Envs are independent for the whole rollout (weights are frozen), so there is no inter-workgroup communication at all.
+// Storage index convention (ppo.py:113-141): actions/log_probs at t, obs/values/rewards/dones at t+1; on done the stored obs/value
+// are those of the RESET state.  critic(obs[t+1]) and actor(obs[t+1]) see the same observation, so both nets are evaluated once per
+// step (ppo.py:139 and :120 of the next iteration).
+//
+// History (numbers in profiles/r02_rollout_stamps.txt; the code of the superseded forms is in git history only):
+//   r01  rollout_kernel<E>     one wave per E envs, lane = hidden unit, VALU FMAs from register-resident rows          0.36-0.40 ms
+//   r01  rollout_mfma_kernel   16 envs per 4-wave workgroup on 16x16x4 MFMA, one barrier per step                      0.245 ms
+//   r02  rollout_q4_kernel     4 envs per actor / critic wave pair on the 16-block 4x4x1 MFMA, no barrier (below)      0.207-0.216 ms
 #include "mi_common.h"
 
-struct net_regs {
-    float w1[OBS], b1, w2[HID], b2;
-};
-
-__device__ __forceinline__ void load_net(net_regs& r, const float* __restrict__ p, int j) {
-    const float4 w = *reinterpret_cast<const float4*>(p + N_W1 + 4 * j);
-    r.w1[0] = w.x; r.w1[1] = w.y; r.w1[2] = w.z; r.w1[3] = w.w;
-    r.b1 = p[N_B1 + j];
-#pragma unroll
-    for (int k = 0; k < HID; k += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(p + N_W2 + HID * j + k);
-        r.w2[k] = q.x; r.w2[k + 1] = q.y; r.w2[k + 2] = q.z; r.w2[k + 3] = q.w;
-    }
-    r.b2 = p[N_B2 + j];
-}
-
-// hidden layer 2 for one env: hrow = wave-private LDS row holding tanh(layer 1) of all 64 units
-__device__ __forceinline__ float layer2(const net_regs& r, const float* hrow) {
-    float acc0 = 0.0f, acc1 = 0.0f;  // two chains for ILP
-#pragma unroll
-    for (int k = 0; k < HID; k += 8) {
-        const float4 a = *reinterpret_cast<const float4*>(hrow + k);
-        const float4 b = *reinterpret_cast<const float4*>(hrow + k + 4);
-        acc0 = __builtin_fmaf(r.w2[k + 0], a.x, acc0); acc0 = __builtin_fmaf(r.w2[k + 1], a.y, acc0);
-        acc0 = __builtin_fmaf(r.w2[k + 2], a.z, acc0); acc0 = __builtin_fmaf(r.w2[k + 3], a.w, acc0);
-        acc1 = __builtin_fmaf(r.w2[k + 4], b.x, acc1); acc1 = __builtin_fmaf(r.w2[k + 5], b.y, acc1);
-        acc1 = __builtin_fmaf(r.w2[k + 6], b.z, acc1); acc1 = __builtin_fmaf(r.w2[k + 7], b.w, acc1);
-    }
-    return (acc0 + acc1) + r.b2;
-}
-
-#define ROLLOUT_WAVES 4
-
-__device__ __forceinline__ float bcast_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-
-// E envs per wave.  The 64-wide MLP work is done env by env with lane = hidden unit; the per-env SCALAR work
-// (Categorical draw, log-prob, fp64 CartPole step, TimeLimit, episode statistics, auto-reset, storage writes)
-// is done ONCE per step for all E envs at a time with lane e = env e (lanes >= E idle through it), so its
-// cost does not grow with E and env e's scalar state lives in lane e's registers only.
-template <int E>
-__global__ void __launch_bounds__(64 * ROLLOUT_WAVES, 2)
-rollout_kernel(mi_env e, const float* __restrict__ params, int T, float* __restrict__ obs_cur, float* __restrict__ observations,
-               float* __restrict__ values, int64_t* __restrict__ actions, float* __restrict__ log_probs,
-               float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
-               const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
-               mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep) {
-    __shared__ __attribute__((aligned(16))) float hbuf[ROLLOUT_WAVES][E][2][HID];
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int N = e.n;
-    const int env0 = (blockIdx.x * ROLLOUT_WAVES + wib) * E;
-    if (env0 >= N) return;  // wave-uniform
-
-    net_regs an, cn;
-    load_net(an, params, lane);
-    load_net(cn, params + C_BASE, lane);
-    const float w3a0 = params[A_W3 + lane], w3a1 = params[A_W3 + HID + lane], w3c = params[C_BASE + N_W3 + lane];
-    const float b3a0 = params[A_B3], b3a1 = params[A_B3 + 1], b3c = params[C_BASE + N_W3 + HID];
-
-    // scalar state of env (env0 + lane) in lane `lane` (< E)
-    const bool mine = lane < E && env0 + lane < N;
-    const int g = mine ? env0 + lane : env0;  // idle lanes shadow env0 and never write
-    double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
-    int elapsed = e.elapsed[g], eplen = e.ep_len[g];
-    float epret = e.ep_ret[g];
-    uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
-    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
-    float my_l0 = 0.0f, my_l1 = 0.0f, my_val = 0.0f;
-    int st_cnt = 0, st_len = 0, st_max = 0;  // finished episodes of this lane's env: count, sum of lengths, longest
-    uint32_t urand[4] = {0, 0, 0, 0};  // the current Philox block of action draws (steps 4k..4k+3 of this env)
-    const bool keyed_actions = !forced_actions && !forced_uniforms;
-    if (keyed_actions && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
-
-    for (int t = -1; t < T; ++t) {
-        float rew = 0.0f, dn = 0.0f;
-        if (t >= 0) {
-            // ---- sample from the logits of obs[t], step the env (ppo.py:120-129); lane = env ----
-            const size_t row = (size_t)t * N + g;
-            float nl0, nl1, p0, p1, ent;
-            mi_categorical2_fast(my_l0, my_l1, nl0, nl1, p0, p1, ent);
-            int a;
-            if (forced_actions) a = (int)forced_actions[row];
-            else {
-                float u;
-                if (forced_uniforms) u = forced_uniforms[row];
-                else {
-                    const uint32_t w = (uint32_t)stepctr & 3u;
-                    if (w == 0) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
-                    u = mi_u32_to_uniform(w == 0 ? urand[0] : w == 1 ? urand[1] : w == 2 ? urand[2] : urand[3]);
-                }
-                a = (u >= p0) ? 1 : 0;
-            }
-            stepctr += 1;
-            if (mine) { actions[row] = a; log_probs[row] = a ? nl1 : nl0; }  // ppo.py:123-124
-            int term;
-            mi_cartpole_step(sx, sxd, sth, sthd, a, term);
-            elapsed += 1;
-            const bool d = term || elapsed >= CP_MAX_STEPS;
-            epret += 1.0f;
-            eplen += 1;
-            if (d) {
-                if (mine) {
-                    // statistics stay in registers and are flushed once per wave at the end: early in training ~24k episodes
-                    // end per rollout and three atomics each on the same three words were a measurable hot spot
-                    st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
-                    if (max_ep > 0 && episode_stats) {  // the per-episode list (small N): slot from a returning atomic
-                        const int slot = atomicAdd(episode_stats + 3, 1);
-                        if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
-                    }
-                }
-                epret = 0.0f; eplen = 0; elapsed = 0;
-                double s[4];
-                if (forced_resets) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) s[k] = forced_resets[4 * row + k];
-                } else {
-                    mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, s);
-                }
-                episode += 1;
-                sx = s[0]; sxd = s[1]; sth = s[2]; sthd = s[3];
-            }
-            ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
-            rew = 1.0f; dn = d ? 1.0f : 0.0f;
-        }
-        // ---- both nets on obs[t+1] (ppo.py:115/139 critic, :120 actor of the next step); lane = hidden unit ----
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const float o0 = bcast_lane(ob.x, i), o1 = bcast_lane(ob.y, i), o2 = bcast_lane(ob.z, i), o3 = bcast_lane(ob.w, i);
-            float za = an.b1, zc = cn.b1;
-            za = __builtin_fmaf(an.w1[0], o0, za); za = __builtin_fmaf(an.w1[1], o1, za);
-            za = __builtin_fmaf(an.w1[2], o2, za); za = __builtin_fmaf(an.w1[3], o3, za);
-            zc = __builtin_fmaf(cn.w1[0], o0, zc); zc = __builtin_fmaf(cn.w1[1], o1, zc);
-            zc = __builtin_fmaf(cn.w1[2], o2, zc); zc = __builtin_fmaf(cn.w1[3], o3, zc);
-            hbuf[wib][i][0][lane] = mi_tanhf(za);
-            hbuf[wib][i][1][lane] = mi_tanhf(zc);
-        }
-        wave_lds_fence();  // wave-private LDS rows: LDS is in-order per wave, only compiler motion must be stopped
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const float h2a = mi_tanhf(layer2(an, hbuf[wib][i][0]));
-            const float h2c = mi_tanhf(layer2(cn, hbuf[wib][i][1]));
-            const float l0 = wave_sum_uniform(w3a0 * h2a) + b3a0;
-            const float l1 = wave_sum_uniform(w3a1 * h2a) + b3a1;
-            const float vv = wave_sum_uniform(w3c * h2c) + b3c;
-            if (lane == i) { my_l0 = l0; my_l1 = l1; my_val = vv; }
-        }
-        wave_lds_fence();
-        if (mine) {
-            const size_t row = (size_t)(t + 1) * N + g;
-            reinterpret_cast<float4*>(observations)[row] = ob;  // :113,:137 (the reset obs where done)
-            values[row] = my_val;                               // :115,:139
-            if (t >= 0) { rewards[row] = rew; dones[row] = dn; }  // :140-141
-        }
-    }
-    if (episode_stats) {  // one flush per wave (lanes < E hold the counters)
-        int c = 0, l = 0, m = 0;
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            c += __builtin_amdgcn_readlane(st_cnt, i); l += __builtin_amdgcn_readlane(st_len, i);
-            const int mi = __builtin_amdgcn_readlane(st_max, i);
-            m = mi > m ? mi : m;
-        }
-        if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
-    }
-    // carry-over `observation` and env state for the next rollout
-    if (mine) {
-        e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
-        e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen;
-        e.episode[g] = episode; e.step_ctr[g] = stepctr;
-        reinterpret_cast<float4*>(obs_cur)[g] = ob;
-    }
-}
-
-// ---- the same rollout on the matrix cores ----------------------------------------------------------------------------------------
-// A workgroup of 4 waves owns 16 envs for all T steps.  Wave w evaluates net (w >> 1) (0 actor, 1 critic), output tiles 2 (w & 1) and
-// 2 (w & 1) + 1 of its second layer, on v_mfma_f32_16x16x4_f32 in the [unit][env] orientation, every weight register-resident as an A
-// operand for the whole launch:
-//   layer 1  D1[unit][env] = b1[unit] + W1[unit][0..3] . obs[env][0..3]        one k-step per 16-unit tile (the bias is the accumulator input)
-//   layer 2  D2[out][env] += W2[out][u] * tanh(D1)[u][env]                     the layer-1 accumulators ARE the B operands: register r of tile t
-//            in lane group g is unit 16 t + 4 g + r, so k-step (t, r) contracts over g with A = W2[out][16 t + 4 g + r]
-//   heads    dot products over the wave's 32 units, summed across lane groups (2 shuffles) and the net's two waves (LDS, ONE barrier per step)
-// All 64 lanes of all 4 waves carry the fp64 state of env (lane & 15) and run the scalar section (Categorical draw, log-prob, CartPole
-// step, TimeLimit, auto-reset) redundantly — identical IEEE sequences, identical bits — so neither action nor observation is ever
-// exchanged; wave 0 / lane group 0 writes the storage.  36 MFMAs + 24 tanh per wave and step (was: 2 x 4,500 VALU FMAs per env-step).
-#define RM_ENVS 16
-#define RM_GAE_T 128
-typedef float rm_f32x4 __attribute__((ext_vector_type(4)));
-#define RM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-__global__ void __launch_bounds__(256)
-rollout_mfma_kernel(mi_env e, const float* __restrict__ params, int T, float* __restrict__ obs_cur, float* __restrict__ observations,
-                    float* __restrict__ values, int64_t* __restrict__ actions, float* __restrict__ log_probs,
-                    float* __restrict__ rewards, float* __restrict__ dones, const int64_t* __restrict__ forced_actions,
-                    const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
-                    mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep,
-                    float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n) {
-    __shared__ float hp[2][4][RM_ENVS][2];
-    if (zero_f64 && blockIdx.x == 0) for (int k = threadIdx.x; k < zero_n; k += 256) zero_f64[k] = 0.0;   // scratch the next launches accumulate into
-    // fused GAE (adv != NULL, T <= RM_GAE_T): the workgroup keeps values / rewards / dones of its 16 envs for the whole rollout and runs the
-    // reverse scan of ppo.py:144-151 itself at the end — same expression order as gae_kernel, bit for bit, without a launch of its own
-    __shared__ float gv[RM_GAE_T + 1][RM_ENVS], gr[RM_GAE_T + 1][RM_ENVS], gd[RM_GAE_T + 1][RM_ENVS];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
-    const int net = w >> 1, half = w & 1;
-    const int N = e.n;
-    const int i = blockIdx.x * RM_ENVS + j;
-    const bool mine = i < N, writer = mine && w == 0 && lg == 0;
-    const int g = mine ? i : N - 1;
-    // ---- resident operands of this wave's net ----
-    const float* p = params + (net ? C_BASE : 0);
-    float w1a[4], w2a[2][4][4];
-    rm_f32x4 b1v[4], b2v[2], w3v[2][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        w1a[t] = p[N_W1 + 4 * (16 * t + j) + lg];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b1v[t][r] = p[N_B1 + 16 * t + 4 * lg + r];
-    }
-#pragma unroll
-    for (int TT = 0; TT < 2; ++TT) {
-        const int row = 16 * (2 * half + TT) + j;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w2a[TT][t][r] = p[N_W2 + HID * row + 16 * t + 4 * lg + r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * (2 * half + TT) + 4 * lg + r;
-            b2v[TT][r] = p[N_B2 + o];
-            w3v[TT][0][r] = p[N_W3 + o];
-            w3v[TT][1][r] = net == 0 ? p[N_W3 + HID + o] : 0.0f;
-        }
-    }
-    const float b3a0 = params[A_B3], b3a1 = params[A_B3 + 1], b3c = params[C_BASE + N_W3 + HID];
-    // ---- env state: every lane group of every wave holds a copy of env (lane & 15) ----
-    double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
-    int elapsed = e.elapsed[g], eplen = e.ep_len[g];
-    float epret = e.ep_ret[g];
-    uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
-    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
-    float my_l0 = 0.0f, my_l1 = 0.0f, my_val = 0.0f;
-    int st_cnt = 0, st_len = 0, st_max = 0;
-    uint32_t urand[4] = {0, 0, 0, 0};
-    const bool keyed_actions = !forced_actions && !forced_uniforms;
-    if (keyed_actions && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
-
-    for (int t = -1; t < T; ++t) {
-        float rew = 0.0f, dn = 0.0f;
-        if (t >= 0) {
-            // ---- sample from the logits of obs[t], step the env (ppo.py:120-129) ----
-            const size_t row = (size_t)t * N + g;
-            float nl0, nl1, p0, p1, ent;
-            mi_categorical2_fast(my_l0, my_l1, nl0, nl1, p0, p1, ent);
-            int a;
-            if (forced_actions) a = (int)forced_actions[row];
-            else {
-                float u;
-                if (forced_uniforms) u = forced_uniforms[row];
-                else {
-                    const uint32_t wd = (uint32_t)stepctr & 3u;
-                    if (wd == 0) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
-                    u = mi_u32_to_uniform(wd == 0 ? urand[0] : wd == 1 ? urand[1] : wd == 2 ? urand[2] : urand[3]);
-                }
-                a = (u >= p0) ? 1 : 0;
-            }
-            stepctr += 1;
-            if (writer) { actions[row] = a; log_probs[row] = a ? nl1 : nl0; }  // ppo.py:123-124
-            int term;
-            mi_cartpole_step(sx, sxd, sth, sthd, a, term);
-            elapsed += 1;
-            const bool d = term || elapsed >= CP_MAX_STEPS;
-            epret += 1.0f;
-            eplen += 1;
-            if (d) {
-                if (writer) {
-                    st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
-                    if (max_ep > 0 && episode_stats) {
-                        const int slot = atomicAdd(episode_stats + 3, 1);
-                        if (slot < max_ep) episodes[slot] = mi_episode_t{g, t, epret, eplen};
-                    }
-                }
-                epret = 0.0f; eplen = 0; elapsed = 0;
-                double sr[4];
-                if (forced_resets) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sr[k] = forced_resets[4 * row + k];
-                } else {
-                    mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, sr);
-                }
-                episode += 1;
-                sx = sr[0]; sxd = sr[1]; sth = sr[2]; sthd = sr[3];
-            }
-            ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
-            rew = 1.0f; dn = d ? 1.0f : 0.0f;
-        }
-        // ---- this wave's net on obs[t+1] (ppo.py:115/139 critic, :120 actor of the next step) ----
-        const float b0 = lg == 0 ? ob.x : lg == 1 ? ob.y : lg == 2 ? ob.z : ob.w;
-        rm_f32x4 h1[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) h1[tt] = RM_MFMA(w1a[tt], b0, b1v[tt]);
-        rm_f32x4 h2[2] = {b2v[0], b2v[1]};
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h1[tt][r] = mi_tanhf(h1[tt][r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                h2[0] = RM_MFMA(w2a[0][tt][r], h1[tt][r], h2[0]);
-                h2[1] = RM_MFMA(w2a[1][tt][r], h1[tt][r], h2[1]);
-            }
-        }
-        float q0 = 0.0f, q1 = 0.0f;
-#pragma unroll
-        for (int TT = 0; TT < 2; ++TT)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float hv = mi_tanhf(h2[TT][r]);
-                q0 = __builtin_fmaf(w3v[TT][0][r], hv, q0); q1 = __builtin_fmaf(w3v[TT][1][r], hv, q1);
-            }
-        q0 += __shfl_xor(q0, 16); q0 += __shfl_xor(q0, 32);
-        q1 += __shfl_xor(q1, 16); q1 += __shfl_xor(q1, 32);
-        const int par = (t + 1) & 1;                             // alternate buffers: one barrier per step is enough
-        if (lg == 0) { hp[par][w][j][0] = q0; hp[par][w][j][1] = q1; }
-        __syncthreads();
-        my_l0 = (hp[par][0][j][0] + hp[par][1][j][0]) + b3a0;
-        my_l1 = (hp[par][0][j][1] + hp[par][1][j][1]) + b3a1;
-        my_val = (hp[par][2][j][0] + hp[par][3][j][0]) + b3c;
-        if (writer) {
-            const size_t row = (size_t)(t + 1) * N + g;
-            reinterpret_cast<float4*>(observations)[row] = ob;  // :113,:137 (the reset obs where done)
-            values[row] = my_val;                               // :115,:139
-            if (t >= 0) { rewards[row] = rew; dones[row] = dn; }  // :140-141
-        }
-        if (adv && w == 0 && lg == 0) { gv[t + 1][j] = my_val; gr[t + 1][j] = rew; gd[t + 1][j] = dn; }
-    }
-    if (adv && writer) {       // GAE over this lane's env (ppo.py:144-151; expression order of gae_kernel)
-        float last = 0.0f;
-        float vnext = gv[T][j];
-        adv[(size_t)T * N + g] = 0.0f;
-        returns[(size_t)T * N + g] = 0.0f + vnext;
-#pragma unroll 8
-        for (int t = T - 1; t >= 0; --t) {
-            const size_t c = (size_t)t * N + g;
-            const float vcur = gv[t][j];
-            const float a = gamma * (1.0f - gd[t + 1][j]);
-            const float b = vnext + lam * last;
-            float v = gr[t + 1][j] + a * b;
-            v = v - vcur;
-            adv[c] = v;
-            returns[c] = v + vcur;
-            last = v;
-            vnext = vcur;
-        }
-    }
-    if (w == 0 && lg == 0) {   // lanes 0..15 of wave 0: one flush per workgroup
-        if (episode_stats) {
-            int c = mine ? st_cnt : 0, l = mine ? st_len : 0, m = mine ? st_max : 0;
-#pragma unroll
-            for (int sft = 1; sft < 16; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
-            if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
-        }
-        if (mine) {   // carry-over `observation` and env state for the next rollout
-            e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
-            e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen;
-            e.episode[g] = episode; e.step_ctr[g] = stepctr;
-            reinterpret_cast<float4*>(obs_cur)[g] = ob;
-        }
-    }
-}
-
-// ---- round 2: 4 envs per actor / critic wave pair on the 16-block 4x4x1 MFMA ------------------------------------------------------
-// The 16-env workgroup above spends 2,900 of its ~4,000 cycles per step in the two nets although their MFMAs need 1,150: four waves
-// meet at a barrier every step, each evaluates half a net, and the critic sits on the critical path although nothing waits for a value
+// ---- 4 envs per actor / critic wave pair on the 16-block 4x4x1 MFMA ---------------------------------------------------------------
+// The r01 16-env workgroup spent 2,900 of its ~4,000 cycles per step in the two nets although their MFMAs need 1,150: four waves
+// met at a barrier every step, each evaluated half a net, and the critic sat on the critical path although nothing waits for a value
 // before the GAE scan.  This form cuts the dependency chain to what the algorithm needs:
 //   * a workgroup = 2 waves owns 4 envs: wave 0 = ACTOR (forward, draw, env step — NO global memory traffic inside its loop), wave 1 =
 //     CRITIC (forward on the observations the actor publishes through an LDS ring, ALL the storage writes, GAE scan at the end): a
@@ -713,47 +341,17 @@ static int rollout_impl(void* handle, const float* params, int T, float* obs_cur
     mi_env* e = (mi_env*)handle;
     hipStream_t s = (hipStream_t)stream;
     // statistics double-buffered by the caller (stats_next): episode_stats is zero on entry and this launch zeroes the other buffer — no reset launch
-#if !defined(ROLLOUT_VALU) && !defined(ROLLOUT_MFMA16)
     if (episode_stats && !stats_next) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
-#else
-    if (episode_stats) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
-    if (stats_next) { zero_i32x4_kernel<<<1, 64, 0, s>>>(stats_next); MI_LAUNCH_CHECK(); }
-#endif
     mi_prof_scope prof(MI_PROF_ROLLOUT, s);
-#if !defined(ROLLOUT_VALU) && !defined(ROLLOUT_MFMA16)
-    {
-        const bool forced = forced_actions || forced_uniforms || forced_resets, eplog = max_ep > 0 && episode_stats;
-        const dim3 grid((e->n + RQ_ENVS - 1) / RQ_ENVS);
-        const dim3 block(128);
+    const bool forced = forced_actions || forced_uniforms || forced_resets, eplog = max_ep > 0 && episode_stats;
+    const dim3 grid((e->n + RQ_ENVS - 1) / RQ_ENVS);
+    const dim3 block(128);
 #define RQ_LAUNCH(F, L) rollout_q4_kernel<F, L><<<grid, block, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, \
                                                                      forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep, \
                                                                      advantages, returns, gamma, lam, zero_f64, zero_n, stats_next)
-        if (forced) { if (eplog) RQ_LAUNCH(true, true); else RQ_LAUNCH(true, false); }
-        else { if (eplog) RQ_LAUNCH(false, true); else RQ_LAUNCH(false, false); }
+    if (forced) { if (eplog) RQ_LAUNCH(true, true); else RQ_LAUNCH(true, false); }
+    else { if (eplog) RQ_LAUNCH(false, true); else RQ_LAUNCH(false, false); }
 #undef RQ_LAUNCH
-    }
-    MI_LAUNCH_CHECK();
-    return MI_OK;
-#elif !defined(ROLLOUT_VALU)
-    rollout_mfma_kernel<<<(e->n + RM_ENVS - 1) / RM_ENVS, 256, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones,
-                                                                      forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep,
-                                                                      advantages, returns, gamma, lam, zero_f64, zero_n);
-    MI_LAUNCH_CHECK();
-    return MI_OK;
-#endif
-    if (zero_f64) MI_HIP(hipMemsetAsync(zero_f64, 0, sizeof(double) * (size_t)zero_n, s));
-    // the VALU formulation (-DROLLOUT_VALU, kept for A/B): E=2 halves the wave count (2 waves/SIMD at N=4096); E=1 for tiny N keeps every env on its own wave.
-    if (e->n >= 512) {
-        const int waves = (e->n + 1) / 2, blocks = (waves + ROLLOUT_WAVES - 1) / ROLLOUT_WAVES;
-        rollout_kernel<2><<<blocks, 64 * ROLLOUT_WAVES, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards,
-                                                                 dones, forced_actions, forced_uniforms, forced_resets, episodes,
-                                                                 episode_stats, max_ep);
-    } else {
-        const int blocks = (e->n + ROLLOUT_WAVES - 1) / ROLLOUT_WAVES;
-        rollout_kernel<1><<<blocks, 64 * ROLLOUT_WAVES, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards,
-                                                                 dones, forced_actions, forced_uniforms, forced_resets, episodes,
-                                                                 episode_stats, max_ep);
-    }
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -766,21 +364,17 @@ extern "C" int mi_ppo_rollout(void* handle, const float* params, int T, float* o
                         episodes, episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, nullptr, 0, nullptr, stream);
 }
 
-// rollout + GAE (ppo.py:110-151): the rollout workgroups scan their own envs at the end of the launch (T <= 128; otherwise, and in the
-// -DROLLOUT_VALU build, mi_gae runs as a launch of its own).  advantages / returns: dev f32 [T+1, N], bit-identical to mi_gae's.
-// rollout + GAE (ppo.py:110-151): the rollout workgroups scan their own envs at the end of the launch (T <= 128; otherwise, and in the
-// -DROLLOUT_VALU build, mi_gae runs as a launch of its own).  advantages / returns: dev f32 [T+1, N], bit-identical to mi_gae's.
+// rollout + GAE (ppo.py:110-151): the rollout workgroups scan their own envs at the end of the launch (T <= RQ_GAE_T; otherwise mi_gae runs
+// as a launch of its own).  advantages / returns: dev f32 [T+1, N], bit-identical to mi_gae's.
 // internal (mi_ppo_update): additionally zero-fills an fp64 scratch the following launches accumulate into (saves the memset launch)
 int mi_rollout_gae_internal(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values,
                             int64_t* actions, float* log_probs, float* rewards, float* dones, mi_episode_t* episodes,
                             int32_t* episode_stats, int max_ep, float gamma, float gae_lambda, float* advantages, float* returns, double* zero_f64, int zero_n,
                             int32_t* stats_next, void* stream) {
     MI_CHECK_ARG(advantages && returns, "NULL advantages / returns");
-#ifndef ROLLOUT_VALU
-    if (T <= RM_GAE_T)
+    if (T <= RQ_GAE_T)
         return rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
                             episode_stats, max_ep, advantages, returns, gamma, gae_lambda, zero_f64, zero_n, stats_next, stream);
-#endif
     const int rc = rollout_impl(handle, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, nullptr, nullptr, nullptr, episodes,
                                 episode_stats, max_ep, nullptr, nullptr, 0.0f, 0.0f, zero_f64, zero_n, stats_next, stream);
     if (rc) return rc;

@@ -154,7 +154,7 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 //     dh1^T = W2^T dz2^T      64 MFMA     B operand = dz2's registers as they stand
 //     dW2 += dz2^T h1         64 MFMA     both operands re-read transposed through a wave-private LDS tile
 //     dW1 += dz1^T x           16 v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1 row)
-//     dW3 += dout^T h2         16 / 32 FMAs per lane on its own row and units (summed over the rows at exit; GRAD_DW3_VALU)
+//     dW3 += dout^T h2         16 / 32 FMAs per lane on its own row and units (summed over the rows at exit)
 // "As they stand": a 16x16 accumulator tile mt holds, in lane (j = row = lane&15, g = lane>>4), register r, the hidden
 // unit 16mt + 4g + r.  An MFMA sums over k in ANY order as long as A and B agree, so k-step s of the next product
 // takes B from register (s&3) of tile (s>>2) and A = W[..][16(s>>2) + 4g + (s&3)] — no lane movement, no LDS
@@ -167,7 +167,7 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 //   W2t[(o>>2)][i][o&3]  =   W2[o][i]   the same for dh1 = W2^T dz2 (A[i][k = o]): 16 ds_read_b128 per tile instead of 64 ds_read_b32
 //   bufA / bufB [row][68]               wave-private staging images; the dW2 k-step s takes rows s + 4g (NOT 4s + g: lane groups g, g+1
 //                                       must sit 16 banks apart — (s+4g)*68 = 4s + 16g mod 32 — which removed the 2-way conflict of r01)
-// c = 2 log2(e) (GRAD_PRESCALE): the tanh argument scale is folded into W1, b1, W2, b2 when they are staged, so tanh is
+// c = 2 log2(e): the tanh argument scale is folded into W1, b1, W2, b2 when they are staged, so tanh is
 // 4 instructions (v_exp, v_add, v_rcp, v_fma) on z' = c z; the backward products use the unscaled W2t.
 //
 // 16-row tiles keep an activation in 16 registers (a 32-row tile on 32x32x2 spilled 100 VGPRs at 2 waves/SIMD and
@@ -184,33 +184,16 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 // mi_ppo_update therefore runs 2 launches per optimizer step (gradient, slab sum) instead of 3.
 // =====================================================================================================
 #define W2S 68  // padded LDS row stride in floats: 68 = 4 (mod 32) keeps b128 row writes and b32 row reads conflict-free
-#ifndef GRAD_WAVES
-#define GRAD_WAVES 8      // waves per workgroup: 8 = ONE 512-thread workgroup per CU (two waves per SIMD share one staged copy of the weights, half as
-                          // many slabs to write and to sum, half the prologue traffic); 4 = the r01 form, two workgroups per CU (A/B switch)
-#endif
-#define GRAD_WPS 2        // waves per SIMD the kernel is built for
+// Fixed design constants.  Each was an A/B switch in rounds 1-2; the alternatives are recorded negatives (profiles/r02a_grad_stamps.txt) and were
+// retired in round 3: 4 waves per workgroup / two workgroups per CU (+0 %, twice the slabs), a start-time stagger between co-resident workgroups (no effect),
+// alternating s_setprio per tile (no effect), other role bits (+-1 %), unscaled tanh (5 instead of 4 instructions), dW3 on the 4x4x1 MFMA from an LDS image
+// (one staging image and a 16-MFMA chain more), LLVM's iglp_opt(0/1) on the tile body (no effect).
+#define GRAD_WAVES 8        // ONE 512-thread workgroup per CU: two waves per SIMD share one staged copy of the weights
+#define GRAD_WPS 2          // waves per SIMD the kernel is built for
 #define GRAD_OCC (GRAD_WPS * 4 / GRAD_WAVES)   // workgroups per CU
-#ifndef GRAD_STAGGER
-#define GRAD_STAGGER 0    // diagnostic: s_sleep(127) count the second-round workgroups wait before their first tile
-#endif
-#ifndef GRAD_OLD_SHARE
-#define GRAD_OLD_SHARE 10 // of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves
-#endif
-#ifndef GRAD_ROLE_BIT
-#define GRAD_ROLE_BIT 3   // which blockIdx bit selects actor / critic (bit 0 would pin one net per XCD)
-#endif
-#ifndef GRAD_ALT_PRIO
-#define GRAD_ALT_PRIO 0   // 1: the two waves sharing a SIMD take turns at s_setprio 1, tile by tile
-#endif
-#ifndef GRAD_PRESCALE
-#define GRAD_PRESCALE 1   // fold tanh's 2 log2(e) into the staged W1 / b1 / W2 / b2
-#endif
-#ifndef GRAD_ACTOR_EXTRA
-#define GRAD_ACTOR_EXTRA 2   // per 128 workgroups: how many more serve the actor than the critic (0 = even split)
-#endif
-#ifndef GRAD_DW3_VALU
-#define GRAD_DW3_VALU 1   // 1: dW3 as per-lane VALU partial sums (no h2 staging image, no 4x4x1 chain); 0: the r01 form (16 4x4x1 MFMAs from an LDS image)
-#endif
+#define GRAD_OLD_SHARE 10   // of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves (age arbitration: -3 %)
+#define GRAD_ROLE_BIT 3     // which blockIdx bit selects actor / critic (bit 0 would pin one net per XCD)
+#define GRAD_ACTOR_EXTRA 2  // per 128 workgroups: how many more serve the actor than the critic (an actor tile costs ~3.5 % more)
 #define TROWS 16
 #define PART_STRIDE 4624
 #define PART_LOSS 4610
@@ -218,7 +201,6 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #define GRAD_SPARE_SLABS 16                 // the workspace's last slabs hold mi_ppo_update's two spare optimizer-state sets
 #define RED_STRIDE 4640                     // per-wave slot of the exit reduction: 4096 dW2 + 544 small values
 #define STATE_STRIDE 9216                   // floats between params / exp_avg / exp_avg_sq inside a spare set
-static_assert(GRAD_WAVES == 4 || GRAD_WAVES == 8, "GRAD_WAVES");
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -226,18 +208,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
-// tanh of z given z' = z * 2 log2(e) (GRAD_PRESCALE) — the same function as mi_tanhf, with the scale already applied by the weights
+// tanh of z given z' = z * 2 log2(e) — the same function as mi_tanhf, with the scale already applied by the weights
 __device__ __forceinline__ float tanh_prescaled(float zs) {
     const float e = __builtin_amdgcn_exp2f(zs);
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
-#if GRAD_PRESCALE
 #define GRAD_TANH(x) tanh_prescaled(x)
 #define GRAD_PS 2.8853900817779268f
-#else
-#define GRAD_TANH(x) mi_tanhf(x)
-#define GRAD_PS 1.0f
-#endif
 
 // ---- GRAD_BX (experiment): the two contractions whose B operand is an activation in accumulator registers (layer 2 forward,
 // dh1 backward) on v_mfma_f32_16x16x32_bf16 with BOTH operands split into three bf16 parts (x = hi + mid + lo exactly up to 2^-27 |x|) and six products
@@ -520,7 +497,7 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
     const int need = 2 * ((tiles + GRAD_WAVES - 1) / GRAD_WAVES);
     if (need < blocks) blocks = need;  // (the role swizzle falls back to identity when the grid is not a multiple of 2^(bit+1))
     // full grids: the actor gets GRAD_ACTOR_EXTRA of every 128 workgroups more than the critic (see grad_role)
-    const int extra = (GRAD_WAVES == 8 && blocks == grad_blocks() && blocks >= 128) ? GRAD_ACTOR_EXTRA * (blocks / 128) / 2 : 0;
+    const int extra = (blocks == grad_blocks() && blocks >= 128) ? GRAD_ACTOR_EXTRA * (blocks / 128) / 2 : 0;
     {
         mi_prof_scope prof(MI_PROF_GRAD, s);
         if (g_contraction == MI_CONTRACTION_BF16X3)

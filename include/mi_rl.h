@@ -48,7 +48,10 @@
 extern "C" {
 #endif
 
-#define MI_VERSION 100
+/* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
+ * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count).  Bindings must compare mi_version()
+ * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
+#define MI_VERSION 101
 #define MI_PPO_NPARAMS 9155
 #define MI_PPO_ACTOR_NPARAMS 4610
 #define MI_OBS_DIM 4

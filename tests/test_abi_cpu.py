@@ -29,7 +29,7 @@ def test_header_symbols_all_exported_and_bound(N):
     for name in declared:
         assert hasattr(L, name), "libmirl.so does not export %s" % name
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
-    assert N.lib().mi_version() == 100
+    assert N.lib().mi_version() == N.ABI_VERSION == int(re.search(r"#define MI_VERSION (\d+)", hdr).group(1))
 
 
 def test_struct_layouts_match_header(N):

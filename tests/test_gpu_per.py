@@ -78,6 +78,44 @@ def test_sampler_and_weights_bit_exact_indices(dev, R, n_envs, slots, frac):
     assert np.allclose(eng.weights.cpu().numpy(), R.per_weights(prio, mine, ALPHA, np.float32(eng.beta()), total_alpha, n), rtol=2e-5)
 
 
+def test_alpha_zero_is_uniform_per_not_nan(dev, R):
+    """alpha = 0 (uniform PER, a legitimate per.py setting): 0^0 := 0, so never-written entries and the write head contribute +0 and
+    nothing becomes NaN; every importance weight is exactly 1 (per.py:145-146 normalises by the maximum); indices bit-exact vs the oracle; the
+    incremental sums of a ring that fills under acting + training equal a full pass."""
+    n_envs, slots = 64, 64
+    eng = _engine(dev, n_envs, slots, seed=9, batch_size=256, total_timesteps=10 * slots, alpha=0.0)
+    rng = np.random.default_rng(3)
+    cap = slots * n_envs
+    prio = rng.gamma(0.5, 1.0, cap).astype(np.float32)
+    prio[rng.random(cap) < 0.2] = 0.0
+    prio[40 * n_envs:] = 0.0
+    eng.priorities.copy_(torch.from_numpy(prio.reshape(slots, n_envs)))
+    eng.refresh_sums()
+    eng.global_step = 40
+    eng.update_index = 5
+    eng.sample()
+    n = 40 * n_envs
+    s0, s1, total, total_alpha = R.per_sums(prio, n, 0.0)
+    assert total_alpha == float((prio[:n] > 0).sum())          # p^0 = 1 for written entries, 0 for the rest
+    ws = eng._per_ws.view(torch.float64)
+    assert torch.isfinite(ws[:2 * ((cap + 63) // 64)]).all()
+    got = eng.batch_inds.cpu().numpy()
+    assert np.array_equal(got, R.per_sample(9, 5, prio, n, s0, s1, total, 256)) and (prio[got] > 0).all()
+    w = eng.weights.cpu().numpy()
+    assert (w == 1.0).all()
+    assert np.array_equal(w, R.per_weights(prio, got, 0.0, np.float32(eng.beta()), total_alpha, n))
+    # production acting + training at alpha = 0: finite, incremental == full pass
+    eng2 = _engine(dev, 64, 37, seed=4, batch_size=128, learning_starts=0, total_timesteps=3700, alpha=0.0)
+    eng2.reset()
+    for it in range(8):
+        eng2.act(10); eng2.train_step()
+    inc = eng2._per_ws.clone()
+    eng2.refresh_sums()
+    n0 = (37 * 64 + 63) // 64; n1 = (n0 + 63) // 64
+    assert torch.equal(inc.view(torch.float64)[:2 * n0 + 2 * n1], eng2._per_ws.view(torch.float64)[:2 * n0 + 2 * n1])
+    assert bool(torch.isfinite(eng2.weights).all()) and bool(torch.isfinite(eng2.q.flat).all()) and float(eng2.weights.max()) == 1.0
+
+
 def test_scatter_last_duplicate_wins_and_max_priority(dev, R):
     eng = _engine(dev, 5, 100, batch_size=512)
     rng = np.random.default_rng(1)

@@ -141,3 +141,21 @@ def test_sampler_contract():
     top = np.argsort(prio[:n])[-5:]
     for t in top:
         assert abs((idx == t).mean() - prio[t] / total) < 6 * np.sqrt(prio[t] / total / idx.size)
+
+
+def test_alpha_zero_convention():
+    """0^alpha := 0 for every alpha (ref_per_pow): at alpha = 0 the sum counts the written entries only and every weight is exactly 1 — what per.py:145-146
+    gives under torch's 0 ** 0 = 1 as well, because the weights are normalised by their maximum."""
+    rng = np.random.default_rng(2)
+    n = 5000
+    prio = rng.gamma(0.5, 1.0, n).astype(np.float32)
+    prio[rng.random(n) < 0.3] = 0.0
+    s0, s1, total, total_alpha = R.per_sums(prio, n, 0.0)
+    assert total_alpha == float((prio > 0).sum()) and np.isfinite(total)
+    idx = R.per_sample(1, 0, prio, n, s0, s1, total, 256)
+    w = R.per_weights(prio, idx, 0.0, np.float32(0.4), total_alpha, n)
+    assert (w == 1.0).all()
+    # torch's convention on the same data: a different (larger) sum, identical weights
+    torch_sum = float(n)
+    w_torch = (np.float32(n) * (np.float32(1.0) / np.float32(torch_sum))) ** np.float32(-0.4)
+    assert w_torch / w_torch == 1.0

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import deep_rl_amd as D
 
-WAVES = int(os.environ.get("GRAD_WAVES", "8"))
+WAVES = 8   # GRAD_WAVES (fixed since round 3)
 dev = torch.device("cuda", 0)
 env = D.make("CartPole-v1", num_envs=4096, device=dev, seed=1)
 torch.manual_seed(1)
