@@ -2,7 +2,10 @@
 """bench.py — headline benchmark: PPO / CartPole-v1 at 4096 envs per GPU (BASELINE.json configs[1] / [4]).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    N > 1 without WORLD_SIZE in the environment: this process — before it imports torch or touches a GPU — starts
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py --gpus N ...
+    as a CHILD process (never exec), relays rank 0's JSON line and exits with the child's return code.  Launched by the driver through
+    torch.distributed.run itself (WORLD_SIZE set), it is a rank.
 
 One "step" = one outer update of reference ppo.py:105-192 over synthetic CartPole data: a 128-step rollout of
 4096 envs (on-device env.step, keyed RNG), the GAE scan, and 4 epochs x 4 minibatches of 131,072 rows
@@ -282,6 +285,84 @@ def cpu_baseline_sac(actor0, q0, envs, slots, batch, min_seconds):
             "sample": "%d loop iterations (1 step x %d envs + critic / actor / alpha update each) in %.1f s, C oracle, OpenMP over envs / rows" % (gs, envs, dt)}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1: start the N ranks as a child process and relay rank 0's line.  The parent makes no GPU call
+    and never replaces itself (a process that has initialised HIP must not exec; this one has not even imported torch)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the pool's driver only supports dmabuf IPC (RCCL / CUDA-tensor sharing)
+    env.setdefault("OMP_NUM_THREADS", "1")              # what torch.distributed.run would set itself (with a warning)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = 0
+    for line in child.stdout:               # rank 0 prints exactly one JSON line; anything else a rank writes to stdout goes to our stderr
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line); sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, saw %d\n" % lines)
+        return 1
+    return rc
+
+
+def collective_diagnostics(eng, comm, world, dev, breakdown, n_break):
+    """What the sharded update's 17 collectives cost, so that a scaling run carries its own diagnosis:
+      in_update   the in-stream ncclAllReduce calls bracketed by HIP events INSIDE the update (mi_prof tags comm_grad / comm_stats; native route only):
+                  includes waiting for the slowest rank's gradient launch, i.e. the exposed cost on the critical path
+      back_to_back  100 all-reduces of the same 9,159-float buffer on an otherwise idle stream through the carrier in use: the collective's own latency"""
+    import ctypes as C
+
+    import torch
+
+    from deep_rl_amd import _native as N
+    from deep_rl_amd import dist as DD
+
+    out = {"per_update": 17, "grad_allreduce": {"count_per_update": 16, "elements": N.NPARAMS + 4, "bytes": 4 * (N.NPARAMS + 4), "dtype": "f32"},
+           "stats_allreduce": {"count_per_update": 1, "elements": eng._adv_sums_all.numel(), "bytes": 8 * eng._adv_sums_all.numel(), "dtype": "f64"}}
+    if comm is not None:
+        ws, rk, ver, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        N.check(N.lib().mi_comm_info(comm, C.byref(ws), C.byref(rk), C.byref(ver), C.byref(cnt)), "mi_comm_info")
+        out["carrier"] = "RCCL direct (rccl.h via libmirl mi_comm, in-stream ncclAllReduce inside ONE C call per update)"
+        out["rccl_version"] = ver.value
+        out["rccl_comm_count"] = cnt.value
+        g, st = breakdown.get("comm_grad", (0.0, 0)), breakdown.get("comm_stats", (0.0, 0))
+        out["in_update"] = {"us_per_allreduce_grad": round(1e3 * g[0] / max(g[1], 1), 2), "us_per_allreduce_stats": round(1e3 * st[0] / max(st[1], 1), 2),
+                            "ms_per_update": round((g[0] + st[0]) / max(n_break, 1), 4), "samples": [g[1], st[1]],
+                            "note": "HIP events around each in-stream ncclAllReduce inside the update: includes the wait for the slowest rank (exposed cost)"}
+    else:
+        out["carrier"] = "torch.distributed %s (host-sequenced: 17 all_reduce calls between the launches)" % torch.distributed.get_backend()
+    buf, sums = torch.zeros(N.NPARAMS + 4, device=dev), torch.zeros_like(eng._adv_sums_all)
+
+    def once(t, dtype):
+        if comm is not None:
+            N.check(N.lib().mi_comm_allreduce_sum(comm, N.ptr(t), t.numel(), dtype, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+        else:
+            DD.allreduce_sum_(t, eng.pg)
+    b2b = {}
+    for name, t, dtype in (("us_per_allreduce_grad", buf, 0), ("us_per_allreduce_stats", sums, 1)):
+        for _ in range(10):
+            once(t, dtype)
+        torch.cuda.synchronize(); torch.distributed.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            once(t, dtype)
+        torch.cuda.synchronize()
+        b2b[name] = round(1e6 * (time.perf_counter() - t0) / 100, 2)
+    b2b["note"] = "100 back-to-back all-reduces on an idle stream, wall clock / 100, this rank"
+    out["back_to_back"] = b2b
+    out["world_size"] = world
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +371,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the config-3 (DQN) / config-4 (SAC) extra keys")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
 
@@ -365,7 +449,9 @@ def main():
     breakdown = N.prof_end()
 
     from deep_rl_amd import dist as _dist
-    eng_native = world > 1 and _dist.native_comm(eng.pg) is not None
+    comm = _dist.native_comm(eng.pg) if world > 1 else None
+    eng_native = comm is not None
+    collectives = collective_diagnostics(eng, comm, world, dev, breakdown, 3) if world > 1 else None   # every rank takes part in the collectives
     finite = bool(torch.isfinite(agent.flat).all().item())
     ep = stats_host.tolist()
     if rank == 0:
@@ -404,6 +490,8 @@ def main():
             "last_rollout": {"episodes": ep[0], "mean_return": round(ep[1] / max(ep[0], 1), 2), "max_return": ep[2]},
             "params_finite": finite,
         }
+        if collectives is not None:
+            out["collectives"] = collectives
         if variant is not None:
             v_dt, v_prof = variant
             vg_ms, vg_n = v_prof["grad"]

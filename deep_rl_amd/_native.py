@@ -37,7 +37,7 @@ class PPOBuffers(C.Structure):
 
 class SacOwedAlpha(C.Structure):   # mi_sac_owed_alpha_t
     _fields_ = [("log_alpha", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("alpha", C.c_void_p), ("out", C.c_void_p),
-                ("target_entropy", C.c_float), ("step", C.c_int64), ("lr", C.c_double), ("update_index", C.c_uint64)]
+                ("target_entropy", C.c_float), ("step", C.c_int64), ("lr", C.c_double), ("update_index", C.c_uint64), ("epoch", C.c_int32), ("stash_slot", C.c_int32)]
 
 
 class PPOHparams(C.Structure):
@@ -57,6 +57,7 @@ SIGNATURES = {
     "mi_env_destroy": (_I, [_VP]),
     "mi_env_reset": (_I, [_VP, _VP, _VP, _VP]),
     "mi_env_step": (_I, [_VP] * 10),
+    "mi_env_step_ex": (_I, [_VP] * 11),
     "mi_env_get_state": (_I, [_VP, _VP, _VP, _VP]),
     "mi_ppo_forward": (_I, [_VP, _VP, _I, _VP, _VP, _VP]),
     "mi_ppo_rollout": (_I, [_VP, _VP, _I] + [_VP] * 12 + [_I, _VP]),
@@ -75,7 +76,7 @@ SIGNATURES = {
     "mi_comm_unique_id": (_I, [_VP]),
     "mi_comm_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
     "mi_comm_destroy": (_I, [_VP]),
-    "mi_comm_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "mi_comm_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "mi_comm_allreduce_sum": (_I, [_VP, _VP, _SZ, _I, _VP]),
     "mi_dqn_forward": (_I, [_VP, _VP, _I, _VP, _VP]),
     "mi_dqn_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP]),
@@ -113,6 +114,11 @@ SIGNATURES = {
     "mi_sac_actor_update_owed": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _VP, _VP]),
     "mi_sac_alpha_step_owed": (_I, [_VP, _I, _U64, _VP, _VP, _VP]),
     "mi_sac_owed_alpha_fits": (_I, [_I]),
+    "mi_sac_check": (_I, [_VP, _I]),
+    "mi_sac_clear_error": (_I, [_VP, _I, _VP]),
+    "mi_sac_set_max_cus": (_I, [_I]),
+    "mi_sac_usable_cus": (_I, []),
+    "mi_sac_test_fault": (_I, [_I]),
     "mi_sac_alpha_step": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP, _VP]),
     "mi_sac_mean_logp": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _D, _VP, _VP, _VP]),
     "mi_sac_alpha_adam": (_I, [_VP, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP]),
@@ -191,7 +197,7 @@ def stream_ptr(device=None):
 
 
 PROF_TAGS = ("rollout", "gae", "grad", "reduce", "clip_adam", "stats", "dqn_act", "dqn_td", "dqn_reduce", "per",
-             "sac_act", "sac_critic", "sac_actor", "sac_gemm", "sac_assemble", "sac_logp")   # == enum MI_PROF_* of include/mi_rl.h
+             "sac_act", "sac_critic", "sac_actor", "sac_gemm", "sac_assemble", "sac_logp", "comm_grad", "comm_stats")   # == enum MI_PROF_* of include/mi_rl.h
 
 
 def prof_begin(max_launches, tags=None):

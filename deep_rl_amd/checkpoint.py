@@ -130,6 +130,7 @@ def load(path, engine):
             if name in z:
                 getattr(engine, name).copy_(t(name))
     else:
+        engine.drop_owed()   # a pending alpha debt / stash belongs to the state being replaced (the in-launch epoch counter is engine-private and keeps growing)
         engine.actor.flat.copy_(t("actor")); engine.q_flat.copy_(t("q")); engine.qt_flat.copy_(t("q_target"))
         engine.log_alpha.copy_(t("log_alpha")); engine.alpha.copy_(t("alpha")); engine._alpha_m.copy_(t("alpha_m")); engine._alpha_v.copy_(t("alpha_v"))
         engine.alpha_steps, engine.global_step = int(z["alpha_steps"]), int(z["global_step"])

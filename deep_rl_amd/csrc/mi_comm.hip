@@ -17,6 +17,7 @@ struct rccl_api_t {
     decltype(&ncclAllReduce) AllReduce;
     decltype(&ncclGetErrorString) GetErrorString;
     decltype(&ncclGetVersion) GetVersion;
+    decltype(&ncclCommCount) CommCount;
 };
 static rccl_api_t g_rccl = {};
 
@@ -35,6 +36,7 @@ static int rccl_bind() {
     a.AllReduce = (decltype(a.AllReduce))dlsym(so, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(so, "ncclGetErrorString");
     a.GetVersion = (decltype(a.GetVersion))dlsym(so, "ncclGetVersion");
+    a.CommCount = (decltype(a.CommCount))dlsym(so, "ncclCommCount");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
         mi_set_error("mi_comm: librccl.so lacks an ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce entry point");
         return MI_ESTATE;
@@ -88,12 +90,13 @@ extern "C" int mi_comm_destroy(void* comm) {
     return MI_OK;
 }
 
-extern "C" int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version) {
+extern "C" int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version, int* comm_count) {
     MI_CHECK_ARG(comm != nullptr, "comm is NULL");
     mi_comm* c = (mi_comm*)comm;
     if (world_size) *world_size = c->world;
     if (rank) *rank = c->rank;
     if (rccl_version) { int v = 0; if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&v); *rccl_version = v; }
+    if (comm_count) { int n = -1; if (g_rccl.CommCount && g_rccl.CommCount(c->comm, &n) != ncclSuccess) n = -1; *comm_count = n; }
     return MI_OK;
 }
 

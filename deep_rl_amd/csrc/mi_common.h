@@ -71,7 +71,6 @@ int mi_rollout_gae_internal(void* handle, const float* params, int T, float* obs
                             float* rewards, float* dones, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, float gamma, float gae_lambda,
                             float* advantages, float* returns, double* zero_f64, int zero_n, int32_t* stats_next, void* stream);
 
-extern "C" int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version);
 int mi_comm_allreduce_impl(void* comm, void* buf, size_t n, int dtype /* 0 f32, 1 f64 */, hipStream_t s);   // mi_comm.hip
 
 // ---- RNG contract (include/mi_rl.h) ----------------------------------------------------------------

@@ -37,12 +37,13 @@ __global__ void __launch_bounds__(256) env_reset_kernel(mi_env e, float* __restr
 __global__ void __launch_bounds__(256)
 env_step_kernel(mi_env e, const int64_t* __restrict__ actions, const double* __restrict__ forced_reset, float* __restrict__ obs,
                 float* __restrict__ reward, uint8_t* __restrict__ done, uint8_t* __restrict__ truncated,
-                float* __restrict__ fin_ret, int32_t* __restrict__ fin_len) {
+                float* __restrict__ fin_ret, int32_t* __restrict__ fin_len, float* __restrict__ raw_obs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.n) return;
     double s[4] = {e.x[i], e.x_dot[i], e.theta[i], e.theta_dot[i]};
     int term;
     mi_cartpole_step(s[0], s[1], s[2], s[3], (int)actions[i], term);
+    if (raw_obs) reinterpret_cast<float4*>(raw_obs)[i] = make_float4((float)s[0], (float)s[1], (float)s[2], (float)s[3]);   // what gym's env.step returned, before ppo.py:128-129's reset
     const int el = e.elapsed[i] + 1;
     int trunc = 0, d = term;
     if (el >= CP_MAX_STEPS) { trunc = !term; d = 1; }
@@ -157,7 +158,20 @@ extern "C" int mi_env_step(void* handle, const int64_t* actions, const double* f
     mi_env* e = (mi_env*)handle;
     MI_CHECK_ARG(e->kind == MI_ENV_CARTPOLE_V1, "discrete-action step on a continuous-action env (use mi_env_step_cont)");
     env_step_kernel<<<(e->n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*e, actions, forced_reset, obs, reward, done,
-                                                                        truncated, fin_ret, fin_len);
+                                                                        truncated, fin_ret, fin_len, nullptr);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+int mi_pend_step_ex_impl(mi_env* e, const float* actions, const double* forced_reset, float* obs, float* reward, uint8_t* done, uint8_t* truncated, float* fin_ret,
+                         int32_t* fin_len, float* raw_obs, hipStream_t s);   // mi_sac.hip
+extern "C" int mi_env_step_ex(void* handle, const void* actions, const double* forced_reset, float* obs, float* reward, uint8_t* done, uint8_t* truncated,
+                              float* fin_ret, int32_t* fin_len, float* raw_obs, void* stream) {
+    MI_CHECK_ARG(handle && actions && obs && reward && done && truncated && fin_ret && fin_len, "NULL pointer");
+    mi_env* e = (mi_env*)handle;
+    if (e->kind == MI_ENV_PENDULUM_V1)
+        return mi_pend_step_ex_impl(e, (const float*)actions, forced_reset, obs, reward, done, truncated, fin_ret, fin_len, raw_obs, (hipStream_t)stream);
+    env_step_kernel<<<(e->n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*e, (const int64_t*)actions, forced_reset, obs, reward, done, truncated, fin_ret, fin_len, raw_obs);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }

@@ -668,7 +668,7 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
 extern "C" int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* comm, void* stream) {
     int world = 1;
     if (comm) {
-        int rc = mi_comm_info(comm, &world, nullptr, nullptr);
+        int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr);
         if (rc) return rc;
         MI_CHECK_ARG(b && b->loss_terms == b->grads + NPARAMS, "sharded update: loss_terms must be grads + MI_PPO_NPARAMS (one buffer, one all-reduce)");
     }
@@ -707,6 +707,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
         if (rc) return rc;
     }
     if (comm) {   // global advantage mean / std (ppo.py:169 over the union minibatch): one SUM all-reduce of every epoch's local sums
+        mi_prof_scope prof(MI_PROF_COMM_STATS, s);
         rc = mi_comm_allreduce_impl(comm, b->adv_sums, (size_t)3 * hp->n_minibatch * hp->update_epochs, 1, s);
         if (rc) return rc;
     }
@@ -740,6 +741,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
                                  b->loss_terms, s);
             if (rc) return rc;
             if (comm) {   // gradient shares (already scaled by 1/(world*mb)) + the 4 loss-term shares: one SUM all-reduce (ppo.py:189 -> :191)
+                mi_prof_scope prof(MI_PROF_COMM_GRAD, s);
                 rc = mi_comm_allreduce_impl(comm, b->grads, (size_t)NPARAMS + 4, 0, s);
                 if (rc) return rc;
             }

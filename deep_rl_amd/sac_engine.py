@@ -43,8 +43,11 @@ class SACEngine:
         self._alpha_m_t = torch.zeros(1, dtype=torch.float32, device=dev)
         self._alpha_v_t = torch.zeros(1, dtype=torch.float32, device=dev)
         self._alpha_steps = 0
-        self._owed = None            # (update key of the owed step's log-prob draw)
+        self._owed = None            # (update key of the owed step's log-prob draw, stash slot holding its observations)
+        self._owed_epoch = 0         # owed steps handed to this workspace so far: the in-launch hand-off's epoch.  Engine-private and only ever grows — independent of
+                                     # alpha_steps, which checkpoint.load() and the alpha_steps setter may rewind (a rewound epoch let consumers skip the wait)
         self._stash_fresh = False
+        self._stash_slot = 0         # the stash slot the last fused actor update wrote
         self._owed_fits = bool(N.lib().mi_sac_owed_alpha_fits(self.batch_size))   # the carrying launch must leave half of the device's CUs free
         self.observations = torch.zeros((S, Nn, 3), dtype=torch.float32, device=dev)           # :126
         self.actions = torch.zeros((S, Nn), dtype=torch.float32, device=dev)                   # :127 (one action dim)
@@ -75,10 +78,17 @@ class SACEngine:
         if self._owed is None:
             return None
         self._alpha_steps += 1
+        self._owed_epoch += 1
+        key, slot = self._owed
         o = N.SacOwedAlpha(N.ptr(self._log_alpha), N.ptr(self._alpha_m_t), N.ptr(self._alpha_v_t), N.ptr(self._alpha), N.ptr(self._alpha_out),
-                           self.target_entropy, self._alpha_steps, self.alpha_lr, self._owed)
+                           self.target_entropy, self._alpha_steps, self.alpha_lr, key, ((self._owed_epoch - 1) % 0x7FFFFFFF) + 1, slot)
         self._owed = None
         return o
+
+    def drop_owed(self):
+        """Forget a pending alpha debt and the stash (the state is about to be replaced wholesale: checkpoint.load)."""
+        self._owed = None
+        self._stash_fresh = False
 
     def flush_alpha(self):
         """Run an owed alpha step now (a launch of its own)."""
@@ -86,6 +96,16 @@ class SACEngine:
         if o is not None:
             N.check(N.lib().mi_sac_alpha_step_owed(N.ptr(self.actor.flat), self.batch_size, self.env._seed, C.byref(o), N.ptr(self.workspace), self._s()),
                     "mi_sac_alpha_step_owed")
+
+    def check(self, wait=True):
+        """Raise MiError (MI_ESTATE) if a wait between the workgroups of one of this process's SAC launches has timed out (include/mi_rl.h: mi_sac_check);
+        wait=True synchronises the stream first."""
+        N.check(N.lib().mi_sac_check(self._s(), 1 if wait else 0), "mi_sac_check")
+
+    def clear_error(self):
+        """After restoring the state (e.g. checkpoint.load): clear the status word and the workspace's hand-off words."""
+        self.drop_owed()
+        N.check(N.lib().mi_sac_clear_error(N.ptr(self.workspace), self.batch_size, self._s()), "mi_sac_clear_error")
 
     def _settled(self, t):
         self.flush_alpha()
@@ -206,7 +226,9 @@ class SACEngine:
                 self.env._seed, self._key(self.actor_updates), N.ptr(self._alpha), N.ptr(self.workspace), N.ptr(self.actor_grads),
                 N.ptr(self.actor_out), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                 C.byref(owed) if owed is not None else None, self._s()), "mi_sac_actor_update_owed")
-            self._stash_fresh = True     # this launch stashed its batch observations: an alpha step may be owed on them
+            # this launch stashed its batch observations — in the slot a debt it carried did not read — so an alpha step may be owed on them
+            self._stash_slot = (owed.stash_slot ^ 1) if owed is not None else 0
+            self._stash_fresh = True
         else:
             self.actor_grad(eps)
             self.actor_optimizer.step(self.actor_grads)
@@ -217,7 +239,7 @@ class SACEngine:
             # keyed draws, single process, right after a fused actor update: the step is OWED — the next row-group launch (actor or critic update) carries its
             # log-prob pass on workgroups of its own and hands alpha to its consumers in the launch; reading the state (or flush_alpha()) settles it alone
             self.flush_alpha()
-            self._owed = self._key(self.actor_updates)
+            self._owed = (self._key(self.actor_updates), self._stash_slot)
             self._stash_fresh = False
             self.actor_updates += 1
             return

@@ -91,6 +91,11 @@ int mi_env_reset(void* handle, float* obs, const double* forced_state, void* str
  * (episode statistics of envs that finished this step, else 0). */
 int mi_env_step(void* handle, const int64_t* actions, const double* forced_reset, float* obs, float* reward,
                 uint8_t* done, uint8_t* truncated, float* fin_ret, int32_t* fin_len, void* stream);
+/* the same for either env kind (actions: dev i64 [N] for CartPole-v1, dev f32 [N] for Pendulum-v1; forced_reset f64 [N,4] / [N,2]) with one more output:
+ * raw_obs dev f32 [N,obs_dim] (nullable) = the observation gym's env.step returned BEFORE the script's `if done: observation = env.reset()` — the terminal
+ * observation the fused rollout / acting kernels never store.  Used by deep_rl_amd/trace.py to write a run in the golden fixtures' key layout. */
+int mi_env_step_ex(void* handle, const void* actions, const double* forced_reset, float* obs, float* reward, uint8_t* done, uint8_t* truncated,
+                   float* fin_ret, int32_t* fin_len, float* raw_obs, void* stream);
 /* debug/test: copy the float64 state out as dev f64 [N,4] and the TimeLimit counters as dev i32 [N] (nullable). */
 int mi_env_get_state(void* handle, double* state, int32_t* elapsed, void* stream);
 
@@ -200,7 +205,9 @@ int mi_ppo_update(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparam
 int mi_comm_unique_id(void* id128);
 int mi_comm_create(const void* id128, int world_size, int rank, void** comm);
 int mi_comm_destroy(void* comm);
-int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version); /* any out pointer may be NULL */
+/* world_size / rank: as given to mi_comm_create; rccl_version: ncclGetVersion; comm_count: the rank count RCCL itself reports for the communicator
+ * (ncclCommCount; -1 if the entry point is missing).  Any out pointer may be NULL. */
+int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version, int* comm_count);
 int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stream);
 int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* comm, void* stream);
 
@@ -364,6 +371,10 @@ int mi_sac_alpha_step(const float* actor, const float* observations, const int64
 typedef struct {
     float* log_alpha; float* exp_avg; float* exp_avg_sq; float* alpha; float* out /* nullable, [2] = {alpha_loss, d / d log_alpha} */;
     float target_entropy; int64_t step; double lr; uint64_t update_index /* key of the log-prob draw: the actor update's update_index */;
+    int32_t epoch;       /* the caller's count of owed steps handed to THIS workspace: strictly increasing from 1 (compared wrap-safely), independent of `step`
+                          * — a checkpoint load may rewind the Adam step number, never this counter */
+    int32_t stash_slot;  /* 0 / 1: which observation stash the debt reads.  mi_sac_actor_update_owed writes the OTHER slot when it carries a debt and slot 0 when it
+                          * carries none, so a debt always reads the observations of the actor update that created it, whatever was sampled since */
 } mi_sac_owed_alpha_t;
 int mi_sac_critic_update_owed(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
                               const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
@@ -374,7 +385,24 @@ int mi_sac_actor_update_owed(float* actor, const float* q, const float* observat
                              uint64_t update_index, const float* alpha, void* workspace, float* grads, float* out, float* exp_avg, float* exp_avg_sq,
                              int64_t step, double lr, double beta1, double beta2, double adam_eps, const mi_sac_owed_alpha_t* owed, void* stream);
 int mi_sac_alpha_step_owed(const float* actor, int batch, uint64_t seed, const mi_sac_owed_alpha_t* owed, void* workspace, void* stream);
-int mi_sac_owed_alpha_fits(int batch);   /* 1 when a launch at this batch may carry an owed alpha step on the current device (half of its CUs stay free) */
+int mi_sac_owed_alpha_fits(int batch);   /* 1 when a launch at this batch may carry an owed alpha step on the current device (half of its usable CUs stay free) */
+
+/* ---- waits between the workgroups of one SAC launch (sibling roles of a row group, the owed alpha step): every waiter only waits for workgroups that precede
+ * it in dispatch order, and every spin is bounded (100 ms of wall clock).  A wait that runs out stores a code in a host-pinned status word, takes NaN as the
+ * value (the launch's gradients, losses and stepped parameters come out NaN) and lets the kernel finish: the failure surfaces as MI_ESTATE from the NEXT
+ * mi_sac_* update call (a plain host read, no synchronisation) or from mi_sac_check.
+ *   mi_sac_check(stream, wait)        wait != 0: synchronise `stream` first.  MI_OK, or MI_ESTATE with mi_last_error() naming what was not published.
+ *   mi_sac_clear_error(ws, batch, s)  after the caller has restored its parameters / optimizer state: clears the status word and (workspace != NULL) zeroes
+ *                                     the workspace's hand-off words, ticket, stash and epoch word (synchronises `stream`).
+ *   mi_sac_set_max_cus(n)             how many CUs sibling roles may assume (0 = the device's count cut by HSA_CU_MASK / ROC_GLOBAL_CU_MASK, which
+ *                                     hipDeviceProp_t.multiProcessorCount does not see); steers performance only.  mi_sac_usable_cus() reports the figure in use.
+ *   mi_sac_test_fault(mode)           TEST HOOK: bit 0 = publishing siblings skip their hand-off words, bit 1 = the owed alpha role does not publish its epoch
+ *                                     (later launches then time out as they would if a producer never ran); 0 = off. */
+int mi_sac_check(void* stream, int wait);
+int mi_sac_clear_error(void* workspace, int batch, void* stream);
+int mi_sac_set_max_cus(int max_cus);
+int mi_sac_usable_cus(void);
+int mi_sac_test_fault(int mode);
 /* the same in two halves for sharded runs (all-reduce *mean_logp between them): mean_logp dev f32 [1] = inv_count * sum of this rank's
  * fresh log-probs; then the Adam step on log_alpha from the global mean. */
 int mi_sac_mean_logp(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
@@ -405,7 +433,9 @@ enum { MI_PROF_ROLLOUT = 0, MI_PROF_GAE = 1, MI_PROF_GRAD = 2, MI_PROF_REDUCE = 
        MI_PROF_DQN_ACT = 6, MI_PROF_DQN_TD = 7, MI_PROF_DQN_REDUCE = 8, MI_PROF_PER = 9,
        /* SAC (config 4): acting launch, row-group critic / actor kernels, dW2 GEMM, assembly (+ Adam + polyak), log-prob + alpha */
        MI_PROF_SAC_ACT = 10, MI_PROF_SAC_CRITIC = 11, MI_PROF_SAC_ACTOR = 12, MI_PROF_SAC_GEMM = 13, MI_PROF_SAC_ASSEMBLE = 14, MI_PROF_SAC_LOGP = 15,
-       MI_PROF_NTAGS = 16 };
+       /* the in-stream collectives of mi_ppo_update_sharded: the 9,159-float gradient all-reduce (16 per update), the advantage-statistics all-reduce (1) */
+       MI_PROF_COMM_GRAD = 16, MI_PROF_COMM_STATS = 17,
+       MI_PROF_NTAGS = 18 };
 int mi_prof_begin(int max_launches, uint32_t tag_mask);
 int mi_prof_end(float* total_ms, int32_t* count);
 

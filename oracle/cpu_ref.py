@@ -407,6 +407,19 @@ def dqn_act_steps(env, params, st, obs_cur, n_steps, global_step, learning_start
                                    _p(fa), _p(fr))
 
 
+def dqn_act_steps_log(env, params, st, obs_cur, n_steps, global_step, learning_starts=10_000, start_e=1.0, end_e=0.05,
+                      exploration_fraction=0.5, total_timesteps=100_000, forced_actions=None, forced_resets=None, max_ep=0):
+    """dqn_act_steps that also returns the finished episodes: -> ([(env, step_in_call, return, length)], count)."""
+    p = _c(params, np.float32); fa = _c(forced_actions, np.int64); fr = _c(forced_resets, np.float64)
+    eps = (Episode * max(max_ep, 1))()
+    f = lib().ref_dqn_act_steps_log
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int64] + [C.c_void_p] * 8 + [C.c_int]
+    n = f(env.h, _p(p), n_steps, global_step, st.slots, learning_starts, start_e, end_e, exploration_fraction, total_timesteps, _p(obs_cur), _p(st.observations),
+          _p(st.actions), _p(st.rewards), _p(st.terminated), _p(fa), _p(fr), C.cast(eps, C.c_void_p), max_ep)
+    return [(e.env, e.t, e.ret, e.len) for e in eps[: min(n, max_ep)]], n
+
+
 def dqn_sample(seed, update_index, upper_flat, batch):
     idx = np.empty(batch, np.int64)
     lib().ref_dqn_sample(seed, update_index, upper_flat, batch, _p(idx))

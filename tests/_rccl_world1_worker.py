@@ -24,9 +24,9 @@ dev = torch.device("cuda", local_rank)
 torch.cuda.set_device(dev)
 comm = DD.native_comm()
 assert comm is not None
-ws, rk, ver = N.C.c_int(), N.C.c_int(), N.C.c_int()
-N.check(N.lib().mi_comm_info(comm, N.C.byref(ws), N.C.byref(rk), N.C.byref(ver)), "mi_comm_info")
-assert ws.value == 1 and rk.value == 0 and ver.value > 0
+ws, rk, ver, cnt = N.C.c_int(), N.C.c_int(), N.C.c_int(), N.C.c_int()
+N.check(N.lib().mi_comm_info(comm, N.C.byref(ws), N.C.byref(rk), N.C.byref(ver), N.C.byref(cnt)), "mi_comm_info")
+assert ws.value == 1 and rk.value == 0 and ver.value > 0 and cnt.value == 1
 
 # the collective itself: in-stream, in place, f32 and f64
 x = torch.arange(9159, dtype=torch.float32, device=dev) * 0.25

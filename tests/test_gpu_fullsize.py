@@ -191,7 +191,91 @@ def test_dqn_fullsize_td_grad_vs_oracle(dev, R):
         assert np.array_equal(eng.grads.cpu().numpy(), g)
 
 
+def test_dqn_fullsize_act_vs_oracle(dev, R):
+    """dqn_act4_kernel (the fourth wave computes both CartPole successors) at BASELINE config 3's size — 4096 envs x 256 slots, 300 steps in 30 launches, epsilon
+    decaying through the run, the ring wrapping at step 256 — with the device's own actions replayed on the oracle's acting loop (reference dqn.py:86-108):
+    observations / actions / rewards / terminated of the whole 1,048,576-transition ring, the carried-over observation and the episode log bit-exact after
+    EVERY launch; the decisions themselves checked against the RNG contract and the oracle's Q-values on a sample of envs."""
+    import deep_rl_amd as D
+
+    n, S, ls, tt = 4096, 256, 100, 600
+    env = D.make("CartPole-v1", num_envs=n, device=dev, seed=2)
+    torch.manual_seed(2)
+    q = D.QNetwork(env); tgt = D.QNetwork(env)
+    rng = np.random.default_rng(11)
+    params = (q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    q.load_flat(params); tgt.load_flat(params)
+    eng = D.DQNEngine(env, q, tgt, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=S, batch_size=128, learning_starts=ls, total_timesteps=tt, max_episodes_logged=8192)
+    renv = R.VecCartPole(n, seed=2)
+    st = R.ReplayStorage(S, n)
+    obs_cur = renv.reset(); st.observations[0] = obs_cur
+    assert np.array_equal(eng.reset().cpu().numpy(), obs_cur)
+    gs, n_greedy, n_random, total_ep = 0, 0, 0, 0
+    for call in range(30):
+        obs_before = obs_cur.copy()
+        eng.act(10)
+        n_ep, eps = eng.drain_episodes()
+        fa = np.stack([eng.actions[(gs + s) % S].cpu().numpy() for s in range(10)])
+        reps, rn = R.dqn_act_steps_log(renv, params, st, obs_cur, 10, gs, learning_starts=ls, total_timesteps=tt, forced_actions=fa, max_ep=8192)
+        for name in ["observations", "actions", "rewards", "terminated"]:
+            assert np.array_equal(getattr(eng, name).cpu().numpy(), getattr(st, name)), (call, name)
+        assert np.array_equal(eng.observation.cpu().numpy(), obs_cur), call
+        assert n_ep == rn and sorted(eps) == sorted(reps), (call, n_ep, rn)
+        total_ep += n_ep
+        # the first decision of the launch against the contract (its observation is known: obs_before), 256 envs spread over the workgroups
+        e_ = np.float32(R.dqn_epsilon(gs, total_timesteps=tt))
+        qv = R.dqn_forward(params, obs_before)
+        for e in range(0, n, 16):
+            u, ra = R.dqn_explore_draw(2, e, gs)
+            if gs < ls or u < e_:
+                assert fa[0, e] == ra; n_random += 1
+            elif abs(qv[e, 0] - qv[e, 1]) > 1e-4:
+                assert fa[0, e] == int(qv[e, 1] > qv[e, 0]); n_greedy += 1
+        gs += 10
+    assert eng.global_step == 300 and total_ep > 20000 and st.terminated.sum() > 1000
+    assert n_greedy > 1000 and n_random > 2000, (n_greedy, n_random)
+
+
 # ------------------------------------------------------------------- SAC, config 4 -------------------------------------------------
+def test_sac_fullsize_act_vs_oracle(dev, R):
+    """sac_act_kernel at BASELINE config 4's size — 2048 Pendulum envs x 512 slots, 600 steps (the ring wraps at 512), 40 keyed warm-up steps then the actor with
+    supplied normal draws (reference sac.py:138-158).  Per step: the device's actions against the oracle's actor sample on the (bit-identical) observation <= 2e-6
+    (tanh-Gaussian through two 256-wide layers), then the oracle env is stepped with the DEVICE's actions: observations / rewards of the ring slot and the
+    carried-over observation bit-exact, nothing terminated, episode boundaries (TimeLimit 200) on the same steps."""
+    import deep_rl_amd as D
+
+    n, S, ls, steps = 2048, 512, 40, 600
+    env = D.make("Pendulum-v1", num_envs=n, device=dev, seed=6)
+    torch.manual_seed(6)
+    a = D.Actor(env)
+    qs = [D.SoftQNetwork(env) for _ in range(4)]
+    rng = np.random.default_rng(21)
+    a_p = (a.flat.cpu().numpy() + rng.normal(0, 0.03, R.AC_NPARAMS)).astype(np.float32)
+    a.load_flat(a_p)
+    eng = D.SACEngine(env, a, *qs, slots=S, batch_size=256, learning_starts=ls, max_episodes_logged=0)
+    ref = R.VecPendulum(n, seed=6)
+    obs = ref.reset()
+    assert np.array_equal(eng.reset().cpu().numpy(), obs)
+    worst, n_done = 0.0, 0
+    for t in range(steps):
+        eps = rng.standard_normal(n).astype(np.float32)
+        eng.act(forced_eps=torch.from_numpy(eps) if t >= ls else None)
+        a_dev = eng.actions[t % S].cpu().numpy()
+        if t >= ls:
+            ra, _ = R.sac_actor_sample(a_p, obs, eps)
+            worst = max(worst, float(np.abs(a_dev - ra).max()))
+        else:
+            assert a_dev.min() >= -2.0 and a_dev.max() < 2.0
+        obs, rew, done, _, _ = ref.step(a_dev)
+        n_done += int(done.sum())
+        s = (t + 1) % S
+        assert np.array_equal(eng.observations[s].cpu().numpy(), obs) and np.array_equal(eng.rewards[s].cpu().numpy(), rew), t
+        assert np.array_equal(eng.observation.cpu().numpy(), obs), t
+    assert worst <= 2e-6, worst
+    assert not eng.terminated.any() and n_done == 3 * n      # TimeLimit 200: every env finished exactly 3 episodes in 600 steps
+    assert np.abs(eng.actions.cpu().numpy()).max() <= 2.0
+
+
 def _rel(a, b):
     return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(np.asarray(b, np.float64)).max(), 1e-30)
 

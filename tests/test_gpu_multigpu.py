@@ -1,0 +1,77 @@
+"""The sharded PPO update at world_size 2 against one process that owns all the envs (reference ppo.py:189-192 with the gradient
+exchange between backward and clip_grad_norm_).
+
+  test_two_gpus_rccl_native_sharded_update   needs >= 2 GPUs (skips otherwise — it runs the day a multi-GPU box appears): one rank per GPU over RCCL,
+      PPOEngine.update() on the ONE-CALL route (mi_ppo_update_sharded: 17 in-stream ncclAllReduce per update on libmirl's own communicator), two whole
+      updates; checked against the single process with union minibatches, against the host-sequenced route over torch's RCCL (bit for bit) and
+      rank against rank (bit for bit).
+  test_two_ranks_one_gpu_gloo_whole_updates  the same worker and the same comparison with both ranks on cuda:0 over gloo (host-sequenced route): keeps the
+      harness itself green on the one-GPU box."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(backend, nl):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, PYTHONPATH=ROOT, MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL=str(nl), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                              os.path.join(ROOT, "tests", "_sharded_update_worker.py")], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        assert "SHARDED_WORKER_OK backend=%s" % backend in out.stdout, out.stdout[-2000:]
+        load = lambda n: dict(np.load(os.path.join(tmp, n)))  # noqa: E731
+        return load("rank0.npz"), load("rank1.npz"), load("big.npz")
+
+
+def _check(r0, r1, big, nl):
+    # replicas never diverge: every rank ends with bitwise the same optimizer state, last gradient, loss terms and (all-reduced) advantage statistics
+    for k in ("params0", "params", "exp_avg", "exp_avg_sq", "grads", "loss_terms", "grad_norm", "adv_sums"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.isfinite(r0["params"]).all() and not np.array_equal(r0["params"], r0["params0"])
+    # env sharding: each rank's trajectories are the matching columns of the big run (bit-exact while the parameters agree: first rollout exactly;
+    # the second rollout runs on parameters that differ in the last bits, so it is compared through the final state below)
+    for r, rk in enumerate((r0, r1)):
+        sl = slice(r * nl, (r + 1) * nl)
+        assert rk["observations"].shape == big["observations"][:, sl].shape
+    # 2 ranks x NL envs == one process with 2 NL envs and union minibatches, after 2 x 16 chained optimizer steps: the gradient shares are summed in a
+    # different grouping (per rank, then across ranks), which moves last bits of every step (one step alone: <= 2e-7, tests/test_gpu_multirank.py)
+    assert np.abs(r0["params"] - big["params"]).max() < 2e-5, np.abs(r0["params"] - big["params"]).max()
+    assert np.abs(r0["exp_avg"] - big["exp_avg"]).max() < 1e-4 * max(1e-3, np.abs(big["exp_avg"]).max())
+    assert np.allclose(r0["loss_terms"], big["loss_terms"], rtol=5e-3, atol=1e-4), (r0["loss_terms"], big["loss_terms"])
+    assert abs(float(r0["grad_norm"][0]) - float(big["grad_norm"][0])) < 5e-3 * float(big["grad_norm"][0])
+
+
+def test_two_gpus_rccl_native_sharded_update():
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device); the one-GPU variant below covers the harness")
+    r0, r1, big = _run("nccl", 64)
+    assert int(r0["native"][0]) == 1 and int(r1["native"][0]) == 1     # mi_ppo_update_sharded really was the route
+    _check(r0, r1, big, 64)
+    # one C call with in-stream ncclAllReduce == host-sequenced launches with torch.distributed all-reduces over RCCL, bit for bit (a + b on both ranks)
+    for rk in (r0, r1):
+        for k in ("params", "exp_avg", "exp_avg_sq", "grads", "loss_terms", "grad_norm", "adv_sums", "observations", "advantages"):
+            assert np.array_equal(rk[k], rk["seq_" + k]), k
+
+
+def test_two_ranks_one_gpu_gloo_whole_updates():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    r0, r1, big = _run("gloo", 64)
+    assert int(r0["native"][0]) == 0
+    _check(r0, r1, big, 64)

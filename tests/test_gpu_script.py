@@ -158,24 +158,34 @@ def test_bench_contract_line():
 
 
 def test_bench_two_ranks_code_path_on_one_gpu():
-    """The N > 1 path of bench.py (torch.distributed.run launch, barriers, MAX over ranks, one JSON line from rank 0, whole-job value)
-    with both ranks on cuda:0 over gloo — RCCL on 2..8 GPUs is the driver's run."""
+    """`python bench.py --gpus 2` as the driver types it: the parent (no GPU call, no torch import) starts the two ranks through torch.distributed.run as a
+    CHILD process, relays rank 0's one JSON line and returns the child's code.  Both ranks on cuda:0 over gloo here — RCCL on
+    2..8 GPUs is the driver's run (tests/test_gpu_multigpu.py covers it when >= 2 GPUs are visible)."""
     import json
-    import socket
     import torch
 
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, PYTHONPATH=ROOT, MIRL_BENCH_BACKEND="gloo", MIRL_BENCH_ONE_GPU="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]     # exactly one line on stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["params_finite"] is True
     assert abs(d["value"] - 2 * 2 * 128 * 4096 / (2 * d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]      # whole-job aggregate over both ranks
     assert "x2" in d["config"]["parallelism"] and d["roofline"]["launches"] == 2 * 16
+    c = d["collectives"]
+    assert c["per_update"] == 17 and c["world_size"] == 2 and "gloo" in c["carrier"] and c["grad_allreduce"]["bytes"] == 4 * 9159
+    assert c["back_to_back"]["us_per_allreduce_grad"] > 0 and c["back_to_back"]["us_per_allreduce_stats"] > 0
+
+
+def test_bench_self_launch_propagates_failure():
+    """The self-launching parent exits with the child's return code (here: every rank fails in init_process_group on an unknown backend) and prints no JSON line."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_BENCH_BACKEND="no-such-backend")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and out.stdout.strip() == "", (out.returncode, out.stdout[-500:])
