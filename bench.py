@@ -104,15 +104,30 @@ DQN_MACS_FWD = 4 * 120 + 120 * 84 + 84 * 2          # 10,728 per Q-network forwa
 SAC_MACS_NET = 4 * 256 + 256 * 256 + 256            # 66,816: critic (3+1 -> 256 -> 256 -> 1); the actor (3 -> 256 -> 256 -> 2 heads) has the same count
 
 
-def bench_dqn(dev, iters=300, cpu_seconds=3.0):
+def pmc_traffic(key):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/latest_pmc.json, written by tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of the same workloads) -> (bytes | None, source text | None).  Static: not measured in this run."""
+    pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    try:
+        j = json.load(open(pmc))
+        e = j.get(key)
+        if not e or e.get("hbm_bytes_per_launch") is None:
+            return None, None
+        return e["hbm_bytes_per_launch"], "profiles/latest_pmc.json[%s] (static: separate rocprofv3 --pmc passes, build %s; not measured in this run)" % (key, j.get("build", "?"))
+    except Exception:
+        return None, None
+
+
+def bench_dqn(dev, iters=300, cpu_seconds=3.0, batch=128):
     """dqn.py CartPole-v1, 4096 envs, 256-slot ring (1,048,576 transitions on HBM), batch 128, train every 10 steps (dqn.py:84-137).
-    One step = one loop iteration: 10 env steps of every env (one launch) + sample + TD update (+ target sync every 500 steps)."""
+    One step = one loop iteration: 10 env steps of every env (one launch) + sample + TD update (+ target sync every 500 steps).
+    batch != 128: the SCALED-batch line SURVEY.md §8d asks for beside the reference's batch (labelled as such by the caller)."""
     import torch
 
     import deep_rl_amd as D
     from deep_rl_amd import _native as N
 
-    envs, slots, batch = 4096, 256, 128
+    envs, slots = 4096, 256
     env = D.make("CartPole-v1", num_envs=envs, device=dev, seed=1)
     torch.manual_seed(1)
     q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
@@ -143,17 +158,20 @@ def bench_dqn(dev, iters=300, cpu_seconds=3.0):
     # work and the fraction below an upper bound too); TD = target forward + online forward + ~2x backward per batch row
     act_flops = 2 * DQN_MACS_FWD * envs * 10
     td_flops = 2 * DQN_MACS_FWD * 4 * batch
+    act_traffic, act_src = pmc_traffic("dqn_act4_kernel")
+    td_traffic, td_src = pmc_traffic("dqn_td_kernel@%d" % batch)
     out = {"workload": "dqn.py CartPole-v1, %d envs, %d-slot ring (%d transitions on HBM), batch %d, train every 10 steps" % (envs, slots, envs * slots, batch),
            "value": round(iters * 10 * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(iters / dt, 1), "ms_per_step": round(1e3 * dt / iters, 5),
            "step": "10 env steps of every env + 1 TD update", "dtype": "f32", "kernel_us": {k: round(v, 2) for k, v in us.items()},
            "roofline": {"bound": "mfma", "kernel": "dqn_act4_kernel", "achieved": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(act_flops / (us["dqn_act"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": act_traffic, "traffic_source": act_src,
                         "flops_per_launch": act_flops, "avg_launch_us": round(us["dqn_act"], 2),
                         "note": "10 dependent env steps per launch: 16 envs per workgroup (3 forward waves + 1 wave computing both CartPole successors), latency-bound chain (forward, barrier, argmax)"},
            "roofline_td": {"bound": "latency (f32 VALU peak quoted)", "kernel": "dqn_td_kernel", "achieved": round(td_flops / (us["dqn_td"] * 1e-6) / 1e12, 4),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(td_flops / (us["dqn_td"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 5),
-                           "flops_per_launch": td_flops, "avg_launch_us": round(us["dqn_td"], 2),
-                           "note": "the reference's batch of 128 rows is 16 workgroups on a 256-CU chip: the launch is a fixed ~12 us latency, not a throughput"},
+                           "traffic": td_traffic, "traffic_source": td_src, "flops_per_launch": td_flops, "avg_launch_us": round(us["dqn_td"], 2),
+                           "note": ("the reference's batch of 128 rows is 16 workgroups on a 256-CU chip: the launch is a fixed ~12 us latency, not a throughput" if batch == 128 else
+                                    "%d rows = %d workgroups of 8 rows" % (batch, batch // 8))},
            "loss": float(eng.loss.item())}
     out["cpu_baseline"] = cpu_baseline_dqn(params0, envs, slots, batch, cpu_seconds)
     return out
@@ -189,15 +207,16 @@ def cpu_baseline_dqn(params0, envs, slots, batch, min_seconds):
             "sample": "%d loop iterations (10 steps x %d envs + 1 update each) in %.1f s, C oracle, OpenMP over envs / rows" % (k, envs, dt)}
 
 
-def bench_sac(dev, iters=400, cpu_seconds=3.0):
+def bench_sac(dev, iters=400, cpu_seconds=3.0, batch=256):
     """sac.py on Pendulum-v1, 2048 envs, 512-slot ring, batch 256 (sac.py:137-217): one step = one env step of every env + one critic
-    update (+ polyak) + one actor + one alpha update (the reference does two of each every 2nd step)."""
+    update (+ polyak) + one actor + one alpha update (the reference does two of each every 2nd step).
+    batch != 256: the SCALED-batch line SURVEY.md §8d asks for beside the reference's batch (labelled as such by the caller)."""
     import torch
 
     import deep_rl_amd as D
     from deep_rl_amd import _native as N
 
-    envs, slots, batch = 2048, 512, 256
+    envs, slots = 2048, 512
     env = D.make("Pendulum-v1", num_envs=envs, device=dev, seed=1)
     torch.manual_seed(1)
     actor = D.Actor(env)
@@ -228,6 +247,10 @@ def bench_sac(dev, iters=400, cpu_seconds=3.0):
     per_it = {k: round(1e3 * v[0] / 100, 2) for k, v in prof.items() if v[1]}
     # sac_critic_kernel per batch row: actor forward on the next observation, two target-Q forwards, two critic forwards + ~2x backward
     critic_flops = 2 * SAC_MACS_NET * (1 + 2 + 2 * 3) * batch
+    cr_traffic, cr_src = pmc_traffic("sac_critic_kernel@%d" % batch)
+    nrg = (batch + 15) // 16
+    shape_note = ("batch 256 = 16 row groups x 4 workgroups (two target roles, two critic roles) on a 256-CU chip: 3 dependent 256x256 passes + one hand-off on the critical path, "
+                  "latency-bound (DESIGN.md §7c)") if batch == 256 else "%d row groups of 16 rows, one workgroup each (7 dependent 256x256 passes per workgroup)" % nrg
     out = {"workload": "sac.py Pendulum-v1, %d envs, %d-slot ring (%d transitions on HBM), batch %d, 1 critic + 1 actor + 1 alpha update per time step" % (
                envs, slots, envs * slots, batch),
            "value": round(iters * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(iters / dt, 1), "ms_per_step": round(1e3 * dt / iters, 5),
@@ -235,8 +258,8 @@ def bench_sac(dev, iters=400, cpu_seconds=3.0):
            "kernel_us": {k: round(v, 2) for k, v in us.items()}, "kernel_us_per_step": per_it,
            "roofline": {"bound": "mfma", "kernel": "sac_critic_kernel", "achieved": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12, 3),
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": None, "flops_per_launch": critic_flops, "avg_launch_us": round(us["sac_critic"], 2),
-                        "note": "batch 256 = 16 row groups x 4 workgroups (two target roles, two critic roles) on a 256-CU chip: 3 dependent 256x256 passes + one hand-off on the critical path, latency-bound (DESIGN.md §7c)"},
+                        "traffic": cr_traffic, "traffic_source": cr_src, "flops_per_launch": critic_flops, "avg_launch_us": round(us["sac_critic"], 2),
+                        "note": shape_note},
            "alpha": float(eng.alpha), "q_losses": [round(float(x), 5) for x in eng.q_losses.tolist()]}
     out["cpu_baseline"] = cpu_baseline_sac(a0, q0, envs, slots, batch, cpu_seconds)
     return out
@@ -460,15 +483,7 @@ def main():
         g_ms, g_n = prof["grad"]
         flops_per_launch = FLOPS_PER_ROW_UPDATE * mb
         ach = flops_per_launch / (g_ms / max(g_n, 1) * 1e-3) / 1e12 if g_n else 0.0
-        traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                traffic = j.get("grad_kernel", {}).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/latest_pmc.json (static: separate rocprofv3 --pmc passes of this command, build %s; not measured in this run)" % j.get("build", "?")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic("grad_kernel")
         steps_per_s = env_steps / dt
         out = {
             "metric": "env-steps/sec + updates/sec, PPO CartPole-v1 4096 envs/GPU",
@@ -508,6 +523,9 @@ def main():
             del eng, env, agent, opt
             out["config3_dqn"] = bench_dqn(dev, cpu_seconds=cs)
             out["config4_sac"] = bench_sac(dev, cpu_seconds=cs)
+            # "(also a scaled batch, stated)" — NOT the reference's batch: the same loops with batch 4,096, where the update kernels are throughputs, not fixed latencies
+            out["config3_dqn_scaled"] = dict(bench_dqn(dev, iters=150, cpu_seconds=min(cs, 2.0), batch=4096), scaled="batch 4096 instead of the reference's 128 (dqn.py:46)")
+            out["config4_sac_scaled"] = dict(bench_sac(dev, iters=150, cpu_seconds=min(cs, 2.0), batch=4096), scaled="batch 4096 instead of the reference's 256 (sac.py:85)")
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

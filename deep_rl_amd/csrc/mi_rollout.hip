@@ -111,10 +111,36 @@ struct __attribute__((aligned(16))) rq_slot {   // what the actor publishes per 
 };
 struct __attribute__((aligned(16))) rq_smem {
     rq_slot ring[RQ_RING][RQ_ENVS];
-    float gv[RQ_GAE_T + 1][RQ_ENVS];    // fused GAE (T <= RQ_GAE_T): the critic's values (rewards / dones: the ring, which does not wrap then)
+    float4 wstage[HID * HID / 4];       // W2 of one net on its way into the lanes' registers (rq_load_w2): the actor wave first, then the critic wave
+    float gv[RQ_GAE_T + 1][RQ_ENVS];    // the critic's values (T <= RQ_GAE_T: every row of the rollout; rewards / dones: the ring, which does not wrap then)
+    float ga[RQ_GAE_T + 1][RQ_ENVS];    // fused GAE: advantages / returns of the 4 envs, scanned by 4 lanes, written out by all 64
+    float gr[RQ_GAE_T + 1][RQ_ENVS];
     int produced;                       // slots published so far (actor -> critic)
     int consumed;                       // slots the critic is done with (critic -> actor; only read when T + 1 > RQ_RING)
 };
+// 39.2 KB per workgroup: 4 workgroups (8 waves) per CU, what the headline's 1,024 workgroups need on 256 CUs.
+
+// A lane's row of W2 (64 floats) into its registers.  Round 2 let every lane read its own row straight from global memory — 16 float4 loads whose 64 lanes touch 64
+// different 256-byte rows each: 5.6 us until the first step could start (profiles/r02_rollout_stamps.txt).  Here the wave reads the matrix as 16 fully coalesced 1 KB
+// loads, drops it into LDS with the 16-byte chunks of row r XOR-swizzled by (r & 15) (stores and row reads are both conflict-free in the b128 lane groups),
+// and every lane picks up its row with 16 ds_read_b128.
+__device__ __forceinline__ void rq_load_w2(const float* __restrict__ W2, float (&w2)[HID], float4* stage, int lane) {
+    float4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = reinterpret_cast<const float4*>(W2)[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = 4 * i + (lane >> 4), j = lane & 15;
+        stage[r * 16 + (j ^ (r & 15))] = v[i];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const float4 q = stage[lane * 16 + (jj ^ (lane & 15))];
+        w2[4 * jj] = q.x; w2[4 * jj + 1] = q.y; w2[4 * jj + 2] = q.z; w2[4 * jj + 3] = q.w;
+    }
+    wave_lds_fence();
+}
 
 // FORCED: parity mode (forced_actions / forced_uniforms / forced_resets may be given); EPLOG: the per-episode list is kept (max_ep > 0).
 // Separate instantiations, not run-time branches: a conditional global LOAD (or returning atomic) inside the step loop makes the compiler
@@ -152,17 +178,15 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
     {
         const float4 a = *reinterpret_cast<const float4*>(p + N_W1 + 4 * lane);
         w1[0] = a.x; w1[1] = a.y; w1[2] = a.z; w1[3] = a.w;
-#pragma unroll
-        for (int k = 0; k < HID; k += 4) {
-            const float4 q = *reinterpret_cast<const float4*>(p + N_W2 + HID * lane + k);
-            w2[k] = q.x; w2[k + 1] = q.y; w2[k + 2] = q.z; w2[k + 3] = q.w;
-        }
     }
     const float b1 = p[N_B1 + lane], b2 = p[N_B2 + lane];
     const float w3a = p[N_W3 + lane], w3b = net == 0 ? p[N_W3 + HID + lane] : 0.0f;
     const float b3a0 = params[A_B3], b3a1 = params[A_B3 + 1], b3c = params[C_BASE + N_W3 + HID];
     const bool ringed = T + 1 > RQ_RING;   // long rollouts: the ring wraps and the actor must not overrun the critic
-    __syncthreads();                       // counters initialised
+    // W2 through the one staging image: the actor (the chain the launch lasts) first; the critic takes its turn behind the barrier, which the actor only passes through
+    if (net == 0) rq_load_w2(p + N_W2, w2, sm.wstage, lane);
+    __syncthreads();                       // counters initialised; the actor is done with the staging image
+    if (net == 1) rq_load_w2(p + N_W2, w2, sm.wstage, lane);
 
     if (net == 0) {
         // ================================================= ACTOR wave =================================================
@@ -276,45 +300,88 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
         }
     } else {
         // ================================================= CRITIC wave ================================================
-        for (int t = -1; t < T; ++t) {
-            while (lds_peek(&sm.produced) < t + 2) __builtin_amdgcn_s_sleep(1);   // the ring read below is issued after the poll that saw the counter
-            const rq_slot& sl = sm.ring[(t + 1) % RQ_RING][en];
-            const float4 ob = sl.ob;
-            const float4 misc = *reinterpret_cast<const float4*>(&sl.rew);
-            const rq_f32x4 h2 = rq_hidden(ob, w1, b1, w2, b2, q0, q1);
-            const float val = quad_env_reduce(h2 * w3a, q0, q1) + b3c;   // ppo.py:115,:139
-            if (writer) {   // the storage of time step t (action, log-prob) and t + 1 (everything that resulted from it)
-                const size_t row = (size_t)(t + 1) * N + g;
+        // Storage writes (ppo.py:113-141).  A vector store costs the issuing wave ~100 cycles whatever its lane count, and with 4 envs per workgroup a per-step store is 4
+        // lanes wide (six of them per step in round 2: 600 cycles of this wave's issue on a SIMD it shares with an actor wave, 1.5x write amplification).  While the ring does
+        // not wrap (T <= RQ_GAE_T) everything a row needs stays in LDS, so the rows are written 16 at a time by ALL 64 lanes — lane l = (row l >> 2, env l & 3): one
+        // instruction per tensor and 16 rows, each row's 4 envs one contiguous 16 / 32 / 64-byte segment.
+        const int rr = lane >> 2;                                  // row within a 16-row chunk (env = en = lane & 3)
+        auto flush_rows = [&](int r0, int cnt) {
+            wave_lds_fence();                                      // the values of these rows were written to sm.gv by lanes 0..3 of this wave
+            const int r = r0 + rr;
+            if (rr < cnt && mine) {
+                const rq_slot& sl = sm.ring[r][en];
+                const float4 ob = sl.ob;
+                const float4 misc = *reinterpret_cast<const float4*>(&sl.rew);
+                const size_t row = (size_t)r * N + g;
                 reinterpret_cast<float4*>(observations)[row] = ob;      // :113,:137 (the reset obs where done)
-                values[row] = val;
-                if (t >= 0) {
+                values[row] = sm.gv[r][en];                             // :115,:139
+                if (r >= 1) {
                     rewards[row] = misc.x; dones[row] = misc.y;         // :140-141
                     log_probs[row - N] = misc.z; actions[row - N] = (int64_t)__builtin_bit_cast(int, misc.w);   // :123-124
                 }
             }
-            if (adv && lane < RQ_ENVS) sm.gv[t + 1][lane] = val;
-            if (ringed && lane == 0) lds_publish(&sm.consumed, t + 2);
+        };
+        if (!ringed) {
+            for (int t = -1; t < T; ++t) {
+                while (lds_peek(&sm.produced) < t + 2) __builtin_amdgcn_s_sleep(1);   // the ring read below is issued after the poll that saw the counter
+                const rq_slot& sl = sm.ring[t + 1][en];
+                const float4 ob = sl.ob;
+                const rq_f32x4 h2 = rq_hidden(ob, w1, b1, w2, b2, q0, q1);
+                const float val = quad_env_reduce(h2 * w3a, q0, q1) + b3c;   // ppo.py:115,:139
+                if (lane < RQ_ENVS) sm.gv[t + 1][lane] = val;
+                if (((t + 1) & 15) == 15) flush_rows(t + 1 - 15, 16);
 #ifdef RQ_STAMPS
-            if (blockIdx.x == 517 && lane == 0 && t + 1 < 200) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + 256 + t + 1] = rt_; }
+                if (blockIdx.x == 517 && lane == 0 && t + 1 < 200) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + 256 + t + 1] = rt_; }
 #endif
+            }
+            if ((T + 1) & 15) flush_rows((T + 1) & ~15, (T + 1) & 15);
+        } else {
+            for (int t = -1; t < T; ++t) {
+                while (lds_peek(&sm.produced) < t + 2) __builtin_amdgcn_s_sleep(1);
+                const rq_slot& sl = sm.ring[(t + 1) % RQ_RING][en];
+                const float4 ob = sl.ob;
+                const float4 misc = *reinterpret_cast<const float4*>(&sl.rew);
+                const rq_f32x4 h2 = rq_hidden(ob, w1, b1, w2, b2, q0, q1);
+                const float val = quad_env_reduce(h2 * w3a, q0, q1) + b3c;
+                if (writer) {   // the storage of time step t (action, log-prob) and t + 1 (everything that resulted from it)
+                    const size_t row = (size_t)(t + 1) * N + g;
+                    reinterpret_cast<float4*>(observations)[row] = ob;
+                    values[row] = val;
+                    if (t >= 0) {
+                        rewards[row] = misc.x; dones[row] = misc.y;
+                        log_probs[row - N] = misc.z; actions[row - N] = (int64_t)__builtin_bit_cast(int, misc.w);
+                    }
+                }
+                if (lane == 0) lds_publish(&sm.consumed, t + 2);
+            }
         }
-        if (adv && writer) {       // GAE over this lane's env (ppo.py:144-151; expression order of gae_kernel): every reward / done is published
-            float last = 0.0f;
-            float vnext = sm.gv[T][lane];
-            adv[(size_t)T * N + g] = 0.0f;
-            returns[(size_t)T * N + g] = 0.0f + vnext;
+        if (adv) {       // GAE (ppo.py:144-151; expression order of gae_kernel): T <= RQ_GAE_T here, every reward / done / value of the 4 envs is in LDS
+            if (lane < RQ_ENVS) {   // the scan is sequential in t: 4 lanes, results to LDS
+                float last = 0.0f;
+                float vnext = sm.gv[T][lane];
+                sm.ga[T][lane] = 0.0f;
+                sm.gr[T][lane] = 0.0f + vnext;
 #pragma unroll 8
-            for (int t = T - 1; t >= 0; --t) {
-                const size_t c = (size_t)t * N + g;
-                const float vcur = sm.gv[t][lane];
-                const float a = gamma * (1.0f - sm.ring[t + 1][lane].dn);
-                const float b = vnext + lam * last;
-                float v = sm.ring[t + 1][lane].rew + a * b;
-                v = v - vcur;
-                adv[c] = v;
-                returns[c] = v + vcur;
-                last = v;
-                vnext = vcur;
+                for (int t = T - 1; t >= 0; --t) {
+                    const float vcur = sm.gv[t][lane];
+                    const float a = gamma * (1.0f - sm.ring[t + 1][lane].dn);
+                    const float b = vnext + lam * last;
+                    float v = sm.ring[t + 1][lane].rew + a * b;
+                    v = v - vcur;
+                    sm.ga[t][lane] = v;
+                    sm.gr[t][lane] = v + vcur;
+                    last = v;
+                    vnext = vcur;
+                }
+            }
+            wave_lds_fence();
+            for (int r0 = 0; r0 <= T; r0 += 16) {   // 16 rows per store instruction, all 64 lanes
+                const int r = r0 + rr;
+                if (r <= T && mine) {
+                    const size_t c = (size_t)r * N + g;
+                    adv[c] = sm.ga[r][en];
+                    returns[c] = sm.gr[r][en];
+                }
             }
         }
     }

@@ -289,34 +289,62 @@ __device__ __forceinline__ f32x16 bx_mac32(const bf16x8 (&a)[3], const bf16x8 (&
     return acc;
 }
 
-// Total L2 norm of a flat gradient, recomputed identically by every 256-thread workgroup that calls it: all loads in flight at
-// once (float4, compile-time trip count; a strided scalar loop costs nine dependent L2 round trips instead of one), per-thread
-// partial sums in f64 in a fixed order, xor-butterfly, four wave sums added in wave order.  Contains ONE __syncthreads.
-__device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads, int n, int vec_ok, double* ws /* shared [4] */) {
-    constexpr int NV4 = (MI_PPO_NPARAMS + 3) / 4, PER_T = (NV4 + 255) / 256;
-    const bool act = threadIdx.x < 256;   // the first 256 threads of the workgroup carry the sum (the same thread -> element map in every caller); the rest only meet the barrier
-    float4 gv[PER_T];
-#pragma unroll
-    for (int k = 0; k < PER_T; ++k) {
-        const int q = threadIdx.x + 256 * k;
-        gv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!act) continue;
-        if (vec_ok && 4 * q + 3 < n) gv[k] = reinterpret_cast<const float4*>(grads)[q];
-        else {  // ragged tail (and the generic-n path): scalar, bounds-checked
-            if (4 * q + 0 < n) gv[k].x = grads[4 * q + 0];
-            if (4 * q + 1 < n) gv[k].y = grads[4 * q + 1];
-            if (4 * q + 2 < n) gv[k].z = grads[4 * q + 2];
-            if (4 * q + 3 < n) gv[k].w = grads[4 * q + 3];
-        }
+// Total L2 norm of a flat gradient — ONE expression tree wherever it is evaluated, so every route to the same optimizer step (the clip + Adam launch, the
+// owed step on a gradient launch's weight staging, single rank or sharded) gets bitwise the same clip coefficient:
+//   s_b   = xor-butterfly (32, 16, 8, 4, 2, 1) over the 64 lanes of g[pos(64 b + lane)]^2, in f64           (block sums)
+//   S_t   = s_t + s_(t+256) + ...  sequentially, t < 256
+//   W_w   = xor-butterfly over the 64 lanes of S_(64 w + lane), w < 4;   total = (W_0 + W_1) + (W_2 + W_3);   norm = (float) sqrt(total)
+// pos() is the identity, except for a PPO parameter vector (n == NPARAMS), where the blocks follow the order in which grad_reduce_kernel produces the elements
+// (W2's gradient leaves the slabs in accumulator-fragment order): that kernel holds block b's 64 summed elements in one wave and writes s_b as it goes
+// (`parts`), so the 256 workgroups of the next gradient launch each read 144 doubles instead of the whole 36.6 KB gradient (6,100 of the
+// prologue's 15,000 cycles).  Without `parts` (mi_clip_adam on a caller's gradient; the sharded route, where the all-reduce changes the gradient after the block sums
+// were taken) the same tree is evaluated from the gradient itself: wave w of the workgroup takes blocks w, w + nw, ... (256 % nw == 0, so S_t has one owner).
+// Contains __syncthreads (1 with parts, 3 without); every thread of the workgroup must call it; blockDim.x is a multiple of 64 and >= 256.
+__device__ __forceinline__ int ppo_slab_to_param(int p) {   // position in [actor slab | critic slab] order -> index in the flat parameter vector
+    const int base = p < C_BASE ? 0 : C_BASE, off = p - base;
+    if (off >= N_W2 && off < N_W2 + HID * HID) {
+        const int s = off - N_W2, r = s & 3, F = s >> 2, ln = F & 63, frag = F >> 6;
+        return base + N_W2 + (16 * (frag >> 2) + 4 * (ln >> 4) + r) * HID + 16 * (frag & 3) + (ln & 15);
     }
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < PER_T; ++k)
-        s += ((double)gv[k].x * gv[k].x + (double)gv[k].y * gv[k].y) + ((double)gv[k].z * gv[k].z + (double)gv[k].w * gv[k].w);
-    if (act) for (int k = 4 * 256 * PER_T + threadIdx.x; k < n; k += 256) { const double g = grads[k]; s += g * g; }  // n beyond the unrolled part
+    return p;
+}
+__device__ __forceinline__ double wave_butterfly_f64(double s) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (act && (threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    return s;
+}
+#define NORM_BLOCKS ((NPARAMS + 63) / 64)   // 144
+__device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads, const double* __restrict__ parts, int n, double* ws /* shared [4] */,
+                                                 double* sparts /* shared [256] */) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, nw = (int)blockDim.x >> 6;
+    const int nb = (n + 63) >> 6;
+    double S = 0.0;
+    if (parts) {
+        if (t < 256) for (int b = t; b < nb; b += 256) S += parts[b];
+    } else {
+        const bool perm = n == NPARAMS;
+        if (t < 256) sparts[t] = 0.0;
+        __syncthreads();
+        constexpr int U = 6;   // blocks in flight per wave
+        for (int b0 = w; b0 < nb; b0 += nw * U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + nw * u, p = 64 * b + lane;
+                x[u] = (b < nb && p < n) ? grads[perm ? ppo_slab_to_param(p) : p] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + nw * u;
+                const double sb = wave_butterfly_f64((double)x[u] * (double)x[u]);
+                if (lane == 0 && b < nb) sparts[b & 255] = sparts[b & 255] + sb;   // (b & 255) % nw == w: this wave is the only writer, in increasing b
+            }
+        }
+        __syncthreads();
+        if (t < 256) S = sparts[t];
+    }
+    S = wave_butterfly_f64(S);
+    if (t < 256 && lane == 0) ws[w] = S;
     __syncthreads();
     return (float)sqrt((ws[0] + ws[1]) + (ws[2] + ws[3]));
 }
@@ -327,8 +355,8 @@ struct grad_pending_t {
     const float* p_in; const float* m_in; const float* v_in;   // optimizer state before the owed step
     float* p_out; float* m_out; float* v_out;             // ... after it (never the *_in buffers)
     float* grad_norm;                                     // nullable: pre-clip total norm of `grads`
+    const double* norm_parts;                             // nullable: the block sums of squares grad_reduce_kernel wrote for `grads` (single rank only: see block_grad_norm)
     float w1, b2, w2, step_size, rbc2, eps, max_norm;
-    int vec_ok;
 };
 
 // Which net a slab / workgroup serves.  Slab index vb: even = actor, odd = critic, except that the first `extra` critic slabs serve the actor too: an
@@ -396,7 +424,7 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 #define RED_GROUPS 16
 __global__ void __launch_bounds__(RED_PARAMS * RED_GROUPS)
 grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra, float ent_coef, float vf_coef, double inv_count,
-                   float* __restrict__ grads, float* __restrict__ loss_terms) {
+                   float* __restrict__ grads, float* __restrict__ loss_terms, double* __restrict__ norm_parts) {
     const int pblocks = (NPARAMS + RED_PARAMS - 1) / RED_PARAMS;
     if ((int)blockIdx.x < pblocks) {
         __shared__ float part[RED_GROUPS][RED_PARAMS];
@@ -421,17 +449,16 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra,
         }
         part[sg][pl] = acc;
         __syncthreads();
-        if (sg == 0 && p < NPARAMS) {
+        if (sg == 0) {   // wave 0: one element per lane (0 past the end)
             float t = 0.0f;
+            if (p < NPARAMS) {
 #pragma unroll
-            for (int k = 0; k < RED_GROUPS; ++k) t += part[k][pl];
-            int dst = p;
-            if (off >= N_W2 && off < N_W2 + HID * HID) {
-                const int s = off - N_W2, r = s & 3, F = s >> 2, ln = F & 63, frag = F >> 6;
-                const int o = 16 * (frag >> 2) + 4 * (ln >> 4) + r, i = 16 * (frag & 3) + (ln & 15);
-                dst = (role ? C_BASE : 0) + N_W2 + o * HID + i;
+                for (int k = 0; k < RED_GROUPS; ++k) t += part[k][pl];
+                grads[ppo_slab_to_param(p)] = t;
             }
-            grads[dst] = t;
+            // block sum of squares for the next launch's clip coefficient (block_grad_norm's s_b: same butterfly, same element -> lane map)
+            const double sb = wave_butterfly_f64((double)t * (double)t);
+            if (pl == 0) norm_parts[blockIdx.x] = sb;
         }
     } else {
         // loss terms: pg / entropy from actor blocks, value loss from critic blocks
@@ -470,7 +497,12 @@ static int grad_blocks() {
     }
     return g_grad_blocks;
 }
-static_assert((size_t)GRAD_SPARE_SLABS * PART_STRIDE >= 6 * (size_t)STATE_STRIDE, "spare optimizer-state sets must fit behind the slabs");
+#define NORM_PARTS_OFF (6 * (size_t)STATE_STRIDE)   // floats behind the two spare sets: NORM_BLOCKS doubles written by grad_reduce_kernel
+static_assert((size_t)GRAD_SPARE_SLABS * PART_STRIDE >= NORM_PARTS_OFF + 2 * NORM_BLOCKS, "spare optimizer-state sets + norm block sums must fit behind the slabs");
+static_assert(NORM_PARTS_OFF % 2 == 0 && ((size_t)(GRAD_MAX_BLOCKS - GRAD_SPARE_SLABS) * PART_STRIDE) % 2 == 0, "norm block sums must be 8-byte aligned");
+static double* ws_norm_parts(void* workspace) {
+    return reinterpret_cast<double*>(reinterpret_cast<float*>(workspace) + (size_t)(GRAD_MAX_BLOCKS - GRAD_SPARE_SLABS) * PART_STRIDE + NORM_PARTS_OFF);
+}
 static_assert(STATE_STRIDE >= NPARAMS && STATE_STRIDE % 4 == 0, "STATE_STRIDE");
 
 extern "C" size_t mi_ppo_workspace_bytes(void) { return (size_t)GRAD_MAX_BLOCKS * PART_STRIDE * sizeof(float); }
@@ -510,8 +542,9 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
     MI_LAUNCH_CHECK();
     {
         mi_prof_scope prof(MI_PROF_REDUCE, s);
-        grad_reduce_kernel<<<(NPARAMS + RED_PARAMS - 1) / RED_PARAMS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>((const float*)workspace, blocks, extra, ent_coef, vf_coef, inv_count,
-                                                                     grads, loss_terms);
+        static_assert((NPARAMS + RED_PARAMS - 1) / RED_PARAMS == NORM_BLOCKS && RED_PARAMS == 64, "one norm block per reduction workgroup");
+        grad_reduce_kernel<<<NORM_BLOCKS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>((const float*)workspace, blocks, extra, ent_coef, vf_coef, inv_count,
+                                                                     grads, loss_terms, ws_norm_parts(workspace));
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -538,13 +571,13 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
 __global__ void __launch_bounds__(256) clip_adam_kernel(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out,
                                                          const float* __restrict__ grads, int n, float w1, float b2,
                                                          float w2, float step_size, float rbc2, float eps, float max_norm,
-                                                         float* __restrict__ grad_norm, int vec_ok) {
-    __shared__ double ws[4];
+                                                         float* __restrict__ grad_norm, const double* __restrict__ norm_parts) {
+    __shared__ double ws[4], sparts[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n;
     float pm = live ? m_in[i] : 0.0f, pv = live ? v_in[i] : 0.0f;
     const float pp = live ? p_in[i] : 0.0f, pg = live ? grads[i] : 0.0f;
-    const float total = block_grad_norm(grads, n, vec_ok, ws);
+    const float total = block_grad_norm(grads, norm_parts, n, ws, sparts);
     float coef = max_norm / (total + 1e-6f);
     coef = coef > 1.0f ? 1.0f : coef;
     if (grad_norm && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm = total;
@@ -565,10 +598,10 @@ static adam_consts_t adam_consts(int64_t step, double lr, double beta1, double b
 }
 
 static int clip_adam_launch(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out, const float* grads, int n,
-                            const adam_consts_t& k, float max_norm, float* grad_norm, hipStream_t s) {
+                            const adam_consts_t& k, float max_norm, float* grad_norm, const double* norm_parts, hipStream_t s) {
     mi_prof_scope prof(MI_PROF_CLIP_ADAM, s);
     clip_adam_kernel<<<(n + 255) / 256, 256, 0, s>>>(p_in, m_in, v_in, p_out, m_out, v_out, grads, n, k.w1, k.b2, k.w2, k.step_size, k.rbc2, k.eps, max_norm,
-                                                    grad_norm, ((uintptr_t)grads & 15) == 0 ? 1 : 0);
+                                                    grad_norm, norm_parts);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -578,7 +611,7 @@ extern "C" int mi_clip_adam(float* params, const float* grads, float* exp_avg, f
     MI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "NULL pointer");
     MI_CHECK_ARG(n > 0 && step >= 1, "n must be positive and step 1-based");
     return clip_adam_launch(params, exp_avg, exp_avg_sq, params, exp_avg, exp_avg_sq, grads, n, adam_consts(step, lr, beta1, beta2, eps), max_norm, grad_norm,
-                            (hipStream_t)stream);
+                            nullptr, (hipStream_t)stream);
 }
 
 // =====================================================================================================
@@ -733,7 +766,8 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
                 flip ^= 1;
                 pend.grads = b->grads; pend.p_in = cur.p; pend.m_in = cur.m; pend.v_in = cur.v; pend.p_out = out.p; pend.m_out = out.m; pend.v_out = out.v;
                 pend.grad_norm = b->grad_norm; pend.w1 = c.w1; pend.b2 = c.b2; pend.w2 = c.w2; pend.step_size = c.step_size; pend.rbc2 = c.rbc2; pend.eps = c.eps;
-                pend.max_norm = hp->max_grad_norm; pend.vec_ok = ((uintptr_t)b->grads & 15) == 0 ? 1 : 0;
+                pend.max_norm = hp->max_grad_norm;
+                pend.norm_parts = world > 1 ? nullptr : ws_norm_parts(b->workspace);   // sharded: the all-reduce changed the gradient after the block sums were taken
                 cur = out;   // what this launch trains on and what the next owed step starts from
             }
             rc = ppo_grad_launch(owed ? nullptr : cur.p, pend, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
@@ -750,7 +784,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
         }
     }
     return clip_adam_launch(cur.p, cur.m, cur.v, caller.p, caller.m, caller.v, b->grads, NPARAMS, adam_consts(step, hp->lr, hp->beta1, hp->beta2, hp->eps),
-                            hp->max_grad_norm, b->grad_norm, s);
+                            hp->max_grad_norm, b->grad_norm, world > 1 ? nullptr : ws_norm_parts(b->workspace), s);
 }
 
 // =====================================================================================================

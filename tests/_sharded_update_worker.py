@@ -5,9 +5,9 @@
   backend gloo (both ranks on cuda:0): the host-sequenced route over the same launches — run on the one-GPU box so that the comparison
       harness below is itself exercised every round.
 
-Each rank owns NL envs (global ids [rank*NL, (rank+1)*NL)), runs UPDATES whole updates and dumps its final state to OUT_DIR/rank<r>.npz; rank 0
-then plays the single process that owns all 2*NL envs: it walks the explicit launch sequence with the UNION minibatches (each rank's keyed local
-permutation mapped into the big run's row numbering) and the test compares.  With nccl, a second pair of engines repeats the updates on the
+Each rank owns NL envs (global ids [rank*NL, (rank+1)*NL)), runs UPDATES whole updates and dumps its final state to OUT_DIR/rank<r>.npz; the TEST process
+(no process group: an engine built inside a rank would join the ranks' collectives) then plays the single process that owns all 2*NL envs — the explicit
+launch sequence with the UNION minibatches, each rank's keyed local permutation mapped into the big run's row numbering — and compares.  With nccl, a second pair of engines repeats the updates on the
 host-sequenced route (torch.distributed all-reduces over RCCL between the launches): at world_size 2 a SUM all-reduce is a + b on every rank
 whatever the algorithm, so the two routes must agree bit for bit."""
 import os
@@ -78,30 +78,6 @@ if native:   # the host-sequenced route over torch's RCCL all-reduces, from the 
         st["seq_" + k] = v
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **st)
 torch.distributed.barrier()
-
-if rank == 0:
-    # ---- the single process that owns all 2*NL envs, union minibatches ----
-    big = mk(2 * NL, 0)
-    big.agent.load_flat(params0)
-    big.reset()
-    scratch = torch.zeros(T * NL, dtype=torch.int32, device=dev)
-    mb = T * NL // big.n_minibatch
-    for u in range(UPDATES):
-        big.rollout(); big.compute_gae()
-        for ep in range(big.update_epochs):
-            key = N.lib().mi_perm_key(SEED, u, ep)            # every rank draws the same keyed permutation of its LOCAL rows
-            N.check(N.lib().mi_make_perm(T * NL, key, N.ptr(scratch), N.stream_ptr(dev)), "mi_make_perm")
-            local = scratch.cpu().numpy().astype(np.int64)
-            for k in range(big.n_minibatch):
-                part = local[k * mb:(k + 1) * mb]
-                union = np.concatenate([(part // NL) * (2 * NL) + r * NL + part % NL for r in range(2)]).astype(np.int32)   # local row t*NL + e -> t*(2 NL) + r*NL + e
-                big.perm[:2 * mb].copy_(torch.from_numpy(union).to(dev))
-                big.adv_stats(mb=2 * mb, n_mb=1)
-                big.minibatch_grad(0, mb=2 * mb)
-                big.optimizer_step()
-        big.update_index += 1
-    torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "big.npz"), **state(big))
 
 torch.distributed.barrier()
 DD.destroy_native_comms()

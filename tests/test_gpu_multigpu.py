@@ -28,11 +28,52 @@ def _run(backend, nl):
         env = dict(os.environ, PYTHONPATH=ROOT, MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL=str(nl), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
         # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP)
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                              os.path.join(ROOT, "tests", "_sharded_update_worker.py")], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                              os.path.join(ROOT, "tests", "_sharded_update_worker.py")], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
         assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
         assert "SHARDED_WORKER_OK backend=%s" % backend in out.stdout, out.stdout[-2000:]
         load = lambda n: dict(np.load(os.path.join(tmp, n)))  # noqa: E731
-        return load("rank0.npz"), load("rank1.npz"), load("big.npz")
+        r0, r1 = load("rank0.npz"), load("rank1.npz")
+    return r0, r1, _single_process(r0["params0"], nl)
+
+
+T, UPDATES, SEED = 128, 2, 11
+
+
+def _single_process(params0, nl):
+    """One process that owns all 2 * nl envs: the explicit launch sequence with the UNION minibatches (each rank draws the same keyed permutation of its LOCAL rows;
+    local row t * nl + e of rank r is row t * (2 nl) + r * nl + e here)."""
+    import torch
+
+    import deep_rl_amd as D
+    from deep_rl_amd import _native as N
+
+    dev = torch.device("cuda", 0)
+    env = D.make("CartPole-v1", num_envs=2 * nl, device=dev, seed=SEED)
+    torch.manual_seed(SEED)
+    agent = D.ActorCritic(env)
+    big = D.PPOEngine(env, agent, D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5), num_steps=T)
+    assert big.world_size == 1
+    big.agent.load_flat(params0)
+    big.reset()
+    scratch = torch.zeros(T * nl, dtype=torch.int32, device=dev)
+    mb = T * nl // big.n_minibatch
+    for u in range(UPDATES):
+        big.rollout(); big.compute_gae()
+        for ep in range(big.update_epochs):
+            N.check(N.lib().mi_make_perm(T * nl, N.lib().mi_perm_key(SEED, u, ep), N.ptr(scratch), N.stream_ptr(dev)), "mi_make_perm")
+            local = scratch.cpu().numpy().astype(np.int64)
+            for k in range(big.n_minibatch):
+                part = local[k * mb:(k + 1) * mb]
+                union = np.concatenate([(part // nl) * (2 * nl) + r * nl + part % nl for r in range(2)]).astype(np.int32)
+                big.perm[:2 * mb].copy_(torch.from_numpy(union).to(dev))
+                big.adv_stats(mb=2 * mb, n_mb=1)
+                big.minibatch_grad(0, mb=2 * mb)
+                big.optimizer_step()
+        big.update_index += 1
+    torch.cuda.synchronize()
+    o = big.optimizer
+    return {"params": big.agent.flat.cpu().numpy(), "exp_avg": o.exp_avg.cpu().numpy(), "loss_terms": big.loss_terms.cpu().numpy(), "grad_norm": o.grad_norm.cpu().numpy(),
+            "observations": big.observations.cpu().numpy()}
 
 
 def _check(r0, r1, big, nl):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""profiles/latest_pmc.json from the PMC summaries of one profiling round (tools/profile_round.sh): HBM bytes per launch of the kernels bench.py quotes a
+`roofline.traffic` for.  usage: make_latest_pmc.py <build tag> <dir with pmc_summary*.json>  (prints the JSON)
+
+FETCH_SIZE / WRITE_SIZE per MI355X_MICROARCH.md §HBM: KiB units; FETCH_SIZE under-reports a WIDE coalesced stream by 2x on gfx950.  The kernels here gather 4-16-byte
+elements (PPO / DQN / SAC replay rows) or stream weights every workgroup re-reads from L2, not one wide stream from HBM, so the RAW figure is used and the x2 figure is
+kept beside it."""
+import json, os, sys
+
+tag, d = sys.argv[1], sys.argv[2]
+
+
+def load(name):
+    try:
+        return json.load(open(os.path.join(d, name)))
+    except Exception:
+        return {}
+
+
+def entry(summary, kernel, src):
+    m = summary.get(kernel)
+    if not m or "hbm_read_bytes_raw" not in m:
+        return None
+    e = {"hbm_read_bytes_raw": m["hbm_read_bytes_raw"], "hbm_read_bytes_x2": m.get("hbm_read_bytes_x2_wide_stream_correction"), "hbm_write_bytes": m.get("hbm_write_bytes"),
+         "avg_us_profiled": m.get("avg_us"), "source": "%s, kernel %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch, raw FETCH_SIZE: narrow gathers)" % (src, kernel)}
+    e["hbm_bytes_per_launch"] = e["hbm_read_bytes_raw"] + (e["hbm_write_bytes"] or 0.0)
+    for c in ("pmc_SQ_WAVES_avg", "pmc_SQ_BUSY_CYCLES_avg", "pmc_SQ_WAVE_CYCLES_avg", "pmc_SQ_WAIT_INST_ANY_avg", "pmc_SQ_VALU_MFMA_BUSY_CYCLES_avg", "pmc_SQ_WAIT_ANY_avg"):
+        if c in m:
+            e[c[4:-4]] = m[c]
+    return e
+
+
+out = {"build": tag}
+ppo = load("pmc_summary.json")
+e = entry(ppo, "grad_kernel_f32", "profiles/%s_pmc_summary.json" % tag)
+if e:
+    out["grad_kernel"] = e
+for name, kernels in (("dqn_b128", {"dqn_act4_kernel": "dqn_act4_kernel", "dqn_td_kernel": "dqn_td_kernel@128"}), ("dqn_b4096", {"dqn_td_kernel": "dqn_td_kernel@4096"}),
+                      ("sac_b256", {"sac_critic_kernel": "sac_critic_kernel@256", "sac_actor_kernel": "sac_actor_kernel@256", "sac_act_kernel": "sac_act_kernel"}),
+                      ("sac_b4096", {"sac_critic_kernel": "sac_critic_kernel@4096", "sac_actor_kernel": "sac_actor_kernel@4096"})):
+    sm = load("pmc_summary_%s.json" % name)
+    for k, key in kernels.items():
+        e = entry(sm, k, "profiles/%s_pmc_summary_%s.json" % (tag, name))
+        if e:
+            out[key] = e
+print(json.dumps(out, indent=1, sort_keys=True))

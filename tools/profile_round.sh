@@ -30,4 +30,23 @@ for CTRS in "FETCH_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU S
 done
 unset MIRL_PPO_CONTRACTION
 python3 $REPO/tools/summarize_pmc.py /tmp/bx_trace.csv /tmp/bx_pmc*.csv > $OUT/pmc_summary_bf16x3.json 2>> $OUT/pmc_summary.err
+# BASELINE configs 3 / 4: kernel stats + counter passes of tools/bench_dqn.py / bench_sac.py at the reference's batch and at the scaled batch 4,096.
+# The program stands directly behind `--`, counters in passes of their own (never together with a trace domain beyond --kernel-trace).
+for W in "dqn_b128 bench_dqn.py --batch 128 --iters 120" "dqn_b4096 bench_dqn.py --batch 4096 --iters 120" "sac_b256 bench_sac.py --batch 256 --iters 120" "sac_b4096 bench_sac.py --batch 4096 --iters 120"; do
+  set -- $W
+  NAME=$1; shift
+  WCMD="python3 $REPO/tools/$*"
+  rm -rf /tmp/rp_${NAME}_*
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_${NAME}_stats -o stats -- $WCMD > $OUT/${NAME}_stats_run.log 2>&1
+  find /tmp/rp_${NAME}_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${NAME}_kernel_stats.csv \;
+  find /tmp/rp_${NAME}_stats -name '*kernel_trace.csv' -exec cp {} /tmp/${NAME}_trace.csv \;
+  i=0
+  for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY"; do
+    i=$((i+1))
+    rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/rp_${NAME}_pmc$i -o pmc -- $WCMD > $OUT/${NAME}_pmc${i}_run.log 2>&1
+    find /tmp/rp_${NAME}_pmc$i -name '*counter_collection.csv' -exec cp {} /tmp/${NAME}_pmc$i.csv \;
+  done
+  python3 $REPO/tools/summarize_pmc.py /tmp/${NAME}_trace.csv /tmp/${NAME}_pmc*.csv > $OUT/pmc_summary_${NAME}.json 2>> $OUT/pmc_summary.err
+done
+python3 $REPO/tools/make_latest_pmc.py $TAG $OUT > $OUT/latest_pmc.json 2>> $OUT/pmc_summary.err
 ls -la $OUT
