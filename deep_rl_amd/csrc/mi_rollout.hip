@@ -35,6 +35,7 @@
 #define RQ_ENVS 4
 #define RQ_GAE_T 128
 #define RQ_RING (RQ_GAE_T + 1)
+#define RQ_UNI_BLOCKS (RQ_GAE_T / 4 + 2)   // Philox blocks (4 steps each) a launch of <= RQ_GAE_T steps can touch, whatever its first step's phase
 
 #ifndef RQ_CHAINS
 #define RQ_CHAINS 4   // independent accumulator chains of layer 2 (k mod RQ_CHAINS); 8 measured no faster: the wave is issue-bound, not MFMA-latency-bound
@@ -84,8 +85,11 @@ __device__ unsigned long long rq_stamp_dbg[1024 * 8 + 1024];   // [8192 ..): per
 extern "C" int mi_debug_rollout_stamps(unsigned long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(rq_stamp_dbg), sizeof(unsigned long long) * (size_t)(n < 9216 ? n : 9216)) == hipSuccess ? 0 : -2;
 }
+// wall-clock mark k of workgroup 517 (tools/rollout_timeline.py): 600 kernel entry, 601 actor weights in registers, 700 critic loop + last flush done, 701 GAE scanned, 702 GAE written
+#define RQ_MARK(k) do { if (blockIdx.x == 517 && (threadIdx.x & 63) == 0) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + (k)] = rt_; } } while (0)
 #else
 #define RQ_STAMP(k) do {} while (0)
+#define RQ_MARK(k) do {} while (0)
 #endif
 
 // LDS mailbox words between the waves of a workgroup.  The accesses must be ds_read / ds_write: a `volatile int*` to __shared__ memory
@@ -111,14 +115,19 @@ struct __attribute__((aligned(16))) rq_slot {   // what the actor publishes per 
 };
 struct __attribute__((aligned(16))) rq_smem {
     rq_slot ring[RQ_RING][RQ_ENVS];
-    float4 wstage[HID * HID / 4];       // W2 of one net on its way into the lanes' registers (rq_load_w2): the actor wave first, then the critic wave
+    union {
+        float4 wstage[HID * HID / 4];   // launch start: W2 of one net on its way into the lanes' registers (rq_load_w2): the actor wave first, then the critic wave
+        struct {                        // launch end: fused GAE — advantages / returns of the 4 envs, scanned by 4 lanes, written out by all 64
+            float ga[RQ_GAE_T + 1][RQ_ENVS];
+            float gr[RQ_GAE_T + 1][RQ_ENVS];
+        } g;
+    };
     float gv[RQ_GAE_T + 1][RQ_ENVS];    // the critic's values (T <= RQ_GAE_T: every row of the rollout; rewards / dones: the ring, which does not wrap then)
-    float ga[RQ_GAE_T + 1][RQ_ENVS];    // fused GAE: advantages / returns of the 4 envs, scanned by 4 lanes, written out by all 64
-    float gr[RQ_GAE_T + 1][RQ_ENVS];
+    float uni[RQ_UNI_BLOCKS * 4][RQ_ENVS];   // the action uniforms of the launch's steps (RNG contract stream 1), drawn up front by the critic wave: row = step - 4 (step0 >> 2)
     int produced;                       // slots published so far (actor -> critic)
     int consumed;                       // slots the critic is done with (critic -> actor; only read when T + 1 > RQ_RING)
 };
-// 39.2 KB per workgroup: 4 workgroups (8 waves) per CU, what the headline's 1,024 workgroups need on 256 CUs.
+// 37.2 KB per workgroup: 4 workgroups (8 waves) per CU, what the headline's 1,024 workgroups need on 256 CUs.
 
 // A lane's row of W2 (64 floats) into its registers.  Round 2 let every lane read its own row straight from global memory — 16 float4 loads whose 64 lanes touch 64
 // different 256-byte rows each: 5.6 us until the first step could start (profiles/r02_rollout_stamps.txt).  Here the wave reads the matrix as 16 fully coalesced 1 KB
@@ -165,7 +174,14 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
     const int lane = threadIdx.x & 63, net = threadIdx.x >> 6, en = lane & 3;
     const bool q0 = lane & 1, q1 = lane & 2;
     const int N = e.n;
-    const int i = blockIdx.x * RQ_ENVS + en;
+    // XCD-aware env-group map.  Workgroups are dealt round-robin over the 8 XCDs (b % 8), each with an L2 of its own, and a group of 4 envs writes 16-byte pieces of
+    // the (T+1, N) tensors' rows: with group = blockIdx the eight groups that share a 128-byte line sit on eight different XCDs and every L2 holds one dirty piece of
+    // the line; with group = (b % 8) * (grid / 8) + b / 8 neighbouring groups share an XCD, whose L2 can merge their pieces into whole lines before they leave.
+    // Measured neutral on the launch time (204.2 vs 204.4 us, profiles/r03_rollout_notes.txt: the launch does not wait for its stores) — kept for the HBM traffic.
+    // Results do not depend on which workgroup carries an env (keyed RNG by global env id).
+    const unsigned nblk = gridDim.x;
+    const unsigned egrp = (nblk & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int i = (int)egrp * RQ_ENVS + en;
     const bool mine = i < N, writer = mine && lane < RQ_ENVS;
     const int g = mine ? i : N - 1;   // lanes past the end shadow the last env and never write
     if (threadIdx.x == 0) { sm.produced = 0; sm.consumed = 0; }
@@ -184,7 +200,19 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
     const float b3a0 = params[A_B3], b3a1 = params[A_B3 + 1], b3c = params[C_BASE + N_W3 + HID];
     const bool ringed = T + 1 > RQ_RING;   // long rollouts: the ring wraps and the actor must not overrun the critic
     // W2 through the one staging image: the actor (the chain the launch lasts) first; the critic takes its turn behind the barrier, which the actor only passes through
-    if (net == 0) rq_load_w2(p + N_W2, w2, sm.wstage, lane);
+    if (net == 0) { rq_load_w2(p + N_W2, w2, sm.wstage, lane); RQ_MARK(601); }
+    else if (!ringed && (!FORCED || (!forced_actions && !forced_uniforms))) {
+        // the critic wave has nothing to do until the actor publishes the first observation: it draws the launch's action uniforms (one Philox block feeds 4 steps of an
+        // env; lane l = (block l >> 2, env l & 3): all 64 lanes useful) — ~40 instructions per step that no longer sit in the actor wave's chain
+        const uint64_t blk0 = e.step_ctr[g] >> 2;
+#pragma unroll 1
+        for (int j = lane >> 2; j < RQ_UNI_BLOCKS; j += 16) {
+            uint32_t r4[4];
+            mi_philox(e.seed, e.env_id_base + (uint64_t)g, blk0 + (uint64_t)j, STREAM_ACTION, r4);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sm.uni[4 * j + w][en] = mi_u32_to_uniform(r4[w]);
+        }
+    }
     __syncthreads();                       // counters initialised; the actor is done with the staging image
     if (net == 1) rq_load_w2(p + N_W2, w2, sm.wstage, lane);
 
@@ -203,7 +231,8 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
         int st_cnt = 0, st_len = 0, st_max = 0;
         uint32_t urand[4] = {0, 0, 0, 0};
         const bool keyed_actions = !FORCED || (!forced_actions && !forced_uniforms);
-        if (keyed_actions && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
+        const uint64_t ubase = stepctr & ~3ull;   // sm.uni row 0 = the first step of the Philox block this launch starts in
+        if (keyed_actions && ringed && (stepctr & 3)) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
         // every value loaded so far is consumed HERE, so that no load is pending when the loop starts (a pending load at the loop head
         // becomes an s_waitcnt vmcnt(small) inside the body, which in steady state waits for the previous step's stores instead)
         asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr));
@@ -224,6 +253,7 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                 else {
                     float u;
                     if (FORCED && forced_uniforms) u = forced_uniforms[row];
+                    else if (!ringed) u = sm.uni[(int)(stepctr - ubase)][en];   // drawn up front by the critic wave
                     else {
                         const uint32_t wd = (uint32_t)stepctr & 3u;
                         if (wd == 0) mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr >> 2, STREAM_ACTION, urand);
@@ -334,7 +364,9 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                 if (blockIdx.x == 517 && lane == 0 && t + 1 < 200) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + 256 + t + 1] = rt_; }
 #endif
             }
+            RQ_MARK(703);
             if ((T + 1) & 15) flush_rows((T + 1) & ~15, (T + 1) & 15);
+            RQ_MARK(700);
         } else {
             for (int t = -1; t < T; ++t) {
                 while (lds_peek(&sm.produced) < t + 2) __builtin_amdgcn_s_sleep(1);
@@ -356,33 +388,48 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
             }
         }
         if (adv) {       // GAE (ppo.py:144-151; expression order of gae_kernel): T <= RQ_GAE_T here, every reward / done / value of the 4 envs is in LDS
-            if (lane < RQ_ENVS) {   // the scan is sequential in t: 4 lanes, results to LDS
-                float last = 0.0f;
-                float vnext = sm.gv[T][lane];
-                sm.ga[T][lane] = 0.0f;
-                sm.gr[T][lane] = 0.0f + vnext;
-#pragma unroll 8
-                for (int t = T - 1; t >= 0; --t) {
-                    const float vcur = sm.gv[t][lane];
-                    const float a = gamma * (1.0f - sm.ring[t + 1][lane].dn);
-                    const float b = vnext + lam * last;
-                    float v = sm.ring[t + 1][lane].rew + a * b;
-                    v = v - vcur;
-                    sm.ga[t][lane] = v;
-                    sm.gr[t][lane] = v + vcur;
-                    last = v;
-                    vnext = vcur;
+            // The scan is sequential in t (the expression order is the parity contract): 4 lanes, 16 steps at a time — the block's 48 inputs are requested from LDS
+            // together (as one dependent load -> compute -> store chain per step the scan took 7.9 us: round-3 timeline), then 16 x 5 dependent operations; the block's
+            // 16 rows are then written by all 64 lanes while the next block is scanned.
+            float last = 0.0f, vnext = 0.0f;
+            if (lane < RQ_ENVS) vnext = sm.gv[T][lane];
+            if (writer) { adv[(size_t)T * N + g] = 0.0f; returns[(size_t)T * N + g] = 0.0f + vnext; }
+            for (int hi = T - 1; hi >= 0; hi -= 16) {
+                const int lo = hi >= 15 ? hi - 15 : 0;
+                if (lane < RQ_ENVS) {
+                    float vc[16], dn[16], rw[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int t = hi - k >= lo ? hi - k : lo;
+                        vc[k] = sm.gv[t][lane]; dn[k] = sm.ring[t + 1][lane].dn; rw[k] = sm.ring[t + 1][lane].rew;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int t = hi - k;
+                        if (t >= lo) {
+                            const float vcur = vc[k];
+                            const float a = gamma * (1.0f - dn[k]);
+                            const float b = vnext + lam * last;
+                            float v = rw[k] + a * b;
+                            v = v - vcur;
+                            sm.g.ga[t][lane] = v;
+                            sm.g.gr[t][lane] = v + vcur;
+                            last = v;
+                            vnext = vcur;
+                        }
+                    }
                 }
-            }
-            wave_lds_fence();
-            for (int r0 = 0; r0 <= T; r0 += 16) {   // 16 rows per store instruction, all 64 lanes
-                const int r = r0 + rr;
-                if (r <= T && mine) {
+                wave_lds_fence();
+                if (hi == T - 1) RQ_MARK(705);
+                const int r = lo + rr;
+                if (r <= hi && mine) {
                     const size_t c = (size_t)r * N + g;
-                    adv[c] = sm.ga[r][en];
-                    returns[c] = sm.gr[r][en];
+                    adv[c] = sm.g.ga[r][en];
+                    returns[c] = sm.g.gr[r][en];
                 }
+                if (hi == T - 1) RQ_MARK(706);
             }
+            RQ_MARK(702);
         }
     }
 }

@@ -23,3 +23,6 @@ print("critic step-end times, steps 0..15:", np.round(cri[:16], 2))
 print("actor step durations: first 10 %s ... mean of 20..128 %.3f us" % (np.round(np.diff(act[:11]), 2), np.diff(act[20:129]).mean()))
 print("critic step durations: first 10 %s ... mean of 20..128 %.3f us" % (np.round(np.diff(cri[:11]), 2), np.diff(cri[20:129]).mean()))
 print("actor end %.1f us, critic end %.1f us" % (act[128], cri[128]))
+m = lambda k: (a[8192 + k] - t0) / 100.0  # noqa: E731
+print("marks (us since kernel entry): actor W2 in registers %.2f | critic loop done %.1f | last rows flushed %.1f | first GAE block scanned %.1f, its rows stored %.1f | GAE done %.1f" % (
+    m(601), m(703), m(700), m(705), m(706), m(702)))
