@@ -801,6 +801,62 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
     }
 }
 
+// The same for MANY slabs (scaled batches: 512 slabs at batch 4,096, where the kernel above is 32 dependent rounds of 16 loads per thread: 135 us).  Workgroup = 64
+// parameters x 16 slab groups (the shape of PPO's grad_reduce_kernel): group sg sums slabs sg, sg + 16, ... eight loads at a time, the 16 group sums are added in group
+// order through LDS.  A different (fixed) summation order than the kernel above: each batch size always takes the same kernel, so every run is reproducible.
+#define DR_PARAMS 64
+#define DR_GROUPS 16
+#define DR_MIN_SLABS 64   // from this many slabs on
+__global__ void __launch_bounds__(DR_PARAMS * DR_GROUPS) dqn_reduce2_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
+                                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
+    const int pl = threadIdx.x & (DR_PARAMS - 1), sg = threadIdx.x >> 6;
+    const int pblocks = (DQ_NP + DR_PARAMS - 1) / DR_PARAMS;
+    if ((int)blockIdx.x < pblocks) {
+        __shared__ float part[DR_GROUPS][DR_PARAMS];
+        const int p = blockIdx.x * DR_PARAMS + pl;
+        float pi = 0.0f, mi = 0.0f, vi = 0.0f;
+        if (sg == 0 && p < DQ_NP && opt.params) { pi = opt.params[p]; mi = opt.m[p]; vi = opt.v[p]; }
+        float acc = 0.0f;
+        if (p < DQ_NP) {
+            const float* src = workspace + p;
+            int b = sg;
+            for (; b + 7 * DR_GROUPS < n_slabs; b += 8 * DR_GROUPS) {
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = src[(size_t)(b + DR_GROUPS * k) * TD_SLAB];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += x[k];
+            }
+            for (; b < n_slabs; b += DR_GROUPS) acc += src[(size_t)b * TD_SLAB];
+        }
+        part[sg][pl] = acc;
+        __syncthreads();
+        if (sg == 0 && p < DQ_NP) {
+            float g = 0.0f;
+#pragma unroll
+            for (int k = 0; k < DR_GROUPS; ++k) g += part[k][pl];
+            grads[p] = g;
+            if (opt.params) {
+                opt.params[p] = mi_adam_elem(pi, g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
+                opt.m[p] = mi; opt.v[p] = vi;
+            }
+        }
+    } else if (loss) {   // the slab losses: lane-strided partial sums in f64, fixed butterfly, 16 wave sums added in wave order
+        __shared__ double wsum[DR_GROUPS];
+        double l = 0.0;
+        for (int b = threadIdx.x; b < n_slabs; b += DR_PARAMS * DR_GROUPS) l += workspace[(size_t)b * TD_SLAB + DQ_NP];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        if (pl == 0) wsum[sg] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int k = 0; k < DR_GROUPS; ++k) t += wsum[k];
+            loss[0] = (float)(t * inv_count);
+        }
+    }
+}
+
 extern "C" size_t mi_dqn_workspace_bytes(int batch) {
     return (size_t)((batch + TD_R - 1) / TD_R) * TD_SLAB * sizeof(float);
 }
@@ -825,7 +881,10 @@ static int dqn_td_impl(const float* params, const float* target_params, const fl
     MI_LAUNCH_CHECK();
     {
         mi_prof_scope prof(MI_PROF_DQN_REDUCE, s);
-        dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
+        if (blocks >= DR_MIN_SLABS)
+            dqn_reduce2_kernel<<<(DQ_NP + DR_PARAMS - 1) / DR_PARAMS + 1, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
+        else
+            dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
