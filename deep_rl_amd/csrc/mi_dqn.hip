@@ -897,6 +897,27 @@ extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, c
                        nullptr, nullptr, dqn_no_opt(), 0, 0, 0, stream);
 }
 
+// sharded runs, ONE C call (the pattern of mi_ppo_update_sharded): TD gradient share (scaled by 1 / (world * batch)) + slab sum, an in-stream RCCL SUM all-reduce
+// of gradbuf = {grads [MI_DQN_NPARAMS], loss, pad} and optimizer.step() (mi_clip_adam with `max_norm`) — the same launches as the host-sequenced route
+// (mi_dqn_td_grad / mi_per_td_grad, torch.distributed.all_reduce, mi_clip_adam), so the two agree bit for bit; no Python between launches.
+extern "C" int mi_dqn_td_update_sharded(float* params, const float* target_params, const float* observations, const int64_t* actions, const float* rewards,
+                                        const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, const float* weights,
+                                        float* td_abs, void* workspace, float* gradbuf, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1,
+                                        double beta2, double eps, float max_norm, float* grad_norm, void* comm, void* stream) {
+    MI_CHECK_ARG(gradbuf && exp_avg && exp_avg_sq && step >= 1, "NULL optimizer state / bad step");
+    int world = 1;
+    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    int rc = dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / ((double)batch * world), workspace,
+                         gradbuf, gradbuf + DQ_NP, weights, td_abs, dqn_no_opt(), 0, 0, 0, stream);
+    if (rc) return rc;
+    if (comm) {
+        mi_prof_scope prof(MI_PROF_COMM_GRAD, (hipStream_t)stream);
+        rc = mi_comm_allreduce_impl(comm, gradbuf, (size_t)DQ_NP + 2, 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return mi_clip_adam(params, gradbuf, exp_avg, exp_avg_sq, DQ_NP, step, lr, beta1, beta2, eps, max_norm, grad_norm, stream);
+}
+
 // single-process fusion: TD gradient (optionally importance-weighted, weights / td_abs nullable together) + optimizer.step() in two launches
 extern "C" int mi_dqn_td_update(float* params, const float* target_params, const float* observations, const int64_t* actions,
                                 const float* rewards, const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots,

@@ -1469,6 +1469,60 @@ extern "C" int mi_sac_actor_update(float* actor, const float* q, const float* ob
                                     adam_eps, nullptr, stream);
 }
 
+// ---- sharded runs, ONE C call per update (the pattern of mi_ppo_update_sharded): the *_grad launches with the share scaled by 1 / (world * batch), an in-stream RCCL
+// SUM all-reduce of the caller's {gradient, 2 scalars} buffer, then mi_adam (and mi_polyak) — exactly the launches of the host-sequenced route (sac_engine.py: *_grad,
+// torch.distributed.all_reduce, Adam.step, update_targets), so the two agree bit for bit; no Python between launches.
+extern "C" int mi_sac_critic_update_sharded(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                                            const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                                            uint64_t update_index, const float* alpha, float gamma, void* workspace, float* qbuf /* grads [2 Q_NP] + losses [2] */,
+                                            float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, float tau,
+                                            void* comm, void* stream) {
+    MI_CHECK_ARG(qbuf && exp_avg && exp_avg_sq && step >= 1, "NULL optimizer state / bad step");
+    int world = 1;
+    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    int rc = mi_sac_critic_grad(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
+                                1.0 / ((double)batch * world), workspace, qbuf, qbuf + 2 * SQ_NP, stream);
+    if (rc) return rc;
+    if (comm) {
+        mi_prof_scope prof(MI_PROF_COMM_GRAD, (hipStream_t)stream);
+        rc = mi_comm_allreduce_impl(comm, qbuf, (size_t)2 * SQ_NP + 2, 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    rc = mi_adam(q, qbuf, exp_avg, exp_avg_sq, 2 * SQ_NP, step, lr, beta1, beta2, adam_eps, stream);
+    if (rc || tau < 0.0f) return rc;
+    return mi_polyak(q_target, q, 2 * SQ_NP, tau, stream);
+}
+extern "C" int mi_sac_actor_update_sharded(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                                           uint64_t update_index, const float* alpha, void* workspace, float* abuf /* grads [ACTOR_NP] + out [2] */, float* exp_avg,
+                                           float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, void* comm, void* stream) {
+    MI_CHECK_ARG(abuf && exp_avg && exp_avg_sq && step >= 1, "NULL optimizer state / bad step");
+    int world = 1;
+    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    int rc = mi_sac_actor_grad(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / ((double)batch * world), workspace, abuf, abuf + AC_NP, stream);
+    if (rc) return rc;
+    if (comm) {
+        mi_prof_scope prof(MI_PROF_COMM_GRAD, (hipStream_t)stream);
+        rc = mi_comm_allreduce_impl(comm, abuf, (size_t)AC_NP + 2, 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return mi_adam(actor, abuf, exp_avg, exp_avg_sq, AC_NP, step, lr, beta1, beta2, adam_eps, stream);
+}
+extern "C" int mi_sac_alpha_step_sharded(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                                         uint64_t update_index, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr,
+                                         float* alpha, float* out, float* mean_logp /* dev f32 [1] scratch */, void* workspace, void* comm, void* stream) {
+    MI_CHECK_ARG(mean_logp != nullptr, "mean_logp scratch is NULL");
+    int world = 1;
+    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    int rc = mi_sac_mean_logp(actor, observations, idx, batch, eps, seed, update_index, 1.0 / ((double)batch * world), mean_logp, workspace, stream);
+    if (rc) return rc;
+    if (comm) {
+        mi_prof_scope prof(MI_PROF_COMM_STATS, (hipStream_t)stream);
+        rc = mi_comm_allreduce_impl(comm, mean_logp, 1, 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return mi_sac_alpha_adam(mean_logp, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, stream);
+}
+
 // ================================================ alpha, Adam, polyak ============================================================
 // one wave.  mean_in: nullable device scalar holding the (already all-reduced) mean log-prob; NULL = sum this rank's slabs (lane-strided, then the fixed DPP tree)
 __global__ void __launch_bounds__(64)

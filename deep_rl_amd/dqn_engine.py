@@ -4,10 +4,15 @@ Owns the four replay tensors with the reference's names (dqn.py:73-76) plus an e
 time-major ring (iqn.py:174-232 semantics; slots = total_timesteps + 1 gives the reference's linear storage).  Methods are
 thin launch wrappers over the C ABI (include/mi_rl.h "DQN"); nothing is computed in Python.
 """
+import os
+
 import torch
 
 from . import _native as N
 from . import dist as D
+
+# diagnostics (tests/_rccl_world1_worker.py): walk the sharded branch even at world_size 1, so that RCCL really runs on a one-GPU box
+_FORCE_SHARDED = os.environ.get("MIRL_OFFPOLICY_SHARDED", "0") == "1"
 
 
 class DQNEngine:
@@ -104,7 +109,8 @@ class DQNEngine:
         """One optimisation step (dqn.py:114-133).  Single process without gradient clipping: the launch that sums the gradient slabs also
         applies Adam (mi_dqn_td_update, bit-identical to td_grad() + optimizer.step())."""
         g = self.optimizer.param_groups[0]
-        fusable = self.world_size == 1 and g["max_grad_norm"] == float("inf") and type(self).td_grad in (DQNEngine.td_grad, PERDQNEngine.td_grad)
+        fusable = (self.world_size == 1 and not _FORCE_SHARDED and g["max_grad_norm"] == float("inf")
+                   and type(self).td_grad in (DQNEngine.td_grad, PERDQNEngine.td_grad))
         in_kernel_sampling = fusable and indices is None and type(self).sample is DQNEngine.sample     # uniform randint drawn by the TD launch itself
         if not in_kernel_sampling:
             self.sample(indices)
@@ -121,10 +127,26 @@ class DQNEngine:
                 N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                 self.env._seed, self.update_index, upper, self._s()), "mi_dqn_td_update")
             self._after_td()
+        elif self._native_sharded():
+            # sharded, NCCL process group: ONE C call — TD share, slab sum, in-stream RCCL all-reduce of {grads, loss}, clip + Adam (mi_dqn_td_update_sharded)
+            o = self.optimizer
+            o.step_count += 1
+            w, td = self._row_weights()
+            N.check(N.lib().mi_dqn_td_update_sharded(
+                N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
+                N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self._gradbuf),
+                N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], float(g["max_grad_norm"]),
+                N.ptr(o.grad_norm), D.native_comm(self.pg), self._s()), "mi_dqn_td_update_sharded")
+            self._after_td()
         else:
             self.td_grad()
             self.optimizer.step(self.grads)
         self.update_index += 1
+
+    def _native_sharded(self):
+        """The one-call RCCL route applies to the plain TD launches (DQN, PER) of a sharded run whose process group is NCCL."""
+        return ((self.world_size > 1 or _FORCE_SHARDED) and type(self).td_grad in (DQNEngine.td_grad, PERDQNEngine.td_grad)
+                and os.environ.get("MIRL_NATIVE_COMM", "1") != "0" and D.native_comm(self.pg) is not None)
 
     def sync_target(self):
         """target_network.load_state_dict(q_network.state_dict()) (dqn.py:136-137)."""

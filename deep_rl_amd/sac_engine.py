@@ -17,6 +17,8 @@ from .agent import pack
 from .optim import Adam
 
 _OWE_ALPHA = os.environ.get("MIRL_SAC_OWE_ALPHA", "1") != "0"   # 0: every alpha step is a launch of its own (A/B, debugging)
+# diagnostics (tests/_rccl_world1_worker.py): walk the sharded branches even at world_size 1, so that RCCL really runs on a one-GPU box
+_FORCE_SHARDED = os.environ.get("MIRL_OFFPOLICY_SHARDED", "0") == "1"
 
 
 class SACEngine:
@@ -71,6 +73,15 @@ class SACEngine:
 
     def _s(self):
         return N.stream_ptr(self.device)
+
+    def _single(self):
+        return self.world_size == 1 and not _FORCE_SHARDED
+
+    def _comm(self):
+        """libmirl's RCCL communicator when the sharded updates can run as ONE C call each (NCCL process group), else None (host-sequenced: gloo)."""
+        if os.environ.get("MIRL_NATIVE_COMM", "1") == "0":
+            return None
+        return D.native_comm(self.pg)
 
     # ---- the entropy coefficient's state: reading it settles an owed alpha step first ----
     def _owed_struct(self):
@@ -182,7 +193,7 @@ class SACEngine:
     def update_critic(self, eps=None, polyak=False, sample_in_launch=False):
         """sac.py:170-185 (+ the target update of :213-217 when `polyak`).  Single process: ONE fused call — the launch that assembles the
         gradient also applies Adam and the polyak step; sharded: gradient, all-reduce, Adam (, polyak)."""
-        if self.world_size == 1:
+        if self._single():
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.q_optimizer
             g = o.param_groups[0]
@@ -197,6 +208,17 @@ class SACEngine:
                 N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                 self.tau if polyak else -1.0, self._key(self.update_index), min(self.global_step, self.slots) * self.N if sample_in_launch else 0,
                 C.byref(owed) if owed is not None else None, self._s()), "mi_sac_critic_update_owed")
+        elif self._comm() is not None:
+            # sharded, NCCL process group: ONE C call — gradient share, in-stream RCCL all-reduce of {grads, losses}, Adam, polyak (mi_sac_critic_update_sharded)
+            e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+            o = self.q_optimizer
+            g = o.param_groups[0]
+            o.step_count += 1
+            N.check(N.lib().mi_sac_critic_update_sharded(
+                N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+                N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed, self._key(self.update_index),
+                N.ptr(self.alpha), self.gamma, N.ptr(self.workspace), N.ptr(self._qbuf), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]),
+                g["betas"][0], g["betas"][1], g["eps"], self.tau if polyak else -1.0, self._comm(), self._s()), "mi_sac_critic_update_sharded")
         else:
             self.critic_grad(eps)
             self.q_optimizer.step(self.q_grads)
@@ -215,7 +237,7 @@ class SACEngine:
 
     def update_actor(self, eps=None):
         """sac.py:189-197 (single process: one fused call, as update_critic)."""
-        if self.world_size == 1:
+        if self._single():
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.actor_optimizer
             g = o.param_groups[0]
@@ -229,13 +251,22 @@ class SACEngine:
             # this launch stashed its batch observations — in the slot a debt it carried did not read — so an alpha step may be owed on them
             self._stash_slot = (owed.stash_slot ^ 1) if owed is not None else 0
             self._stash_fresh = True
+        elif self._comm() is not None:
+            e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
+            o = self.actor_optimizer
+            g = o.param_groups[0]
+            o.step_count += 1
+            N.check(N.lib().mi_sac_actor_update_sharded(
+                N.ptr(self.actor.flat), N.ptr(self.q_flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed,
+                self._key(self.actor_updates), N.ptr(self.alpha), N.ptr(self.workspace), N.ptr(self._abuf), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count,
+                float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self._comm(), self._s()), "mi_sac_actor_update_sharded")
         else:
             self.actor_grad(eps)
             self.actor_optimizer.step(self.actor_grads)
 
     def update_alpha(self, eps=None):
         """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
-        if eps is None and self.world_size == 1 and self._stash_fresh and self._owed_fits and _OWE_ALPHA:
+        if eps is None and self._single() and self._stash_fresh and self._owed_fits and _OWE_ALPHA:
             # keyed draws, single process, right after a fused actor update: the step is OWED — the next row-group launch (actor or critic update) carries its
             # log-prob pass on workgroups of its own and hands alpha to its consumers in the launch; reading the state (or flush_alpha()) settles it alone
             self.flush_alpha()
@@ -248,11 +279,16 @@ class SACEngine:
         e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
         self._alpha_steps += 1
         L = N.lib()
-        if self.world_size == 1:
+        if self._single():
             N.check(L.mi_sac_alpha_step(
                 N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed,
                 self._key(self.actor_updates), self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v),
                 self.alpha_steps, self.alpha_lr, N.ptr(self.alpha), N.ptr(self.alpha_out), N.ptr(self.workspace), self._s()), "mi_sac_alpha_step")
+        elif self._comm() is not None:
+            N.check(L.mi_sac_alpha_step_sharded(
+                N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed, self._key(self.actor_updates),
+                self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v), self.alpha_steps, self.alpha_lr, N.ptr(self.alpha),
+                N.ptr(self.alpha_out), N.ptr(self._mean_logp), N.ptr(self.workspace), self._comm(), self._s()), "mi_sac_alpha_step_sharded")
         else:
             N.check(L.mi_sac_mean_logp(
                 N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed,
@@ -271,7 +307,7 @@ class SACEngine:
     def train_step(self, policy_frequency=2, target_network_frequency=1, indices=None):
         """The optimisation half of one loop iteration (sac.py:161-217) at the current global_step.  The target update uses the critic
         parameters, which the actor / alpha updates do not touch, so it rides on the critic update's last launch."""
-        in_launch = indices is None and self.world_size == 1      # the critic launch draws the batch indices itself (same contract as sample())
+        in_launch = indices is None and self._single()            # the critic launch draws the batch indices itself (same contract as sample())
         if not in_launch:
             self.sample(indices)
         self.update_critic(polyak=self.global_step % target_network_frequency == 0, sample_in_launch=in_launch)

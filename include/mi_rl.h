@@ -257,6 +257,14 @@ int mi_dqn_td_update(float* params, const float* target_params, const float* obs
                      float gamma, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, float* exp_avg, float* exp_avg_sq,
                      int64_t step, double lr, double beta1, double beta2, double eps, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper,
                      void* stream);
+/* sharded runs (one process per GPU), ONE call per optimisation step (dqn.py:118-133 with the gradient exchange between backward and step): TD gradient
+ * share scaled by 1 / (world * batch), slab sum, in-stream RCCL SUM all-reduce of gradbuf = dev f32 [MI_DQN_NPARAMS + 2] {grads, loss, pad}, then mi_clip_adam(max_norm,
+ * grad_norm nullable).  weights / td_abs: PER row weights and |td| out (nullable together).  The same launches as mi_dqn_td_grad (mi_per_td_grad) + caller all-reduce +
+ * mi_clip_adam: bit-identical.  comm NULL or world 1: no collective. */
+int mi_dqn_td_update_sharded(float* params, const float* target_params, const float* observations, const int64_t* actions, const float* rewards,
+                             const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, const float* weights, float* td_abs,
+                             void* workspace, float* gradbuf, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,
+                             float max_norm, float* grad_norm, void* comm, void* stream);
 /* optimizer.step() (dqn.py:131-133) = mi_clip_adam(..., n = MI_DQN_NPARAMS, eps = 1e-8, max_norm = +inf);
  * target_network.load_state_dict (dqn.py:136-137) = a device-to-device copy of the flat vector by the caller. */
 
@@ -409,6 +417,20 @@ int mi_sac_mean_logp(const float* actor, const float* observations, const int64_
                      uint64_t update_index, double inv_count, float* mean_logp, void* workspace, void* stream);
 int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, float* alpha, float* out, void* stream);
+/* the three of them as ONE call each with the all-reduce in-stream on libmirl's RCCL communicator (the pattern of mi_ppo_update_sharded; sac.py:165-210 with the exchange
+ * between backward and optimizer.step()): qbuf = dev f32 [2 MI_SAC_Q_NPARAMS + 2] {grads, qf1_loss, qf2_loss}; abuf = dev f32 [MI_SAC_ACTOR_NPARAMS + 2] {grads, actor_loss,
+ * mean log-prob}; mean_logp = dev f32 [1] scratch.  tau < 0 skips the polyak step.  The same launches as the *_grad + caller all-reduce + mi_adam (+ mi_polyak) /
+ * mi_sac_mean_logp + all-reduce + mi_sac_alpha_adam sequences: bit-identical.  comm NULL or world 1: no collective. */
+int mi_sac_critic_update_sharded(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                                 const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed, uint64_t update_index,
+                                 const float* alpha, float gamma, void* workspace, float* qbuf, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1,
+                                 double beta2, double adam_eps, float tau, void* comm, void* stream);
+int mi_sac_actor_update_sharded(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                                uint64_t update_index, const float* alpha, void* workspace, float* abuf, float* exp_avg, float* exp_avg_sq, int64_t step, double lr,
+                                double beta1, double beta2, double adam_eps, void* comm, void* stream);
+int mi_sac_alpha_step_sharded(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed, uint64_t update_index,
+                              float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, float* alpha, float* out,
+                              float* mean_logp, void* workspace, void* comm, void* stream);
 /* optim.Adam.step without clipping (sac.py:108,117; torch single-tensor formula), any n */
 int mi_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1,
             double beta2, double eps, void* stream);

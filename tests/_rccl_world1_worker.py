@@ -3,7 +3,8 @@ process group and libmirl's own RCCL communicator exist on a one-GPU box.  Check
   (a) mi_ppo_update                              single-process fusion, no collective
   (b) mi_ppo_update_sharded over RCCL            ONE C call, 17 in-stream ncclAllReduce per update (world_size 1: the data is unchanged)
   (c) the host-sequenced launches with torch.distributed all-reduces over RCCL between them
-and that mi_comm_allreduce_sum really runs on the stream it is given."""
+and that mi_comm_allreduce_sum really runs on the stream it is given; the same three-way identity for the DQN, PER and SAC engines
+(mi_dqn_td_update_sharded, mi_sac_critic / actor_update_sharded, mi_sac_alpha_step_sharded)."""
 import os
 import sys
 
@@ -63,6 +64,60 @@ for n_envs in (8, 4096):
         for a, b in zip(ref, got):
             assert torch.equal(a, b), (n_envs, mode)
     assert torch.isfinite(ref[0]).all()
+
+# ---- DQN / PER / SAC: fused single-process calls == one-call RCCL route (mi_dqn_td_update_sharded, mi_sac_*_sharded) == host-sequenced route with torch all-reduces ----
+import deep_rl_amd.dqn_engine as DE  # noqa: E402
+import deep_rl_amd.sac_engine as SE  # noqa: E402
+
+
+def set_mode(mode):
+    DE._FORCE_SHARDED = SE._FORCE_SHARDED = mode != "fused"
+    DD._FORCE_COLLECTIVES = mode == "torch"
+    os.environ["MIRL_NATIVE_COMM"] = "0" if mode == "torch" else "1"
+
+
+def run_dqn(mode, per):
+    set_mode(mode)
+    env = D.make("CartPole-v1", num_envs=64, device=dev, seed=5)
+    torch.manual_seed(5)
+    q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
+    Eng = D.PERDQNEngine if per else D.DQNEngine
+    eng = Eng(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=64, batch_size=128, learning_starts=10, total_timesteps=2000, max_episodes_logged=0)
+    eng.reset()
+    rng = np.random.default_rng(3)
+    for k in range(12):
+        eng.act(10)
+        eng.train_step(rng.integers(0, min(eng.global_step, 64) * 64 - 64, 128) if not per else None)
+    torch.cuda.synchronize()
+    return [x.clone() for x in (q.flat, eng.optimizer.exp_avg, eng.optimizer.exp_avg_sq, eng.loss, eng.grads)]
+
+
+def run_sac(mode):
+    set_mode(mode)
+    env = D.make("Pendulum-v1", num_envs=48, device=dev, seed=9)
+    torch.manual_seed(9)
+    actor = D.Actor(env)
+    qs = [D.SoftQNetwork(env) for _ in range(4)]
+    qs[2].load_state_dict(qs[0].state_dict()); qs[3].load_state_dict(qs[1].state_dict())
+    eng = D.SACEngine(env, actor, *qs, slots=40, batch_size=256, learning_starts=4)
+    eng.reset()
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        eng.act()
+        if eng.global_step > 6:
+            eng.train_step(indices=rng.integers(0, min(eng.global_step, 40) * 48 - 48, 256))
+    torch.cuda.synchronize()
+    return [x.clone() for x in (actor.flat, eng.q_flat, eng.qt_flat, eng.log_alpha, eng.alpha, eng._alpha_m, eng.actor_optimizer.exp_avg, eng.q_optimizer.exp_avg_sq, eng.q_losses)]
+
+
+for name, fn in (("dqn", lambda m: run_dqn(m, False)), ("per", lambda m: run_dqn(m, True)), ("sac", run_sac)):
+    ref = fn("fused")
+    for mode in ("native", "torch"):
+        got = fn(mode)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), (name, mode)
+    assert all(torch.isfinite(x).all() for x in ref), name
+set_mode("fused")
 DD.destroy_native_comms()
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
