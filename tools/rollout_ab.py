@@ -27,6 +27,9 @@ def timed(tag):
     print("%-28s rollout+GAE %.1f us mean, %.1f min, %.1f max | mean episode length %.1f" % (tag, np.mean(ts), np.min(ts), np.max(ts), st[1] / max(st[0], 1)))
 
 
+timed("initial policy, cold GPU")
+for _ in range(400):      # ~80 ms of rollouts: the clocks have ramped by now; the policy is still the initial one
+    eng.rollout_gae()
 timed("initial policy")
 for _ in range(40):
     eng.update()
