@@ -517,6 +517,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 // (mats 0,1: critics; 2: actor)
 #define SLAB 3600
 #define GEMM_MAX_SPLIT 16
+#define SAC_FUSED_KP 512   // up to this (padded) batch the dW2 GEMM, the gradient assembly and the optimizer step are ONE launch (sac_dw2_adam_kernel)
 __host__ __device__ inline int ws_kp(int batch) { return (batch + SR - 1) / SR * SR; }
 __host__ __device__ inline size_t ws_mat_floats(int batch) { return (size_t)ws_kp(batch) * SA_H; }
 __host__ __device__ inline size_t ws_slab_off(int batch) { return 6 * ws_mat_floats(batch); }
@@ -1158,14 +1159,14 @@ __device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g, sa
     if (o.target) o.target[i] = o.tau * p + (1.0f - o.tau) * s.t;
 }
 #define RED_SMALL_PER_BLOCK 64
-__global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __restrict__ ws, int batch, int n_slabs, int n_split, int is_actor, double inv_count,
-                                                              float* __restrict__ grads, float* __restrict__ out2, sac_opt_t opt) {
-    __shared__ float part[4][RED_SMALL_PER_BLOCK];
+// (a) + (c) for the 64 thin elements of block `blk`: threads 0..255 of the workgroup (4 slab groups x 64 elements); contains one __syncthreads
+__device__ __forceinline__ void sac_thin_reduce(int blk, float (&part)[4][RED_SMALL_PER_BLOCK], const float* __restrict__ ws, int batch, int n_slabs, int is_actor,
+                                                double inv_count, float* __restrict__ grads, float* __restrict__ out2, const sac_opt_t& opt) {
     const int per = is_actor ? 1794 : 1793, nets = is_actor ? 1 : 2, n_small = per * nets + 2;
-    const int nb_small = (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK;
-    if ((int)blockIdx.x < nb_small) {
+    {
         const float* slabs = ws + ws_slab_off(batch);
-        const int e = blockIdx.x * RED_SMALL_PER_BLOCK + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+        const bool live = threadIdx.x < 256;
+        const int e = live ? blk * RED_SMALL_PER_BLOCK + (threadIdx.x & 63) : n_small, grp = (threadIdx.x >> 6) & 3;
         int off = -1;
         if (e < per * nets) off = (e / per) * 1793 + e % per;
         else if (e < n_small) off = (is_actor ? 1794 : 3586) + (e - per * nets);
@@ -1177,7 +1178,7 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
             else dst = net * SQ_NP + (l < 1024 ? SQ_W1 + l : l < 1280 ? SQ_B1 + (l - 1024) : l < 1536 ? SQ_B2 + (l - 1280) : l < 1792 ? SQ_W3 + (l - 1536) : SQ_B3);
         }
         sac_state_t st = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (grp == 0 && dst >= 0) st = sac_state_load(opt, dst);
+        if (live && grp == 0 && dst >= 0) st = sac_state_load(opt, dst);
         float acc = 0.0f;
         if (off >= 0) {   // this group's slabs grp, grp + 4, ...: eight loads in flight at a time, summed in slab order
             int b = grp;
@@ -1197,15 +1198,24 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
             }
             for (; b < n_slabs; b += 4) acc += slabs[(size_t)b * SLAB + off];
         }
-        part[grp][threadIdx.x & 63] = acc;
+        if (live) part[grp][threadIdx.x & 63] = acc;
         __syncthreads();
-        if (grp == 0 && off >= 0) {
+        if (live && grp == 0 && off >= 0) {
             const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
             if (dst >= 0) {
                 grads[dst] = v;
                 if (opt.params) sac_apply(opt, dst, v, st);
             } else if (out2) out2[e - per * nets] = (float)((double)v * inv_count);
         }
+    }
+}
+__global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __restrict__ ws, int batch, int n_slabs, int n_split, int is_actor, double inv_count,
+                                                              float* __restrict__ grads, float* __restrict__ out2, sac_opt_t opt) {
+    __shared__ float part[4][RED_SMALL_PER_BLOCK];
+    const int per = is_actor ? 1794 : 1793, nets = is_actor ? 1 : 2, n_small = per * nets + 2;
+    const int nb_small = (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK;
+    if ((int)blockIdx.x < nb_small) {
+        sac_thin_reduce((int)blockIdx.x, part, ws, batch, n_slabs, is_actor, inv_count, grads, out2, opt);
     } else {
         const int e4 = (blockIdx.x - nb_small) * 256 + threadIdx.x;          // float4 index over nets x 65536
         if (e4 >= nets * (SA_H * SA_H / 4)) return;
@@ -1227,6 +1237,82 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
     }
 }
 
+// Small batches (Kp <= 512: the reference's 256): dW2, its optimizer step and the thin gradients in ONE launch — the two kernels above are a 5.5 us + 5.0 us pair of
+// which ~4.5 us is the boundary between them (round 3: 95 -> 86 us per SAC iteration).  Workgroups [0, 64 nets): one 32 x 32 tile of one dW2 each, the (padded) batch
+// split over EIGHT waves; their partial tiles are summed through LDS in the order the K-split pair of launches used at the reference batch (two groups of four waves
+// = its two K-split partials: bitwise the same gradient), the tile is laid out row-major in LDS, and the 512 threads apply Adam (+ polyak) to 2 consecutive elements
+// each — the element's optimizer state is requested before the K loop.  Workgroups behind them: sac_thin_reduce.
+__global__ void __launch_bounds__(512) sac_dw2_adam_kernel(float* __restrict__ ws, int batch, int mat0, int n_slabs, int is_actor, double inv_count,
+                                                           float* __restrict__ grads, float* __restrict__ out2, sac_opt_t opt) {
+    __shared__ union { f32x4 red[8][4][64]; float tile[32][36]; float part[4][RED_SMALL_PER_BLOCK]; } sm;
+    const int nets = is_actor ? 1 : 2;
+    if ((int)blockIdx.x >= 64 * nets) {
+        sac_thin_reduce((int)blockIdx.x - 64 * nets, sm.part, ws, batch, n_slabs, is_actor, inv_count, grads, out2, opt);
+        return;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x & 63, mat = blockIdx.x >> 6, mg = tile >> 3, ng = tile & 7;
+    const int Kp = ws_kp(batch), steps = Kp / 4;
+    const int s0 = (int)((long long)steps * w / 8), s1 = (int)((long long)steps * (w + 1) / 8);
+    const float* H1 = ws + (size_t)(mat0 + mat) * ws_mat_floats(batch) + 32 * ng + 2 * j;
+    const float* DZ2 = ws + (size_t)(3 + mat0 + mat) * ws_mat_floats(batch) + 32 * mg + 2 * j;
+    // everything this thread will need from memory is requested here, before anything is waited for: the first 8 k-steps' operands (all of them at the reference
+    // batch) and the optimizer state of its 2 elements of the finished tile (row 32 mg + (t >> 4), columns 32 ng + 2 (t & 15), + 1) — one round trip per launch
+    float2 av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const size_t row = (size_t)(4 * (s0 + u < s1 ? s0 + u : s0) + g) * SA_H;
+        av[u] = *reinterpret_cast<const float2*>(DZ2 + row); bv[u] = *reinterpret_cast<const float2*>(H1 + row);
+    }
+    const int d0 = (is_actor ? AC_W2 : mat * SQ_NP + SQ_W2) + (32 * mg + ((int)threadIdx.x >> 4)) * SA_H + 32 * ng + 2 * ((int)threadIdx.x & 15);
+    sac_state_t st[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) st[c] = sac_state_load(opt, d0 + c);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto kstep = [&](const float2& a_, const float2& b_) {
+        const float a2[2] = {a_.x, a_.y}, b2[2] = {b_.x, b_.y};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = MFMA16(a2[a], b2[b], acc[a][b]);
+    };
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (s0 + u < s1) kstep(av[u], bv[u]);   // (wave-uniform)
+    for (int s = s0 + 8; s < s1; ++s) {                                 // batches above 256 rows
+        const size_t row = (size_t)(4 * s + g) * SA_H;
+        kstep(*reinterpret_cast<const float2*>(DZ2 + row), *reinterpret_cast<const float2*>(H1 + row));
+    }
+    // cross-wave sum: every wave leaves its 4 fragments in LDS; wave w then owns half of fragment f = w >> 1 (registers 2 (w & 1), + 1) and adds the eight partials
+    // in the order of the K-split pair of launches this kernel replaces at the reference batch (waves 0-3 = its first partial, 4-7 = its second)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) sm.red[w][2 * a + b][lane] = acc[a][b];
+    __syncthreads();
+    const int f = w >> 1, r0 = 2 * (w & 1);
+    float sum[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float lo = ((sm.red[0][f][lane][r0 + q] + sm.red[1][f][lane][r0 + q]) + sm.red[2][f][lane][r0 + q]) + sm.red[3][f][lane][r0 + q];
+        const float hi = ((sm.red[4][f][lane][r0 + q] + sm.red[5][f][lane][r0 + q]) + sm.red[6][f][lane][r0 + q]) + sm.red[7][f][lane][r0 + q];
+        sum[q] = lo + hi;
+    }
+    __syncthreads();   // every partial has been read: the LDS becomes the row-major tile
+    {   // fragment (a, b), register r = dW2[32 mg + 2 (4 g + r) + a][32 ng + 2 j + b]
+        const int a = f >> 1, b = f & 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sm.tile[2 * (4 * g + r0 + q) + a][2 * j + b] = sum[q];
+    }
+    __syncthreads();
+    const float2 gv = *reinterpret_cast<const float2*>(&sm.tile[threadIdx.x >> 4][2 * (threadIdx.x & 15)]);
+    grads[d0] = gv.x; grads[d0 + 1] = gv.y;
+    if (opt.params) { sac_apply(opt, d0, gv.x, st[0]); sac_apply(opt, d0 + 1, gv.y, st[1]); }
+}
+
 static sac_opt_t sac_no_opt() { sac_opt_t o; memset(&o, 0, sizeof(o)); return o; }
 static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, int64_t step, double lr, double beta1, double beta2, double eps, float tau) {
     sac_opt_t o;
@@ -1238,6 +1324,14 @@ static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, 
 
 static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv_count, float* grads, float* out2, const sac_opt_t& opt, hipStream_t s) {
     const int nb = ws_kp(batch) / SR, nets = is_actor ? 1 : 2, split = gemm_split(batch);
+    if (ws_kp(batch) <= SAC_FUSED_KP) {
+        const int n_small = (is_actor ? 1794 : 2 * 1793) + 2;
+        mi_prof_scope prof(MI_PROF_SAC_GEMM, s);
+        sac_dw2_adam_kernel<<<64 * nets + (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK, 512, 0, s>>>((float*)workspace, batch, is_actor ? 2 : 0, nb, is_actor, inv_count,
+                                                                                                                  grads, out2, opt);
+        MI_LAUNCH_CHECK();
+        return MI_OK;
+    }
     {
         mi_prof_scope prof(MI_PROF_SAC_GEMM, s);
         sac_dw2_gemm_kernel<<<dim3(32 * nets, split), 256, 0, s>>>((float*)workspace, batch, is_actor ? 2 : 0, nets);
