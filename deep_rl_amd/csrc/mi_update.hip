@@ -103,15 +103,10 @@ __global__ void __launch_bounds__(256) adv_stats_kernel(const float* __restrict_
 
 // mi_ppo_update's fused form: out[i] = Feistel(i) and, in the same pass, the advantage sums of the minibatch i belongs to
 // (mb is a multiple of 256 there, so a workgroup never straddles two minibatches).  sums must be zero on entry.
-#ifndef PS_PER_BLOCK
 #define PS_PER_BLOCK 4096  // elements per workgroup: few workgroups per minibatch touch the fp64 atomics (contention; 2048 per workgroup: 26 us instead of 16.7)
-#endif
-#ifndef PS_THREADS
-#define PS_THREADS 256
-#endif
 #define PS_MAX_EPOCHS 8
 struct ps_epochs_t { uint32_t k0[PS_MAX_EPOCHS], k1[PS_MAX_EPOCHS]; int32_t* out[PS_MAX_EPOCHS]; };   // blockIdx.y = epoch: all epochs of an update in one launch
-__global__ void __launch_bounds__(PS_THREADS) perm_stats_kernel(uint32_t n, uint32_t a, uint32_t b, ps_epochs_t ep, int mb, int n_mb,
+__global__ void __launch_bounds__(256) perm_stats_kernel(uint32_t n, uint32_t a, uint32_t b, ps_epochs_t ep, int mb, int n_mb,
                                                          const float* __restrict__ adv, double* __restrict__ sums_all) {
     const uint32_t base = blockIdx.x * PS_PER_BLOCK;
     const uint32_t k0 = ep.k0[blockIdx.y], k1 = ep.k1[blockIdx.y];
@@ -119,7 +114,7 @@ __global__ void __launch_bounds__(PS_THREADS) perm_stats_kernel(uint32_t n, uint
     double* __restrict__ sums = sums_all + (size_t)3 * n_mb * blockIdx.y;
     double s = 0.0, q = 0.0;
 #pragma unroll 4
-    for (uint32_t i = base + threadIdx.x; i < base + PS_PER_BLOCK && i < n; i += PS_THREADS) {
+    for (uint32_t i = base + threadIdx.x; i < base + PS_PER_BLOCK && i < n; i += 256) {
         const uint32_t p = mi_feistel(i, n, a, b, k0, k1);
         out[i] = (int32_t)p;
         const double v = (double)adv[p];
@@ -127,16 +122,13 @@ __global__ void __launch_bounds__(PS_THREADS) perm_stats_kernel(uint32_t n, uint
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    __shared__ double ss[PS_THREADS / 64], qq[PS_THREADS / 64];
+    __shared__ double ss[4], qq[4];
     if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; qq[threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int k = (int)(base / (uint32_t)mb);
-        double S = 0.0, Q = 0.0;
-#pragma unroll
-        for (int w = 0; w < PS_THREADS / 64; w += 4) { S += (ss[w] + ss[w + 1]) + (ss[w + 2] + ss[w + 3]); Q += (qq[w] + qq[w + 1]) + (qq[w + 2] + qq[w + 3]); }
-        atomicAdd(&sums[3 * k + 0], S);
-        atomicAdd(&sums[3 * k + 1], Q);
+        atomicAdd(&sums[3 * k + 0], (ss[0] + ss[1]) + (ss[2] + ss[3]));
+        atomicAdd(&sums[3 * k + 1], (qq[0] + qq[1]) + (qq[2] + qq[3]));
         if (base % (uint32_t)mb == 0) sums[3 * k + 2] = (double)mb;
     }
 }
@@ -683,7 +675,7 @@ extern "C" int mi_ppo_perms_and_stats(uint64_t seed, int update_index, int epoch
         while ((1u << bits) < (uint32_t)n_rows) ++bits;
         if (bits < 2) bits = 2;
         mi_prof_scope prof(MI_PROF_STATS, s);
-        perm_stats_kernel<<<dim3((n_rows + PS_PER_BLOCK - 1) / PS_PER_BLOCK, epochs), PS_THREADS, 0, s>>>((uint32_t)n_rows, bits / 2, bits - bits / 2, pe, mb, n_minibatch, advantages,
+        perm_stats_kernel<<<dim3((n_rows + PS_PER_BLOCK - 1) / PS_PER_BLOCK, epochs), 256, 0, s>>>((uint32_t)n_rows, bits / 2, bits - bits / 2, pe, mb, n_minibatch, advantages,
                                                                                                  sums_all);
         MI_LAUNCH_CHECK();
         return MI_OK;
@@ -740,7 +732,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
         while ((1u << bits) < (uint32_t)B) ++bits;
         if (bits < 2) bits = 2;
         mi_prof_scope prof(MI_PROF_STATS, s);
-        perm_stats_kernel<<<dim3((B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, hp->update_epochs), PS_THREADS, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, pe, mb, hp->n_minibatch,
+        perm_stats_kernel<<<dim3((B + PS_PER_BLOCK - 1) / PS_PER_BLOCK, hp->update_epochs), 256, 0, s>>>((uint32_t)B, bits / 2, bits - bits / 2, pe, mb, hp->n_minibatch,
                                                                                                        b->advantages, b->adv_sums);
         MI_LAUNCH_CHECK();
     } else {
