@@ -3,9 +3,9 @@
 import csv, json, sys, collections
 
 def short(name):
-    for k in ("grad_kernel_bx", "grad_kernel_f32", "grad_kernel", "grad_reduce_kernel", "clip_adam_kernel", "rollout_q4_kernel", "rollout_mfma_kernel", "rollout_kernel", "gae_kernel", "adv_stats_kernel",
-              "perm_stats_kernel", "perm_kernel", "dqn_act4_kernel", "dqn_act_kernel", "dqn_td_kernel", "dqn_reduce_kernel", "sac_critic_kernel", "sac_actor_kernel", "sac_act_kernel",
-              "sac_dw2_adam_kernel", "sac_dw2_gemm_kernel", "sac_grad_reduce_kernel"):
+    for k in ("sac_dw2_adam_kernel", "sac_dw2_gemm_kernel", "sac_grad_reduce_kernel", "sac_critic_kernel", "sac_actor_kernel", "sac_act_kernel",   # (before "grad_reduce_kernel": substring)
+              "grad_kernel_bx", "grad_kernel_f32", "grad_kernel", "grad_reduce_kernel", "clip_adam_kernel", "rollout_q4_kernel", "rollout_mfma_kernel", "rollout_kernel", "gae_kernel",
+              "adv_stats_kernel", "perm_stats_kernel", "perm_kernel", "dqn_act4_kernel", "dqn_act_kernel", "dqn_td_kernel", "dqn_reduce2_kernel", "dqn_reduce_kernel"):
         if k in name:
             return k
     return name[:40]
