@@ -472,9 +472,16 @@ def main():
     breakdown = N.prof_end()
 
     from deep_rl_amd import dist as _dist
-    comm = _dist.native_comm(eng.pg) if world > 1 else None
+    # (MIRL_FORCE_PG=1 makes a single process join a world_size-1 RCCL group: the diagnostics' native-communicator branch then runs on a one-GPU box, tests/test_gpu_script.py)
+    dist_on = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
+    comm = _dist.native_comm(eng.pg) if dist_on else None
     eng_native = comm is not None
-    collectives = collective_diagnostics(eng, comm, world, dev, breakdown, 3) if world > 1 else None   # every rank takes part in the collectives
+    collectives = None
+    if dist_on:   # every rank takes part in the collectives; a failure here must not cost the measurement above its line
+        try:
+            collectives = collective_diagnostics(eng, comm, world, dev, breakdown, 3)
+        except Exception as ex:  # noqa: BLE001
+            collectives = {"error": "%s: %s" % (type(ex).__name__, ex)}
     finite = bool(torch.isfinite(agent.flat).all().item())
     ep = stats_host.tolist()
     if rank == 0:
@@ -527,7 +534,7 @@ def main():
             out["config3_dqn_scaled"] = dict(bench_dqn(dev, iters=150, cpu_seconds=min(cs, 2.0), batch=4096), scaled="batch 4096 instead of the reference's 128 (dqn.py:46)")
             out["config4_sac_scaled"] = dict(bench_sac(dev, iters=150, cpu_seconds=min(cs, 2.0), batch=4096), scaled="batch 4096 instead of the reference's 256 (sac.py:85)")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         from deep_rl_amd.dist import destroy_native_comms
         destroy_native_comms()

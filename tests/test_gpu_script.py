@@ -182,6 +182,32 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert c["back_to_back"]["us_per_allreduce_grad"] > 0 and c["back_to_back"]["us_per_allreduce_stats"] > 0
 
 
+def test_bench_native_rccl_diagnostics_at_world_size_1():
+    """The `collectives` object of an RCCL run (libmirl's own communicator: version, rank count, in-update HIP-event times, back-to-back latencies) — the branch the
+    first multi-GPU run of the driver takes — exercised on the one-GPU box: MIRL_FORCE_PG=1 makes the single process join a world_size-1 RCCL group."""
+    import json
+    import socket
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--headline-only", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["collectives"]
+    assert "error" not in c, c
+    assert "RCCL direct" in c["carrier"] and c["rccl_version"] > 0 and c["rccl_comm_count"] == 1 and c["world_size"] == 1
+    assert c["back_to_back"]["us_per_allreduce_grad"] > 0 and c["back_to_back"]["us_per_allreduce_stats"] > 0 and "in_update" in c
+
+
 def test_bench_self_launch_propagates_failure():
     """The self-launching parent exits with the child's return code (here: every rank fails in init_process_group on an unknown backend) and prints no JSON line."""
     env = dict(os.environ, PYTHONPATH=ROOT, MIRL_BENCH_BACKEND="no-such-backend")
