@@ -67,3 +67,46 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "cpu_ref" not in txt.replace("oracle/cpu_ref.c implements", "") or f in ("mi_common.h",), os.path.join(dirpath, f)
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dirpath, f)
+
+
+_NULL_PROBE = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r)
+from deep_rl_amd import _native as N
+L, out = N.lib(), {}
+for name, (res, args) in sorted(N.SIGNATURES.items()):
+    vals = []
+    for a in args:
+        if a in (C.c_void_p, C.c_char_p) or (hasattr(a, "_type_") and not isinstance(a._type_, str)):
+            vals.append(None)
+        elif a in (C.c_float, C.c_double):
+            vals.append(0.0)
+        else:
+            vals.append(0)
+    r = getattr(L, name)(*vals)
+    out[name] = r if isinstance(r, int) else None
+    print("DONE", name, flush=True)
+print("RESULT", json.dumps(out))
+"""
+
+
+def test_every_entry_point_survives_null_and_zero_arguments(N):
+    """include/mi_rl.h: "every failure is a negative return code".  Each exported function is called with NULL for every pointer and 0 for every number (in a child
+    process: a crash would be a finding, not the end of the test run): none may fault, and every call that cannot possibly succeed must say so in its return code."""
+    import json
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, "-c", _NULL_PROBE % ROOT], capture_output=True, text=True, timeout=240)
+    done = [ln.split()[1] for ln in p.stdout.splitlines() if ln.startswith("DONE")]
+    assert p.returncode == 0, "crashed after %s: %s" % (done[-1] if done else "nothing", p.stderr[-800:])
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0][7:])
+    assert set(res) == set(N.SIGNATURES)
+    harmless = {"mi_comm_destroy", "mi_env_destroy", "mi_timer_destroy",                    # destroying nothing is fine
+                "mi_version", "mi_last_error", "mi_perm_key", "mi_ppo_workspace_bytes", "mi_dqn_workspace_bytes", "mi_sac_workspace_bytes", "mi_per_workspace_bytes",
+                "mi_env_state_bytes", "mi_ppo_get_contraction", "mi_ppo_set_contraction",   # (mode 0 = f32 is valid)
+                "mi_sac_set_max_cus", "mi_sac_usable_cus", "mi_sac_test_fault", "mi_sac_owed_alpha_fits"}
+    for name, r in res.items():
+        if name in harmless:
+            continue
+        assert isinstance(r, int) and r < 0, (name, r)
