@@ -96,6 +96,9 @@ extern "C" int mi_debug_rollout_stamps(unsigned long long* out, int n) {
 // compiles to FLAT instructions with sc0 sc1 and an s_waitcnt vmcnt(0) behind every store, i.e. each publish would wait for all of the
 // wave's outstanding GLOBAL stores (measured: 500 cycles per step).  The LDS executes one wave's accesses in program order, so data
 // written before the counter is visible before it; the empty asm statements keep the COMPILER from reordering around them.
+// Forward progress: both waves belong to ONE workgroup, so they are resident together by construction and each waits only for a counter the other one advances
+// unconditionally (the actor never waits while T + 1 <= RQ_RING; with a wrapped ring it waits for a slot the critic frees after a bounded amount of work, and the
+// critic for a slot the actor fills likewise): unlike the inter-workgroup waits of mi_sac.hip these polls need no co-residency argument and no time budget.
 typedef __attribute__((address_space(3))) int rq_lds_int;
 __device__ __forceinline__ void lds_publish(int* word, int v) {
     asm volatile("" ::: "memory");
