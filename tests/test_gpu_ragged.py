@@ -82,3 +82,65 @@ def test_adv_stats_ragged_minibatches(dev, R, rows, mb, n_mb):
         assert abs(s[k, 0] / mb - mean) <= 1e-9 * max(1.0, abs(mean))
         if mb > 1:
             assert abs(var ** 0.5 - std) <= 1e-6 * max(1.0, std)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 9155, 70001])
+def test_adam_and_polyak_any_length(dev, R, n):
+    """mi_adam / mi_polyak on vectors that are no multiple of a wave or a workgroup; guard bands behind the vectors stay untouched."""
+    import torch
+
+    from deep_rl_amd import _native as N
+
+    rng = np.random.default_rng(n)
+    GUARD = 3
+    p = rng.standard_normal(n + GUARD).astype(np.float32); g = (rng.standard_normal(n + GUARD) * 10.0 ** rng.uniform(-5, 1, n + GUARD)).astype(np.float32)
+    m = np.zeros(n + GUARD, np.float32); v = np.zeros(n + GUARD, np.float32)
+    pd, gd, md, vd = (torch.from_numpy(a.copy()).to(dev) for a in (p, g, m, v))
+    for step in (1, 2, 3):
+        N.check(N.lib().mi_adam(N.ptr(pd), N.ptr(gd), N.ptr(md), N.ptr(vd), n, step, 3e-4, 0.9, 0.999, 1e-8, N.stream_ptr(dev)), "mi_adam")
+        R.adam_step(p[:n], g[:n], m[:n], v[:n], step, 3e-4, eps=1e-8)
+    got = pd.cpu().numpy()
+    assert np.abs(got[:n] - p[:n]).max() <= 1e-9 + 3e-7 * np.abs(p[:n]).max()
+    assert np.array_equal(got[n:], p[n:]) and np.all(md.cpu().numpy()[n:] == 0) and np.all(vd.cpu().numpy()[n:] == 0)
+    t = rng.standard_normal(n + GUARD).astype(np.float32)
+    td = torch.from_numpy(t.copy()).to(dev)
+    N.check(N.lib().mi_polyak(N.ptr(td), N.ptr(pd), n, 0.005, N.stream_ptr(dev)), "mi_polyak")
+    want = t.copy(); w2 = want[:n].copy(); R.polyak(w2, got[:n].copy(), 0.005); want[:n] = w2
+    assert np.array_equal(td.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("upper,batch", [(1, 5), (2, 64), (3, 1), (1000, 257), (2 ** 31 - 1, 128), (2 ** 32 + 5, 128), (2 ** 40 + 12345, 1000)])
+def test_dqn_sample_any_range(dev, R, upper, batch):
+    """torch.randint(0, upper, (batch,)) restated on the keyed contract (dqn.py:115): bit-identical to the oracle for ranges below, at and far above 2^32."""
+    import torch
+
+    from deep_rl_amd import _native as N
+
+    for seed, upd in ((1, 0), (2 ** 45 + 9, 123456)):
+        idx = torch.full((batch + 2,), -7, dtype=torch.int64, device=dev)
+        N.check(N.lib().mi_dqn_sample(seed, upd, upper, batch, N.ptr(idx), N.stream_ptr(dev)), "mi_dqn_sample")
+        got = idx.cpu().numpy()
+        assert got[batch] == -7 and got[batch + 1] == -7
+        assert np.array_equal(got[:batch], R.dqn_sample(seed, upd, upper, batch)) and got[:batch].min() >= 0 and got[:batch].max() < upper
+
+
+@pytest.mark.parametrize("n", [2, 3, 1023, 1025, 100003])
+def test_explained_variance_any_length(dev, R, n):
+    """ppo.py:194-195 as the reference writes it: var_y = torch.var(values); nan if var_y == 0 else 1 - torch.var(values - returns) / var_y (unbiased variances;
+    the denominator is the variance of the VALUES, not of the returns — reproduced, not corrected)."""
+    import torch
+
+    from deep_rl_amd import _native as N
+
+    rng = np.random.default_rng(n)
+    y = rng.normal(3, 2, n).astype(np.float32); pred = (y + rng.normal(0, 1, n)).astype(np.float32)
+    out = torch.zeros(1, dtype=torch.float64, device=dev)
+    yd, pd_ = torch.from_numpy(y).to(dev), torch.from_numpy(pred).to(dev)
+    N.check(N.lib().mi_explained_var(N.ptr(pd_), N.ptr(yd), n, N.ptr(out), N.stream_ptr(dev)), "mi_explained_var")
+    want = R.explained_var(pred, y)
+    assert abs(float(out.item()) - want) <= 1e-9 * max(1.0, abs(want))
+    const = torch.full((n,), 2.5, device=dev)
+    N.check(N.lib().mi_explained_var(N.ptr(const), N.ptr(yd), n, N.ptr(out), N.stream_ptr(dev)), "mi_explained_var")
+    assert np.isnan(float(out.item()))                       # constant values: var_y == 0
+    N.check(N.lib().mi_explained_var(N.ptr(pd_), N.ptr(const), n, N.ptr(out), N.stream_ptr(dev)), "mi_explained_var")
+    assert abs(float(out.item())) <= 1e-9                      # constant returns: var(values - c) == var(values) -> exactly 0 explained
