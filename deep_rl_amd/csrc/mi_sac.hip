@@ -4,8 +4,10 @@
 //   sac_critic_kernel        sac.py:165-185: actor on next obs, two target critics, TD target, two critics forward + backward
 //   sac_actor_kernel         sac.py:193-197: actor forward (rsample), min(Q1,Q2) forward, d(-minQ)/d action, actor backward;
 //                            logp_only: sac.py:203-204 (+ the alpha step by the last workgroup to finish)
-//   sac_dw2_gemm_kernel      the 256x256 weight gradients as split-K batch GEMMs dW2 = dZ2^T H1 on v_mfma_f32_16x16x4_f32
-//   sac_grad_reduce_kernel   fixed-order assembly of slabs and K-split partials (+ Adam + polyak in the single-process fusion)
+//   sac_dw2_adam_kernel      batches <= 512 rows: the 256x256 weight gradients dW2 = dZ2^T H1 on v_mfma_f32_16x16x4_f32, the thin gradients' slab sums and the
+//                            optimizer step (+ polyak) of every element in ONE launch
+//   sac_dw2_gemm_kernel      larger batches: dW2 as split-K batch GEMMs, followed by
+//   sac_grad_reduce_kernel   the fixed-order assembly of slabs and K-split partials (+ Adam + polyak in the single-process fusion)
 //   adam_kernel / polyak_kernel / sac_alpha_kernel   the unfused pieces (sharded runs all-reduce between them)
 // Row-group layout: a 256-thread workgroup owns SR = 16 batch rows; 256x256 layers on the f32 MFMA with weights streamed from L2
 // into registers as one continuous stream per kernel, activations in LDS; see "row-group building blocks" below and DESIGN.md §7c.
