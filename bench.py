@@ -351,19 +351,31 @@ def collective_diagnostics(eng, comm, world, dev, breakdown, n_break):
 
     out = {"per_update": 17, "grad_allreduce": {"count_per_update": 16, "elements": N.NPARAMS + 4, "bytes": 4 * (N.NPARAMS + 4), "dtype": "f32"},
            "stats_allreduce": {"count_per_update": 1, "elements": eng._adv_sums_all.numel(), "bytes": 8 * eng._adv_sums_all.numel(), "dtype": "f64"}}
-    if comm is not None:
-        ws, rk, ver, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        N.check(N.lib().mi_comm_info(comm, C.byref(ws), C.byref(rk), C.byref(ver), C.byref(cnt)), "mi_comm_info")
-        out["carrier"] = "RCCL direct (rccl.h via libmirl mi_comm, in-stream ncclAllReduce inside ONE C call per update)"
-        out["rccl_version"] = ver.value
-        out["rccl_comm_count"] = cnt.value
-        g, st = breakdown.get("comm_grad", (0.0, 0)), breakdown.get("comm_stats", (0.0, 0))
-        out["in_update"] = {"us_per_allreduce_grad": round(1e3 * g[0] / max(g[1], 1), 2), "us_per_allreduce_stats": round(1e3 * st[0] / max(st[1], 1), 2),
-                            "ms_per_update": round((g[0] + st[0]) / max(n_break, 1), 4), "samples": [g[1], st[1]],
-                            "note": "HIP events around each in-stream ncclAllReduce inside the update: includes the wait for the slowest rank (exposed cost)"}
-    else:
-        out["carrier"] = "torch.distributed %s (host-sequenced: 17 all_reduce calls between the launches)" % torch.distributed.get_backend()
-    buf, sums = torch.zeros(N.NPARAMS + 4, device=dev), torch.zeros_like(eng._adv_sums_all)
+    # Everything that can fail on ONE rank (communicator queries, allocations) happens before the first collective of this function, then the ranks agree on going
+    # on: a rank that raised part-way through ~220 collectives would leave the others blocked in ncclAllReduce until the driver's timeout.
+    ok, err = 1, None
+    try:
+        if comm is not None:
+            ws, rk, ver, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            N.check(N.lib().mi_comm_info(comm, C.byref(ws), C.byref(rk), C.byref(ver), C.byref(cnt)), "mi_comm_info")
+            out["carrier"] = "RCCL direct (rccl.h via libmirl mi_comm, in-stream ncclAllReduce inside ONE C call per update)"
+            out["rccl_version"] = ver.value
+            out["rccl_comm_count"] = cnt.value
+            g, st = breakdown.get("comm_grad", (0.0, 0)), breakdown.get("comm_stats", (0.0, 0))
+            out["in_update"] = {"us_per_allreduce_grad": round(1e3 * g[0] / max(g[1], 1), 2), "us_per_allreduce_stats": round(1e3 * st[0] / max(st[1], 1), 2),
+                                "ms_per_update": round((g[0] + st[0]) / max(n_break, 1), 4), "samples": [g[1], st[1]],
+                                "note": "HIP events around each in-stream ncclAllReduce inside the update: includes the wait for the slowest rank (exposed cost)"}
+        else:
+            out["carrier"] = "torch.distributed %s (host-sequenced: 17 all_reduce calls between the launches)" % torch.distributed.get_backend()
+        buf, sums = torch.zeros(N.NPARAMS + 4, device=dev), torch.zeros_like(eng._adv_sums_all)
+    except Exception as ex:  # noqa: BLE001
+        ok, err = 0, "%s: %s" % (type(ex).__name__, ex)
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        out["error"] = err or "another rank failed before the back-to-back measurement; skipped on every rank"
+        out["world_size"] = world
+        return out
 
     def once(t, dtype):
         if comm is not None:
@@ -386,13 +398,69 @@ def collective_diagnostics(eng, comm, world, dev, breakdown, n_break):
     return out
 
 
+def sharded_route_leg(eng, one_update, timed_updates, u0, steps, dev, base_ms, base_grad_us):
+    """What the launches that ONLY a multi-GPU run takes cost, measured on this one GPU (VERDICT r03 missing #2): the same K updates
+      (a) with mi_ppo_test_assume_sharded(1): the owed optimizer steps recompute the clip coefficient from the 9,155 gradients (norm_parts = nullptr) — the prologue every
+          rank of a sharded run executes;
+      (b) the same on mi_ppo_update_sharded over a REAL one-rank RCCL communicator: 17 in-stream ncclAllReduce per update on top.
+    Deltas are against this run's headline window; per optimizer step = / 16.  Untimed for the headline: runs after it."""
+    import socket
+
+    import torch
+
+    import deep_rl_amd.dist as DD
+    import deep_rl_amd.engine as E
+
+    out = {"note": "single GPU; (a) the world_size > 1 form of the owed clip + Adam step without a collective, (b) the same through mi_ppo_update_sharded on a one-rank RCCL "
+                   "communicator (17 in-stream all-reduces per update); deltas vs this run's headline window, per optimizer step = / 16"}
+    E.set_assume_sharded(True)
+    try:
+        for _ in range(2):
+            one_update(u0)
+        dt, prof = timed_updates(u0, steps)
+        g_us = 1e3 * prof["grad"][0] / max(prof["grad"][1], 1)
+        out["assume_sharded"] = {"ms_per_step": round(1e3 * dt / steps, 4), "grad_kernel_avg_launch_us": round(g_us, 2),
+                                 "delta_us_per_update": round(1e3 * (1e3 * dt / steps - base_ms), 1), "delta_us_per_optimizer_step": round(1e3 * (1e3 * dt / steps - base_ms) / 16, 2),
+                                 "grad_kernel_delta_us": round(g_us - base_grad_us, 2)}
+        made_pg = False
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+            made_pg = True
+        try:
+            comm = DD.native_comm(eng.pg)
+            if comm is None:
+                out["rccl_world1"] = {"error": "no native RCCL communicator"}
+            else:
+                E._FORCE_NATIVE_SHARDED = True
+                for _ in range(2):
+                    one_update(u0)
+                dt, prof = timed_updates(u0, steps)
+                E._FORCE_NATIVE_SHARDED = False
+                g_us = 1e3 * prof["grad"][0] / max(prof["grad"][1], 1)
+                out["rccl_world1"] = {"ms_per_step": round(1e3 * dt / steps, 4), "grad_kernel_avg_launch_us": round(g_us, 2),
+                                      "delta_us_per_update": round(1e3 * (1e3 * dt / steps - base_ms), 1),
+                                      "delta_us_per_optimizer_step": round(1e3 * (1e3 * dt / steps - base_ms) / 16, 2)}
+        finally:
+            E._FORCE_NATIVE_SHARDED = False
+            if made_pg:
+                DD.destroy_native_comms()
+                torch.distributed.destroy_process_group()
+    finally:
+        E.set_assume_sharded(False)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--headline-only", action="store_true", help="skip the config-3 (DQN) / config-4 (SAC) extra keys")
+    ap.add_argument("--headline-only", action="store_true", help="skip the config-3 (DQN) / config-4 (SAC) extra keys, the bf16x3 variant and the sharded-route leg")
+    ap.add_argument("--single-window", action="store_true", help="only the one timed window of K steps (no repeat windows)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -454,6 +522,11 @@ def main():
     for u in range(args.warmup):
         one_update(u)
     dt, prof = timed_updates(args.warmup, args.steps)   # THE measurement: f32 contractions
+    # two more windows of the same K updates right behind it: the spread says whether a margin of a fraction of a per cent is signal
+    windows = [dt]
+    if not args.single_window:
+        for _ in range(2):
+            windows.append(timed_updates(num_updates, args.steps)[0])
 
     # beside it, never instead of it: the same K updates with the split-bf16 experiment switched on (include/mi_rl.h, mi_ppo_set_contraction)
     variant = None
@@ -466,10 +539,19 @@ def main():
         variant = (v_dt, v_prof)
 
     # untimed: per-kernel breakdown of 3 more updates (all tags)
-    N.prof_begin(3 * 64 + 64)
-    for u in range(3):
+    n_break = 3
+    N.prof_begin(n_break * 64 + 64)
+    for u in range(n_break):
         eng.update()
     breakdown = N.prof_end()
+
+    sharded = None
+    if world == 1 and not args.headline_only and os.environ.get("MIRL_BENCH_SHARDED_LEG", "1") != "0":
+        try:
+            sharded = sharded_route_leg(eng, one_update, timed_updates, num_updates - 1, args.steps, dev, 1e3 * dt / args.steps,
+                                        1e3 * prof["grad"][0] / max(prof["grad"][1], 1))
+        except Exception as ex:  # noqa: BLE001  (a diagnostic leg must not cost the measurement its line)
+            sharded = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     from deep_rl_amd import dist as _dist
     # (MIRL_FORCE_PG=1 makes a single process join a world_size-1 RCCL group: the diagnostics' native-communicator branch then runs on a one-GPU box, tests/test_gpu_script.py)
@@ -479,7 +561,7 @@ def main():
     collectives = None
     if dist_on:   # every rank takes part in the collectives; a failure here must not cost the measurement above its line
         try:
-            collectives = collective_diagnostics(eng, comm, world, dev, breakdown, 3)
+            collectives = collective_diagnostics(eng, comm, world, dev, breakdown, n_break)
         except Exception as ex:  # noqa: BLE001
             collectives = {"error": "%s: %s" % (type(ex).__name__, ex)}
     finite = bool(torch.isfinite(agent.flat).all().item())
@@ -508,10 +590,16 @@ def main():
             "hbm_roofline": {"algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                              "achieved_GBps_per_gpu": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9, 2), "peak_GBps": PEAK_HBM_GBS,
                              "frac": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9 / PEAK_HBM_GBS, 6)},
-            "kernel_ms_per_update": {k: round(v[0] / 3, 4) for k, v in breakdown.items() if v[1]},
+            "kernel_ms_per_update": {k: round(v[0] / n_break, 4) for k, v in breakdown.items() if v[1]},
             "last_rollout": {"episodes": ep[0], "mean_return": round(ep[1] / max(ep[0], 1), 2), "max_return": ep[2]},
             "params_finite": finite,
         }
+        wms = sorted(1e3 * w / args.steps for w in windows)
+        out["timed_windows"] = {"count": len(wms), "steps_each": args.steps, "ms_per_step": [round(1e3 * w / args.steps, 4) for w in windows],
+                                "min": round(wms[0], 4), "median": round(wms[len(wms) // 2], 4), "max": round(wms[-1], 4),
+                                "note": "window 1 is `value` / `ms_per_step`; the others repeat it back to back (same barriers), learning continuing"}
+        if sharded is not None:
+            out["sharded_route"] = sharded
         if collectives is not None:
             out["collectives"] = collectives
         if variant is not None:

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
-ABI_VERSION = 101   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
+ABI_VERSION = 102   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
@@ -71,6 +71,8 @@ SIGNATURES = {
     "mi_ppo_minibatch_grad": (_I, [_VP] * 8 + [_I, _VP, _F, _F, _F, _D, _VP, _VP, _VP, _VP]),
     "mi_clip_adam": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _D, _D, _D, _D, _F, _VP, _VP]),
     "mi_explained_var": (_I, [_VP, _VP, _SZ, _VP, _VP]),
+    "mi_explained_var_parts": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP]),
+    "mi_ppo_test_assume_sharded": (_I, [_I]),
     "mi_ppo_update": (_I, [_VP, C.POINTER(PPOBuffers), C.POINTER(PPOHparams), _VP]),
     "mi_ppo_update_sharded": (_I, [_VP, C.POINTER(PPOBuffers), C.POINTER(PPOHparams), _VP, _VP]),
     "mi_comm_unique_id": (_I, [_VP]),

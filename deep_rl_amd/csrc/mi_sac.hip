@@ -543,15 +543,22 @@ static int gemm_split(int batch) {   // each wave of a GEMM workgroup reduces >=
 // a higher id.  The dispatcher hands workgroups out in that order, so whoever a resident reader waits for has been dispatched and runs to completion on its own: no
 // co-residency of the whole grid is needed (a CU mask, another process or stream on the chip only make it slower).  (2) BOUND: HIP promises no dispatch order, so
 // every spin also has a wall-clock budget (s_memrealtime, 100 MHz); when it runs out the waiter records a code in the process's status word (host-pinned, read by
-// the next mi_sac_* call without a sync), takes NaN as the value — which poisons the launch's gradients, losses and the parameters its Adam step writes — and goes
-// on to the end of the kernel: a failure is a negative return code, never a hang.
+// the next mi_sac_* call without a sync), takes NaN as the value — which poisons the launch's gradients and losses — and goes on to the end of the kernel: a failure
+// is a negative return code, never a hang.  The same code goes into a DEVICE word (sac_fault_word) that every optimizer step of this file reads first: once it is
+// set, no launch steps parameters, Adam moments, targets or log_alpha any more (one spurious timeout used to overwrite all of them with NaN — recovery
+// needed a checkpoint the caller may not have).  The caller gets MI_ESTATE with its state intact and may mi_sac_clear_error and go on (the faulted update is lost).
 #define SAC_SPIN_TICKS 10000000ull          // 100 ms
 enum { SAC_FAULT_XW = 1, SAC_FAULT_EPOCH = 2 };
-__device__ unsigned int* sac_status_word;   // device pointer of the host-pinned status word (set once by sac_status_init)
+__device__ unsigned int* sac_status_word;   // device pointer of the host-pinned status word (set per device by sac_status_init)
+__device__ unsigned int sac_fault_word;     // != 0: a wait of an earlier launch on this device timed out; cleared by mi_sac_clear_error
 __device__ __noinline__ void sac_timeout(unsigned code) {
+    __hip_atomic_store(&sac_fault_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned int* p = sac_status_word;
     if (p) __hip_atomic_store(p, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// set by a PREVIOUS launch of the stream (the row-group kernels wait, the optimizer steps run in the launches behind them), or by this launch's own waiters in the
+// kernels that both wait and step log_alpha: a plain load suffices for the former, and the latter's steppers do not depend on any hand-off
+__device__ __forceinline__ bool sac_faulted() { return __hip_atomic_load(&sac_fault_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
 // hand-off of one float per row between sibling workgroups: a 64-bit word = (tag 1 << 32) | value bits, written and read with device-scope atomics, so the
 // value travels WITH its "ready" mark (no flag -> fence -> payload sequence: one round trip less); the reader zeroes the word, the next launch finds 0.
 __device__ __forceinline__ void xw_put(unsigned long long* w, float v) {
@@ -563,7 +570,11 @@ __device__ __forceinline__ float xw_take(unsigned long long* w) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         do {
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > SAC_SPIN_TICKS) { sac_timeout(SAC_FAULT_XW); return __builtin_nanf(""); }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SAC_SPIN_TICKS) {
+                sac_timeout(SAC_FAULT_XW);
+                __hip_atomic_store(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the word as a completed hand-off would (a late producer may still fill it: mi_sac_clear_error zeroes all)
+                return __builtin_nanf("");
+            }
             v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } while ((v >> 32) != 1ull);
     }
@@ -574,6 +585,7 @@ __device__ __forceinline__ float xw_take(unsigned long long* w) {
 // alpha step riding on the log-prob launch: the LAST workgroup to finish (ticket in the workspace) sums the slabs in fixed order and does the Adam step
 struct sac_alpha_t { float* log_alpha; float* m; float* v; float* alpha; float* out; unsigned int* ticket; float target_entropy, inv_count, w1, b2, w2, step_size, rbc2, eps; };
 __device__ __forceinline__ void sac_alpha_apply(const sac_alpha_t& a, float mean_lp) {
+    if (sac_faulted()) return;                                 // a timed-out launch on this device: no optimizer state is stepped until mi_sac_clear_error
     const float la = a.log_alpha[0];
     const float g = -(mean_lp + a.target_entropy);            // d/d log_alpha of mean(-log_alpha * (logp + target_entropy)), sac.py:205
     if (a.out) { a.out[0] = -la * (mean_lp + a.target_entropy); a.out[1] = g; }
@@ -1148,13 +1160,14 @@ __global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(float* __restrict__ w
 // (sac.py:185,213-217) cost no launch of their own.
 struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, rbc2, eps, tau; };
 // the element's optimizer state is requested BEFORE its gradient is summed (sac_state_load), so the launch is one memory latency deep, not two
-struct sac_state_t { float p, m, v, t; };
+struct sac_state_t { float p, m, v, t; unsigned fault; };   // fault: the device's fault word, requested with the state (set by an EARLIER launch: a plain load)
 __device__ __forceinline__ sac_state_t sac_state_load(const sac_opt_t& o, int i) {
-    sac_state_t s = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (o.params) { s.p = o.params[i]; s.m = o.m[i]; s.v = o.v[i]; if (o.target) s.t = o.target[i]; }
+    sac_state_t s = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
+    if (o.params) { s.p = o.params[i]; s.m = o.m[i]; s.v = o.v[i]; if (o.target) s.t = o.target[i]; s.fault = sac_fault_word; }
     return s;
 }
 __device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g, sac_state_t s) {
+    if (s.fault) return;                                       // see sac_timeout: {params, exp_avg, exp_avg_sq, target} stay as they were
     const float p = mi_adam_elem(s.p, g, s.m, s.v, o.w1, o.b2, o.w2, o.step_size, o.rbc2, o.eps);
     o.m[i] = s.m; o.v[i] = s.v;
     o.params[i] = p;
@@ -1179,7 +1192,7 @@ __device__ __forceinline__ void sac_thin_reduce(int blk, float (&part)[4][RED_SM
                               : l == 1536 ? AC_BM : l < 1793 ? AC_WL + (l - 1537) : AC_BL;
             else dst = net * SQ_NP + (l < 1024 ? SQ_W1 + l : l < 1280 ? SQ_B1 + (l - 1024) : l < 1536 ? SQ_B2 + (l - 1280) : l < 1792 ? SQ_W3 + (l - 1536) : SQ_B3);
         }
-        sac_state_t st = {0.0f, 0.0f, 0.0f, 0.0f};
+        sac_state_t st = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
         if (live && grp == 0 && dst >= 0) st = sac_state_load(opt, dst);
         float acc = 0.0f;
         if (off >= 0) {   // this group's slabs grp, grp + 4, ...: eight loads in flight at a time, summed in slab order
@@ -1389,12 +1402,16 @@ static int env_cu_limit(int dev, int cus) {
     }
     return cus;
 }
+#define SAC_MAX_DEVICES 64
+static int sac_device() { int dev = 0; return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SAC_MAX_DEVICES) ? dev : 0; }
 static int sac_cus() {
-    static int cus = 0;
+    static int cus_of[SAC_MAX_DEVICES] = {0};   // per device: a process may drive SAC on more than one; g_sac_max_cus / g_sac_fault are process-wide knobs
+    const int dev = sac_device();
+    int& cus = cus_of[dev];
     if (!cus) {
-        int dev = 0; hipDeviceProp_t prop;
+        hipDeviceProp_t prop;
         cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         if (!getenv("MIRL_SAC_IGNORE_CU_MASK")) cus = env_cu_limit(dev, cus);   // (test hook: pretend the mask is not there, to run sibling roles on a masked chip)
     }
     return g_sac_max_cus > 0 && g_sac_max_cus < cus ? g_sac_max_cus : cus;
@@ -1409,23 +1426,29 @@ extern "C" int mi_sac_usable_cus(void) { return sac_cus(); }
 // ---- launch status: ONE host-pinned, device-mapped word per process.  A wait that times out inside a kernel stores a code there (system scope); every mi_sac_*
 // update call reads it on the host first — a plain load, no synchronisation — and refuses with MI_ESTATE once it is set (sticky until mi_sac_clear_error).
 static unsigned int* g_sac_status_host = nullptr;
+static bool g_sac_status_dev[SAC_MAX_DEVICES] = {false};   // sac_status_word is a per-device symbol: every device this process runs SAC on gets the pointer
 static int g_sac_fault = 0;   // mi_sac_test_fault
 static int sac_status_init() {
-    if (g_sac_status_host) return MI_OK;
-    unsigned int* h = nullptr; unsigned int* d = nullptr;
-    MI_HIP(hipHostMalloc((void**)&h, 64, hipHostMallocMapped));
-    h[0] = 0u;
-    MI_HIP(hipHostGetDevicePointer((void**)&d, h, 0));
-    MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sac_status_word), &d, sizeof(d)));
-    g_sac_status_host = h;
+    const int dev = sac_device();
+    if (g_sac_status_host && g_sac_status_dev[dev]) return MI_OK;
+    if (!g_sac_status_host) {
+        unsigned int* h = nullptr;
+        MI_HIP(hipHostMalloc((void**)&h, 64, hipHostMallocMapped | hipHostMallocPortable));
+        h[0] = 0u;
+        g_sac_status_host = h;
+    }
+    unsigned int* d = nullptr;
+    MI_HIP(hipHostGetDevicePointer((void**)&d, g_sac_status_host, 0));
+    MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sac_status_word), &d, sizeof(d)));   // the CURRENT device's copy of the symbol
+    g_sac_status_dev[dev] = true;
     return MI_OK;
 }
 static int sac_status_check(const char* who) {
     if (const int rc = sac_status_init()) return rc;
     const unsigned code = __atomic_load_n(g_sac_status_host, __ATOMIC_RELAXED);
     if (code) {
-        mi_set_error("%s: an earlier SAC launch of this process timed out waiting for a sibling workgroup (%s not published within 100 ms): its outputs are NaN-poisoned; "
-                     "restore the state and call mi_sac_clear_error", who, code == SAC_FAULT_EPOCH ? "the owed alpha step's epoch" : "a row hand-off word");
+        mi_set_error("%s: an earlier SAC launch of this process timed out waiting for a sibling workgroup (%s not published within 100 ms): its gradients and losses are "
+                     "NaN, and no optimizer step has been applied since (parameters, Adam moments and targets are intact); call mi_sac_clear_error to go on", who, code == SAC_FAULT_EPOCH ? "the owed alpha step's epoch" : "a row hand-off word");
         return MI_ESTATE;
     }
     return MI_OK;
@@ -1441,6 +1464,8 @@ extern "C" int mi_sac_clear_error(void* workspace, int batch, void* stream) {
         const size_t from = ws_part_off(batch) + (size_t)GEMM_MAX_SPLIT * 3 * SA_H * SA_H, to = ws_epoch_off(batch) + 4;
         MI_HIP(hipMemsetAsync((float*)workspace + from, 0, (to - from) * sizeof(float), (hipStream_t)stream));
     }
+    const unsigned int zero = 0u;
+    MI_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(sac_fault_word), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, (hipStream_t)stream));   // this device's optimizer steps run again
     MI_HIP(hipStreamSynchronize((hipStream_t)stream));
     __atomic_store_n(g_sac_status_host, 0u, __ATOMIC_RELAXED);
     return MI_OK;
@@ -1707,7 +1732,7 @@ extern "C" int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, f
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
                                                     float w1, float b2, float w2, float step_size, float rbc2, float eps) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || sac_faulted()) return;   // (mi_adam / mi_polyak are the SAC engines' unfused steps: they honour the device's fault word like the fused ones)
     float mi = m[i], vi = v[i];
     p[i] = mi_adam_elem(p[i], g[i], mi, vi, w1, b2, w2, step_size, rbc2, eps);
     m[i] = mi; v[i] = vi;
@@ -1725,7 +1750,7 @@ extern "C" int mi_adam(float* params, const float* grads, float* exp_avg, float*
 
 __global__ void __launch_bounds__(256) polyak_kernel(float* __restrict__ t, const float* __restrict__ p, int n, float tau) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) t[i] = tau * p[i] + (1.0f - tau) * t[i];
+    if (i < n && !sac_faulted()) t[i] = tau * p[i] + (1.0f - tau) * t[i];
 }
 
 extern "C" int mi_polyak(float* target, const float* param, int n, float tau, void* stream) {

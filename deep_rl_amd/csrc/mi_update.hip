@@ -314,6 +314,29 @@ __device__ __forceinline__ double wave_butterfly_f64(double s) {
     return s;
 }
 #define NORM_BLOCKS ((NPARAMS + 63) / 64)   // 144
+// f64 lane exchanges on the VALU (two 32-bit halves each): the stages of wave_butterfly_f64 without its ds_bpermute round trips
+__device__ __forceinline__ double f64_pack(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
+template <int CTRL>
+__device__ __forceinline__ double f64_dpp(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    return f64_pack((unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true), (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true));
+}
+// lanes 0-31: a[i] + a[i + 32]; lanes 32-63: b[i - 32] + b[i]  — the xor-32 stage of TWO butterflies in one add (v_permlane32_swap: the upper half of the first
+// operand trades places with the lower half of the second)
+__device__ __forceinline__ double f64_swap32_sum(double a, double b) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    auto l = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    return f64_pack((unsigned)l[0], (unsigned)h[0]) + f64_pack((unsigned)l[1], (unsigned)h[1]);
+}
+// rows (16 lanes) 0 / 2: a[i] + a[i + 16]; rows 1 / 3: b[i - 16] + b[i]  — the xor-16 stage of two butterflies (v_permlane16_swap: odd rows of the first operand trade
+// places with even rows of the second)
+__device__ __forceinline__ double f64_swap16_sum(double a, double b) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    auto l = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    return f64_pack((unsigned)l[0], (unsigned)h[0]) + f64_pack((unsigned)l[1], (unsigned)h[1]);
+}
 __device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads, const double* __restrict__ parts, int n, double* ws /* shared [4] */,
                                                  double* sparts /* shared [256] */) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, nw = (int)blockDim.x >> 6;
@@ -321,6 +344,39 @@ __device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads
     double S = 0.0;
     if (parts) {
         if (t < 256) for (int b = t; b < nb; b += 256) S += parts[b];
+#ifdef NORM_SHARDED_GENERIC   // A/B build: the sharded gradient launch walks the generic branch below (what it did until round 4)
+    } else if (false) {
+#else
+    } else if (n == NPARAMS && nw == 8) {
+#endif
+        // The sharded gradient launch (8 waves, the all-reduced PPO gradient, no block sums): the SAME tree, evaluated with a quarter of the instructions.  Wave w owns
+        // blocks w + 8k, k < 18 (144 = 18 x 8): all 18 loads in flight before the first add, then the butterflies' xor-32 and xor-16 stages on PAIRS of blocks (one
+        // swap + one add serves two blocks: each half / row of the wave keeps one of them), which leaves 5 values for the four in-row stages instead of 18 for all six.
+        // Every add has the operands of the butterfly's add in that lane (IEEE addition commutes): bitwise the same s_b.  (this branch used to walk
+        // 18 full f64 butterflies on ds_bpermute per wave.)
+        static_assert(NORM_BLOCKS == 144, "18 blocks per wave");
+        float x[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) { const int p = 64 * (w + 8 * k) + lane; x[k] = p < n ? grads[ppo_slab_to_param(p)] : 0.0f; }
+        if (t >= NORM_BLOCKS && t < 256) sparts[t] = 0.0;
+        double r[9], s[5];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r[k] = f64_swap32_sum((double)x[k] * (double)x[k], (double)x[k + 9] * (double)x[k + 9]);   // lower half: block k, upper half: block k + 9
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = f64_swap16_sum(r[2 * q], r[2 * q + 1]);   // rows 0..3: blocks 2q, 2q + 1, 2q + 9, 2q + 10
+        s[4] = f64_swap16_sum(r[8], r[8]);                                            // rows 0, 1: block 8; rows 2, 3: block 17
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {   // lane ^ 8, ^ 4 (a rotation by 4 of values that repeat every 8 lanes), ^ 2, ^ 1 inside the row
+            s[q] += f64_dpp<0x128>(s[q]); s[q] += f64_dpp<0x124>(s[q]); s[q] += f64_dpp<0x4E>(s[q]); s[q] += f64_dpp<0xB1>(s[q]);
+        }
+        if ((lane & 15) == 0) {
+            const int row = lane >> 4, k0 = (row & 1) + 9 * (row >> 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sparts[w + 8 * (2 * q + k0)] = s[q];
+            if ((row & 1) == 0) sparts[w + 8 * (8 + 9 * (row >> 1))] = s[4];
+        }
+        __syncthreads();
+        if (t < 256) S = sparts[t];
     } else {
         const bool perm = n == NPARAMS;
         if (t < 256) sparts[t] = 0.0;
@@ -518,6 +574,11 @@ extern "C" int mi_ppo_get_contraction(void) { return g_contraction; }
 
 static grad_pending_t no_pending() { grad_pending_t z; memset(&z, 0, sizeof(z)); return z; }
 
+// TEST HOOK (include/mi_rl.h): mi_ppo_update / mi_ppo_update_sharded behave as at world_size > 1 in everything but the collective — the owed optimizer steps
+// recompute the clip coefficient from the gradient itself (norm_parts = nullptr) — so the branch only a multi-GPU run takes can be checked and timed on one GPU.
+static int g_assume_sharded = 0;
+extern "C" int mi_ppo_test_assume_sharded(int on) { g_assume_sharded = on ? 1 : 0; return MI_OK; }
+
 // gradient launch + slab sum.  `pend.grads != nullptr`: the launch first applies the owed optimizer step (see grad_pending_t).
 static int ppo_grad_launch(const float* params, const grad_pending_t& pend, const float* observations, const int64_t* actions, const float* log_probs,
                            const float* advantages, const float* returns, const float* values, const int32_t* idx, int mb, const double* adv_sums,
@@ -644,6 +705,34 @@ __global__ void __launch_bounds__(1024) explained_var_kernel(const float* __rest
     if (threadIdx.x == 0) *out = vv == 0.0 ? __builtin_nan("") : 1.0 - vd / vv;
 }
 
+// The same statistic over the rows of ALL ranks of a sharded run (ppo.py:194-195 is over the whole batch), in two halves around the caller's SUM all-reduces:
+// means == nullptr: out = {sum values, sum (values - returns)} of this rank's rows; then, given the GLOBAL means {mean values, mean (values - returns)}:
+// out = {sum (values - m0)^2, sum ((values - returns) - m1)^2}.  explained_var = 1 - out1 / out0 of the all-reduced sums (NaN if out0 == 0).
+__global__ void __launch_bounds__(1024) explained_var_parts_kernel(const float* __restrict__ values, const float* __restrict__ returns, size_t n,
+                                                                    const double* __restrict__ means, double* __restrict__ out) {
+    __shared__ double sh[16];
+    double a = 0.0, b = 0.0;
+    if (means == nullptr) {
+        for (size_t i = threadIdx.x; i < n; i += 1024) { a += values[i]; b += (double)values[i] - returns[i]; }
+    } else {
+        const double mv = means[0], md = means[1];
+        for (size_t i = threadIdx.x; i < n; i += 1024) {
+            const double x = values[i] - mv, y = ((double)values[i] - returns[i]) - md;
+            a += x * x; b += y * y;
+        }
+    }
+    a = block_sum_1024(a, sh); b = block_sum_1024(b, sh);
+    if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
+extern "C" int mi_explained_var_parts(const float* values, const float* returns, size_t n, const double* means, double* out, void* stream) {
+    MI_CHECK_ARG(values && returns && out, "NULL pointer");
+    MI_CHECK_ARG(n >= 1, "n must be >= 1");
+    explained_var_parts_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(values, returns, n, means, out);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
 extern "C" int mi_explained_var(const float* values, const float* returns, size_t n, double* out, void* stream) {
     MI_CHECK_ARG(values && returns && out, "NULL pointer");
     MI_CHECK_ARG(n >= 2, "n must be >= 2");
@@ -716,6 +805,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
     MI_CHECK_ARG(B % hp->n_minibatch == 0, "T*N must be divisible by n_minibatch");
     const int mb = B / hp->n_minibatch;
     const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass; their fp64 accumulators are zeroed by the rollout launch
+    const bool sharded_norm = world > 1 || g_assume_sharded != 0;
     int rc = mi_rollout_gae_internal(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
                                      b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns,
                                      fused ? b->adv_sums : nullptr, 3 * hp->n_minibatch * hp->update_epochs, b->episode_stats_next, stream);
@@ -767,7 +857,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
                 pend.grads = b->grads; pend.p_in = cur.p; pend.m_in = cur.m; pend.v_in = cur.v; pend.p_out = out.p; pend.m_out = out.m; pend.v_out = out.v;
                 pend.grad_norm = b->grad_norm; pend.w1 = c.w1; pend.b2 = c.b2; pend.w2 = c.w2; pend.step_size = c.step_size; pend.rbc2 = c.rbc2; pend.eps = c.eps;
                 pend.max_norm = hp->max_grad_norm;
-                pend.norm_parts = world > 1 ? nullptr : ws_norm_parts(b->workspace);   // sharded: the all-reduce changed the gradient after the block sums were taken
+                pend.norm_parts = sharded_norm ? nullptr : ws_norm_parts(b->workspace);   // sharded: the all-reduce changed the gradient after the block sums were taken
                 cur = out;   // what this launch trains on and what the next owed step starts from
             }
             rc = ppo_grad_launch(owed ? nullptr : cur.p, pend, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
@@ -784,7 +874,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
         }
     }
     return clip_adam_launch(cur.p, cur.m, cur.v, caller.p, caller.m, caller.v, b->grads, NPARAMS, adam_consts(step, hp->lr, hp->beta1, hp->beta2, hp->eps),
-                            hp->max_grad_norm, b->grad_norm, world > 1 ? nullptr : ws_norm_parts(b->workspace), s);
+                            hp->max_grad_norm, b->grad_norm, sharded_norm ? nullptr : ws_norm_parts(b->workspace), s);
 }
 
 // =====================================================================================================

@@ -20,6 +20,8 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
+from ._native import MiError
+
 _FORCE_PG = os.environ.get("MIRL_FORCE_PG", "0") == "1"
 _FORCE_COLLECTIVES = os.environ.get("MIRL_FORCE_COLLECTIVES", "0") == "1"
 
@@ -53,6 +55,42 @@ def allreduce_sum_(t, group=None):
     if world_size(group) > 1 or (_FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def replica_check_interval():
+    """MIRL_CHECK_REPLICAS=K: every K-th update of a sharded engine ends with check_replicas() (0 / unset: never)."""
+    try:
+        return max(int(os.environ.get("MIRL_CHECK_REPLICAS", "0")), 0)
+    except ValueError:
+        return 0
+
+
+def state_checksum(tensors):
+    """Order-sensitive 62-bit checksum of the raw 32-bit words of `tensors` (sum of (word_i + 1) * (2 i + 1), wrapping, i running over the concatenation) as a
+    0-d int64 tensor on the tensors' device.  Plumbing, not arithmetic of the path: torch integer ops, the same on CPU (gloo tests) and GPU."""
+    acc, base = None, 0
+    for t in tensors:
+        w = t.detach().reshape(-1).view(torch.int32).to(torch.int64)
+        k = torch.arange(base, base + w.numel(), dtype=torch.int64, device=w.device) * 2 + 1
+        c = ((w + 1) * k).sum()
+        acc = c if acc is None else acc + c
+        base += w.numel()
+    return acc & 0x3FFFFFFFFFFFFFFF
+
+
+def check_replicas(tensors, group=None, what="replicated state"):
+    """Replica-divergence guard: the replicated state of a sharded run — parameters and optimizer moments, stepped identically on every rank from
+    the same all-reduced gradient (reference ppo.py:189-192 / dqn.py:131-133 / sac.py:185-210 with the exchange in between) — must be BITWISE equal on all ranks.
+    One MAX all-reduce of {c, -c} of its checksum gives max and min; a mismatch raises MiError on every rank.  Host-synchronising; no-op for a single process."""
+    if world_size(group) == 1:
+        return
+    c = state_checksum(tensors)
+    pair = torch.stack([c, -c])
+    dist.all_reduce(pair, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(pair[0].item()), -int(pair[1].item())
+    if hi != lo:
+        raise MiError("replica divergence: %s differs across ranks (checksum of rank %d: %016x; min %016x, max %016x over %d ranks) — the replicas no longer "
+                      "hold the same parameters" % (what, rank(group), int(c.item()), lo, hi, world_size(group)))
 
 
 _native_comms = {}

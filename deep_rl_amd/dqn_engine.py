@@ -43,6 +43,7 @@ class DQNEngine:
         self.observation = None
         self.global_step = 0      # time steps taken (each advances every env once)
         self.update_index = 0
+        self._check_every = D.replica_check_interval()   # MIRL_CHECK_REPLICAS=K: every K-th train_step of a sharded run checks that the replicas still agree bitwise
 
     def _s(self):
         return N.stream_ptr(self.device)
@@ -142,6 +143,16 @@ class DQNEngine:
             self.td_grad()
             self.optimizer.step(self.grads)
         self.update_index += 1
+        self._maybe_check_replicas()
+
+    def _maybe_check_replicas(self):
+        if self._check_every and self.world_size > 1 and self.update_index % self._check_every == 0:
+            self.check_replicas()
+
+    def check_replicas(self):
+        """Raise MiError unless the online / target parameters and the Adam moments are bitwise equal on every rank (deep_rl_amd.dist.check_replicas)."""
+        o = self.optimizer
+        D.check_replicas([self.q.flat, self.target.flat, o.exp_avg, o.exp_avg_sq], self.pg, "%s parameters / Adam moments after update %d" % (type(self).__name__, self.update_index))
 
     def _native_sharded(self):
         """The one-call RCCL route applies to the plain TD launches (DQN, PER) of a sharded run whose process group is NCCL."""
@@ -187,6 +198,7 @@ class DuelingDQNEngine(DQNEngine):
         self.optimizer.step(self.dueling_grads)
         self.q.repack()
         self.update_index += 1
+        self._maybe_check_replicas()
 
     def sync_target(self):
         self.target.flat.copy_(self.q.flat)

@@ -25,6 +25,13 @@ from . import dist as D
 _FORCE_SHARDED_SEQUENCE = os.environ.get("MIRL_PPO_SHARDED_SEQUENCE", "0") == "1"
 # MIRL_PPO_NATIVE_SHARDED=1: take the mi_ppo_update_sharded route whenever an RCCL communicator exists, even at world_size 1 (one-GPU box: RCCL really runs)
 _FORCE_NATIVE_SHARDED = os.environ.get("MIRL_PPO_NATIVE_SHARDED", "0") == "1"
+# MIRL_PPO_ASSUME_SHARDED=1 (test hook, process-wide: mi_ppo_test_assume_sharded): the one-call updates take the world_size > 1 form of the owed optimizer step (the clip
+# coefficient recomputed from the gradient itself) without a second rank, so a one-GPU box can check it bitwise against the default route and time it (bench.py `sharded_route`)
+_ASSUME_SHARDED = os.environ.get("MIRL_PPO_ASSUME_SHARDED", "0") == "1"
+
+
+def set_assume_sharded(on):
+    N.check(N.lib().mi_ppo_test_assume_sharded(1 if on else 0), "mi_ppo_test_assume_sharded")
 
 
 class PPOEngine:
@@ -71,6 +78,10 @@ class PPOEngine:
         self._stats_cur = 0
         self.observation = None  # the carried-over `observation` of the reference loop (ppo.py:101,127-129)
         self.update_index = 0
+        self._ev_parts = z(2, 2, dt=torch.float64)   # sharded explained variance: {sums, squared deviations}
+        self._check_every = D.replica_check_interval()
+        if _ASSUME_SHARDED:
+            set_assume_sharded(True)
 
     # ---- pieces of one outer update ----------------------------------------------------------------
     @property
@@ -161,9 +172,19 @@ class PPOEngine:
         self.optimizer.step(self.grads)
 
     def compute_explained_var(self):
-        """ppo.py:194-195 (over all T+1 rows of this rank)."""
-        N.check(N.lib().mi_explained_var(N.ptr(self.values), N.ptr(self.returns), (self.T + 1) * self.N,
-                                         N.ptr(self.explained_var), self._s()), "mi_explained_var")
+        """ppo.py:194-195 over the whole batch: all (T+1) * N rows of EVERY rank.  Single process: one launch.  Sharded: the two passes of the same statistic
+        (sums -> global means, squared deviations) with a SUM all-reduce of two doubles behind each; only computed when read, never inside update()."""
+        n = (self.T + 1) * self.N
+        if self.world_size == 1:
+            N.check(N.lib().mi_explained_var(N.ptr(self.values), N.ptr(self.returns), n, N.ptr(self.explained_var), self._s()), "mi_explained_var")
+            return self.explained_var
+        sums, dev2 = self._ev_parts[0], self._ev_parts[1]
+        N.check(N.lib().mi_explained_var_parts(N.ptr(self.values), N.ptr(self.returns), n, None, N.ptr(sums), self._s()), "mi_explained_var_parts")
+        D.allreduce_sum_(sums, self.pg)
+        sums /= float(n * self.world_size)
+        N.check(N.lib().mi_explained_var_parts(N.ptr(self.values), N.ptr(self.returns), n, N.ptr(sums), N.ptr(dev2), self._s()), "mi_explained_var_parts")
+        D.allreduce_sum_(dev2, self.pg)
+        self.explained_var.copy_((1.0 - dev2[1] / dev2[0]).reshape(1))   # 0 / 0 -> NaN as np.var gives it (ppo.py:195)
         return self.explained_var
 
     # ---- one whole outer update ------------------------------------------------------------------------
@@ -209,3 +230,10 @@ class PPOEngine:
                     self.optimizer_step()
             self.perm, self.adv_sums = self._perm_all[0], self._adv_sums_all[0]
         self.update_index += 1
+        if self._check_every and self.world_size > 1 and self.update_index % self._check_every == 0:
+            self.check_replicas()
+
+    def check_replicas(self):
+        """Raise MiError unless parameters and Adam moments are bitwise equal on every rank (deep_rl_amd.dist.check_replicas; MIRL_CHECK_REPLICAS=K runs it every K updates)."""
+        o = self.optimizer
+        D.check_replicas([self.agent.flat, o.exp_avg, o.exp_avg_sq], self.pg, "PPO parameters / Adam moments after update %d" % self.update_index)

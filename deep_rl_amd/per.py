@@ -44,7 +44,7 @@ assert target_network_frequency % train_frequency == 0, "target_network_frequenc
 env = make(env_id, num_envs=num_envs, device=device, env_id_base=rank * num_envs)
 
 # Seeding (:60-64)
-seed = 1
+seed = int(os.environ.get("SEED", "1"))  # the reference hard-codes 1; SEED re-keys every counter-based stream (tests/test_gpu_learning.py runs seeds 1..10)
 env.seed(seed)
 np.random.seed(seed)
 torch.manual_seed(seed)
@@ -63,11 +63,15 @@ print_episodes = int(os.environ.get("PRINT_EPISODES", "1" if num_envs <= 8 else 
 engine = PERDQNEngine(env, q_network, target_network, optimizer, slots=memory_size, alpha=alpha, beta_0=beta_0, batch_size=batch_size, gamma=gamma,
                    learning_starts=0, start_e=start_e, end_e=end_e, exploration_fraction=exploration_fraction,
                    total_timesteps=total_timesteps, max_episodes_logged=(4 * train_frequency * num_envs if print_episodes else 0))
-observations, actions, rewards, terminated = engine.observations, engine.actions, engine.rewards, engine.terminated
-priorities = engine.priorities  # per.py:79
+# At num_envs == 1 the storage globals are views WITHOUT the env axis, i.e. exactly the reference's shapes ("reduces to the reference at N = 1"); the
+# engine keeps writing the same memory through its own (T+1, 1, ...) tensors.
+_ref = (lambda t: t.squeeze(1)) if num_envs == 1 else (lambda t: t)
+observations, actions, rewards, terminated = _ref(engine.observations), _ref(engine.actions), _ref(engine.rewards), _ref(engine.terminated).view(torch.bool)
+priorities = _ref(engine.priorities)  # per.py:79
 
 # Initiate the environment and store the initial observation (:79-81)
 observation = engine.reset()
+observation = observation.squeeze(0) if num_envs == 1 else observation
 global_step = 0
 
 # Loop (:84)

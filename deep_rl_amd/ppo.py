@@ -42,7 +42,7 @@ max_grad_norm = 0.5  # :76
 env = make(env_id, num_envs=num_envs, device=device, env_id_base=rank * num_envs)
 
 # Seeding (:83-86), same order: env, numpy, torch — before the agent is built so the init matches
-seed = 1
+seed = int(os.environ.get("SEED", "1"))  # the reference hard-codes 1; SEED re-keys every counter-based stream (tests/test_gpu_learning.py runs seeds 1..10)
 env.seed(seed)
 np.random.seed(seed)
 torch.manual_seed(seed)
@@ -56,11 +56,15 @@ print_episodes = int(os.environ.get("PRINT_EPISODES", "1" if num_envs <= 8 else 
 engine = PPOEngine(env, agent, optimizer, num_steps=num_steps, n_minibatch=4, update_epochs=update_epochs, gamma=gamma,
                    gae_lambda=gae_lambda, clip_coef=clip_coef, ent_coef=ent_coef, vf_coef=vf_coef,
                    max_episodes_logged=(4 * num_steps * num_envs if print_episodes else 0))
-observations, values, actions = engine.observations, engine.values, engine.actions
-log_probs, rewards, dones = engine.log_probs, engine.rewards, engine.dones
+# At num_envs == 1 the storage globals are views WITHOUT the env axis, i.e. exactly the reference's shapes ("reduces to the reference at N = 1"); the
+# engine keeps writing the same memory through its own (T+1, 1, ...) tensors.
+_ref = (lambda t: t.squeeze(1)) if num_envs == 1 else (lambda t: t)
+observations, values, actions = _ref(engine.observations), _ref(engine.values), _ref(engine.actions)   # (129, 4), (129,), (129,) at one env (:93-95)
+log_probs, rewards, dones = _ref(engine.log_probs), _ref(engine.rewards), _ref(engine.dones)               # (129,) each (:96-98)
 
 # Init the env (:101-102)
 observation = engine.reset()
+observation = observation.squeeze(0) if num_envs == 1 else observation   # (4,) at one env; a view of the engine's carried-over observation
 global_step = 0
 
 # Loop (:105)
@@ -82,7 +86,7 @@ for update in range(num_updates):
         print(f"update={update}, global_step={global_step + num_steps * num_envs}, episodes={n_finished}, mean_episodic_return={mean_r:.2f}")
     global_step += num_steps * num_envs
 
-advantages, returns = engine.advantages, engine.returns
+advantages, returns = _ref(engine.advantages), _ref(engine.returns)
 pg_loss, entropy_loss, v_loss, loss = (float(x) for x in engine.loss_terms.cpu())
 explained_var = float(engine.compute_explained_var().item())  # :194-195
 

@@ -38,7 +38,7 @@ alpha_lr = q_lr  # :92
 env = make(env_id, num_envs=num_envs, device=device, env_id_base=rank * num_envs)
 
 # Seeding (:99-104)
-seed = 1
+seed = int(os.environ.get("SEED", "1"))  # the reference hard-codes 1; SEED re-keys every counter-based stream (tests/test_gpu_learning.py runs seeds 1..10)
 env.seed(seed)
 np.random.seed(seed)
 torch.manual_seed(seed)
@@ -65,10 +65,15 @@ engine = SACEngine(env, actor, qf1, qf2, qf1_target, qf2_target, slots=memory_si
                    max_episodes_logged=(4 * num_envs if print_episodes else 0))
 actor_optimizer, q_optimizer = engine.actor_optimizer, engine.q_optimizer
 log_alpha = engine.log_alpha
-observations, actions, rewards, terminated = engine.observations, engine.actions, engine.rewards, engine.terminated
+# At num_envs == 1 the storage globals are views WITHOUT the env axis, i.e. exactly the reference's shapes ("reduces to the reference at N = 1"); the
+# engine keeps writing the same memory through its own (T+1, 1, ...) tensors.
+_ref = (lambda t: t.squeeze(1)) if num_envs == 1 else (lambda t: t)
+# actions keep their (slots, act_dim = 1) shape at one env: the env axis and sac.py:127's action axis coincide
+observations, actions, rewards, terminated = _ref(engine.observations), engine.actions, _ref(engine.rewards), _ref(engine.terminated).view(torch.bool)
 
 # Initiate the environment and store the initial observation (:132-134)
 observation = engine.reset()
+observation = observation.squeeze(0) if num_envs == 1 else observation
 global_step = 0
 
 # Loop (:137)

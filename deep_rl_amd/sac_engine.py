@@ -70,6 +70,7 @@ class SACEngine:
         self.global_step = 0
         self.update_index = 0       # critic updates done
         self.actor_updates = 0
+        self._check_every = D.replica_check_interval()   # MIRL_CHECK_REPLICAS=K: every K-th train_step of a sharded run checks that the replicas still agree bitwise
 
     def _s(self):
         return N.stream_ptr(self.device)
@@ -85,16 +86,22 @@ class SACEngine:
 
     # ---- the entropy coefficient's state: reading it settles an owed alpha step first ----
     def _owed_struct(self):
-        """-> (ctypes struct of the owed alpha step | None); marks it as handed over."""
+        """-> (ctypes struct of the owed alpha step | None) for the NEXT counters.  Nothing is committed here: the C call may refuse before it launches anything
+        (MI_ESTATE from the status word), and then the debt, the Adam step count and the epoch must stay as they were — `_owed_commit()` after N.check.
+        The epoch is a plain wrapping 32-bit counter (the kernel compares `word - epoch` as a signed 32-bit difference, which needs the full mod-2^32 range)."""
         if self._owed is None:
             return None
-        self._alpha_steps += 1
-        self._owed_epoch += 1
         key, slot = self._owed
-        o = N.SacOwedAlpha(N.ptr(self._log_alpha), N.ptr(self._alpha_m_t), N.ptr(self._alpha_v_t), N.ptr(self._alpha), N.ptr(self._alpha_out),
-                           self.target_entropy, self._alpha_steps, self.alpha_lr, key, ((self._owed_epoch - 1) % 0x7FFFFFFF) + 1, slot)
-        self._owed = None
-        return o
+        e = (self._owed_epoch + 1) & 0xFFFFFFFF
+        return N.SacOwedAlpha(N.ptr(self._log_alpha), N.ptr(self._alpha_m_t), N.ptr(self._alpha_v_t), N.ptr(self._alpha), N.ptr(self._alpha_out),
+                              self.target_entropy, self._alpha_steps + 1, self.alpha_lr, key, e - (1 << 32) if e >= (1 << 31) else e, slot)
+
+    def _owed_commit(self, o):
+        """The launch carrying the owed step `o` has been enqueued."""
+        if o is not None:
+            self._alpha_steps += 1
+            self._owed_epoch += 1
+            self._owed = None
 
     def drop_owed(self):
         """Forget a pending alpha debt and the stash (the state is about to be replaced wholesale: checkpoint.load)."""
@@ -107,6 +114,7 @@ class SACEngine:
         if o is not None:
             N.check(N.lib().mi_sac_alpha_step_owed(N.ptr(self.actor.flat), self.batch_size, self.env._seed, C.byref(o), N.ptr(self.workspace), self._s()),
                     "mi_sac_alpha_step_owed")
+            self._owed_commit(o)
 
     def check(self, wait=True):
         """Raise MiError (MI_ESTATE) if a wait between the workgroups of one of this process's SAC launches has timed out (include/mi_rl.h: mi_sac_check);
@@ -199,26 +207,27 @@ class SACEngine:
             g = o.param_groups[0]
             if sample_in_launch and min(self.global_step, self.slots) * self.N == 0:   # 0 means "read batch_inds" to the launch
                 raise N.MiError("update_critic: the replay ring is empty (global_step == 0); act() before training")
-            o.step_count += 1
             owed = self._owed_struct()       # an alpha step owed from the last actor update rides on this launch
             N.check(N.lib().mi_sac_critic_update_owed(
                 N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
                 N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
                 self._key(self.update_index), N.ptr(self._alpha), self.gamma, N.ptr(self.workspace), N.ptr(self.q_grads), N.ptr(self.q_losses),
-                N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                 self.tau if polyak else -1.0, self._key(self.update_index), min(self.global_step, self.slots) * self.N if sample_in_launch else 0,
                 C.byref(owed) if owed is not None else None, self._s()), "mi_sac_critic_update_owed")
+            o.step_count += 1                # counters move only once the call has enqueued its launches (it may refuse with MI_ESTATE before)
+            self._owed_commit(owed)
         elif self._comm() is not None:
             # sharded, NCCL process group: ONE C call — gradient share, in-stream RCCL all-reduce of {grads, losses}, Adam, polyak (mi_sac_critic_update_sharded)
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.q_optimizer
             g = o.param_groups[0]
-            o.step_count += 1
             N.check(N.lib().mi_sac_critic_update_sharded(
                 N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
                 N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed, self._key(self.update_index),
-                N.ptr(self.alpha), self.gamma, N.ptr(self.workspace), N.ptr(self._qbuf), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]),
+                N.ptr(self.alpha), self.gamma, N.ptr(self.workspace), N.ptr(self._qbuf), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]),
                 g["betas"][0], g["betas"][1], g["eps"], self.tau if polyak else -1.0, self._comm(), self._s()), "mi_sac_critic_update_sharded")
+            o.step_count += 1
         else:
             self.critic_grad(eps)
             self.q_optimizer.step(self.q_grads)
@@ -241,13 +250,14 @@ class SACEngine:
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.actor_optimizer
             g = o.param_groups[0]
-            o.step_count += 1
             owed = self._owed_struct()
             N.check(N.lib().mi_sac_actor_update_owed(
                 N.ptr(self.actor.flat), N.ptr(self.q_flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e),
                 self.env._seed, self._key(self.actor_updates), N.ptr(self._alpha), N.ptr(self.workspace), N.ptr(self.actor_grads),
-                N.ptr(self.actor_out), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                N.ptr(self.actor_out), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                 C.byref(owed) if owed is not None else None, self._s()), "mi_sac_actor_update_owed")
+            o.step_count += 1
+            self._owed_commit(owed)
             # this launch stashed its batch observations — in the slot a debt it carried did not read — so an alpha step may be owed on them
             self._stash_slot = (owed.stash_slot ^ 1) if owed is not None else 0
             self._stash_fresh = True
@@ -255,11 +265,11 @@ class SACEngine:
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.actor_optimizer
             g = o.param_groups[0]
-            o.step_count += 1
             N.check(N.lib().mi_sac_actor_update_sharded(
                 N.ptr(self.actor.flat), N.ptr(self.q_flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed,
-                self._key(self.actor_updates), N.ptr(self.alpha), N.ptr(self.workspace), N.ptr(self._abuf), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count,
+                self._key(self.actor_updates), N.ptr(self.alpha), N.ptr(self.workspace), N.ptr(self._abuf), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1,
                 float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self._comm(), self._s()), "mi_sac_actor_update_sharded")
+            o.step_count += 1
         else:
             self.actor_grad(eps)
             self.actor_optimizer.step(self.actor_grads)
@@ -277,17 +287,17 @@ class SACEngine:
         self.flush_alpha()
         self._stash_fresh = False
         e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
-        self._alpha_steps += 1
+        step = self._alpha_steps + 1      # committed after the call (it may refuse before launching)
         L = N.lib()
         if self._single():
             N.check(L.mi_sac_alpha_step(
                 N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed,
                 self._key(self.actor_updates), self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v),
-                self.alpha_steps, self.alpha_lr, N.ptr(self.alpha), N.ptr(self.alpha_out), N.ptr(self.workspace), self._s()), "mi_sac_alpha_step")
+                step, self.alpha_lr, N.ptr(self.alpha), N.ptr(self.alpha_out), N.ptr(self.workspace), self._s()), "mi_sac_alpha_step")
         elif self._comm() is not None:
             N.check(L.mi_sac_alpha_step_sharded(
                 N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e), self.env._seed, self._key(self.actor_updates),
-                self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v), self.alpha_steps, self.alpha_lr, N.ptr(self.alpha),
+                self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v), step, self.alpha_lr, N.ptr(self.alpha),
                 N.ptr(self.alpha_out), N.ptr(self._mean_logp), N.ptr(self.workspace), self._comm(), self._s()), "mi_sac_alpha_step_sharded")
         else:
             N.check(L.mi_sac_mean_logp(
@@ -296,8 +306,9 @@ class SACEngine:
                 "mi_sac_mean_logp")
             D.allreduce_sum_(self._mean_logp, self.pg)
             N.check(L.mi_sac_alpha_adam(
-                N.ptr(self._mean_logp), self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v), self.alpha_steps,
+                N.ptr(self._mean_logp), self.target_entropy, N.ptr(self.log_alpha), N.ptr(self._alpha_m), N.ptr(self._alpha_v), step,
                 self.alpha_lr, N.ptr(self.alpha), N.ptr(self.alpha_out), self._s()), "mi_sac_alpha_adam")
+        self._alpha_steps = step
         self.actor_updates += 1
 
     def update_targets(self):
@@ -315,3 +326,11 @@ class SACEngine:
             for _ in range(policy_frequency):
                 self.update_actor()
                 self.update_alpha()
+        if self._check_every and self.world_size > 1 and self.update_index % self._check_every == 0:
+            self.check_replicas()
+
+    def check_replicas(self):
+        """Raise MiError unless actor, critics, targets, log_alpha and every Adam moment are bitwise equal on every rank (deep_rl_amd.dist.check_replicas)."""
+        a, q = self.actor_optimizer, self.q_optimizer
+        D.check_replicas([self.actor.flat, self.q_flat, self.qt_flat, self.log_alpha, a.exp_avg, a.exp_avg_sq, q.exp_avg, q.exp_avg_sq, self._alpha_m, self._alpha_v], self.pg,
+                         "SAC parameters / Adam moments after update %d" % self.update_index)

@@ -49,9 +49,10 @@ extern "C" {
 #endif
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
- * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count).  Bindings must compare mi_version()
+ * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
+ * mi_ppo_test_assume_sharded).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
-#define MI_VERSION 101
+#define MI_VERSION 102
 #define MI_PPO_NPARAMS 9155
 #define MI_PPO_ACTOR_NPARAMS 4610
 #define MI_OBS_DIM 4
@@ -162,6 +163,11 @@ int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_a
 
 /* ---- explained variance ppo.py:194-195 over n = (T+1)*N entries: out dev f64 [1] */
 int mi_explained_var(const float* values, const float* returns, size_t n, double* out, void* stream);
+/* the same statistic over the rows of ALL ranks of a sharded run (ppo.py:194-195 is over the whole batch), as two launches around the caller's two SUM all-reduces:
+ *   means == NULL:          out dev f64 [2] = {sum values, sum (values - returns)} of this rank's n rows          -> all-reduce, divide by the global row count
+ *   means dev f64 [2] given (the GLOBAL means): out = {sum (values - m0)^2, sum ((values - returns) - m1)^2}      -> all-reduce
+ * explained_var = 1 - out[1] / out[0] of the reduced sums (the unbiased 1 / (n - 1) factors cancel); NaN if out[0] == 0. */
+int mi_explained_var_parts(const float* values, const float* returns, size_t n, const double* means, double* out, void* stream);
 
 /* ---- every epoch's keyed permutation (ppo.py:155) and per-minibatch advantage sums (ppo.py:169) of one update at once (they depend on the
  * advantages and the keys only): perm_all dev i32 [epochs, n_rows], sums_all dev f64 [epochs, n_minibatch, 3] (local sums; sharded runs
@@ -210,6 +216,11 @@ int mi_comm_destroy(void* comm);
 int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version, int* comm_count);
 int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stream);
 int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* comm, void* stream);
+/* TEST HOOK (process-wide; 0 = off): mi_ppo_update / mi_ppo_update_sharded behave as at world_size > 1 in everything but the collective — the owed optimizer steps
+ * recompute the clip coefficient from the (all-reduced) gradient itself instead of reading the slab sum's block sums, the one branch a single-GPU run never takes.
+ * Results are bitwise those of the default route (the two evaluations of the norm are one expression tree); lets a one-GPU box test and time the sharded launches
+ * (tests/test_gpu_sharded_route.py, bench.py `sharded_route`). */
+int mi_ppo_test_assume_sharded(int on);
 
 /* =====================================================================================================================
  * DQN (reference deep_rl/dqn.py; SURVEY.md §8a d1-d8, BASELINE config 3).
@@ -396,12 +407,15 @@ int mi_sac_alpha_step_owed(const float* actor, int batch, uint64_t seed, const m
 int mi_sac_owed_alpha_fits(int batch);   /* 1 when a launch at this batch may carry an owed alpha step on the current device (half of its usable CUs stay free) */
 
 /* ---- waits between the workgroups of one SAC launch (sibling roles of a row group, the owed alpha step): every waiter only waits for workgroups that precede
- * it in dispatch order, and every spin is bounded (100 ms of wall clock).  A wait that runs out stores a code in a host-pinned status word, takes NaN as the
- * value (the launch's gradients, losses and stepped parameters come out NaN) and lets the kernel finish: the failure surfaces as MI_ESTATE from the NEXT
- * mi_sac_* update call (a plain host read, no synchronisation) or from mi_sac_check.
+ * it in dispatch order, and every spin is bounded (100 ms of wall clock).  A wait that runs out stores a code in a host-pinned status word and in a word on the
+ * device, takes NaN as the value (the launch's gradients and losses come out NaN) and lets the kernel finish; from then on every optimizer step of the SAC calls
+ * on that device (fused or not: Adam on critics / actor / log_alpha, polyak) is WITHHELD, so parameters, moments and targets stay as they were before the faulted
+ * update.  The failure surfaces as MI_ESTATE from the NEXT mi_sac_* update call (a plain host read, no synchronisation) or from mi_sac_check; after
+ * mi_sac_clear_error the caller may simply go on (one update lost) or restore a checkpoint first.  One device per status word: the library keeps the word's
+ * device pointer per device, so a process may run SAC on several.
  *   mi_sac_check(stream, wait)        wait != 0: synchronise `stream` first.  MI_OK, or MI_ESTATE with mi_last_error() naming what was not published.
- *   mi_sac_clear_error(ws, batch, s)  after the caller has restored its parameters / optimizer state: clears the status word and (workspace != NULL) zeroes
- *                                     the workspace's hand-off words, ticket, stash and epoch word (synchronises `stream`).
+ *   mi_sac_clear_error(ws, batch, s)  clears the status word and the current device's fault word and (workspace != NULL) zeroes the workspace's hand-off words,
+ *                                     ticket, stash and epoch word (synchronises `stream`).
  *   mi_sac_set_max_cus(n)             how many CUs sibling roles may assume (0 = the device's count cut by HSA_CU_MASK / ROC_GLOBAL_CU_MASK, which
  *                                     hipDeviceProp_t.multiProcessorCount does not see); steers performance only.  mi_sac_usable_cus() reports the figure in use.
  *   mi_sac_test_fault(mode)           TEST HOOK: bit 0 = publishing siblings skip their hand-off words, bit 1 = the owed alpha role does not publish its epoch

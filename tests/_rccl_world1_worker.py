@@ -2,6 +2,7 @@
 process group and libmirl's own RCCL communicator exist on a one-GPU box.  Checks, bit for bit, that the three update routes agree:
   (a) mi_ppo_update                              single-process fusion, no collective
   (b) mi_ppo_update_sharded over RCCL            ONE C call, 17 in-stream ncclAllReduce per update (world_size 1: the data is unchanged)
+  (b') the same with mi_ppo_test_assume_sharded(1): the owed optimizer steps recompute the clip coefficient from the gradient (what world_size > 1 does)
   (c) the host-sequenced launches with torch.distributed all-reduces over RCCL between them
 and that mi_comm_allreduce_sum really runs on the stream it is given; the same three-way identity for the DQN, PER and SAC engines
 (mi_dqn_td_update_sharded, mi_sac_critic / actor_update_sharded, mi_sac_alpha_step_sharded)."""
@@ -40,7 +41,8 @@ assert torch.equal(x, y) and torch.equal(z, z2)
 
 
 def run(mode, n_envs):
-    E._FORCE_NATIVE_SHARDED = mode == "native"
+    E._FORCE_NATIVE_SHARDED = mode.startswith("native")
+    E.set_assume_sharded(mode == "native+assume")   # the world_size > 1 form of the owed optimizer step (norm_parts = nullptr) on the real RCCL route
     E._FORCE_SHARDED_SEQUENCE = mode == "torch"
     DD._FORCE_COLLECTIVES = mode == "torch"
     env = D.make("CartPole-v1", num_envs=n_envs, device=dev, seed=5)
@@ -59,11 +61,12 @@ def run(mode, n_envs):
 
 for n_envs in (8, 4096):
     ref = run("fused", n_envs)
-    for mode in ("native", "torch"):
+    for mode in ("native", "native+assume", "torch"):
         got = run(mode, n_envs)
         for a, b in zip(ref, got):
             assert torch.equal(a, b), (n_envs, mode)
     assert torch.isfinite(ref[0]).all()
+E.set_assume_sharded(False)
 
 # ---- DQN / PER / SAC: fused single-process calls == one-call RCCL route (mi_dqn_td_update_sharded, mi_sac_*_sharded) == host-sequenced route with torch all-reduces ----
 import deep_rl_amd.dqn_engine as DE  # noqa: E402

@@ -167,3 +167,69 @@ def test_offpolicy_gradient_shares_sum_to_the_union_batch():
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])     # every rank holds the same sum
     assert np.abs(res[0][1] - want_d).max() <= 2e-6 * np.abs(want_d).max()                    # fp32 sums in a different grouping
     assert np.abs(res[0][2] - want_s).max() <= 5e-6 * np.abs(want_s).max()
+
+
+# ---------------------------------------------------------------- replica-divergence guard ------------------------------------------
+def _worker_guard(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MIRL_CHECK_REPLICAS="3")
+    from deep_rl_amd import dist as D
+    from deep_rl_amd._native import MiError
+
+    D.init_from_env("gloo")
+    assert D.replica_check_interval() == 3
+    g = torch.Generator().manual_seed(7)           # the same "replicated" state on both ranks
+    params, m, v = (torch.randn(9155, generator=g) for _ in range(3))
+    events = []
+    for update in range(1, 10):                    # the engines' loop: step, then every K-th update check
+        params += 1e-3 * m                         # identical arithmetic on both ranks
+        if update == 4 and rank == 1:
+            params.view(torch.int32)[1234] ^= 1    # ONE mantissa bit, on one rank
+        if update % D.replica_check_interval() == 0:
+            try:
+                D.check_replicas([params, m, v], None, "test state after update %d" % update)
+                events.append((update, "ok"))
+            except MiError as ex:
+                events.append((update, str(ex)))
+                break
+    q.put((rank, events, int(D.state_checksum([params, m, v]).item())))
+    torch.distributed.destroy_process_group()
+
+
+def test_replica_guard_catches_one_flipped_mantissa_bit_within_k_updates():
+    """MIRL_CHECK_REPLICAS=K (deep_rl_amd.dist.check_replicas, called by every sharded engine every K-th update): the replicas' {parameters, Adam moments} must be
+    bitwise equal; one flipped mantissa bit on rank 1 after update 4 raises MiError on BOTH ranks at the next check (update 6 <= 4 + K)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_guard, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, events, _ in res:
+        assert events[0] == (3, "ok"), events
+        assert events[1][0] == 6 and "replica divergence" in events[1][1] and "test state after update 6" in events[1][1], events
+        assert len(events) == 2
+    assert res[0][2] != res[1][2]                  # the checksums really differ by that one bit
+
+
+def test_state_checksum_is_order_and_bit_sensitive():
+    sys.path.insert(0, ROOT)
+    from deep_rl_amd import dist as D
+
+    a = torch.arange(1000, dtype=torch.float32) * 0.37 - 5.0
+    b = a.clone()
+    c0 = int(D.state_checksum([a]).item())
+    assert c0 == int(D.state_checksum([b[:400], b[400:]]).item())      # the concatenation, however it is split
+    b[[10, 11]] = b[[11, 10]]
+    assert int(D.state_checksum([b]).item()) != c0                     # a swap of two elements
+    b = a.clone(); b.view(torch.int32)[999] ^= 1 << 22
+    assert int(D.state_checksum([b]).item()) != c0
+    z = torch.zeros(64)                                                # zeros still count their positions (word + 1)
+    assert int(D.state_checksum([z]).item()) == sum(2 * i + 1 for i in range(64))
+    assert D.check_replicas([a]) is None                               # single process: no-op

@@ -6,7 +6,9 @@ exchange between backward and clip_grad_norm_).
       updates; checked against the single process with union minibatches, against the host-sequenced route over torch's RCCL (bit for bit) and
       rank against rank (bit for bit).
   test_two_ranks_one_gpu_gloo_whole_updates  the same worker and the same comparison with both ranks on cuda:0 over gloo (host-sequenced route): keeps the
-      harness itself green on the one-GPU box."""
+      harness itself green on the one-GPU box.
+  test_two_gpus_rccl_offpolicy_one_call_routes / test_two_ranks_one_gpu_gloo_offpolicy   the same pair for DQNEngine, PERDQNEngine and SACEngine (reference dqn.py:131-133,
+      per.py:147-153, sac.py:185-210 with the gradient exchange between backward and optimizer.step()): tests/_offpolicy_sharded_worker.py."""
 import os
 import socket
 import subprocess
@@ -116,3 +118,111 @@ def test_two_ranks_one_gpu_gloo_whole_updates():
     r0, r1, big = _run("gloo", 64)
     assert int(r0["native"][0]) == 0
     _check(r0, r1, big, 64)
+
+
+# =============================================================== DQN / PER / SAC at world_size 2 ===============================================================
+# (the one-call RCCL routes of the off-policy engines were checked at world_size 1 only.)
+OFF_NL, OFF_STEPS, OFF_B, OFF_ROUNDS, OFF_SEED = 8, 40, 64, 3, 7   # == tests/_offpolicy_sharded_worker.py
+
+
+def _run_off(backend):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, PYTHONPATH=ROOT, MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                              os.path.join(ROOT, "tests", "_offpolicy_sharded_worker.py")], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        assert "OFFPOLICY_WORKER_OK backend=%s" % backend in out.stdout, out.stdout[-2000:]
+        return dict(np.load(os.path.join(tmp, "off_rank0.npz"))), dict(np.load(os.path.join(tmp, "off_rank1.npz")))
+
+
+def _off_inputs(r):
+    rng = np.random.default_rng(1000 + r)
+    return [(rng.integers(0, (OFF_STEPS - 1) * OFF_NL, OFF_B), rng.standard_normal((3, OFF_B)).astype(np.float32)) for _ in range(OFF_ROUNDS)]
+
+
+def _off_single_process(r0):
+    """One process that owns all 2 * NL envs, with the union batches (rank r's local index slot * NL + e is slot * 2 NL + r NL + e here) and the concatenated noise,
+    on the fused single-process calls."""
+    import torch
+
+    import deep_rl_amd as D
+
+    dev = torch.device("cuda", 0)
+    nl, n = OFF_NL, 2 * OFF_NL
+    ins = [_off_inputs(r) for r in range(2)]
+    union = lambda k: np.concatenate([(ins[r][k][0] // nl) * n + r * nl + ins[r][k][0] % nl for r in range(2)])  # noqa: E731
+    env = D.make("CartPole-v1", num_envs=n, device=dev, seed=OFF_SEED)
+    torch.manual_seed(OFF_SEED)
+    q = D.QNetwork(env); t = D.QNetwork(env)
+    q.load_flat(r0["dqn_init"]); t.load_flat(r0["dqn_init"])
+    dqn = D.DQNEngine(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=OFF_STEPS + 1 + 10 * OFF_ROUNDS, batch_size=2 * OFF_B, learning_starts=10, total_timesteps=400,
+                      max_episodes_logged=0)
+    dqn.reset(); dqn.act(OFF_STEPS)
+    for k in range(OFF_ROUNDS):
+        dqn.train_step(union(k))
+    env = D.make("Pendulum-v1", num_envs=n, device=dev, seed=OFF_SEED)
+    torch.manual_seed(OFF_SEED)
+    a = D.Actor(env)
+    qs = [D.SoftQNetwork(env) for _ in range(4)]
+    sac = D.SACEngine(env, a, *qs, slots=OFF_STEPS + 1, batch_size=2 * OFF_B, learning_starts=10, max_episodes_logged=0)
+    a.load_flat(r0["sac_actor_init"])
+    sac.q_flat.copy_(torch.from_numpy(r0["sac_q_init"]).to(dev)); sac.qt_flat.copy_(torch.from_numpy(r0["sac_q_init"]).to(dev))
+    sac.reset()
+    for _ in range(OFF_STEPS):
+        sac.act()
+    for k in range(OFF_ROUNDS):
+        eps = np.concatenate([ins[0][k][1], ins[1][k][1]], axis=1)
+        sac.sample(union(k))
+        sac.update_critic(torch.from_numpy(eps[0]), polyak=True); sac.update_actor(torch.from_numpy(eps[1])); sac.update_alpha(torch.from_numpy(eps[2]))
+    torch.cuda.synchronize()
+    return {"dqn_q": dqn.q.flat.cpu().numpy(), "dqn_loss": dqn.loss.cpu().numpy(), "dqn_obs": dqn.observations.cpu().numpy(), "sac_q": sac.q_flat.cpu().numpy(),
+            "sac_qt": sac.qt_flat.cpu().numpy(), "sac_actor": sac.actor.flat.cpu().numpy(), "sac_log_alpha": sac.log_alpha.cpu().numpy(), "sac_obs": sac.observations.cpu().numpy(),
+            "sac_q_losses": sac.q_losses.cpu().numpy()}
+
+
+def _check_off(r0, r1, big):
+    # replicas stay bitwise identical (the in-worker guard, MIRL_CHECK_REPLICAS=2, has also passed): parameters, moments, all-reduced gradient and losses
+    for k in ("dqn_q", "dqn_m", "dqn_v", "dqn_loss", "dqn_grads", "per_q", "per_m", "per_loss", "sac_q", "sac_qt", "sac_actor", "sac_log_alpha", "sac_q_losses",
+              "sac_actor_out", "sac_qm", "sac_am"):
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.isfinite(r0[k]).all(), k
+    assert not np.array_equal(r0["dqn_q"], r0["dqn_init"]) and not np.array_equal(r0["per_q"], r0["dqn_init"]) and not np.array_equal(r0["sac_actor"], r0["sac_actor_init"])
+    assert not np.array_equal(r0["per_prio_sum"], r1["per_prio_sum"])      # the priorities are per-rank state (each rank's own ring)
+    # env sharding: each rank's ring holds the matching columns of the big run's ring (acting is parameter-independent here: before learning_starts / same actor)
+    nl = OFF_NL
+    for r, rk in enumerate((r0, r1)):
+        assert np.array_equal(rk["dqn_obs"][:OFF_STEPS + 1], big["dqn_obs"][:OFF_STEPS + 1, r * nl:(r + 1) * nl])
+        assert np.array_equal(rk["sac_obs"], big["sac_obs"][:, r * nl:(r + 1) * nl])
+    # 2 ranks x B rows == one process with the union batch of 2 B rows, after 3 chained steps (shares summed in a different grouping move last bits per step)
+    assert np.abs(r0["dqn_q"] - big["dqn_q"]).max() < 2e-5 and abs(float(r0["dqn_loss"][0]) - float(big["dqn_loss"][0])) < 1e-4 * max(1.0, abs(float(big["dqn_loss"][0])))
+    assert np.abs(r0["sac_q"] - big["sac_q"]).max() < 5e-5 and np.abs(r0["sac_qt"] - big["sac_qt"]).max() < 2e-6
+    assert np.abs(r0["sac_actor"] - big["sac_actor"]).max() < 5e-5 and abs(float(r0["sac_log_alpha"][0]) - float(big["sac_log_alpha"][0])) < 1e-5
+    assert np.allclose(r0["sac_q_losses"], big["sac_q_losses"], rtol=1e-3)
+
+
+def test_two_gpus_rccl_offpolicy_one_call_routes():
+    """DQNEngine / PERDQNEngine / SACEngine, one rank per GPU over RCCL: the one-call routes (mi_dqn_td_update_sharded, mi_sac_{critic,actor}_update_sharded,
+    mi_sac_alpha_step_sharded) against the host-sequenced route over torch's RCCL (bit for bit), rank against rank (bit for bit) and the single process with union batches."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device); the one-GPU variant below covers the harness")
+    r0, r1 = _run_off("nccl")
+    assert int(r0["dqn_native"][0]) == 1 and int(r0["sac_native"][0]) == 1
+    _check_off(r0, r1, _off_single_process(r0))
+    for rk in (r0, r1):
+        for k in [k for k in rk if k.startswith("seq_") and not k.endswith("_native")]:
+            assert np.array_equal(rk[k], rk[k[4:]]), k
+
+
+def test_two_ranks_one_gpu_gloo_offpolicy():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    r0, r1 = _run_off("gloo")
+    assert int(r0["dqn_native"][0]) == 0 and int(r0["sac_native"][0]) == 0
+    _check_off(r0, r1, _off_single_process(r0))

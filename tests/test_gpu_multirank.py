@@ -28,6 +28,7 @@ def _mk(dev, n, base, pg_ready):
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from deep_rl_amd import _native as N
     from deep_rl_amd import dist as D
 
     D.init_from_env("gloo")
@@ -36,7 +37,8 @@ def _worker(rank, world, port, q):
     assert eng.world_size == world
     params0 = eng.agent.flat.cpu().numpy().copy()
     eng.reset(); eng.rollout(); eng.compute_gae()
-    out = {"params0": params0, "storage": {n: getattr(eng, n).cpu().numpy() for n in ["observations", "actions", "dones", "advantages"]}}
+    out = {"params0": params0, "storage": {n: getattr(eng, n).cpu().numpy() for n in ["observations", "actions", "dones", "advantages", "values", "returns"]}}
+    out["explained_var"] = float(eng.compute_explained_var().item())   # ppo.py:194-195 over the rows of BOTH ranks (two all-reduces of two doubles)
     eng.make_perm(0)                       # same key on every rank, applied to the rank's local rows
     out["perm"] = eng.perm.cpu().numpy()
     eng.adv_stats()                        # all-reduce #1
@@ -48,6 +50,21 @@ def _worker(rank, world, port, q):
     # and two whole sharded updates through engine.update()'s multi-rank branch
     eng.update(); eng.update()
     out["params3"] = eng.agent.flat.cpu().numpy().copy()
+    # replica-divergence guard (MIRL_CHECK_REPLICAS=K, deep_rl_amd.dist.check_replicas): green so far; one flipped mantissa bit on rank 1 is caught on BOTH ranks by the
+    # check that ends the second update after it (K = 2)
+    eng.check_replicas()
+    eng._check_every = 2
+    assert eng.update_index % 2 == 0
+    if rank == 1:
+        eng.agent.flat.view(torch.int32)[4321] ^= 1
+    caught = None
+    for k in range(2):
+        try:
+            eng.update()
+        except N.MiError as ex:
+            caught = (k, str(ex))
+            break
+    out["guard"] = caught
     q.put((rank, out))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -83,6 +100,14 @@ def test_two_ranks_on_one_gpu_match_single_process():
             big, small = getattr(eng, n)[:, sl].cpu().numpy(), res[r]["storage"][n]
             bad = np.argwhere(big != small)
             assert bad.shape[0] == 0, (r, n, bad.shape[0], bad[:8].tolist(), [(float(big[tuple(b)]), float(small[tuple(b)])) for b in bad[:4]])
+    # explained variance over the whole batch (ppo.py:194-195): both ranks report the single process's value
+    ev = float(eng.compute_explained_var().item())
+    v64, r64 = eng.values.double().cpu().numpy().reshape(-1), eng.returns.double().cpu().numpy().reshape(-1)
+    want = 1.0 - np.var(v64 - r64, ddof=1) / np.var(v64, ddof=1)
+    assert abs(ev - want) < 1e-9 * max(1.0, abs(want))
+    for r in range(2):
+        assert abs(res[r]["explained_var"] - want) < 1e-9 * max(1.0, abs(want)), (res[r]["explained_var"], want)
+        assert res[r]["guard"] is not None and res[r]["guard"][0] == 1 and "replica divergence" in res[r]["guard"][1], res[r]["guard"]
     # union minibatch in the big run's row numbering: local row t*NL + e  ->  t*(2 NL) + r*NL + e
     mb = T * NL // 4
     gidx = np.concatenate([(res[r]["perm"][:mb] // NL) * (2 * NL) + r * NL + res[r]["perm"][:mb] % NL for r in range(2)]).astype(np.int32)

@@ -60,8 +60,9 @@ def _state(eng):
 
 @pytest.mark.parametrize("mode,batch", [(1, 256), (1, 600), (2, 256)])
 def test_lost_producer_is_an_error_code_never_a_hang(dev, tmp_path, mode, batch):
-    """A producer that never publishes (injected: mi_sac_test_fault) makes the waiting workgroups run out of their 100 ms budget: the launches END, the outputs are
-    NaN-poisoned, mi_sac_check and the next update call return MI_ESTATE with text — and after restoring a checkpoint + clear_error the run continues bit for bit."""
+    """A producer that never publishes (injected: mi_sac_test_fault) makes the waiting workgroups run out of their 100 ms budget: the launches END, their losses are
+    NaN, NO optimizer step is applied from then on (parameters, Adam moments, targets, log_alpha stay finite and frozen: ADVICE r03 — a spurious timeout must not destroy
+    the state), mi_sac_check and the next update call return MI_ESTATE with text — and after restoring a checkpoint + clear_error the run continues bit for bit."""
     from deep_rl_amd import _native as N
     from deep_rl_amd import checkpoint as CK
 
@@ -86,8 +87,15 @@ def test_lost_producer_is_an_error_code_never_a_hang(dev, tmp_path, mode, batch)
         eng.check()
     with pytest.raises(N.MiError, match="rc=-4"):     # MI_ESTATE, sticky: every later update call refuses
         eng.update_critic()
-    # the poisoned launch's Adam step wrote NaN: the critics when a hand-off word was lost, the actor (whose loss needs alpha first) when the epoch was
-    assert not bool(torch.isfinite(eng.q_flat).all() and torch.isfinite(eng.actor.flat).all())
+    # the poisoned launch's losses are NaN (the critics' when a hand-off word was lost, the actor's — whose loss needs alpha first — when the epoch was) ...
+    assert not bool(torch.isfinite(eng.q_losses).all() and torch.isfinite(eng.actor_out).all())
+    # ... but every optimizer step behind the timeout was withheld: nothing holds a NaN, and further launches leave the state where it is
+    frozen = [t.clone() for t in (eng.actor.flat, eng.q_flat, eng.qt_flat, eng._log_alpha, eng._alpha_m_t, eng.actor_optimizer.exp_avg, eng.actor_optimizer.exp_avg_sq,
+                                  eng.q_optimizer.exp_avg, eng.q_optimizer.exp_avg_sq)]
+    assert all(bool(torch.isfinite(t).all()) for t in frozen)
+    N.check(N.lib().mi_polyak(N.ptr(eng.qt_flat), N.ptr(eng.q_flat), eng.q_flat.numel(), 0.5, N.stream_ptr(dev)), "mi_polyak")   # an unfused step: withheld too
+    torch.cuda.synchronize()
+    assert torch.equal(frozen[2], eng.qt_flat)
     CK.load(ck, eng)
     eng.clear_error()
     eng.check()

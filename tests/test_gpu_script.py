@@ -18,6 +18,7 @@ def _run(env_over):
             "['env_id','total_timesteps','num_steps','num_updates','minibatch_size','update_epochs','gamma','gae_lambda',"
             "'learning_rate','clip_coef','ent_coef','vf_coef','max_grad_norm','seed','global_step','num_envs']}));"
             "print('SHAPES', [tuple(g[k].shape) for k in ['observations','values','actions','log_probs','rewards','dones','advantages','returns']]);"
+            "print('OBS', tuple(g['observation'].shape), g['observation'].dtype, g['actions'].dtype);"
             "print('LOSS', g['pg_loss'], g['entropy_loss'], g['v_loss'], g['loss'], g['explained_var'])")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -36,7 +37,9 @@ def test_reference_shape_run_n1():
     steps = [int(ln.split(",")[0].split("=")[1]) for ln in lines]
     assert steps == sorted(steps) and steps[-1] < 3840
     assert '"num_updates": 30' in out and '"minibatch_size": 32' in out and '"global_step": 3840' in out
-    assert "SHAPES [(129, 1, 4), (129, 1), (129, 1), (129, 1), (129, 1), (129, 1), (129, 1), (129, 1)]" in out
+    # the reference's own storage shapes (ppo.py:93-98; advantages / returns :144-151): no env axis at one env
+    assert "SHAPES [(129, 4), (129,), (129,), (129,), (129,), (129,), (129,), (129,)]" in out
+    assert "OBS (4,) torch.float32 torch.int64" in out
 
 
 def test_vector_run_learns():
@@ -55,7 +58,7 @@ def _run_dqn(env_over):
     code = ("import runpy, json; g = runpy.run_module('deep_rl_amd.dqn', run_name='__main__');"
             "print('GLOBALS', json.dumps({k: g[k] for k in ['env_id','total_timesteps','learning_starts','train_frequency','batch_size',"
             "'gamma','learning_rate','target_network_frequency','seed','global_step','num_envs','memory_size']}));"
-            "print('SHAPES', [tuple(g[k].shape) for k in ['observations','actions','rewards','terminated']]); print('LOSS', g['loss'])")
+            "print('SHAPES', [tuple(g[k].shape) for k in ['observations','actions','rewards','terminated']], g['terminated'].dtype); print('LOSS', g['loss'])")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     return out.stdout
@@ -70,7 +73,7 @@ def test_dqn_script_reference_shape_n1():
     lines = [ln for ln in out.splitlines() if ln.startswith("global_step=")]
     assert len(lines) > 100 and all(re.fullmatch(r"global_step=\d+, episodic_return=\d+\.\d\d", ln) for ln in lines)  # dqn.py:111
     assert '"learning_starts": 600' in out and '"global_step": 6000' in out and '"memory_size": 6001' in out
-    assert "SHAPES [(6001, 1, 4), (6001, 1), (6001, 1), (6001, 1)]" in out
+    assert "SHAPES [(6001, 4), (6001,), (6001,), (6001,)] torch.bool" in out   # dqn.py:73-76
 
 
 def test_dqn_script_vector_ring_runs():
@@ -108,7 +111,7 @@ def test_sac_script_reference_shape_n1():
     assert [int(ln.split(",")[0].split("=")[1]) for ln in lines] == list(range(200, 3001, 200))
     assert '"env_id": "Pendulum-v1"' in out and '"learning_starts": 500' in out and '"global_step": 3000' in out and '"memory_size": 3001' in out
     assert '"target_entropy": -1.0' in out and '"batch_size": 256' in out
-    assert "SHAPES [(3001, 1, 3), (3001, 1), (3001, 1), (3001, 1)]" in out
+    assert "SHAPES [(3001, 3), (3001, 1), (3001,), (3001,)]" in out   # sac.py:126-129 (actions keep the action axis)
     assert "STEPS 2501 2502 2502" in out    # one critic update per step from learning_starts on; 2 actor + 2 alpha updates every 2nd step
     alpha = float(out.split('"alpha": ')[1].split("}")[0])
     assert 0.0 < alpha < 1.0
@@ -148,6 +151,11 @@ def test_bench_contract_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert "static" in r["traffic_source"]                        # roofline.traffic comes from committed PMC passes, and the line says so
+    w = d["timed_windows"]                                        # the headline window + two repeats of it, so a sub-per-cent margin can be told from noise
+    assert w["count"] == 3 and len(w["ms_per_step"]) == 3 and w["ms_per_step"][0] == d["ms_per_step"] and w["min"] <= w["median"] <= w["max"]
+    sr = d["sharded_route"]                                       # the launches only a multi-GPU run takes, timed on this GPU (hook + real one-rank RCCL)
+    assert "error" not in sr and "error" not in sr["rccl_world1"], sr
+    assert sr["assume_sharded"]["ms_per_step"] > 0 and sr["rccl_world1"]["ms_per_step"] > 0 and "delta_us_per_optimizer_step" in sr["assume_sharded"]
     n1 = d["cpu_baseline_n1"]                                     # the oracle at the reference's own shape (1 env, 1 thread)
     assert n1["cores"] == 1 and n1["value"] > 0 and n1["reference_python_env_steps_per_s"] == 886.0
     for key, kern in (("config3_dqn", "dqn_act4_kernel"), ("config4_sac", "sac_critic_kernel")):   # BASELINE configs[2] / [3] ride on the same line
