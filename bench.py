@@ -546,7 +546,8 @@ def main():
     breakdown = N.prof_end()
 
     sharded = None
-    if world == 1 and not args.headline_only and os.environ.get("MIRL_BENCH_SHARDED_LEG", "1") != "0":
+    leg = os.environ.get("MIRL_BENCH_SHARDED_LEG", "")   # "1": also with --headline-only (A/B builds); "0": never
+    if world == 1 and leg != "0" and (not args.headline_only or leg == "1"):
         try:
             sharded = sharded_route_leg(eng, one_update, timed_updates, num_updates - 1, args.steps, dev, 1e3 * dt / args.steps,
                                         1e3 * prof["grad"][0] / max(prof["grad"][1], 1))
