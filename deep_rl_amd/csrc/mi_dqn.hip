@@ -536,41 +536,50 @@ extern "C" int mi_dqn_sample(uint64_t seed, uint64_t update_index, int64_t upper
     return MI_OK;
 }
 
-// ---- TD loss + gradient.  One 256-thread workgroup per TD_R rows; a thread owns a hidden unit, the rows' activations sit
-//      in LDS (post-ReLU: relu(z) > 0 <=> z > 0, so the mask for the backward pass needs no second copy) --------------------
-#define TD_R 8
+// ---- TD loss + gradient.  A 256-thread workgroup walks groups of R batch rows (group = blockIdx.x, + gridDim.x, ...): a thread owns a hidden unit in the thin
+//      phases, the rows' activations sit in LDS (post-ReLU: relu(z) > 0 <=> z > 0, so the mask for the backward pass needs no second copy), the three 120 x 84
+//      contractions run on v_mfma_f32_16x16x4_f32.  The shape of PPO's grad_kernel (round 4): at most one workgroup per CU, every weight operand
+//      fetched ONCE per workgroup and kept in registers across the groups, the whole gradient accumulated in registers and written as ONE slab per workgroup at the
+//      end — until round 3 every 8 rows got a workgroup of their own that re-read both nets and wrote a full 43.7 KB slab (batch 4,096: 512 slabs, 27.6 MB of
+//      writes for 0.23 MB of gathers).  R = 8 while the batch gives at most TD_MAX_BLOCKS groups of 8 (one group per workgroup: the round-3 arithmetic, bit for bit);
+//      beyond that R = 16, which fills the MFMAs' 16 row columns (at R = 8 half of every B operand is zero) -----------------------------------------------------
+#define TD_R 8                 // rows per group of the small-batch form; also the granule of mi_dqn_workspace_bytes
+#define TD_MAX_BLOCKS 256      // workgroups (= slabs) per launch at most: one per CU of an MI355X
 #define TD_SLAB (DQ_NP + 2)   // + loss
-static_assert(TD_R == 8, "the MFMA passes of dqn_td_kernel take the rows as 2 k-steps of 4 (dW2) and as half of a 16-column B operand");
+template <int R>
 struct __attribute__((aligned(16))) td_smem {
-    float x[2][TD_R][4];          // [0] obs, [1] next obs
-    float h1[2][TD_R][DQ_H1];     // [0] online on obs, [1] target on next obs
-    float h2[2][TD_R][DQ_H2];
-    float q[2][TD_R][2];
-    float dq[TD_R][2];
-    float dz2[DQ_H2][TD_R];       // [unit][row]: one broadcast b128 pair per unit in the dW2 pass
-    float dz1[TD_R][DQ_H1];
-    float td_err[TD_R];
-    int act[TD_R];
+    float x[2][R][4];          // [0] obs, [1] next obs
+    float h1[2][R][DQ_H1];     // [0] online on obs, [1] target on next obs
+    float h2[2][R][DQ_H2];
+    float q[2][R][2];
+    float dq[R][2];
+    float dz2[DQ_H2][R];       // [unit][row]: one broadcast b128 pair per unit in the dW2 pass
+    float dz1[R][DQ_H1];
+    float td_err[R];
+    int act[R];
+    float w3[2][2][DQ_H2];     // both nets' head weights, staged once per workgroup
+    float b3[2][2];
+    long long cur[R], nxt[R];
 };
 
+template <int R>
 __global__ void __launch_bounds__(256)
 dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target_params, const float* __restrict__ observations,
               const int64_t* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
               const int64_t* idx /* may alias idx_out: no __restrict__ */, int batch, int n_envs, long long slots, float gamma, float invn,
               float* __restrict__ workspace, const float* __restrict__ row_w, float* __restrict__ td_abs, uint64_t sample_seed, uint64_t sample_update,
               uint64_t sample_upper, int64_t* idx_out) {
-    __shared__ td_smem sm;
+    static_assert(R == 8 || R == 16, "the MFMA passes take the rows as R / 4 k-steps (dW2) and as (part of) a 16-column B operand");
+    __shared__ td_smem<R> sm;
     const int t = threadIdx.x;
-    const int row0 = blockIdx.x * TD_R;
+    const int n_groups = (batch + R - 1) / R;
     float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
-    __shared__ long long nxt[TD_R];
-    __shared__ long long cur[TD_R];
-    // MFMA roles (layer 2, dh1, dW2): wave mw, lane (mj, mlg).  The layer-2 A operands do not depend on the batch: requested now, they land while the
-    // indices, the gathers and layer 1 run (24 float4 + 12 dwords per lane)
+    // MFMA roles (layer 2, dh1, dW2): wave mw, lane (mj, mlg).  None of the weight operands depends on the batch: requested now, they land while the first group's
+    // indices, gathers and layer 1 run, and they stay in registers for every later group (layer 2: 24 float4 + 12 bias dwords per lane; dh1: 42 dwords)
     const int mw = t >> 6, mj = t & 15, mlg = (t >> 4) & 3;
     const int mnet = mw >> 1;
     const float* mp = mnet ? target_params : params;
-    f32x4_t wA[3][8], acc2[3];
+    f32x4_t wA[3][8], bias2[3];
 #pragma unroll
     for (int T3 = 0; T3 < 3; ++T3) {
         const int T = 3 * (mw & 1) + T3, u2 = 16 * T + mj;
@@ -580,190 +589,226 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             wA[T3][c] = (u2 < DQ_H2 && k < DQ_H1) ? *reinterpret_cast<const f32x4_t*>(mp + DQ_W2 + DQ_H1 * u2 + k) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int o = 16 * T + 4 * mlg + r; acc2[T3][r] = o < DQ_H2 ? mp[DQ_B2 + o] : 0.0f; }
+        for (int r = 0; r < 4; ++r) { const int o = 16 * T + 4 * mlg + r; bias2[T3][r] = o < DQ_H2 ? mp[DQ_B2 + o] : 0.0f; }
     }
-    if (t < TD_R) {
-        const int b = row0 + t < batch ? row0 + t : batch - 1;
-        long long i;
-        if (sample_upper) {     // batch_inds = randint(upper, size=batch) (dqn.py:116) drawn here: the contract of dqn_sample_kernel, no launch of its own
-            uint32_t r[4];
-            mi_philox(sample_seed, sample_update, (uint64_t)b, STREAM_SAMPLE, r);
-            i = (long long)((((uint64_t)r[1] << 32) | r[0]) % sample_upper);
-            if (row0 + t < batch) idx_out[b] = i;
-        } else i = idx[b];
-        cur[t] = i;
-        // next-slot row of the same env: ((i / N + 1) % slots) * N + i % N.  Flat indices below 2^32 (every ring this side of 4 G transitions) take the
-        // 32-bit divider; the wrap is a compare (slot < slots always), not a second modulo.
-        long long sl, en;
-        if ((unsigned long long)i >> 32) { sl = i / n_envs; en = i % n_envs; }
-        else { const unsigned q = (unsigned)i / (unsigned)n_envs; sl = q; en = (unsigned)i - q * (unsigned)n_envs; }
-        sl = sl + 1 == slots ? 0 : sl + 1;
-        nxt[t] = sl * n_envs + en;
-        sm.act[t] = (int)actions[i];
-    }
-    __syncthreads();
-    if (t < 2 * TD_R * 4) {
-        const int net = t / (TD_R * 4), r = (t / 4) % TD_R, k = t & 3;
-        sm.x[net][r][k] = observations[4 * (net ? nxt[r] : cur[r]) + k];
-    }
-    __syncthreads();
-    const int net = t >> 7, u = t & 127;                 // threads 0..127: online net, 128..255: target net
-    const float* p = net ? target_params : params;
-    // ---- layer 1 ----
-    if (u < DQ_H1) {
-        const float4 w = *reinterpret_cast<const float4*>(p + DQ_W1 + 4 * u);
-        const float b = p[DQ_B1 + u];
-#pragma unroll
-        for (int r = 0; r < TD_R; ++r) {
-            float z = b;
-            z = __builtin_fmaf(w.x, sm.x[net][r][0], z); z = __builtin_fmaf(w.y, sm.x[net][r][1], z);
-            z = __builtin_fmaf(w.z, sm.x[net][r][2], z); z = __builtin_fmaf(w.w, sm.x[net][r][3], z);
-            sm.h1[net][r][u] = fmaxf(z, 0.0f);
-        }
-    }
-    __syncthreads();
-    // ---- layer 2 on v_mfma_f32_16x16x4_f32, D[unit][row] = W2[unit][k] h1[k][row]: 2 nets x 6 unit tiles over the 4 waves (wave w: net w >> 1, tiles
-    //      3 (w & 1) ..+2).  Lane (j, lg) supplies k = 16c + 4lg + r in k-step (c, r): A = W2[16T + j][k] (8 float4 loads per tile, issued together;
-    //      each wave-load touches whole 64-byte segments of 16 rows), B = h1[row j][k] (one LDS float4 per c; rows >= TD_R are zero columns).
-    //      (r01 form: thread per unit, its W2 row streamed as 30 dependent float4 loads from 64 different lines each — 12,100 of the kernel's 34,500 cycles.) ----
-    {
-        const int j = mj, lg = mlg;
-        f32x4_t hB[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int k = 16 * c + 4 * lg;
-            hB[c] = (j < TD_R && k < DQ_H1) ? *reinterpret_cast<const f32x4_t*>(&sm.h1[mnet][j][k]) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int T3 = 0; T3 < 3; ++T3) acc2[T3] = DQ_MFMA(wA[T3][c][r], hB[c][r], acc2[T3]);
-#pragma unroll
-        for (int T3 = 0; T3 < 3; ++T3) {
-            const int o = 16 * (3 * (mw & 1) + T3) + 4 * lg;
-            if (j < TD_R && o < DQ_H2)
-                *reinterpret_cast<f32x4_t*>(&sm.h2[mnet][j][o]) = f32x4_t{fmaxf(acc2[T3][0], 0.0f), fmaxf(acc2[T3][1], 0.0f), fmaxf(acc2[T3][2], 0.0f), fmaxf(acc2[T3][3], 0.0f)};
-        }
-    }
-    // the dh1 pass's A operands (W2 read column-wise: 42 dwords per lane), requested now: they land during layer 3 and the loss
+    // the dh1 pass's A operands (W2 read column-wise)
     float wa1[2][21];
 #pragma unroll
     for (int s2 = 0; s2 < 21; ++s2)
 #pragma unroll
         for (int U2 = 0; U2 < 2; ++U2) { const int k = 16 * (2 * mw + U2) + mj; wa1[U2][s2] = k < DQ_H1 ? params[DQ_W2 + DQ_H1 * (4 * s2 + mlg) + k] : 0.0f; }
-    __syncthreads();
-    // ---- layer 3: 2 nets x TD_R rows x 2 actions = 32 dot products of length 84 ----
-    if (t < 2 * TD_R * 2) {
-        const int n3 = t / (TD_R * 2), r = (t >> 1) % TD_R, a = t & 1;
-        const float* pp = n3 ? target_params : params;
-        float acc = 0.0f;
-        for (int j = 0; j < DQ_H2; ++j) acc = __builtin_fmaf(pp[DQ_W3 + a * DQ_H2 + j], sm.h2[n3][r][j], acc);
-        sm.q[n3][r][a] = acc + pp[DQ_B3 + a];
-    }
-    __syncthreads();
-    // ---- TD target, loss, d loss / d q (dqn.py:119-123) ----
-    if (t < TD_R) {
-        const bool valid = row0 + t < batch;
-        const float target_max = fmaxf(sm.q[1][t][0], sm.q[1][t][1]);
-        const float td = rewards[nxt[t]] + gamma * target_max * (terminated[nxt[t]] ? 0.0f : 1.0f);
-        const int a = sm.act[t];
-        const float diff = valid ? td - sm.q[0][t][a] : 0.0f;
-        const float wb = (row_w && valid) ? row_w[row0 + t] : 1.0f;      // importance weight (per.py:145-147); 1 for plain DQN
-        if (td_abs && valid) td_abs[row0 + t] = fabsf(diff);               // the new priority (per.py:141)
-        sm.td_err[t] = wb * (diff * diff);
-        sm.dq[t][0] = a == 0 ? -2.0f * (wb * diff) * invn : 0.0f;
-        sm.dq[t][1] = a == 1 ? -2.0f * (wb * diff) * invn : 0.0f;
-    }
-    __syncthreads();
-    // ---- backward through layer 3 (online net only): thread j < 84 ----
-    if (t < DQ_H2) {
-        const float w0 = params[DQ_W3 + t], w1 = params[DQ_W3 + DQ_H2 + t];
-        float g0 = 0.0f, g1 = 0.0f, gb = 0.0f;
+    // thin parameters: layer 1 of the thread's (net, unit), the online head's column of thread j < 84; both heads into LDS for the forward dot products
+    const int net = t >> 7, u = t & 127;                 // threads 0..127: online net, 128..255: target net
+    const float* p = net ? target_params : params;
+    float4 w1v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float b1v = 0.0f;
+    if (u < DQ_H1) { w1v = *reinterpret_cast<const float4*>(p + DQ_W1 + 4 * u); b1v = p[DQ_B1 + u]; }
+    float w30 = 0.0f, w31 = 0.0f;
+    if (t < DQ_H2) { w30 = params[DQ_W3 + t]; w31 = params[DQ_W3 + DQ_H2 + t]; }
+    for (int i = t; i < 2 * 2 * DQ_H2; i += 256) { const int n3 = i / (2 * DQ_H2), rem = i % (2 * DQ_H2); (&sm.w3[n3][0][0])[rem] = (n3 ? target_params : params)[DQ_W3 + rem]; }
+    if (t < 4) sm.b3[t >> 1][t & 1] = ((t >> 1) ? target_params : params)[DQ_B3 + (t & 1)];
+    // gradient accumulators over the workgroup's groups
+    float g30 = 0.0f, g31 = 0.0f, gb2 = 0.0f;            // t < 84: dW3[0][t], dW3[1][t], db2[t];  t = 84, 85: g30 = db3[t - 84];  t = 86: g30 = loss
+    float gb1 = 0.0f, gw1[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // t < 120: db1[t], dW1[t][0..3]
+    f32x4_t dW2acc[2][6];
 #pragma unroll
-        for (int r = 0; r < TD_R; ++r) {
-            const float h2 = sm.h2[0][r][t];
-            const float d = h2 > 0.0f ? __builtin_fmaf(w1, sm.dq[r][1], w0 * sm.dq[r][0]) : 0.0f;
-            sm.dz2[t][r] = d;
-            g0 = __builtin_fmaf(sm.dq[r][0], h2, g0); g1 = __builtin_fmaf(sm.dq[r][1], h2, g1);
-            gb += d;
+    for (int U2 = 0; U2 < 2; ++U2)
+#pragma unroll
+        for (int T = 0; T < 6; ++T) dW2acc[U2][T] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // (no barrier is needed between two groups: everything the first phases of group g + 1 write — cur, nxt, act — was last read before the final barrier of group g,
+    // and every later phase of g + 1 sits behind at least one of its own barriers)
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int row0 = grp * R;
+        if (t < R) {
+            const int b = row0 + t < batch ? row0 + t : batch - 1;
+            long long i;
+            if (sample_upper) {     // batch_inds = randint(upper, size=batch) (dqn.py:116) drawn here: the contract of dqn_sample_kernel, no launch of its own
+                uint32_t r[4];
+                mi_philox(sample_seed, sample_update, (uint64_t)b, STREAM_SAMPLE, r);
+                i = (long long)((((uint64_t)r[1] << 32) | r[0]) % sample_upper);
+                if (row0 + t < batch) idx_out[b] = i;
+            } else i = idx[b];
+            sm.cur[t] = i;
+            // next-slot row of the same env: ((i / N + 1) % slots) * N + i % N.  Flat indices below 2^32 (every ring this side of 4 G transitions) take the
+            // 32-bit divider; the wrap is a compare (slot < slots always), not a second modulo.
+            long long sl, en;
+            if ((unsigned long long)i >> 32) { sl = i / n_envs; en = i % n_envs; }
+            else { const unsigned q = (unsigned)i / (unsigned)n_envs; sl = q; en = (unsigned)i - q * (unsigned)n_envs; }
+            sl = sl + 1 == slots ? 0 : sl + 1;
+            sm.nxt[t] = sl * n_envs + en;
+            sm.act[t] = (int)actions[i];
         }
-        part[DQ_W3 + t] = g0; part[DQ_W3 + DQ_H2 + t] = g1; part[DQ_B2 + t] = gb;
-    } else if (t < DQ_H2 + 2) {
-        const int a = t - DQ_H2;
-        float gb = 0.0f;
+        __syncthreads();
+        if (t < 2 * R * 4) {
+            const int nt = t / (R * 4), r = (t / 4) % R, k = t & 3;
+            sm.x[nt][r][k] = observations[4 * (nt ? sm.nxt[r] : sm.cur[r]) + k];
+        }
+        __syncthreads();
+        // ---- layer 1 ----
+        if (u < DQ_H1) {
 #pragma unroll
-        for (int r = 0; r < TD_R; ++r) gb += sm.dq[r][a];
-        part[DQ_B3 + a] = gb;
-    } else if (t == DQ_H2 + 2) {
-        float l = 0.0f;
-#pragma unroll
-        for (int r = 0; r < TD_R; ++r) l += sm.td_err[r];
-        part[DQ_NP] = l;
-    }
-    __syncthreads();
-    // ---- dh1[k][row] = sum_j W2[j][k] dz2[j][row] on the MFMA: 8 k-tiles over the 4 waves (wave w: tiles 2w, 2w + 1), 21 k-steps over j = 4s + lg.
-    //      A = W2[j][16U + kk] (one dword per lane and k-step: 16 consecutive floats of 4 rows), B = dz2[j][row] from LDS; D: lane (row, lg), register r <-> k = 16U + 4lg + r ----
-    {
-        const int w = mw, j = mj, lg = mlg;
-        f32x4_t dh[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
-        float db[21];
-#pragma unroll
-        for (int s2 = 0; s2 < 21; ++s2) db[s2] = j < TD_R ? sm.dz2[4 * s2 + lg][j] : 0.0f;
-#pragma unroll
-        for (int s2 = 0; s2 < 21; ++s2)
-#pragma unroll
-            for (int U2 = 0; U2 < 2; ++U2) dh[U2] = DQ_MFMA(wa1[U2][s2], db[s2], dh[U2]);
-#pragma unroll
-        for (int U2 = 0; U2 < 2; ++U2) {
-            const int k = 16 * (2 * w + U2) + 4 * lg;
-            if (j < TD_R && k < DQ_H1) {
-                const f32x4_t h = *reinterpret_cast<const f32x4_t*>(&sm.h1[0][j][k]);
-                *reinterpret_cast<f32x4_t*>(&sm.dz1[j][k]) = f32x4_t{h[0] > 0.0f ? dh[U2][0] : 0.0f, h[1] > 0.0f ? dh[U2][1] : 0.0f, h[2] > 0.0f ? dh[U2][2] : 0.0f, h[3] > 0.0f ? dh[U2][3] : 0.0f};
+            for (int r = 0; r < R; ++r) {
+                float z = b1v;
+                z = __builtin_fmaf(w1v.x, sm.x[net][r][0], z); z = __builtin_fmaf(w1v.y, sm.x[net][r][1], z);
+                z = __builtin_fmaf(w1v.z, sm.x[net][r][2], z); z = __builtin_fmaf(w1v.w, sm.x[net][r][3], z);
+                sm.h1[net][r][u] = fmaxf(z, 0.0f);
             }
         }
+        __syncthreads();
+        // ---- layer 2 on v_mfma_f32_16x16x4_f32, D[unit][row] = W2[unit][k] h1[k][row]: 2 nets x 6 unit tiles over the 4 waves (wave w: net w >> 1, tiles
+        //      3 (w & 1) ..+2).  Lane (j, lg) supplies k = 16c + 4lg + r in k-step (c, r): A = W2[16T + j][k] (register-resident), B = h1[row j][k] (one LDS float4
+        //      per c; rows >= R are zero columns).
+        //      (r01 form: thread per unit, its W2 row streamed as 30 dependent float4 loads from 64 different lines each — 12,100 of the kernel's 34,500 cycles.) ----
+        {
+            const int j = mj, lg = mlg;
+            f32x4_t hB[8], acc2[3];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int k = 16 * c + 4 * lg;
+                hB[c] = (j < R && k < DQ_H1) ? *reinterpret_cast<const f32x4_t*>(&sm.h1[mnet][j][k]) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int T3 = 0; T3 < 3; ++T3) acc2[T3] = bias2[T3];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int T3 = 0; T3 < 3; ++T3) acc2[T3] = DQ_MFMA(wA[T3][c][r], hB[c][r], acc2[T3]);
+#pragma unroll
+            for (int T3 = 0; T3 < 3; ++T3) {
+                const int o = 16 * (3 * (mw & 1) + T3) + 4 * lg;
+                if (j < R && o < DQ_H2)
+                    *reinterpret_cast<f32x4_t*>(&sm.h2[mnet][j][o]) = f32x4_t{fmaxf(acc2[T3][0], 0.0f), fmaxf(acc2[T3][1], 0.0f), fmaxf(acc2[T3][2], 0.0f), fmaxf(acc2[T3][3], 0.0f)};
+            }
+        }
+        __syncthreads();
+        // ---- layer 3: 2 nets x R rows x 2 actions dot products of length 84 ----
+        if (t < 2 * R * 2) {
+            const int n3 = t / (R * 2), r = (t >> 1) % R, a = t & 1;
+            float acc = 0.0f;
+            for (int j = 0; j < DQ_H2; ++j) acc = __builtin_fmaf(sm.w3[n3][a][j], sm.h2[n3][r][j], acc);
+            sm.q[n3][r][a] = acc + sm.b3[n3][a];
+        }
+        __syncthreads();
+        // ---- TD target, loss, d loss / d q (dqn.py:119-123) ----
+        if (t < R) {
+            const bool valid = row0 + t < batch;
+            const float target_max = fmaxf(sm.q[1][t][0], sm.q[1][t][1]);
+            const float td = rewards[sm.nxt[t]] + gamma * target_max * (terminated[sm.nxt[t]] ? 0.0f : 1.0f);
+            const int a = sm.act[t];
+            const float diff = valid ? td - sm.q[0][t][a] : 0.0f;
+            const float wb = (row_w && valid) ? row_w[row0 + t] : 1.0f;      // importance weight (per.py:145-147); 1 for plain DQN
+            if (td_abs && valid) td_abs[row0 + t] = fabsf(diff);               // the new priority (per.py:141)
+            sm.td_err[t] = wb * (diff * diff);
+            sm.dq[t][0] = a == 0 ? -2.0f * (wb * diff) * invn : 0.0f;
+            sm.dq[t][1] = a == 1 ? -2.0f * (wb * diff) * invn : 0.0f;
+        }
+        __syncthreads();
+        // ---- backward through layer 3 (online net only): thread j < 84 ----
+        if (t < DQ_H2) {
+            float g0 = 0.0f, g1 = 0.0f, gb = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float h2 = sm.h2[0][r][t];
+                const float d = h2 > 0.0f ? __builtin_fmaf(w31, sm.dq[r][1], w30 * sm.dq[r][0]) : 0.0f;
+                sm.dz2[t][r] = d;
+                g0 = __builtin_fmaf(sm.dq[r][0], h2, g0); g1 = __builtin_fmaf(sm.dq[r][1], h2, g1);
+                gb += d;
+            }
+            g30 += g0; g31 += g1; gb2 += gb;
+        } else if (t < DQ_H2 + 2) {
+            const int a = t - DQ_H2;
+            float gb = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) gb += sm.dq[r][a];
+            g30 += gb;
+        } else if (t == DQ_H2 + 2) {
+            float l = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) l += sm.td_err[r];
+            g30 += l;
+        }
+        __syncthreads();
+        // ---- dh1[k][row] = sum_j W2[j][k] dz2[j][row] on the MFMA: 8 k-tiles over the 4 waves (wave w: tiles 2w, 2w + 1), 21 k-steps over j = 4s + lg.
+        //      A = W2[j][16U + kk] (register-resident), B = dz2[j][row] from LDS; D: lane (row, lg), register r <-> k = 16U + 4lg + r ----
+        {
+            const int w = mw, j = mj, lg = mlg;
+            f32x4_t dh[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
+            float db[21];
+#pragma unroll
+            for (int s2 = 0; s2 < 21; ++s2) db[s2] = j < R ? sm.dz2[4 * s2 + lg][j] : 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 21; ++s2)
+#pragma unroll
+                for (int U2 = 0; U2 < 2; ++U2) dh[U2] = DQ_MFMA(wa1[U2][s2], db[s2], dh[U2]);
+#pragma unroll
+            for (int U2 = 0; U2 < 2; ++U2) {
+                const int k = 16 * (2 * w + U2) + 4 * lg;
+                if (j < R && k < DQ_H1) {
+                    const f32x4_t h = *reinterpret_cast<const f32x4_t*>(&sm.h1[0][j][k]);
+                    *reinterpret_cast<f32x4_t*>(&sm.dz1[j][k]) = f32x4_t{h[0] > 0.0f ? dh[U2][0] : 0.0f, h[1] > 0.0f ? dh[U2][1] : 0.0f, h[2] > 0.0f ? dh[U2][2] : 0.0f, h[3] > 0.0f ? dh[U2][3] : 0.0f};
+                }
+            }
+        }
+        // ---- dW2 on the MFMA, computed transposed so that a lane ends up with 4 consecutive k of one row: D[k][j] += sum_r h1[r][k] dz2[j][r] (K = the R rows =
+        //      R / 4 k-steps); 8 x 6 output tiles, 12 per wave (k tiles 2w, 2w + 1).  A = h1[r = 4s + lg][16U + kk], B = dz2[16T + jj][r = 4s + lg];
+        //      D: lane (jj, lg), register r <-> k = 16U + 4lg + r: accumulated over the groups, one float4 store per lane and tile at the end ----
+        {
+            const int w = mw, kk = mj, lg = mlg;
+            float b2[6][R / 4];
+#pragma unroll
+            for (int T = 0; T < 6; ++T)
+#pragma unroll
+                for (int s2 = 0; s2 < R / 4; ++s2) { const int jj = 16 * T + kk; b2[T][s2] = jj < DQ_H2 ? sm.dz2[jj][4 * s2 + lg] : 0.0f; }
+#pragma unroll
+            for (int U2 = 0; U2 < 2; ++U2) {
+                const int ka = 16 * (2 * w + U2) + kk;
+                float a2[R / 4];
+#pragma unroll
+                for (int s2 = 0; s2 < R / 4; ++s2) a2[s2] = ka < DQ_H1 ? sm.h1[0][4 * s2 + lg][ka] : 0.0f;
+#pragma unroll
+                for (int T = 0; T < 6; ++T)
+#pragma unroll
+                    for (int s2 = 0; s2 < R / 4; ++s2) dW2acc[U2][T] = DQ_MFMA(a2[s2], b2[T][s2], dW2acc[U2][T]);
+            }
+        }
+        __syncthreads();   // dz1 complete
+        // ---- db1, dW1: thread k < 120 ----
+        if (t < DQ_H1) {
+            float gb = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float d = sm.dz1[r][t];
+                gb += d;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gw[c] = __builtin_fmaf(d, sm.x[0][r][c], gw[c]);
+            }
+            gb1 += gb;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gw1[c] += gw[c];
+        }
     }
-    // ---- dW2 on the MFMA, computed transposed so that a lane ends up with 4 consecutive k of one row: D[k][j] = sum_r h1[r][k] dz2[j][r] (K = the TD_R rows =
-    //      2 k-steps); 8 x 6 output tiles, 12 per wave (k tiles 2w, 2w + 1).  A = h1[r = 4s + lg][16U + kk], B = dz2[16T + jj][r = 4s + lg];
-    //      D: lane (jj, lg), register r <-> k = 16U + 4lg + r: one float4 store per lane and tile, into row 16T + jj of the slab ----
+    // ---- the workgroup's slab: every gradient element once ----
+    if (t < DQ_H2) { part[DQ_W3 + t] = g30; part[DQ_W3 + DQ_H2 + t] = g31; part[DQ_B2 + t] = gb2; }
+    else if (t < DQ_H2 + 2) part[DQ_B3 + (t - DQ_H2)] = g30;
+    else if (t == DQ_H2 + 2) part[DQ_NP] = g30;
     {
         const int w = mw, kk = mj, lg = mlg;
-        float b2[6][2];
-#pragma unroll
-        for (int T = 0; T < 6; ++T)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) { const int jj = 16 * T + kk; b2[T][s2] = jj < DQ_H2 ? sm.dz2[jj][4 * s2 + lg] : 0.0f; }
 #pragma unroll
         for (int U2 = 0; U2 < 2; ++U2) {
-            const int ka = 16 * (2 * w + U2) + kk;
-            float a2[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) a2[s2] = ka < DQ_H1 ? sm.h1[0][4 * s2 + lg][ka] : 0.0f;
             const int k0 = 16 * (2 * w + U2) + 4 * lg;
 #pragma unroll
             for (int T = 0; T < 6; ++T) {
-                f32x4_t d = {0.0f, 0.0f, 0.0f, 0.0f};
-                d = DQ_MFMA(a2[0], b2[T][0], d);
-                d = DQ_MFMA(a2[1], b2[T][1], d);
                 const int jj = 16 * T + kk;
-                if (jj < DQ_H2 && k0 < DQ_H1) *reinterpret_cast<f32x4_t*>(part + DQ_W2 + DQ_H1 * jj + k0) = d;
+                if (jj < DQ_H2 && k0 < DQ_H1) *reinterpret_cast<f32x4_t*>(part + DQ_W2 + DQ_H1 * jj + k0) = dW2acc[U2][T];
             }
         }
     }
-    __syncthreads();   // dz1 complete
-    // ---- db1, dW1: thread k < 120 ----
     if (t < DQ_H1) {
-        float gb = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int r = 0; r < TD_R; ++r) {
-            const float d = sm.dz1[r][t];
-            gb += d;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) gw[c] = __builtin_fmaf(d, sm.x[0][r][c], gw[c]);
-        }
-        part[DQ_B1 + t] = gb;
-        *reinterpret_cast<float4*>(part + DQ_W1 + 4 * t) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+        part[DQ_B1 + t] = gb1;
+        *reinterpret_cast<float4*>(part + DQ_W1 + 4 * t) = make_float4(gw1[0], gw1[1], gw1[2], gw1[3]);
     }
 }
 
@@ -871,12 +916,21 @@ static int dqn_td_impl(const float* params, const float* target_params, const fl
     MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (batch + TD_R - 1) / TD_R;
+    // one group of 8 rows per workgroup while that gives at most TD_MAX_BLOCKS workgroups (the reference's batch of 128: 16); larger batches: groups of 16 rows dealt
+    // round-robin to TD_MAX_BLOCKS workgroups, one slab each.  A batch size always takes the same form: every run is reproducible.
+    const int groups8 = (batch + TD_R - 1) / TD_R, groups16 = (batch + 15) / 16;
+    const bool wide = groups8 > TD_MAX_BLOCKS;
+    const int blocks = wide ? (groups16 < TD_MAX_BLOCKS ? groups16 : TD_MAX_BLOCKS) : groups8;
     {
         mi_prof_scope prof(MI_PROF_DQN_TD, s);
-        dqn_td_kernel<<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
-                                             (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update, (uint64_t)sample_upper,
-                                             (int64_t*)idx);
+        if (wide)
+            dqn_td_kernel<16><<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
+                                                     (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update,
+                                                     (uint64_t)sample_upper, (int64_t*)idx);
+        else
+            dqn_td_kernel<TD_R><<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
+                                                       (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update,
+                                                       (uint64_t)sample_upper, (int64_t*)idx);
     }
     MI_LAUNCH_CHECK();
     {

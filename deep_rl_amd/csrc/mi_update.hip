@@ -193,7 +193,9 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #define GRAD_OCC (GRAD_WPS * 4 / GRAD_WAVES)   // workgroups per CU
 #define GRAD_OLD_SHARE 10   // of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves (age arbitration: -3 %)
 #define GRAD_ROLE_BIT 3     // which blockIdx bit selects actor / critic (bit 0 would pin one net per XCD)
-#define GRAD_ACTOR_EXTRA 2  // per 128 workgroups: how many more serve the actor than the critic (an actor tile costs ~3.5 % more)
+#ifndef GRAD_ACTOR_EXTRA
+#define GRAD_ACTOR_EXTRA 2  // per 128 workgroups: how many more serve the actor than the critic (an actor tile costs ~3.5 % more; with GRAD_ANTISYM the two cost the same: 0)
+#endif
 #define TROWS 16
 #define PART_STRIDE 4624
 #define PART_LOSS 4610
@@ -460,6 +462,9 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 #define STAMP(k) do {} while (0)
 #endif
 
+#ifndef GRAD_ANTISYM
+#define GRAD_ANTISYM 0   // 1: the actor tiles evaluate one head, d = l0 - l1 (mi_grad_kernel.inc); A/B switch until its parity run is recorded
+#endif
 // ---- the two instantiations of grad_kernel (mi_grad_kernel.inc) ----
 #define GRAD_BX 0
 #define GV(x) x##_f32
@@ -629,12 +634,12 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
 // hand-off — and then updates its own 256-parameter slice.  Out of place when the *_out pointers differ from *_in
 // (mi_ppo_update's last step: from the spare set back into the caller's tensors).
 // =====================================================================================================
-__global__ void __launch_bounds__(256) clip_adam_kernel(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out,
+__global__ void __launch_bounds__(512) clip_adam_kernel(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out,
                                                          const float* __restrict__ grads, int n, float w1, float b2,
                                                          float w2, float step_size, float rbc2, float eps, float max_norm,
                                                          float* __restrict__ grad_norm, const double* __restrict__ norm_parts) {
     __shared__ double ws[4], sparts[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 256 threads, or 512 for a PPO parameter vector (block_grad_norm's 8-wave branch when there are no block sums)
     const bool live = i < n;
     float pm = live ? m_in[i] : 0.0f, pv = live ? v_in[i] : 0.0f;
     const float pp = live ? p_in[i] : 0.0f, pg = live ? grads[i] : 0.0f;
@@ -661,8 +666,9 @@ static adam_consts_t adam_consts(int64_t step, double lr, double beta1, double b
 static int clip_adam_launch(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out, const float* grads, int n,
                             const adam_consts_t& k, float max_norm, float* grad_norm, const double* norm_parts, hipStream_t s) {
     mi_prof_scope prof(MI_PROF_CLIP_ADAM, s);
-    clip_adam_kernel<<<(n + 255) / 256, 256, 0, s>>>(p_in, m_in, v_in, p_out, m_out, v_out, grads, n, k.w1, k.b2, k.w2, k.step_size, k.rbc2, k.eps, max_norm,
-                                                    grad_norm, norm_parts);
+    const int threads = n == NPARAMS ? 512 : 256;   // same tree for any block size; 8 waves take the cheap branch on a PPO vector without block sums (sharded runs, mi_clip_adam)
+    clip_adam_kernel<<<(n + threads - 1) / threads, threads, 0, s>>>(p_in, m_in, v_in, p_out, m_out, v_out, grads, n, k.w1, k.b2, k.w2, k.step_size, k.rbc2, k.eps, max_norm,
+                                                                    grad_norm, norm_parts);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }

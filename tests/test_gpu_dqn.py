@@ -220,9 +220,11 @@ def test_first_300_updates_chained_on_device(dev, R, dqn_trace):
     assert abs(eng.q.flat.double().sum().item() - g["psum_all"][299]) < 1e-4
 
 
-@pytest.mark.parametrize("batch", [128, 1000, 4096])
+@pytest.mark.parametrize("batch", [128, 1000, 2048, 2056, 4096, 5000])
 def test_td_grad_batches_and_ring(dev, R, batch):
-    """Bigger / ragged batches on a wrapped 64-slot ring of 32 envs (successor index crosses the ring end)."""
+    """Bigger / ragged batches on a wrapped 64-slot ring of 32 envs (successor index crosses the ring end).  Up to 2,048 rows dqn_td_kernel runs one 8-row group per
+    workgroup; 2,056 is the first batch on the 16-row form (129 workgroups, the last group half empty); 5,000 rows = 313 groups dealt to 256 workgroups (57 of them walk
+    two groups and accumulate both in registers, the last group ragged)."""
     n, S = 32, 64
     eng = _engine(dev, n, slots=S, seed=3, batch_size=batch, learning_starts=0, total_timesteps=1000)
     rng = np.random.default_rng(4)

@@ -157,12 +157,13 @@ def test_ppo_update_equals_launch_sequence_bitwise(dev, n_envs, monkeypatch):
 # ------------------------------------------------------------------- DQN, config 3 -------------------------------------------------
 def test_dqn_fullsize_td_grad_vs_oracle(dev, R):
     """4096 envs x 256 slots = 1,048,576 transitions, filled by 300 acting steps (the ring has wrapped): the TD gradient of batches of
-    128 (the reference's) and 1,024 rows drawn by the keyed sampler from the whole ring, against the oracle on a copy of the ring."""
+    128 (the reference's), 1,024, 4,096 (bench.py's scaled batch: the 16-row form of dqn_td_kernel, 256 workgroups x 1 group) and 4,100 rows (257 groups: a second,
+    ragged group in workgroup 0) drawn by the keyed sampler from the whole ring, against the oracle on a copy of the ring."""
     import deep_rl_amd as D
 
     n, S = 4096, 256
     rng = np.random.default_rng(11)
-    for batch in (128, 1024):
+    for batch in (128, 1024, 4096, 4100):
         env = D.make("CartPole-v1", num_envs=n, device=dev, seed=2)
         torch.manual_seed(2)
         q = D.QNetwork(env); tgt = D.QNetwork(env)

@@ -250,5 +250,5 @@ def test_script_reference_shape_n1():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("global_step=")]
     assert len(lines) > 100 and all(re.fullmatch(r"global_step=\d+, episodic_return=\d+\.\d\d", ln) for ln in lines)
     assert '"alpha": 0.6' in out.stdout and '"beta_0": 0.4' in out.stdout and '"global_step": 6000' in out.stdout
-    assert "PRIO (6001, 1) 6000 True 541" in out.stdout
+    assert "PRIO (6001,) 6000 True 541" in out.stdout     # per.py:79: no env axis at one env
     assert np.isfinite(float(out.stdout.split("LOSS")[1].split()[0]))
