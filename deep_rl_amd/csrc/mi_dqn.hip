@@ -559,7 +559,7 @@ struct __attribute__((aligned(16))) td_smem {
     int act[R];
     float w3[2][2][DQ_H2];     // both nets' head weights, staged once per workgroup
     float b3[2][2];
-    long long cur[R], nxt[R];
+    float rw[R], live[R];      // reward and (not terminated) of the successor row
 };
 
 template <int R>
@@ -574,8 +574,45 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
     const int t = threadIdx.x;
     const int n_groups = (batch + R - 1) / R;
     float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
-    // MFMA roles (layer 2, dh1, dW2): wave mw, lane (mj, mlg).  None of the weight operands depends on the batch: requested now, they land while the first group's
-    // indices, gathers and layer 1 run, and they stay in registers for every later group (layer 2: 24 float4 + 12 bias dwords per lane; dh1: 42 dwords)
+    // The batch rows of a group: thread (net nt = t / 4R, row r, component k = t & 3) < 8R derives row r's index ITSELF (the four threads of a row repeat the draw or
+    // the load: no LDS hand-over, no barrier between index and gather) and fetches its element of obs (nt = 0) or next obs (nt = 1); the k = 0 threads also fetch the
+    // row's action / the successor's reward and terminated flag.  The index of the NEXT group is requested a whole group ahead, and the very first one BEFORE the
+    // weight operands (loads return in order: a gather issued behind 43 KB of weight requests would wait for all of them).
+    const bool gth = t < 2 * R * 4;
+    const int g_nt = t / (R * 4), g_r = (t >> 2) % R, g_k = t & 3;
+    auto row_index = [&](int grp) -> long long {   // -> this thread's row's flat ring index
+        const int b = grp * R + g_r < batch ? grp * R + g_r : batch - 1;
+        if (sample_upper) {     // batch_inds = randint(upper, size=batch) (dqn.py:116) drawn here: the contract of dqn_sample_kernel, no launch of its own
+            uint32_t r4[4];
+            mi_philox(sample_seed, sample_update, (uint64_t)b, STREAM_SAMPLE, r4);
+            return (long long)((((uint64_t)r4[1] << 32) | r4[0]) % sample_upper);
+        }
+        return idx[b];
+    };
+    auto gather_group = [&](int grp, long long i) {
+        if (!gth) return;
+        // next-slot row of the same env: ((i / N + 1) % slots) * N + i % N.  Flat indices below 2^32 (every ring this side of 4 G transitions) take the
+        // 32-bit divider; the wrap is a compare (slot < slots always), not a second modulo.
+        long long sl, en;
+        if ((unsigned long long)i >> 32) { sl = i / n_envs; en = i % n_envs; }
+        else { const unsigned q = (unsigned)i / (unsigned)n_envs; sl = q; en = (unsigned)i - q * (unsigned)n_envs; }
+        sl = sl + 1 == slots ? 0 : sl + 1;
+        const long long nx = sl * n_envs + en;
+        const float xv = observations[4 * (g_nt ? nx : i) + g_k];
+        if (g_k == 0) {
+            if (g_nt == 0) {
+                sm.act[g_r] = (int)actions[i];
+                if (sample_upper && grp * R + g_r < batch) idx_out[grp * R + g_r] = i;
+            } else {
+                sm.rw[g_r] = rewards[nx];
+                sm.live[g_r] = terminated[nx] ? 0.0f : 1.0f;
+            }
+        }
+        sm.x[g_nt][g_r][g_k] = xv;
+    };
+    long long i_cur = (gth && (int)blockIdx.x < n_groups) ? row_index((int)blockIdx.x) : 0;
+    // MFMA roles (layer 2, dh1, dW2): wave mw, lane (mj, mlg).  None of the weight operands depends on the batch: requested once, they stay in registers for every
+    // group of the workgroup (layer 2: 24 float4 + 12 bias dwords per lane; dh1: 42 dwords, requested behind the first group's gathers)
     const int mw = t >> 6, mj = t & 15, mlg = (t >> 4) & 3;
     const int mnet = mw >> 1;
     const float* mp = mnet ? target_params : params;
@@ -591,8 +628,9 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int o = 16 * T + 4 * mlg + r; bias2[T3][r] = o < DQ_H2 ? mp[DQ_B2 + o] : 0.0f; }
     }
-    // the dh1 pass's A operands (W2 read column-wise)
-    float wa1[2][21];
+    float wa1[2][21];   // the dh1 pass's A operands (W2 read column-wise)
+    if ((int)blockIdx.x < n_groups) gather_group((int)blockIdx.x, i_cur);
+    // the dh1 operands, behind the first group's gathers
 #pragma unroll
     for (int s2 = 0; s2 < 21; ++s2)
 #pragma unroll
@@ -616,35 +654,14 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 #pragma unroll
         for (int T = 0; T < 6; ++T) dW2acc[U2][T] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // (no barrier is needed between two groups: everything the first phases of group g + 1 write — cur, nxt, act — was last read before the final barrier of group g,
-    // and every later phase of g + 1 sits behind at least one of its own barriers)
+    // (between two groups one extra barrier — for x[0], which the dW1 phase reads last — in front of the next group's gather; everything else that gather writes was
+    // last read before the final barrier of the group, and every later phase sits behind barriers of its own)
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int row0 = grp * R;
-        if (t < R) {
-            const int b = row0 + t < batch ? row0 + t : batch - 1;
-            long long i;
-            if (sample_upper) {     // batch_inds = randint(upper, size=batch) (dqn.py:116) drawn here: the contract of dqn_sample_kernel, no launch of its own
-                uint32_t r[4];
-                mi_philox(sample_seed, sample_update, (uint64_t)b, STREAM_SAMPLE, r);
-                i = (long long)((((uint64_t)r[1] << 32) | r[0]) % sample_upper);
-                if (row0 + t < batch) idx_out[b] = i;
-            } else i = idx[b];
-            sm.cur[t] = i;
-            // next-slot row of the same env: ((i / N + 1) % slots) * N + i % N.  Flat indices below 2^32 (every ring this side of 4 G transitions) take the
-            // 32-bit divider; the wrap is a compare (slot < slots always), not a second modulo.
-            long long sl, en;
-            if ((unsigned long long)i >> 32) { sl = i / n_envs; en = i % n_envs; }
-            else { const unsigned q = (unsigned)i / (unsigned)n_envs; sl = q; en = (unsigned)i - q * (unsigned)n_envs; }
-            sl = sl + 1 == slots ? 0 : sl + 1;
-            sm.nxt[t] = sl * n_envs + en;
-            sm.act[t] = (int)actions[i];
-        }
-        __syncthreads();
-        if (t < 2 * R * 4) {
-            const int nt = t / (R * 4), r = (t / 4) % R, k = t & 3;
-            sm.x[nt][r][k] = observations[4 * (nt ? sm.nxt[r] : sm.cur[r]) + k];
-        }
-        __syncthreads();
+        __syncthreads();                                   // this group's rows are in LDS (gather_group below: before the loop / at the end of the previous group)
+        const int nxt_grp = grp + (int)gridDim.x;
+        long long i_nxt = 0;
+        if (gth && nxt_grp < n_groups) i_nxt = row_index(nxt_grp);   // requested a whole group ahead
         // ---- layer 1 ----
         if (u < DQ_H1) {
 #pragma unroll
@@ -696,7 +713,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         if (t < R) {
             const bool valid = row0 + t < batch;
             const float target_max = fmaxf(sm.q[1][t][0], sm.q[1][t][1]);
-            const float td = rewards[sm.nxt[t]] + gamma * target_max * (terminated[sm.nxt[t]] ? 0.0f : 1.0f);
+            const float td = sm.rw[t] + gamma * target_max * sm.live[t];
             const int a = sm.act[t];
             const float diff = valid ? td - sm.q[0][t][a] : 0.0f;
             const float wb = (row_w && valid) ? row_w[row0 + t] : 1.0f;      // importance weight (per.py:145-147); 1 for plain DQN
@@ -789,6 +806,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 #pragma unroll
             for (int c = 0; c < 4; ++c) gw1[c] += gw[c];
         }
+        if (nxt_grp < n_groups) { __syncthreads(); gather_group(nxt_grp, i_nxt); }
     }
     // ---- the workgroup's slab: every gradient element once ----
     if (t < DQ_H2) { part[DQ_W3 + t] = g30; part[DQ_W3 + DQ_H2 + t] = g31; part[DQ_B2 + t] = gb2; }

@@ -191,7 +191,10 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #define GRAD_WAVES 8        // ONE 512-thread workgroup per CU: two waves per SIMD share one staged copy of the weights
 #define GRAD_WPS 2          // waves per SIMD the kernel is built for
 #define GRAD_OCC (GRAD_WPS * 4 / GRAD_WAVES)   // workgroups per CU
-#define GRAD_OLD_SHARE 10   // of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves (age arbitration: -3 %)
+#ifndef GRAD_OLD_SHARE
+#define GRAD_OLD_SHARE 10
+#endif
+// GRAD_OLD_SHARE: of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves (age arbitration: -3 %)
 #define GRAD_ROLE_BIT 3     // which blockIdx bit selects actor / critic (bit 0 would pin one net per XCD)
 #ifndef GRAD_ACTOR_EXTRA
 #define GRAD_ACTOR_EXTRA 2  // per 128 workgroups: how many more serve the actor than the critic (an actor tile costs ~3.5 % more; with GRAD_ANTISYM the two cost the same: 0)
@@ -421,15 +424,23 @@ struct grad_pending_t {
 // actor tile costs ~3.5 % more than a critic tile (the policy loss), and with one workgroup per CU that is a per-CU imbalance, so the actor gets
 // `extra` more CUs (130 : 126 at 256).  ri = index within the role (the order grad_reduce_kernel sums in), nr = workgroups of that role.
 struct grad_role_t { int role, ri, nr; };
+// extra > 0: the actor gets `extra` of the odd (critic) slabs as well; extra < 0: the critic gets -extra of the even (actor) slabs; |extra| < n_blocks / 2
 __host__ __device__ inline grad_role_t grad_role(unsigned vb, int n_blocks, int extra) {
     const int half = n_blocks >> 1, k = (int)(vb >> 1);
-    if ((vb & 1u) == 0) return grad_role_t{0, k, half + extra};
-    if (k < extra) return grad_role_t{0, half + k, half + extra};
-    return grad_role_t{1, k - extra, half - extra};
+    if (extra >= 0) {
+        if ((vb & 1u) == 0) return grad_role_t{0, k, half + extra};
+        if (k < extra) return grad_role_t{0, half + k, half + extra};
+        return grad_role_t{1, k - extra, half - extra};
+    }
+    const int e = -extra;
+    if ((vb & 1u) != 0) return grad_role_t{1, k, half + e};
+    if (k < e) return grad_role_t{1, half + k, half + e};
+    return grad_role_t{0, k - e, half - e};
 }
 __host__ __device__ inline int grad_slab(int role, int ri, int n_blocks, int extra) {   // inverse: the slab of workgroup ri of a role
     const int half = n_blocks >> 1;
-    return role == 0 ? (ri < half ? 2 * ri : 2 * (ri - half) + 1) : 2 * (ri + extra) + 1;
+    if (extra >= 0) return role == 0 ? (ri < half ? 2 * ri : 2 * (ri - half) + 1) : 2 * (ri + extra) + 1;
+    return role == 1 ? (ri < half ? 2 * ri + 1 : 2 * (ri - half)) : 2 * (ri - extra);
 }
 
 struct row_in {
