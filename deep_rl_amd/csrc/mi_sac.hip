@@ -138,6 +138,16 @@ int mi_pend_step_ex_impl(mi_env* e, const float* actions, const double* forced_r
 // one pass ahead as one coalesced value per thread and handed to the D layout through LDS.  Thin layers (3/4 -> 256, heads, bias
 // and thin weight gradients) are thread-per-unit VALU code on the same LDS images.
 #define LDW 260
+// SA_WAVES waves per row-group workgroup.  8 (round 4): TWO waves per SIMD, each owning two of the sixteen 16-unit output tiles of a 256 x 256 pass, so that one wave's
+// MFMAs cover the other's weight-stream waits (a pass on one wave per SIMD took 4.0 - 4.9 us against the 3.56 us of its MFMAs).  4: the round-3 form (one wave
+// per SIMD, four tiles each), kept as an A/B build (-DSA_WAVES=4).  Output tile G = SA_NT * wave + t covers units 16 G .. 16 G + 15 in both forms; the thread-per-unit
+// ("thin") phases run on the first 256 threads.
+#ifndef SA_WAVES
+#define SA_WAVES 8
+#endif
+#define SA_THREADS (64 * SA_WAVES)
+#define SA_NT (16 / SA_WAVES)
+static_assert(SA_WAVES == 4 || SA_WAVES == 8, "row-group workgroups have 4 or 8 waves");
 struct __attribute__((aligned(16))) sac_smem {
     float b0[SR][LDW], b1[SR][LDW], b2[SR][LDW];   // activation images
     float pb[3][SA_H];         // this pass's layer-2 bias and head weights per unit
@@ -146,7 +156,7 @@ struct __attribute__((aligned(16))) sac_smem {
     uint32_t qmask[2][SA_H];
     float x[SR][4];            // obs (3) + action
     float xn[SR][4];           // next obs (3) + next action
-    float red[4][SR][2];       // cross-wave partial sums
+    float red[SA_WAVES][SR][2]; // cross-wave partial sums
     float rv[SR][16];          // per-row scalars
     long long cur[SR], nxt[SR];
     int fault;                 // set by a timed-out wait of thread 0 (wait_owed_alpha)
@@ -163,13 +173,13 @@ __device__ __forceinline__ float keyed_normal(uint64_t seed, uint64_t tag_update
 // ---- thin parameters of one net for thread j: layer-1 row, bias 1, bias 2, head weight(s) ----
 struct thin_t { float w1[4], b1, b2, h0, h1; };
 __device__ __forceinline__ void issue_thin_q(const float* __restrict__ p, thin_t& th) {
-    const int j = threadIdx.x;
+    const int j = threadIdx.x & (SA_H - 1);   // (threads >= 256 of an 8-wave workgroup fetch a copy they never use: the thin phases run on the first 256 threads)
     const float4 w = *reinterpret_cast<const float4*>(p + SQ_W1 + 4 * j);   // dword-aligned x4 (the second critic's block is only 4-byte aligned)
     th.w1[0] = w.x; th.w1[1] = w.y; th.w1[2] = w.z; th.w1[3] = w.w;
     th.b1 = p[SQ_B1 + j]; th.b2 = p[SQ_B2 + j]; th.h0 = p[SQ_W3 + j]; th.h1 = 0.0f;
 }
 __device__ __forceinline__ void issue_thin_actor(const float* __restrict__ p, thin_t& th) {
-    const int j = threadIdx.x;
+    const int j = threadIdx.x & (SA_H - 1);
     th.w1[0] = p[AC_W1 + 3 * j]; th.w1[1] = p[AC_W1 + 3 * j + 1]; th.w1[2] = p[AC_W1 + 3 * j + 2]; th.w1[3] = 0.0f;
     th.b1 = p[AC_B1 + j]; th.b2 = p[AC_B2 + j]; th.h0 = p[AC_WM + j]; th.h1 = p[AC_WL + j];
 }
@@ -180,6 +190,7 @@ template <int IN>
 __device__ __forceinline__ uint32_t layer1(sac_smem& sm, const thin_t& th, const float (*x)[4], float (*h)[LDW]) {
     const int j = threadIdx.x;
     uint32_t mask = 0;
+    if (j >= SA_H) return mask;   // 8-wave workgroups: unit phases run on the first 256 threads
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
         float z = 0.0f;
@@ -200,29 +211,29 @@ __device__ __forceinline__ uint32_t layer1(sac_smem& sm, const thin_t& th, const
 #ifndef SAC_EXP
 #define SAC_EXP 0         // diagnostics (wrong results): 1 = stream only the first pass's first stages (MFMA-only time)
 #endif
-struct wstream { float r[L2_NBUF][32]; };
+struct wstream { float r[L2_NBUF][8 * SA_NT]; };
 
-// one stage (32 reduction indices) of this wave's 64 output units.
-// forward  (out unit = weight row):    d[4 (2 t + h) + e] = W[64 w + 16 t + i][32 st + 16 h + 4 g + e]       (float4 loads)
-// backward (out unit = weight column): d[16 h + 4 s + t]  = W[32 st + 16 h + 4 g + s][64 w + 16 t + i]       (dword loads, 64 B per row)
+// one stage (32 reduction indices) of this wave's 16 SA_NT output units (tiles SA_NT w .. SA_NT w + SA_NT - 1).
+// forward  (out unit = weight row):    d[4 (2 t + h) + e]        = W[16 (SA_NT w + t) + i][32 st + 16 h + 4 g + e]       (float4 loads)
+// backward (out unit = weight column): d[SA_NT (4 h + s) + t]    = W[32 st + 16 h + 4 g + s][16 (SA_NT w + t) + i]       (dword loads, 64 B per row)
 template <bool BWD>
-__device__ __forceinline__ void issue_stage(const float* __restrict__ W, const int st, float (&d)[32]) {
+__device__ __forceinline__ void issue_stage(const float* __restrict__ W, const int st, float (&d)[8 * SA_NT]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     if (!BWD) {
-        const float* wp = W + (size_t)(64 * w + i) * SA_H + 4 * g + st * 32;
+        const float* wp = W + (size_t)(16 * SA_NT * w + i) * SA_H + 4 * g + st * 32;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < SA_NT; ++t)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * SA_H + h * 16);
                 d[4 * (2 * t + h) + 0] = v.x; d[4 * (2 * t + h) + 1] = v.y; d[4 * (2 * t + h) + 2] = v.z; d[4 * (2 * t + h) + 3] = v.w;
             }
     } else {
-        const float* wp = W + (size_t)(4 * g + st * 32) * SA_H + 64 * w + i;
+        const float* wp = W + (size_t)(4 * g + st * 32) * SA_H + 16 * SA_NT * w + i;
 #pragma unroll
         for (int hs = 0; hs < 8; ++hs)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) d[4 * hs + t] = wp[(size_t)((hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
+            for (int t = 0; t < SA_NT; ++t) d[SA_NT * hs + t] = wp[(size_t)((hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
     }
 }
 
@@ -236,11 +247,11 @@ __device__ __forceinline__ void stream_prime(const float* __restrict__ W, wstrea
 // one pass through a 256 x 256 layer.  forward: acc[t][r] = sum_k W[64 w + 16 t + 4 g + r][k] in[i][k];
 // backward-data: acc[t][r] = sum_j W[j][64 w + 16 t + 4 g + r] in[i][j].  Wn (nullable): the next pass's matrix (direction NBWD).
 template <bool BWD, bool NBWD>
-__device__ __forceinline__ void mfma_pass(const float* __restrict__ W, const float* __restrict__ Wn, const float (*in)[LDW], wstream& ws, f32x4 acc[4]) {
+__device__ __forceinline__ void mfma_pass(const float* __restrict__ W, const float* __restrict__ Wn, const float (*in)[LDW], wstream& ws, f32x4 acc[SA_NT]) {
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const float* bp = &in[i][4 * g];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < SA_NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     float4 bc[2], bn[2];                     // the B operand is read one stage ahead as well
     bc[0] = *reinterpret_cast<const float4*>(bp); bc[1] = *reinterpret_cast<const float4*>(bp + 16);
 #pragma unroll
@@ -259,11 +270,11 @@ __device__ __forceinline__ void mfma_pass(const float* __restrict__ W, const flo
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < SA_NT; ++t) {
 #if SAC_EXP == 2
-                    acc[t][s] += (BWD ? a[16 * h + 4 * s + t] : a[4 * (2 * t + h) + s]) * bs[s];
+                    acc[t][s] += (BWD ? a[SA_NT * (4 * h + s) + t] : a[4 * (2 * t + h) + s]) * bs[s];
 #else
-                    acc[t] = MFMA16(BWD ? a[16 * h + 4 * s + t] : a[4 * (2 * t + h) + s], bs[s], acc[t]);
+                    acc[t] = MFMA16(BWD ? a[SA_NT * (4 * h + s) + t] : a[4 * (2 * t + h) + s], bs[s], acc[t]);
 #endif
                 }
         }
@@ -273,23 +284,23 @@ __device__ __forceinline__ void mfma_pass(const float* __restrict__ W, const flo
 }
 
 // acc <- relu(acc + bias 2) in the D layout (bias published by layer1)
-__device__ __forceinline__ void relu_bias(const sac_smem& sm, f32x4 acc[4]) {
+__device__ __forceinline__ void relu_bias(const sac_smem& sm, f32x4 acc[SA_NT]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&sm.pb[0][64 * w + 16 * t + 4 * g]);
+    for (int t = 0; t < SA_NT; ++t) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&sm.pb[0][16 * (SA_NT * w + t) + 4 * g]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r] + b[r], 0.0f);
     }
 }
 
 // this wave's share of a 256 -> 1 head for the lane's row (valid in every lane after the two cross-group exchanges)
-__device__ __forceinline__ float head_partial(const f32x4 acc[4], const float* wh /* LDS, per unit */) {
+__device__ __forceinline__ float head_partial(const f32x4 acc[SA_NT], const float* wh /* LDS, per unit */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
     float p = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f32x4 hw = *reinterpret_cast<const f32x4*>(&wh[64 * w + 16 * t + 4 * g]);
+    for (int t = 0; t < SA_NT; ++t) {
+        const f32x4 hw = *reinterpret_cast<const f32x4*>(&wh[16 * (SA_NT * w + t) + 4 * g]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) p = __builtin_fmaf(hw[r], acc[t][r], p);
     }
@@ -298,29 +309,34 @@ __device__ __forceinline__ float head_partial(const f32x4 acc[4], const float* w
     return p;
 }
 
-// combine the four waves' per-row partials (fixed order): result in sm.rv[row][slot0 / slot1], visible to all threads on return
+// combine the waves' per-row partials (fixed order: pairs, then pairs of pairs, in wave order): result in sm.rv[row][slot0 / slot1], visible to all threads on return
 __device__ __forceinline__ void rows_combine2(sac_smem& sm, float p0, float p1, int slot0, int slot1) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < SR) { sm.red[w][lane][0] = p0; sm.red[w][lane][1] = p1; }
     __syncthreads();
     if (threadIdx.x < SR) {
         const int r = threadIdx.x;
+#if SA_WAVES == 4
         sm.rv[r][slot0] = (sm.red[0][r][0] + sm.red[1][r][0]) + (sm.red[2][r][0] + sm.red[3][r][0]);
         sm.rv[r][slot1] = (sm.red[0][r][1] + sm.red[1][r][1]) + (sm.red[2][r][1] + sm.red[3][r][1]);
+#else
+        sm.rv[r][slot0] = ((sm.red[0][r][0] + sm.red[1][r][0]) + (sm.red[2][r][0] + sm.red[3][r][0])) + ((sm.red[4][r][0] + sm.red[5][r][0]) + (sm.red[6][r][0] + sm.red[7][r][0]));
+        sm.rv[r][slot1] = ((sm.red[0][r][1] + sm.red[1][r][1]) + (sm.red[2][r][1] + sm.red[3][r][1])) + ((sm.red[4][r][1] + sm.red[5][r][1]) + (sm.red[6][r][1] + sm.red[7][r][1]));
+#endif
     }
     __syncthreads();
 }
 
 // D layout -> LDS image [row][unit]
-__device__ __forceinline__ void store_acc(const f32x4 acc[4], float (*out)[LDW]) {
+__device__ __forceinline__ void store_acc(const f32x4 acc[SA_NT], float (*out)[LDW]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&out[i][64 * w + 16 * t + 4 * g]) = acc[t];
+    for (int t = 0; t < SA_NT; ++t) *reinterpret_cast<f32x4*>(&out[i][16 * (SA_NT * w + t) + 4 * g]) = acc[t];
 }
 
 // SoftQNetwork forward, layer 2 onward (layer 1 image in `h1`, thin parameters published): relu(h2) left in acc, q[r] -> sm.rv[r][slot]
 template <bool NBWD>
-__device__ __forceinline__ void q_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[4], int slot) {
+__device__ __forceinline__ void q_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[SA_NT], int slot) {
     mfma_pass<false, NBWD>(p + SQ_W2, Wn, h1, ws, acc);
     relu_bias(sm, acc);
     rows_combine2(sm, head_partial(acc, sm.pb[1]), 0.0f, slot, 15);
@@ -330,7 +346,7 @@ __device__ __forceinline__ void q_forward2(sac_smem& sm, const float* __restrict
 
 // rv slots used by the actor: 0 mean, 1 sraw, 2 ls, 3 sd, 4 u, 5 logp, 6 action, 7 eps.   relu(h2) left in acc.
 template <bool NBWD>
-__device__ __forceinline__ void actor_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[4],
+__device__ __forceinline__ void actor_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[SA_NT],
                                                const float eps_row /*valid in threads < SR*/) {
     mfma_pass<false, NBWD>(p + AC_W2, Wn, h1, ws, acc);
     relu_bias(sm, acc);
@@ -353,11 +369,11 @@ __device__ __forceinline__ void actor_forward2(sac_smem& sm, const float* __rest
 }
 
 // ================================================ forward-only API kernels ======================================================
-__global__ void __launch_bounds__(256) sac_actor_sample_kernel(const float* __restrict__ actor, const float* __restrict__ obs, const float* __restrict__ eps,
+__global__ void __launch_bounds__(SA_THREADS) sac_actor_sample_kernel(const float* __restrict__ actor, const float* __restrict__ obs, const float* __restrict__ eps,
                                                                 int n, float* __restrict__ action, float* __restrict__ logp) {
     __shared__ sac_smem sm;
     const int row0 = blockIdx.x * SR;
-    wstream ws; thin_t th; f32x4 acc[4];
+    wstream ws; thin_t th; f32x4 acc[SA_NT];
     issue_thin_actor(actor, th);
     stream_prime<false>(actor + AC_W2, ws);
     if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int b = row0 + r < n ? row0 + r : n - 1; sm.x[r][k] = obs[3 * (size_t)b + k]; }
@@ -372,7 +388,7 @@ __global__ void __launch_bounds__(256) sac_actor_sample_kernel(const float* __re
 
 extern "C" int mi_sac_actor_sample(const float* actor, const float* obs, const float* eps, int n, float* action, float* logp, void* stream) {
     MI_CHECK_ARG(actor && obs && eps && action && n > 0, "bad arguments");
-    sac_actor_sample_kernel<<<(n + SR - 1) / SR, 256, 0, (hipStream_t)stream>>>(actor, obs, eps, n, action, logp);
+    sac_actor_sample_kernel<<<(n + SR - 1) / SR, SA_THREADS, 0, (hipStream_t)stream>>>(actor, obs, eps, n, action, logp);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -382,14 +398,14 @@ extern "C" int mi_sac_actor_sample(const float* actor, const float* obs, const f
 #else
 #define STAMP(k)
 #endif
-__global__ void __launch_bounds__(256) sac_q_forward_kernel(const float* __restrict__ q, const float* __restrict__ obs, const float* __restrict__ act, int n,
+__global__ void __launch_bounds__(SA_THREADS) sac_q_forward_kernel(const float* __restrict__ q, const float* __restrict__ obs, const float* __restrict__ act, int n,
                                                              float* __restrict__ out) {
     __shared__ sac_smem sm;
 #ifdef SAC_STAMPS
     __shared__ unsigned long long stamp[8];
 #endif
     const int row0 = blockIdx.x * SR;
-    wstream ws; thin_t th; f32x4 acc[4];
+    wstream ws; thin_t th; f32x4 acc[SA_NT];
     STAMP(0);
     issue_thin_q(q, th);
     stream_prime<false>(q + SQ_W2, ws);
@@ -406,11 +422,11 @@ __global__ void __launch_bounds__(256) sac_q_forward_kernel(const float* __restr
 #ifndef SAC_STAMP_BWD
 #define SAC_STAMP_BWD false
 #endif
-    f32x4 accx[4];
+    f32x4 accx[SA_NT];
     mfma_pass<false, SAC_STAMP_BWD>(q + SQ_W2, q + SQ_W2, sm.b0, ws, accx);     // first touch of the matrix in this kernel
     STAMP(6);
     mfma_pass<SAC_STAMP_BWD, false>(q + SQ_W2, nullptr, sm.b0, ws, acc);
-    for (int t = 0; t < 4; ++t) acc[t] += accx[t];
+    for (int t = 0; t < SA_NT; ++t) acc[t] += accx[t];
 #else
     mfma_pass<false, false>(q + SQ_W2, nullptr, sm.b0, ws, acc);
 #endif
@@ -432,13 +448,13 @@ __global__ void __launch_bounds__(256) sac_q_forward_kernel(const float* __restr
 
 extern "C" int mi_sac_q_forward(const float* q, const float* obs, const float* act, int n, float* out, void* stream) {
     MI_CHECK_ARG(q && obs && act && out && n > 0, "bad arguments");
-    sac_q_forward_kernel<<<(n + SR - 1) / SR, 256, 0, (hipStream_t)stream>>>(q, obs, act, n, out);
+    sac_q_forward_kernel<<<(n + SR - 1) / SR, SA_THREADS, 0, (hipStream_t)stream>>>(q, obs, act, n, out);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
 
 // ================================================ acting ========================================================================
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SA_THREADS)
 sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step, long long slots, long long learning_starts, float* __restrict__ obs_cur,
                float* __restrict__ observations, float* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
                const float* __restrict__ forced_actions, const float* __restrict__ forced_eps, const double* __restrict__ forced_resets,
@@ -447,7 +463,7 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
     const int N = e.n, row0 = blockIdx.x * SR;
     const bool policy = !forced_actions && global_step >= learning_starts;   // block-uniform
     if (policy) {
-        wstream ws; thin_t th; f32x4 acc[4];
+        wstream ws; thin_t th; f32x4 acc[SA_NT];
         issue_thin_actor(actor, th);
         stream_prime<false>(actor + AC_W2, ws);
         if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
@@ -505,7 +521,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
     hipStream_t s = (hipStream_t)stream;
     if (episode_stats) { sac_zero4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
     mi_prof_scope prof(MI_PROF_SAC_ACT, s);
-    sac_act_kernel<<<(e->n + SR - 1) / SR, 256, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations,
+    sac_act_kernel<<<(e->n + SR - 1) / SR, SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations,
                                                        actions, rewards, terminated, forced_actions, forced_eps, forced_resets, episodes, episode_stats, max_ep);
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -628,7 +644,7 @@ __device__ void sac_owed_alpha_role(sac_smem& sm, const float* __restrict__ acto
     const int t = threadIdx.x, row0 = rg * SR;
     const float* stash = ws_ + ws_stash_off(batch) + (size_t)ow.slot * 3 * (size_t)ws_kp(batch);   // the slot the actor update that owes this step wrote
     float* part = ws_ + ws_lp_off(batch);
-    wstream ws; thin_t th; f32x4 acc[4];
+    wstream ws; thin_t th; f32x4 acc[SA_NT];
     issue_thin_actor(actor, th);
     stream_prime<false>(actor + AC_W2, ws);
     if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; sm.x[r][k] = stash[3 * (size_t)b + k]; }
@@ -668,7 +684,7 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
     const float* p = q + (size_t)NET * SQ_NP;
     float* sl = slab + NET * 1793;
-    f32x4 acc[4];
+    f32x4 acc[SA_NT];
     layer1<4>(sm, th, sm.x, sm.b0);
     __syncthreads();
     q_forward2<true>(sm, p, p + SQ_W2, sm.b0, ws, acc, 8);          // h1 in b0, relu(h2) in acc; the stream continues with this net's backward
@@ -696,8 +712,8 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
         const float dq = sm.rv[li][8];
         store_acc(acc, sm.b2);
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int u = 64 * wv + 16 * tt + 4 * lg;
+        for (int tt = 0; tt < SA_NT; ++tt) {
+            const int u = 16 * (SA_NT * wv + tt) + 4 * lg;
             const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.pb[1][u]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[tt][r] = acc[tt][r] > 0.0f ? w3[r] * dq : 0.0f;
@@ -706,7 +722,7 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
         store_acc(acc, sm.b1);
     }
     __syncthreads();
-    {   // unit j = t: thin gradients of layer 3 / bias 2, H1 rows for the GEMM
+    if (t < SA_H) {   // unit j = t: thin gradients of layer 3 / bias 2, H1 rows for the GEMM
         float gw3 = 0.0f, gb2 = 0.0f;
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
@@ -718,15 +734,15 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
     }
     mfma_pass<true, false>(p + SQ_W2, Wnext, sm.b1, ws, acc);      // dh1 in the D layout
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][64 * wv + 16 * tt + 4 * lg]);
+    for (int tt = 0; tt < SA_NT; ++tt) {
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][16 * (SA_NT * wv + tt) + 4 * lg]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
     }
     __syncthreads();                                 // every thread is done reading b2 (h2)
     store_acc(acc, sm.b2);                           // dz1 image
     __syncthreads();
-    {   // input unit k = t: thin gradients of layer 1
+    if (t < SA_H) {   // input unit k = t: thin gradients of layer 1
         float gb1 = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
@@ -741,7 +757,7 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SA_THREADS)
 sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, const float* __restrict__ actor, const float* __restrict__ observations,
                   const float* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
                   const int64_t* idx /* may alias idx_out: no __restrict__ */, int batch, int n_envs, long long slots, const float* __restrict__ eps, uint64_t seed,
@@ -767,7 +783,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     const size_t matf = ws_mat_floats(batch);
     float* H1 = ws_; float* DZ2 = ws_ + 3 * matf;
     float* slab = ws_ + ws_slab_off(batch) + (size_t)bx * SLAB;
-    wstream ws; thin_t th, th2; f32x4 acc[4];
+    wstream ws; thin_t th, th2; f32x4 acc[SA_NT];
     if (role >= 2) issue_thin_q(q + (role - 2) * SQ_NP, th); else
     issue_thin_actor(actor, th);
     // the batch rows: thread (r = t / 4, k = t & 3) derives row r's index itself (four threads repeat the draw: no LDS hand-over, no barrier) and requests its
@@ -857,12 +873,12 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
 // slab layout (actor): W1 768 | b1 256 | b2 256 | Wm 256 | bm 1 | Wl 256 | bl 1 | [1794] sum(alpha*logp - minq) | [1795] sum logp
 // passes: actor fwd -> critic 1 fwd -> critic 2 fwd -> critic 1 bwd -> critic 2 bwd -> actor bwd
 // d(-min Q)/d action of one critic for the lane's row: this wave's share (summed over lane groups), from dh1 in the D layout
-__device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, const f32x4 acc[4]) {
+__device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, const f32x4 acc[SA_NT]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     float v = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int k = 64 * w + 16 * t + 4 * g;
+    for (int t = 0; t < SA_NT; ++t) {
+        const int k = 16 * (SA_NT * w + t) + 4 * g;
         const f32x4 w13 = *reinterpret_cast<const f32x4*>(&sm.qw13[net][k]);
         const uint4 mk = *reinterpret_cast<const uint4*>(&sm.qmask[net][k]);
         const uint32_t m[4] = {mk.x, mk.y, mk.z, mk.w};
@@ -874,7 +890,7 @@ __device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, 
     return v;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SA_THREADS)
 sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, const float* __restrict__ observations, const int64_t* __restrict__ idx,
                  int batch, const float* __restrict__ eps, uint64_t seed, uint64_t update, const float* __restrict__ alpha_p, float invn,
                  float* __restrict__ ws_, int logp_only, sac_alpha_t al, sac_owed_t ow, int stash_slot) {
@@ -893,7 +909,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     // nobody, hands (q2, d q2 / d action) per row over through the workspace and exits); the row group's main workgroup y = 1 runs critic 1 and goes on with the actor's
     // backward: 4 matrix passes + one hand-off on the critical path instead of 6.
     const bool split = gridDim.y == 2, second = split && blockIdx.y == 0;
-    wstream ws; thin_t th; f32x4 acc[4];
+    wstream ws; thin_t th; f32x4 acc[SA_NT];
     uint32_t h2mask[2];                                           // the critics' layer-2 ReLU masks in the D layout (bit 4 t + r), kept for the backward
     issue_thin_actor(actor, th);
     float gv = 0.0f;
@@ -940,19 +956,19 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         const int net = second ? 1 : 0;
         unsigned long long* xw = reinterpret_cast<unsigned long long*>(ws_ + ws_xch_off(batch)) + 2 * (size_t)row0;
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
-        sm.qmask[net][t] = mk; sm.qw13[net][t] = th.w1[3]; sm.qw3[net][t] = th.h0;
+        if (t < SA_H) { sm.qmask[net][t] = mk; sm.qw13[net][t] = th.w1[3]; sm.qw3[net][t] = th.h0; }
         __syncthreads();
         q_forward2<true>(sm, qn, qn + SQ_W2, sm.b2, ws, acc, 8);                // q_net(obs, pi(obs)) -> rv[8]; next pass: the same matrix, column-wise
         uint32_t hm = 0;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < SA_NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hm |= (acc[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
         if (t < SR) sm.rv[t][10] = sm.rv[t][8];                                  // this critic's q
         const float dq = row0 + li < batch ? -invn : 0.0f;                       // unit routing weight
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.qw3[net][64 * wv + 16 * tt + 4 * lg]);
+        for (int tt = 0; tt < SA_NT; ++tt) {
+            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.qw3[net][16 * (SA_NT * wv + tt) + 4 * lg]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[tt][r] = (hm >> (4 * tt + r)) & 1u ? w3[r] * dq : 0.0f;
         }
@@ -981,13 +997,13 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     // ---- min(Q1, Q2)(obs, pi(obs)) (:194-196) ----
     {
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
-        sm.qmask[0][t] = mk; sm.qw13[0][t] = th.w1[3]; sm.qw3[0][t] = th.h0;
+        if (t < SA_H) { sm.qmask[0][t] = mk; sm.qw13[0][t] = th.w1[3]; sm.qw3[0][t] = th.h0; }
         issue_thin_q(q + SQ_NP, th);
         __syncthreads();
         q_forward2<false>(sm, q, q + SQ_NP + SQ_W2, sm.b2, ws, acc, 8);
         h2mask[0] = 0;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < SA_NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h2mask[0] |= (acc[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
         if (t < SR) sm.rv[t][10] = sm.rv[t][8];
@@ -995,12 +1011,12 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     }
     {
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
-        sm.qmask[1][t] = mk; sm.qw13[1][t] = th.w1[3]; sm.qw3[1][t] = th.h0;
+        if (t < SA_H) { sm.qmask[1][t] = mk; sm.qw13[1][t] = th.w1[3]; sm.qw3[1][t] = th.h0; }
         __syncthreads();
         q_forward2<true>(sm, q + SQ_NP, q + SQ_W2, sm.b2, ws, acc, 8);
         h2mask[1] = 0;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < SA_NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h2mask[1] |= (acc[tt][r] > 0.0f ? 1u : 0u) << (4 * tt + r);
     }
@@ -1020,8 +1036,8 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     for (int net = 0; net < 2; ++net) {
         const float dq = -invn * sm.rv[li][net == 0 ? 10 : 12];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.qw3[net][64 * wv + 16 * tt + 4 * lg]);
+        for (int tt = 0; tt < SA_NT; ++tt) {
+            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.qw3[net][16 * (SA_NT * wv + tt) + 4 * lg]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[tt][r] = (h2mask[net] >> (4 * tt + r)) & 1u ? w3[r] * dq : 0.0f;
         }
@@ -1048,7 +1064,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         sm.rv[t][1] = 0.5f * (SA_LOG_STD_MAX - SA_LOG_STD_MIN) * dL * (1.0f - ls * ls);                // d / d sraw
     }
     __syncthreads();
-    {   // unit j = t of the actor: dz2, thin gradients of the heads / bias 2, H1 / DZ2 rows
+    if (t < SA_H) {   // unit j = t of the actor: dz2, thin gradients of the heads / bias 2, H1 / DZ2 rows
         float gwm = 0.0f, gwl = 0.0f, gb2 = 0.0f;
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
@@ -1068,14 +1084,14 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     __syncthreads();
     mfma_pass<true, false>(actor + AC_W2, nullptr, sm.b2, ws, acc);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][64 * wv + 16 * tt + 4 * lg]);
+    for (int tt = 0; tt < SA_NT; ++tt) {
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][16 * (SA_NT * wv + tt) + 4 * lg]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
     }
     store_acc(acc, sm.b1);                                       // dz1 image (the h2 image was last read before the previous barrier)
     __syncthreads();
-    {
+    if (t < SA_H) {
         float gb1 = 0.0f, gw[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
@@ -1509,7 +1525,7 @@ static int sac_critic_impl(float* q, float* q_target, const float* actor, const 
     sac_owed_t ow = ow_in; ow.fault = g_sac_fault;
     {
         mi_prof_scope prof(MI_PROF_SAC_CRITIC, s);
-        sac_critic_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 4)), 256, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
+        sac_critic_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 4)), SA_THREADS, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
                                                            seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
                                                            (int64_t*)idx, ow);
     }
@@ -1558,7 +1574,7 @@ static int sac_actor_impl(float* actor, const float* q, const float* observation
         mi_prof_scope prof(MI_PROF_SAC_ACTOR, s);
         const int nrg = ws_kp(batch) / SR;
         // the batch observations go to the stash slot that a debt carried by THIS launch does not read (no debt: slot 0)
-        sac_actor_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 2)), 256, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count,
+        sac_actor_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 2)), SA_THREADS, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count,
                                                                                  (float*)workspace, 0, sac_alpha_t{}, ow, ow.n_lp ? (ow.slot ^ 1) : 0);
     }
     MI_LAUNCH_CHECK();
@@ -1675,7 +1691,7 @@ static int sac_launch_logp(const float* actor, const float* observations, const 
     if (const int rc = sac_status_check("SAC log-prob pass")) return rc;
     {
         mi_prof_scope prof(MI_PROF_SAC_LOGP, s);
-        sac_actor_kernel<<<ws_kp(batch) / SR, 256, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al, sac_owed_t{}, 0);
+        sac_actor_kernel<<<ws_kp(batch) / SR, SA_THREADS, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al, sac_owed_t{}, 0);
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -1693,7 +1709,7 @@ extern "C" int mi_sac_alpha_step(const float* actor, const float* observations, 
 }
 
 // an owed alpha step that found no launch to ride on (the state is read, the run ends, ...): its workgroups alone
-__global__ void __launch_bounds__(256) sac_owed_alpha_kernel(const float* __restrict__ actor, int batch, float* __restrict__ ws_, sac_owed_t ow) {
+__global__ void __launch_bounds__(SA_THREADS) sac_owed_alpha_kernel(const float* __restrict__ actor, int batch, float* __restrict__ ws_, sac_owed_t ow) {
     __shared__ sac_smem sm;
     sac_owed_alpha_role(sm, actor, batch, ws_, ow, (int)blockIdx.x);
 }
@@ -1704,7 +1720,7 @@ extern "C" int mi_sac_alpha_step_owed(const float* actor, int batch, uint64_t se
     sac_owed_t ow = sac_make_owed(owed, batch, seed, workspace);
     ow.fault = g_sac_fault;
     mi_prof_scope prof(MI_PROF_SAC_LOGP, (hipStream_t)stream);
-    sac_owed_alpha_kernel<<<ow.n_lp, 256, 0, (hipStream_t)stream>>>(actor, batch, (float*)workspace, ow);
+    sac_owed_alpha_kernel<<<ow.n_lp, SA_THREADS, 0, (hipStream_t)stream>>>(actor, batch, (float*)workspace, ow);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
