@@ -138,30 +138,23 @@ int mi_pend_step_ex_impl(mi_env* e, const float* actions, const double* forced_r
 // one pass ahead as one coalesced value per thread and handed to the D layout through LDS.  Thin layers (3/4 -> 256, heads, bias
 // and thin weight gradients) are thread-per-unit VALU code on the same LDS images.
 #define LDW 260
-// SA_WAVES waves per row-group workgroup.  8 (round 4): TWO waves per SIMD, each owning two of the sixteen 16-unit output tiles of a 256 x 256 pass, so that one wave's
-// MFMAs cover the other's weight-stream waits (a pass on one wave per SIMD took 4.0 - 4.9 us against the 3.56 us of its MFMAs).  4: the round-3 form (one wave
-// per SIMD, four tiles each), kept as an A/B build (-DSA_WAVES=4).  Output tile G = SA_NT * wave + t covers units 16 G .. 16 G + 15 in both forms; the thread-per-unit
-// ("thin") phases run on the first 256 threads.
+// Waves per row-group workgroup (round 4, measured: profiles/r04_sac_waves.txt).  TWO waves per SIMD, each owning two of the sixteen 16-unit output tiles of a pass, let one
+// wave's MFMAs cover the other's weight-stream waits — which pays on a kernel that is ONE pass long (acting: 15.0 -> 13.6 us: its stream starts cold) and not on the
+// multi-pass update kernels, whose later passes are requested three stages ahead anyway while every one of their ~20 barriers gets dearer with eight waves (critic 31.1 ->
+// 31.4 us, actor 37.0 -> 38.3 us).  So: 8 for the single-pass kernels, 4 for the update kernels; -DSA_WAVES=8 / -DSA_WAVES_ACT=4 build the other forms for A/B.
 #ifndef SA_WAVES
-#define SA_WAVES 8
+#define SA_WAVES 4
 #endif
-#define SA_THREADS (64 * SA_WAVES)
-#define SA_NT (16 / SA_WAVES)
-static_assert(SA_WAVES == 4 || SA_WAVES == 8, "row-group workgroups have 4 or 8 waves");
-struct __attribute__((aligned(16))) sac_smem {
-    float b0[SR][LDW], b1[SR][LDW], b2[SR][LDW];   // activation images
-    float pb[3][SA_H];         // this pass's layer-2 bias and head weights per unit
-    float qw3[2][SA_H];        // actor update: the critics' W3, W1[:,3] and layer-1 ReLU masks (bit r = row r), kept for the backward
-    float qw13[2][SA_H];
-    uint32_t qmask[2][SA_H];
-    float x[SR][4];            // obs (3) + action
-    float xn[SR][4];           // next obs (3) + next action
-    float red[SA_WAVES][SR][2]; // cross-wave partial sums
-    float rv[SR][16];          // per-row scalars
-    long long cur[SR], nxt[SR];
-    int fault;                 // set by a timed-out wait of thread 0 (wait_owed_alpha)
-};
-
+#ifndef SA_WAVES_ACT
+#define SA_WAVES_ACT 8
+#endif
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define L2_STAGES 8       // 256 reduction indices in stages of 32
+#define L2_NBUF 4         // ring of stage buffers (8 stages = 0 mod 4: every pass starts at slot 0)
+#define L2_AHEAD 3        // stages in flight ahead of the MFMAs
+#ifndef SAC_EXP
+#define SAC_EXP 0         // diagnostics (wrong results): 1 = stream only the first pass's first stages (MFMA-only time)
+#endif
 // keyed standard normal (production mode): Box-Muller on two Philox words
 __device__ __forceinline__ float keyed_normal(uint64_t seed, uint64_t tag_update, uint64_t row) {
     uint32_t r[4];
@@ -170,205 +163,20 @@ __device__ __forceinline__ float keyed_normal(uint64_t seed, uint64_t tag_update
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-// ---- thin parameters of one net for thread j: layer-1 row, bias 1, bias 2, head weight(s) ----
-struct thin_t { float w1[4], b1, b2, h0, h1; };
-__device__ __forceinline__ void issue_thin_q(const float* __restrict__ p, thin_t& th) {
-    const int j = threadIdx.x & (SA_H - 1);   // (threads >= 256 of an 8-wave workgroup fetch a copy they never use: the thin phases run on the first 256 threads)
-    const float4 w = *reinterpret_cast<const float4*>(p + SQ_W1 + 4 * j);   // dword-aligned x4 (the second critic's block is only 4-byte aligned)
-    th.w1[0] = w.x; th.w1[1] = w.y; th.w1[2] = w.z; th.w1[3] = w.w;
-    th.b1 = p[SQ_B1 + j]; th.b2 = p[SQ_B2 + j]; th.h0 = p[SQ_W3 + j]; th.h1 = 0.0f;
-}
-__device__ __forceinline__ void issue_thin_actor(const float* __restrict__ p, thin_t& th) {
-    const int j = threadIdx.x & (SA_H - 1);
-    th.w1[0] = p[AC_W1 + 3 * j]; th.w1[1] = p[AC_W1 + 3 * j + 1]; th.w1[2] = p[AC_W1 + 3 * j + 2]; th.w1[3] = 0.0f;
-    th.b1 = p[AC_B1 + j]; th.b2 = p[AC_B2 + j]; th.h0 = p[AC_WM + j]; th.h1 = p[AC_WL + j];
-}
-
-// layer 1 of unit j = threadIdx.x for all rows: h[r][j] = relu(b1 + w1 . x[r][:IN]); publishes bias 2 / head weights for the D layout;
-// returns the ReLU mask over rows.  ONE expression for z everywhere (FMA chain in index order, then + b1).
-template <int IN>
-__device__ __forceinline__ uint32_t layer1(sac_smem& sm, const thin_t& th, const float (*x)[4], float (*h)[LDW]) {
-    const int j = threadIdx.x;
-    uint32_t mask = 0;
-    if (j >= SA_H) return mask;   // 8-wave workgroups: unit phases run on the first 256 threads
-#pragma unroll
-    for (int r = 0; r < SR; ++r) {
-        float z = 0.0f;
-#pragma unroll
-        for (int k = 0; k < IN; ++k) z = __builtin_fmaf(th.w1[k], x[r][k], z);
-        z += th.b1;
-        mask |= (z > 0.0f ? 1u : 0u) << r;
-        h[r][j] = fmaxf(z, 0.0f);
-    }
-    sm.pb[0][j] = th.b2; sm.pb[1][j] = th.h0; sm.pb[2][j] = th.h1;
-    return mask;
-}
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-#define L2_STAGES 8       // 256 reduction indices in stages of 32
-#define L2_NBUF 4         // ring of stage buffers (8 stages = 0 mod 4: every pass starts at slot 0)
-#define L2_AHEAD 3        // stages in flight ahead of the MFMAs
-#ifndef SAC_EXP
-#define SAC_EXP 0         // diagnostics (wrong results): 1 = stream only the first pass's first stages (MFMA-only time)
-#endif
-struct wstream { float r[L2_NBUF][8 * SA_NT]; };
-
-// one stage (32 reduction indices) of this wave's 16 SA_NT output units (tiles SA_NT w .. SA_NT w + SA_NT - 1).
-// forward  (out unit = weight row):    d[4 (2 t + h) + e]        = W[16 (SA_NT w + t) + i][32 st + 16 h + 4 g + e]       (float4 loads)
-// backward (out unit = weight column): d[SA_NT (4 h + s) + t]    = W[32 st + 16 h + 4 g + s][16 (SA_NT w + t) + i]       (dword loads, 64 B per row)
-template <bool BWD>
-__device__ __forceinline__ void issue_stage(const float* __restrict__ W, const int st, float (&d)[8 * SA_NT]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-    if (!BWD) {
-        const float* wp = W + (size_t)(16 * SA_NT * w + i) * SA_H + 4 * g + st * 32;
-#pragma unroll
-        for (int t = 0; t < SA_NT; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 v = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * SA_H + h * 16);
-                d[4 * (2 * t + h) + 0] = v.x; d[4 * (2 * t + h) + 1] = v.y; d[4 * (2 * t + h) + 2] = v.z; d[4 * (2 * t + h) + 3] = v.w;
-            }
-    } else {
-        const float* wp = W + (size_t)(4 * g + st * 32) * SA_H + 16 * SA_NT * w + i;
-#pragma unroll
-        for (int hs = 0; hs < 8; ++hs)
-#pragma unroll
-            for (int t = 0; t < SA_NT; ++t) d[SA_NT * hs + t] = wp[(size_t)((hs >> 2) * 16 + (hs & 3)) * SA_H + 16 * t];
-    }
-}
-
-// start a kernel's weight stream: the first L2_AHEAD stages of its first pass
-template <bool BWD>
-__device__ __forceinline__ void stream_prime(const float* __restrict__ W, wstream& ws) {
-#pragma unroll
-    for (int st = 0; st < L2_AHEAD; ++st) issue_stage<BWD>(W, st, ws.r[st]);
-}
-
-// one pass through a 256 x 256 layer.  forward: acc[t][r] = sum_k W[64 w + 16 t + 4 g + r][k] in[i][k];
-// backward-data: acc[t][r] = sum_j W[j][64 w + 16 t + 4 g + r] in[i][j].  Wn (nullable): the next pass's matrix (direction NBWD).
-template <bool BWD, bool NBWD>
-__device__ __forceinline__ void mfma_pass(const float* __restrict__ W, const float* __restrict__ Wn, const float (*in)[LDW], wstream& ws, f32x4 acc[SA_NT]) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    const float* bp = &in[i][4 * g];
-#pragma unroll
-    for (int t = 0; t < SA_NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float4 bc[2], bn[2];                     // the B operand is read one stage ahead as well
-    bc[0] = *reinterpret_cast<const float4*>(bp); bc[1] = *reinterpret_cast<const float4*>(bp + 16);
-#pragma unroll
-    for (int st = 0; st < L2_STAGES; ++st) {
-        const int ld = st + L2_AHEAD;
-        if (SAC_EXP != 1) {
-            if (ld < L2_STAGES) issue_stage<BWD>(W, ld, ws.r[ld % L2_NBUF]);
-            else if (Wn) issue_stage<NBWD>(Wn, ld - L2_STAGES, ws.r[ld % L2_NBUF]);
-        }
-        if (st + 1 < L2_STAGES) { bn[0] = *reinterpret_cast<const float4*>(bp + (st + 1) * 32); bn[1] = *reinterpret_cast<const float4*>(bp + (st + 1) * 32 + 16); }
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads L2_AHEAD stages ahead of their use: the scheduler would sink them next to the MFMAs
-        const float* a = ws.r[st % L2_NBUF];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float bs[4] = {bc[h].x, bc[h].y, bc[h].z, bc[h].w};
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < SA_NT; ++t) {
-#if SAC_EXP == 2
-                    acc[t][s] += (BWD ? a[SA_NT * (4 * h + s) + t] : a[4 * (2 * t + h) + s]) * bs[s];
-#else
-                    acc[t] = MFMA16(BWD ? a[SA_NT * (4 * h + s) + t] : a[4 * (2 * t + h) + s], bs[s], acc[t]);
-#endif
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        bc[0] = bn[0]; bc[1] = bn[1];
-    }
-}
-
-// acc <- relu(acc + bias 2) in the D layout (bias published by layer1)
-__device__ __forceinline__ void relu_bias(const sac_smem& sm, f32x4 acc[SA_NT]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < SA_NT; ++t) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&sm.pb[0][16 * (SA_NT * w + t) + 4 * g]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r] + b[r], 0.0f);
-    }
-}
-
-// this wave's share of a 256 -> 1 head for the lane's row (valid in every lane after the two cross-group exchanges)
-__device__ __forceinline__ float head_partial(const f32x4 acc[SA_NT], const float* wh /* LDS, per unit */) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
-    float p = 0.0f;
-#pragma unroll
-    for (int t = 0; t < SA_NT; ++t) {
-        const f32x4 hw = *reinterpret_cast<const f32x4*>(&wh[16 * (SA_NT * w + t) + 4 * g]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p = __builtin_fmaf(hw[r], acc[t][r], p);
-    }
-    p += __shfl_xor(p, 16);
-    p += __shfl_xor(p, 32);
-    return p;
-}
-
-// combine the waves' per-row partials (fixed order: pairs, then pairs of pairs, in wave order): result in sm.rv[row][slot0 / slot1], visible to all threads on return
-__device__ __forceinline__ void rows_combine2(sac_smem& sm, float p0, float p1, int slot0, int slot1) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane < SR) { sm.red[w][lane][0] = p0; sm.red[w][lane][1] = p1; }
-    __syncthreads();
-    if (threadIdx.x < SR) {
-        const int r = threadIdx.x;
-#if SA_WAVES == 4
-        sm.rv[r][slot0] = (sm.red[0][r][0] + sm.red[1][r][0]) + (sm.red[2][r][0] + sm.red[3][r][0]);
-        sm.rv[r][slot1] = (sm.red[0][r][1] + sm.red[1][r][1]) + (sm.red[2][r][1] + sm.red[3][r][1]);
-#else
-        sm.rv[r][slot0] = ((sm.red[0][r][0] + sm.red[1][r][0]) + (sm.red[2][r][0] + sm.red[3][r][0])) + ((sm.red[4][r][0] + sm.red[5][r][0]) + (sm.red[6][r][0] + sm.red[7][r][0]));
-        sm.rv[r][slot1] = ((sm.red[0][r][1] + sm.red[1][r][1]) + (sm.red[2][r][1] + sm.red[3][r][1])) + ((sm.red[4][r][1] + sm.red[5][r][1]) + (sm.red[6][r][1] + sm.red[7][r][1]));
-#endif
-    }
-    __syncthreads();
-}
-
-// D layout -> LDS image [row][unit]
-__device__ __forceinline__ void store_acc(const f32x4 acc[SA_NT], float (*out)[LDW]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < SA_NT; ++t) *reinterpret_cast<f32x4*>(&out[i][16 * (SA_NT * w + t) + 4 * g]) = acc[t];
-}
-
-// SoftQNetwork forward, layer 2 onward (layer 1 image in `h1`, thin parameters published): relu(h2) left in acc, q[r] -> sm.rv[r][slot]
-template <bool NBWD>
-__device__ __forceinline__ void q_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[SA_NT], int slot) {
-    mfma_pass<false, NBWD>(p + SQ_W2, Wn, h1, ws, acc);
-    relu_bias(sm, acc);
-    rows_combine2(sm, head_partial(acc, sm.pb[1]), 0.0f, slot, 15);
-    if (threadIdx.x < SR) sm.rv[threadIdx.x][slot] += p[SQ_B3];
-    __syncthreads();
-}
-
-// rv slots used by the actor: 0 mean, 1 sraw, 2 ls, 3 sd, 4 u, 5 logp, 6 action, 7 eps.   relu(h2) left in acc.
-template <bool NBWD>
-__device__ __forceinline__ void actor_forward2(sac_smem& sm, const float* __restrict__ p, const float* __restrict__ Wn, const float (*h1)[LDW], wstream& ws, f32x4 acc[SA_NT],
-                                               const float eps_row /*valid in threads < SR*/) {
-    mfma_pass<false, NBWD>(p + AC_W2, Wn, h1, ws, acc);
-    relu_bias(sm, acc);
-    rows_combine2(sm, head_partial(acc, sm.pb[1]), head_partial(acc, sm.pb[2]), 0, 1);
-    if (threadIdx.x < SR) {
-        const int r = threadIdx.x;
-        const float mean = sm.rv[r][0] + p[AC_BM], sraw = sm.rv[r][1] + p[AC_BL];
-        const float ls = tanhf(sraw);
-        const float L = SA_LOG_STD_MIN + 0.5f * (SA_LOG_STD_MAX - SA_LOG_STD_MIN) * (ls + 1.0f);   // sac.py:69
-        const float sd = expf(L);
-        const float z = mean + eps_row * sd;                                                     // :71
-        const float u = tanhf(z);                                                                // :72
-        const float d = z - mean;
-        float lp = -(d * d) / (2.0f * (sd * sd)) - logf(sd) - 0.91893853320467274178f;           // :73
-        lp -= logf(SA_ACT_SCALE * (1.0f - u * u) + 1e-6f);                                       // :75
-        sm.rv[r][0] = mean; sm.rv[r][1] = sraw; sm.rv[r][2] = ls; sm.rv[r][3] = sd; sm.rv[r][4] = u; sm.rv[r][5] = lp;
-        sm.rv[r][6] = u * SA_ACT_SCALE + SA_ACT_BIAS; sm.rv[r][7] = eps_row;                      // :77
-    }
-    __syncthreads();
-}
+namespace rg_act {
+#define SA_W SA_WAVES_ACT
+#include "mi_sac_rowgroup.inc"
+#undef SA_W
+}  // namespace rg_act
+namespace rg {
+#define SA_W SA_WAVES
+#include "mi_sac_rowgroup.inc"
+#undef SA_W
+}  // namespace rg
+using namespace rg;   // everything below is the 4-wave form unless it sits in namespace rg_act
 
 // ================================================ forward-only API kernels ======================================================
+namespace rg_act {
 __global__ void __launch_bounds__(SA_THREADS) sac_actor_sample_kernel(const float* __restrict__ actor, const float* __restrict__ obs, const float* __restrict__ eps,
                                                                 int n, float* __restrict__ action, float* __restrict__ logp) {
     __shared__ sac_smem sm;
@@ -385,10 +193,11 @@ __global__ void __launch_bounds__(SA_THREADS) sac_actor_sample_kernel(const floa
     actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e);
     if (threadIdx.x < SR && row0 + threadIdx.x < n) { action[row0 + threadIdx.x] = sm.rv[threadIdx.x][6]; if (logp) logp[row0 + threadIdx.x] = sm.rv[threadIdx.x][5]; }
 }
+}  // namespace rg_act
 
 extern "C" int mi_sac_actor_sample(const float* actor, const float* obs, const float* eps, int n, float* action, float* logp, void* stream) {
     MI_CHECK_ARG(actor && obs && eps && action && n > 0, "bad arguments");
-    sac_actor_sample_kernel<<<(n + SR - 1) / SR, SA_THREADS, 0, (hipStream_t)stream>>>(actor, obs, eps, n, action, logp);
+    rg_act::sac_actor_sample_kernel<<<(n + SR - 1) / SR, rg_act::SA_THREADS, 0, (hipStream_t)stream>>>(actor, obs, eps, n, action, logp);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -454,6 +263,7 @@ extern "C" int mi_sac_q_forward(const float* q, const float* obs, const float* a
 }
 
 // ================================================ acting ========================================================================
+namespace rg_act {
 __global__ void __launch_bounds__(SA_THREADS)
 sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step, long long slots, long long learning_starts, float* __restrict__ obs_cur,
                float* __restrict__ observations, float* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
@@ -507,6 +317,7 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
         }
     }
 }
+}  // namespace rg_act
 
 __global__ void sac_zero4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
@@ -521,7 +332,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
     hipStream_t s = (hipStream_t)stream;
     if (episode_stats) { sac_zero4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
     mi_prof_scope prof(MI_PROF_SAC_ACT, s);
-    sac_act_kernel<<<(e->n + SR - 1) / SR, SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations,
+    rg_act::sac_act_kernel<<<(e->n + SR - 1) / SR, rg_act::SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations,
                                                        actions, rewards, terminated, forced_actions, forced_eps, forced_resets, episodes, episode_stats, max_ep);
     MI_LAUNCH_CHECK();
     return MI_OK;

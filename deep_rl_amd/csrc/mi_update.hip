@@ -191,13 +191,22 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #define GRAD_WAVES 8        // ONE 512-thread workgroup per CU: two waves per SIMD share one staged copy of the weights
 #define GRAD_WPS 2          // waves per SIMD the kernel is built for
 #define GRAD_OCC (GRAD_WPS * 4 / GRAD_WAVES)   // workgroups per CU
-#ifndef GRAD_OLD_SHARE
-#define GRAD_OLD_SHARE 10
+// GRAD_ANTISYM (round 4, default 1): the actor tiles evaluate ONE head, d = l0 - l1 (mi_grad_kernel.inc); 0 = both heads, the round-3 form (A/B build).
+#ifndef GRAD_ANTISYM
+#define GRAD_ANTISYM 1
 #endif
-// GRAD_OLD_SHARE: of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves (age arbitration: -3 %)
+// GRAD_OLD_SHARE: of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves (age arbitration: the older wave of a SIMD wins every issue
+// conflict).  Measured per launch with GRAD_ANTISYM (profiles/r04_grad_ab.txt): 9: 71.6, 10: 71.0, 11: 70.4, 12: 71.9, 13: 73.3 us.
+#ifndef GRAD_OLD_SHARE
+#define GRAD_OLD_SHARE (GRAD_ANTISYM ? 11 : 10)
+#endif
 #define GRAD_ROLE_BIT 3     // which blockIdx bit selects actor / critic (bit 0 would pin one net per XCD)
+// GRAD_ACTOR_EXTRA: per 128 workgroups, how many more serve the actor than the critic (negative: the critic gets more).  The minibatch is 8,192 tiles per net = exactly 16
+// per SIMD at 128 : 128 workgroups; any other split leaves some SIMDs with a 17th tile (+6 % on their CU), so it only pays when one net's tile costs > 6 % more: round 3's
+// two-head actor tile (835 against 725 instructions) ran best at +2; with GRAD_ANTISYM the two tiles cost the same (740 / 725) and 0 is best (-2: 74.2, -1: 74.2, 0: 71.0,
+// +1: 73.1, +2: 73.1 us per launch).
 #ifndef GRAD_ACTOR_EXTRA
-#define GRAD_ACTOR_EXTRA 2  // per 128 workgroups: how many more serve the actor than the critic (an actor tile costs ~3.5 % more; with GRAD_ANTISYM the two cost the same: 0)
+#define GRAD_ACTOR_EXTRA (GRAD_ANTISYM ? 0 : 2)
 #endif
 #define TROWS 16
 #define PART_STRIDE 4624
@@ -473,9 +482,6 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 #define STAMP(k) do {} while (0)
 #endif
 
-#ifndef GRAD_ANTISYM
-#define GRAD_ANTISYM 0   // 1: the actor tiles evaluate one head, d = l0 - l1 (mi_grad_kernel.inc); A/B switch until its parity run is recorded
-#endif
 // ---- the two instantiations of grad_kernel (mi_grad_kernel.inc) ----
 #define GRAD_BX 0
 #define GV(x) x##_f32
