@@ -49,9 +49,9 @@ def test_assume_sharded_route_is_bitwise_the_default_route(n_envs):
 
 
 def test_explicit_sequence_equals_assume_sharded_route(monkeypatch):
-    """The explicit launch sequence {mi_ppo_minibatch_grad, mi_clip_adam} x 16 (MIRL_PPO_SHARDED_SEQUENCE: what gloo runs walk) — mi_clip_adam has no block sums
-    either and evaluates block_grad_norm's GENERIC branch with 4 waves — equals the one-call update whose owed steps take the 8-wave sharded branch: three
-    evaluations of one tree, bit for bit."""
+    """The explicit launch sequence {mi_ppo_minibatch_grad, mi_clip_adam} x 16 (MIRL_PPO_SHARDED_SEQUENCE: what gloo runs walk) — every step a launch of its own,
+    the norm recomputed from the gradient inside clip_adam_kernel — equals the one-call update whose owed steps recompute it on the gradient launches' weight staging:
+    bit for bit, like the default route that reads grad_reduce_kernel's block sums."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     from deep_rl_amd import engine as E
