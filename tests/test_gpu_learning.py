@@ -4,7 +4,8 @@ Teacher-forced parity pins the arithmetic; it says nothing about keyed Philox ac
 numpy / gym generators (ppo.py:83-86, dqn.py:60-64).  Bit-level agreement is impossible there by construction, so the claim is distributional: over seeds 1..10 the mean
 episodic return of the last tenth of a run's episodes (the `global_step=…, episodic_return=…` lines of ppo.py:130 / dqn.py:110-111) has the same distribution for
   * the UNMODIFIED reference scripts run on the CPU under oracle/gym_shim (tests/golden/learning_stats.npz, written by oracle/capture_learning_stats.py), and
-  * the drop-in scripts `python -m deep_rl_amd.<script>` at the reference's own shape (NUM_ENVS=1, default budgets) on the MI355X, SEED=1..10.
+  * the drop-in scripts `python -m deep_rl_amd.<script>` at the reference's own shape (NUM_ENVS=1, default budgets) on the MI355X, SEED=1..10 (sac.py on
+    Pendulum-v1: seeds 1..6, sac.py:100-104,160-161).
 Asserted per script: two-sided Mann-Whitney U p > 0.01 AND |difference of means| <= 2 pooled standard errors.  Both samples are written to
 gpurun_out/learning_stats_gpu.json (copied to profiles/ when a round's numbers are recorded).  Deterministic: fixed seeds, counter-based streams."""
 import json
@@ -17,7 +18,6 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SEEDS = list(range(1, 11))
 
 _CODE = r"""
 import contextlib, io, json, os, runpy, sys
@@ -37,11 +37,11 @@ def last_tenth(rets):
     return float(np.mean(rets[-max(len(rets) // 10, 1):]))
 
 
-def _ours(script):
+def _ours(script, seeds):
     env = dict(os.environ, PYTHONPATH=ROOT)
     for k in ("SEED", "NUM_ENVS", "TOTAL_TIMESTEPS", "MEMORY_SIZE", "BATCH_SIZE", "LEARNING_STARTS", "PRINT_EPISODES"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, "-c", _CODE, script, ",".join(map(str, SEEDS))], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    out = subprocess.run([sys.executable, "-c", _CODE, script, ",".join(map(str, seeds))], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("LEARNING_JSON ")][0]
     return {int(k): v for k, v in json.loads(line[len("LEARNING_JSON "):]).items()}
@@ -51,11 +51,12 @@ def _compare(script):
     from scipy.stats import mannwhitneyu
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "learning_stats.npz"))
-    assert g[script + "_seeds"].tolist() == SEEDS
+    SEEDS = g[script + "_seeds"].tolist()          # 1..10 (sac.py: 1..6 — the reference needs 7 CPU-minutes per seed)
+    assert SEEDS == list(range(1, len(SEEDS) + 1)) and len(SEEDS) >= 6
     ref = g[script + "_last_tenth_mean"].astype(np.float64)
     off, rets = g[script + "_offsets"], g[script + "_episode_return"]
     assert np.allclose([last_tenth(rets[off[i]:off[i + 1]]) for i in range(len(SEEDS))], ref)   # the fixture's statistic is the one computed here
-    runs = _ours(script)
+    runs = _ours(script, SEEDS)
     ours = np.array([last_tenth(runs[s]) for s in SEEDS])
     p = float(mannwhitneyu(ours, ref, alternative="two-sided").pvalue)
     se = float(np.sqrt(ours.var(ddof=1) / len(ours) + ref.var(ddof=1) / len(ref)))
@@ -74,7 +75,7 @@ def _compare(script):
     assert abs(ours.mean() - ref.mean()) <= 2.0 * se, rec
 
 
-@pytest.mark.parametrize("script", ["ppo", "dqn", "dueling_dqn", "per"])
+@pytest.mark.parametrize("script", ["ppo", "dqn", "dueling_dqn", "per", "sac"])
 def test_production_rng_path_learns_like_the_reference(script):
     import torch
 
