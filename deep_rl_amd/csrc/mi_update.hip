@@ -369,28 +369,12 @@ __device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads
         // Every add has the operands of the butterfly's add in that lane (IEEE addition commutes): bitwise the same s_b.  (this branch used to walk
         // 18 full f64 butterflies on ds_bpermute per wave.)
         static_assert(NORM_BLOCKS == 144, "18 blocks per wave");
-        // slab position -> parameter index with the block's share of ppo_slab_to_param on the SCALAR unit (the general form is ~12 vector instructions per load,
-        // 230 per wave: most of what this branch cost in its first version).  Inside a net's W2 range the map is a permutation of the 12 position bits s:
-        // out = s[11:10] | s[7:6] << 8 | s[1:0] << 6 | s[9:8] << 4 | s[5:2]; the actor's range starts on a block boundary (320 = 5 x 64), so s = 64 (b - 5) + lane splits
-        // into a per-lane constant and a per-block scalar; the critic's starts 2 lanes into block 77 (4930 = 77 x 64 + 2): lanes 0, 1 belong to the block before.
-        static_assert(N_W2 == 5 * 64 && C_BASE + N_W2 == 77 * 64 + 2 && HID == 64, "block structure of the slab order");
-        const int wu = __builtin_amdgcn_readfirstlane(w);
-        const int lane_c = (lane - 2) & 63;                                   // lane inside the critic's W2 numbering
-        const int cl_a = ((lane & 3) << 6) | (lane >> 2), cl_c = ((lane_c & 3) << 6) | (lane_c >> 2);
-        auto cb = [](int xb) { return ((xb & 0x30) << 6) | ((xb & 3) << 8) | ((xb & 0xC) << 2); };   // scalar: the block's bits
+        // (Tried, measured slower, removed: the block's share of ppo_slab_to_param on the scalar unit — per-lane constants + per-block scalars, 1 - 3 vector instructions per
+        // load instead of ~12.  As `if (block range)` around the index: every load in a basic block of its own, +3.6 us per launch; as selects with unconditional clamped
+        // loads: +2.4 us — two scalar branches per block for the scalar selects cost more than the vector arithmetic they replace.  This form: +1.2 us.)
         float x[18];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) {   // selects only, no branch, no guarded load: all 18 loads must be in flight together (a version whose loads sat behind
-            // `if (p < n)` / `if (block range)` had a basic block and an `s_waitcnt vmcnt(0)` per load: +3.6 us per launch instead of +1.2)
-            const int b = wu + 8 * k, p = 64 * b + lane;
-            const bool is_a = b >= 5 && b < 69, is_c = b >= 77 && b <= 141;
-            const int base_a = N_W2 + cb(b - 5), base_c0 = C_BASE + N_W2 + cb(b - 77), base_c1 = C_BASE + N_W2 + cb(b - 78);   // scalar
-            const bool in_c = is_c && (b > 77 || lane >= 2) && (b < 141 || lane < 2);
-            const int idx_c = cl_c + (lane < 2 ? base_c1 : base_c0);
-            const int idx = is_a ? cl_a + base_a : (in_c ? idx_c : p);
-            const float v = grads[p < n ? idx : 0];   // unconditional load from a clamped address: a guarded load is a branch with `s_waitcnt vmcnt(0)` at its join
-            x[k] = p < n ? v : 0.0f;
-        }
+        for (int k = 0; k < 18; ++k) { const int p = 64 * (w + 8 * k) + lane; x[k] = p < n ? grads[ppo_slab_to_param(p)] : 0.0f; }
         if (t >= NORM_BLOCKS && t < 256) sparts[t] = 0.0;
         double r[9], s[5];
 #pragma unroll
