@@ -129,12 +129,6 @@ struct __attribute__((aligned(16))) rq_smem {
     float uni[RQ_UNI_BLOCKS * 4][RQ_ENVS];   // the action uniforms of the launch's steps (RNG contract stream 1), drawn up front by the critic wave: row = step - 4 (step0 >> 2)
     int produced;                       // slots published so far (actor -> critic)
     int consumed;                       // slots the critic is done with (critic -> actor; only read when T + 1 > RQ_RING)
-    // reset states prepared by the critic wave (round 4): state #k of env e (the one its k-th `done` of this launch resets to: RNG contract stream 0, episode index
-    // e0 + k) sits in rst[k & 1][e] once rst_ready[e] > k.  The critic prepares #0 before the loop and #k + 1 when it sees done #k in the ring; the actor takes a prepared
-    // state or, if the critic has not got there yet, computes the same numbers itself — so the ~300 instructions of Philox + conversions leave the actor's dependent chain
-    // (short episodes cost the launch 22 us: DESIGN 3.1) without ever making it wait.
-    double rst[2][RQ_ENVS][4];
-    int rst_ready[RQ_ENVS];
 };
 // 37.2 KB per workgroup: 4 workgroups (8 waves) per CU, what the headline's 1,024 workgroups need on 256 CUs.
 
@@ -194,7 +188,6 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
     const bool mine = i < N, writer = mine && lane < RQ_ENVS;
     const int g = mine ? i : N - 1;   // lanes past the end shadow the last env and never write
     if (threadIdx.x == 0) { sm.produced = 0; sm.consumed = 0; }
-    if (threadIdx.x < RQ_ENVS) sm.rst_ready[threadIdx.x] = 0;
 #ifdef RQ_STAMPS
     if (lane == 0 && blockIdx.x < 1024) rq_stamp_dbg[blockIdx.x * 8 + 4 + (threadIdx.x >> 6)] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
@@ -223,23 +216,8 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
             for (int w = 0; w < 4; ++w) sm.uni[4 * j + w][en] = mi_u32_to_uniform(r4[w]);
         }
     }
-    const bool prep_resets = !ringed && !(FORCED && forced_resets);   // the critic wave prepares reset states (see rq_smem)
-    uint64_t ep_c = 0;                     // critic wave, lanes 0..3: episode index of the next state to prepare for env `lane`
-    int rst_k = 1;                         // ... and its ordinal in this launch
     __syncthreads();                       // counters initialised; the actor is done with the staging image
-    if (net == 1) {
-        if (prep_resets && lane < RQ_ENVS) {
-            ep_c = e.episode[g];
-            double sr[4];
-            mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, ep_c, sr);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sm.rst[0][lane][k] = sr[k];
-            ep_c += 1;
-            wave_lds_fence();
-            lds_publish(&sm.rst_ready[lane], 1);
-        }
-        rq_load_w2(p + N_W2, w2, sm.wstage, lane);
-    }
+    if (net == 1) rq_load_w2(p + N_W2, w2, sm.wstage, lane);
 
     if (net == 0) {
         // ================================================= ACTOR wave =================================================
@@ -254,7 +232,6 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
         float my_d = 0.0f;
         const float w3d = w3a - w3b, b3d = b3a0 - b3a1;
         int st_cnt = 0, st_len = 0, st_max = 0;
-        int rst_used = 0;                  // reset states this env has consumed in this launch
         uint32_t urand[4] = {0, 0, 0, 0};
         const bool keyed_actions = !FORCED || (!forced_actions && !forced_uniforms);
         const uint64_t ubase = stepctr & ~3ull;   // sm.uni row 0 = the first step of the Philox block this launch starts in
@@ -308,13 +285,9 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                     if (FORCED && forced_resets) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) sr[k] = forced_resets[4 * row + k];
-                    } else if (prep_resets && lds_peek(&sm.rst_ready[en]) > rst_used) {   // prepared by the critic wave: the same numbers, off this wave's chain
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) sr[k] = sm.rst[rst_used & 1][en][k];
                     } else {
                         mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, sr);
                     }
-                    rst_used += 1;
                     episode += 1;
                     sx = sr[0]; sxd = sr[1]; sth = sr[2]; sthd = sr[3];
                 }
@@ -386,16 +359,6 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                 while (lds_peek(&sm.produced) < t + 2) __builtin_amdgcn_s_sleep(1);   // the ring read below is issued after the poll that saw the counter
                 const rq_slot& sl = sm.ring[t + 1][en];
                 const float4 ob = sl.ob;
-                if (prep_resets && lane < RQ_ENVS && sl.dn != 0.0f) {   // env `lane` has just consumed a reset state: prepare its next one (lanes 0..3: en == lane)
-                    const int k = rst_k++;                               // ordinal of the state to prepare (no global load in this loop: see the FORCED / EPLOG note)
-                    double sr[4];
-                    mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, ep_c, sr);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) sm.rst[k & 1][lane][c] = sr[c];
-                    ep_c += 1;
-                    wave_lds_fence();
-                    lds_publish(&sm.rst_ready[lane], k + 1);
-                }
                 const rq_f32x4 h2 = rq_hidden(ob, w1, b1, w2, b2, q0, q1);
                 const float val = quad_env_reduce(h2 * w3a, q0, q1) + b3c;   // ppo.py:115,:139
                 if (lane < RQ_ENVS) sm.gv[t + 1][lane] = val;
@@ -480,6 +443,11 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
 // step (two IEEE fp64 divisions, ~130 fp64 operations at 3 waves per SIMD), more than the actor's whole step, and the launch is not purely
 // latency-bound — per SIMD and step the two nets' MFMAs (1,088 cycles), their VALU work (~800) and one physics step (~600) already fill
 // ~75 % of the issue slots, so work added to shorten the chain is paid in full.
+
+// Negative result (round 4, measured, removed): the CRITIC wave preparing every env's next reset state (Philox + four fp64 conversions, ~300 instructions) in LDS so that
+// the actor takes it on `done` instead of computing it on its dependent chain (with a fallback to computing it when the critic lags; bit-identical).  187.4 against 188.0 us
+// at the initial policy (episodes of 22 steps: a reset in 18 % of a wave's steps), 183.5 against 182.4 us after 40 updates (tools/rollout_ab.py, two runs each): nothing.
+// The "22 us for short episodes" of round 3 was mostly a cold-GPU artefact (202 us for the first 40 launches of a process, 188 us warm, whatever the build).
 
 __global__ void zero_i32x4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
