@@ -39,6 +39,7 @@ BYTES_PER_ENV_STEP = 292                         # rollout 40 + env state 72 + G
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
 REFERENCE_PY_STEPS_PER_S = 886.0                 # the unmodified reference ppo.py, torch CPU, 1 thread, build container
+PREWARM_UPDATES = 60                             # ~90 ms of throwaway updates before the W warm-up steps: the GPU's clocks have ramped by then (see main)
 
 
 def usable_cpus():
@@ -461,6 +462,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the config-3 (DQN) / config-4 (SAC) extra keys, the bf16x3 variant and the sharded-route leg")
     ap.add_argument("--single-window", action="store_true", help="only the one timed window of K steps (no repeat windows)")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the clock ramp (PREWARM_UPDATES throwaway updates on a scratch engine before the W warm-up steps)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -481,6 +483,22 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+
+    # Clock ramp, reported as `prewarm` in the line: a fresh process runs its first ~80 ms of GPU work at ramping clocks (tools/rollout_ab.py: 202 us per rollout for the
+    # first 40 launches, 188 us afterwards, whatever the build), which is longer than W = 5 warm-up updates (7 ms) and put the first timed window of a short run 1.2 - 1.8 %
+    # above the windows behind it (timed_windows, profiles/r04_grad_ab.txt).  A THROWAWAY engine of the same shape runs PREWARM_UPDATES updates first; the engine that is
+    # measured is built afterwards and starts from its own fresh state (same seed, same parameters, same W warm-up and K timed updates as without the ramp).
+    prewarm_updates = 0 if args.no_prewarm else PREWARM_UPDATES
+    if prewarm_updates:
+        p_env = D.make("CartPole-v1", num_envs=ENVS_PER_GPU, device=dev, seed=12345, env_id_base=rank * ENVS_PER_GPU)
+        torch.manual_seed(12345)
+        p_agent = D.ActorCritic(p_env)
+        p_eng = D.PPOEngine(p_env, p_agent, D.ClipAdam(p_agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5), num_steps=T, n_minibatch=4, update_epochs=4)
+        p_eng.reset()
+        for _ in range(prewarm_updates):
+            p_eng.update()
+        torch.cuda.synchronize()
+        del p_eng, p_agent, p_env
 
     num_updates = args.warmup + args.steps
     env = D.make("CartPole-v1", num_envs=ENVS_PER_GPU, device=dev, seed=1, env_id_base=rank * ENVS_PER_GPU)
@@ -594,11 +612,14 @@ def main():
             "kernel_ms_per_update": {k: round(v[0] / n_break, 4) for k, v in breakdown.items() if v[1]},
             "last_rollout": {"episodes": ep[0], "mean_return": round(ep[1] / max(ep[0], 1), 2), "max_return": ep[2]},
             "params_finite": finite,
+            "prewarm": {"updates": prewarm_updates, "what": "throwaway engine of the same shape, run and discarded BEFORE the engine that is measured is built (clock ramp of a fresh "
+                                                             "process: ~80 ms); the W warm-up and K timed updates are the measured engine's first W + K updates; --no-prewarm turns it off"},
         }
         wms = sorted(1e3 * w / args.steps for w in windows)
         out["timed_windows"] = {"count": len(wms), "steps_each": args.steps, "ms_per_step": [round(1e3 * w / args.steps, 4) for w in windows],
                                 "min": round(wms[0], 4), "median": round(wms[len(wms) // 2], 4), "max": round(wms[-1], 4),
-                                "note": "window 1 is `value` / `ms_per_step`; the others repeat it back to back (same barriers), learning continuing"}
+                                "note": "window 1 is `value` / `ms_per_step`; the others repeat it back to back (same barriers), learning continuing (episodes get longer: "
+                                        "fewer resets per rollout)"}
         if sharded is not None:
             out["sharded_route"] = sharded
         if collectives is not None:
