@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
-ABI_VERSION = 102   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
+ABI_VERSION = 103   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
@@ -38,6 +38,12 @@ class PPOBuffers(C.Structure):
 class SacOwedAlpha(C.Structure):   # mi_sac_owed_alpha_t
     _fields_ = [("log_alpha", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("alpha", C.c_void_p), ("out", C.c_void_p),
                 ("target_entropy", C.c_float), ("step", C.c_int64), ("lr", C.c_double), ("update_index", C.c_uint64), ("epoch", C.c_int32), ("stash_slot", C.c_int32)]
+
+
+class SacCriticStep(C.Structure):   # mi_sac_critic_step_t
+    _fields_ = [("workspace", C.c_void_p), ("batch", C.c_int32), ("q", C.c_void_p), ("q_target", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("grads", C.c_void_p), ("losses", C.c_void_p), ("step", C.c_int64), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double),
+                ("tau", C.c_float)]
 
 
 class PPOHparams(C.Structure):
@@ -119,6 +125,9 @@ SIGNATURES = {
     "mi_sac_critic_update_owed": (_I, [_VP] * 8 + [_I, _I, _I64, _VP, _U64, _U64, _VP, _F, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _F, _U64, _I64, _VP, _VP]),
     "mi_sac_actor_update_owed": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _VP, _VP]),
     "mi_sac_alpha_step_owed": (_I, [_VP, _I, _U64, _VP, _VP, _VP]),
+    "mi_sac_critic_update_deferred": (_I, [_VP] * 8 + [_I, _I, _I64, _VP, _U64, _U64, _VP, _F, _VP, _U64, _I64, _VP, _VP]),
+    "mi_sac_critic_step": (_I, [_VP, _VP]),
+    "mi_sac_act_step_carry": (_I, [_VP, _VP, _I64, _I64, _I64] + [_VP] * 10 + [_I, _VP, _VP]),
     "mi_sac_owed_alpha_fits": (_I, [_I]),
     "mi_sac_check": (_I, [_VP, _I]),
     "mi_sac_clear_error": (_I, [_VP, _I, _VP]),

@@ -262,82 +262,6 @@ extern "C" int mi_sac_q_forward(const float* q, const float* obs, const float* a
     return MI_OK;
 }
 
-// ================================================ acting ========================================================================
-namespace rg_act {
-__global__ void __launch_bounds__(SA_THREADS)
-sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step, long long slots, long long learning_starts, float* __restrict__ obs_cur,
-               float* __restrict__ observations, float* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
-               const float* __restrict__ forced_actions, const float* __restrict__ forced_eps, const double* __restrict__ forced_resets,
-               mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep) {
-    __shared__ sac_smem sm;
-    const int N = e.n, row0 = blockIdx.x * SR;
-    const bool policy = !forced_actions && global_step >= learning_starts;   // block-uniform
-    if (policy) {
-        wstream ws; thin_t th; f32x4 acc[SA_NT];
-        issue_thin_actor(actor, th);
-        stream_prime<false>(actor + AC_W2, ws);
-        if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
-        float eps = 0.0f;
-        if (threadIdx.x < SR) {
-            const int g = row0 + threadIdx.x < N ? row0 + threadIdx.x : N - 1;
-            eps = forced_eps ? forced_eps[g] : keyed_normal(e.seed, (1ull << 40) + e.env_id_base + (uint64_t)g, (uint64_t)global_step);
-        }
-        __syncthreads();
-        layer1<3>(sm, th, sm.x, sm.b0);
-        __syncthreads();
-        actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, eps);
-    }
-    if (threadIdx.x < SR && row0 + threadIdx.x < N) {
-        const int g = row0 + threadIdx.x;
-        float a;
-        if (forced_actions) a = forced_actions[g];
-        else if (policy) a = sm.rv[threadIdx.x][6];
-        else {   // env.action_space.sample() (sac.py:139): uniform in [low, high), keyed
-            uint32_t r[4];
-            mi_philox(e.seed, e.env_id_base + (uint64_t)g, (uint64_t)global_step, STREAM_UNIF_ACT, r);
-            a = -SA_ACT_SCALE + 2.0f * SA_ACT_SCALE * ((float)(r[0] >> 8) * (1.0f / 16777216.0f));
-        }
-        const long long slot = global_step % slots, nslot = (global_step + 1) % slots;
-        actions[slot * N + g] = a;                                                        // sac.py:145
-        double th = e.x[g], thd = e.x_dot[g];
-        int elapsed = e.elapsed[g], eplen = e.ep_len[g];
-        float epret = e.ep_ret[g];
-        uint64_t episode = e.episode[g];
-        const pend_out r = pend_step_one(e, g, a, forced_resets ? forced_resets + 2 * (size_t)g : nullptr, th, thd, elapsed, epret, eplen, episode);
-        e.x[g] = th; e.x_dot[g] = thd; e.elapsed[g] = elapsed; e.ep_len[g] = eplen; e.ep_ret[g] = epret; e.episode[g] = episode;
-        e.step_ctr[g] += 1;
-        const size_t no = (size_t)(nslot * N + g);
-        observations[3 * no] = r.o0; observations[3 * no + 1] = r.o1; observations[3 * no + 2] = r.o2;   // :156 (reset obs where done)
-        rewards[no] = r.reward;                                                           // :157
-        terminated[no] = 0;                                                               // :158: done and not truncated == False for Pendulum
-        obs_cur[3 * (size_t)g] = r.o0; obs_cur[3 * (size_t)g + 1] = r.o1; obs_cur[3 * (size_t)g + 2] = r.o2;
-        if (r.done && episode_stats) {
-            atomicAdd(episode_stats, 1); atomicAdd(episode_stats + 1, r.fin_len);
-            if (max_ep > 0) { const int sl = atomicAdd(episode_stats + 3, 1); if (sl < max_ep) episodes[sl] = mi_episode_t{g, 0, r.fin_ret, r.fin_len}; }
-        }
-    }
-}
-}  // namespace rg_act
-
-__global__ void sac_zero4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
-
-extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_step, int64_t slots, int64_t learning_starts, float* obs_cur,
-                               float* observations, float* actions, float* rewards, uint8_t* terminated, const float* forced_actions,
-                               const float* forced_eps, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
-                               void* stream) {
-    MI_CHECK_ARG(handle && actor && obs_cur && observations && actions && rewards && terminated, "NULL pointer");
-    mi_env* e = (mi_env*)handle;
-    MI_CHECK_ARG(e->kind == MI_ENV_PENDULUM_V1, "SAC path needs a Pendulum-v1 handle");
-    MI_CHECK_ARG(slots >= 2 && global_step >= 0 && max_ep >= 0 && (max_ep == 0 || episodes), "bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    if (episode_stats) { sac_zero4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
-    mi_prof_scope prof(MI_PROF_SAC_ACT, s);
-    rg_act::sac_act_kernel<<<(e->n + SR - 1) / SR, rg_act::SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations,
-                                                       actions, rewards, terminated, forced_actions, forced_eps, forced_resets, episodes, episode_stats, max_ep);
-    MI_LAUNCH_CHECK();
-    return MI_OK;
-}
-
 // ================================================ workspace layout ==============================================================
 // Kp = batch rounded up to a row group.  [H1 mats: 3 x Kp x 256][DZ2 mats: 3 x Kp x 256][slabs: nblocks x SLAB][GEMM partials: GEMM_MAX_SPLIT x 3 x 65536][ticket 4]
 // [hand-off between the sibling workgroups of a row group: Kp x 6 tagged 64-bit words (xw_put / xw_take; self-resetting; both kernels use the same words)]
@@ -1084,16 +1008,20 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
 // split over EIGHT waves; their partial tiles are summed through LDS in the order the K-split pair of launches used at the reference batch (two groups of four waves
 // = its two K-split partials: bitwise the same gradient), the tile is laid out row-major in LDS, and the 512 threads apply Adam (+ polyak) to 2 consecutive elements
 // each — the element's optimizer state is requested before the K loop.  Workgroups behind them: sac_thin_reduce.
-__global__ void __launch_bounds__(512) sac_dw2_adam_kernel(float* __restrict__ ws, int batch, int mat0, int n_slabs, int is_actor, double inv_count,
-                                                           float* __restrict__ grads, float* __restrict__ out2, sac_opt_t opt) {
-    __shared__ union { f32x4 red[8][4][64]; float tile[32][36]; float part[4][RED_SMALL_PER_BLOCK]; } sm;
+// The launch's body as a ROLE (workgroup `bi` of 64 nets + thin blocks, 512 threads): sac_dw2_adam_kernel runs it alone; rg_act::sac_act_kernel carries the critics'
+// step owed from the last critic update on extra workgroups of the acting launch (mi_sac_act_step_carry).
+union __attribute__((aligned(16))) sac_dw2_smem { f32x4 red[8][4][64]; float tile[32][36]; float part[4][RED_SMALL_PER_BLOCK]; };
+struct sac_dw2_args_t { float* ws; int batch, mat0, n_slabs, is_actor; double inv_count; float* grads; float* out2; sac_opt_t opt; };
+static int sac_dw2_blocks(int is_actor) { return 64 * (is_actor ? 1 : 2) + ((is_actor ? 1794 : 2 * 1793) + 2 + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK; }
+__device__ __forceinline__ void sac_dw2_adam_role(sac_dw2_smem& sm, const int bi, float* __restrict__ ws, int batch, int mat0, int n_slabs, int is_actor, double inv_count,
+                                                  float* __restrict__ grads, float* __restrict__ out2, const sac_opt_t& opt) {
     const int nets = is_actor ? 1 : 2;
-    if ((int)blockIdx.x >= 64 * nets) {
-        sac_thin_reduce((int)blockIdx.x - 64 * nets, sm.part, ws, batch, n_slabs, is_actor, inv_count, grads, out2, opt);
+    if (bi >= 64 * nets) {
+        sac_thin_reduce(bi - 64 * nets, sm.part, ws, batch, n_slabs, is_actor, inv_count, grads, out2, opt);
         return;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x & 63, mat = blockIdx.x >> 6, mg = tile >> 3, ng = tile & 7;
+    const int tile = bi & 63, mat = bi >> 6, mg = tile >> 3, ng = tile & 7;
     const int Kp = ws_kp(batch), steps = Kp / 4;
     const int s0 = (int)((long long)steps * w / 8), s1 = (int)((long long)steps * (w + 1) / 8);
     const float* H1 = ws + (size_t)(mat0 + mat) * ws_mat_floats(batch) + 32 * ng + 2 * j;
@@ -1154,6 +1082,10 @@ __global__ void __launch_bounds__(512) sac_dw2_adam_kernel(float* __restrict__ w
     grads[d0] = gv.x; grads[d0 + 1] = gv.y;
     if (opt.params) { sac_apply(opt, d0, gv.x, st[0]); sac_apply(opt, d0 + 1, gv.y, st[1]); }
 }
+__global__ void __launch_bounds__(512) sac_dw2_adam_kernel(sac_dw2_args_t a) {
+    __shared__ sac_dw2_smem sm;
+    sac_dw2_adam_role(sm, (int)blockIdx.x, a.ws, a.batch, a.mat0, a.n_slabs, a.is_actor, a.inv_count, a.grads, a.out2, a.opt);
+}
 
 static sac_opt_t sac_no_opt() { sac_opt_t o; memset(&o, 0, sizeof(o)); return o; }
 static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, int64_t step, double lr, double beta1, double beta2, double eps, float tau) {
@@ -1169,8 +1101,9 @@ static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv
     if (ws_kp(batch) <= SAC_FUSED_KP) {
         const int n_small = (is_actor ? 1794 : 2 * 1793) + 2;
         mi_prof_scope prof(MI_PROF_SAC_GEMM, s);
-        sac_dw2_adam_kernel<<<64 * nets + (n_small + RED_SMALL_PER_BLOCK - 1) / RED_SMALL_PER_BLOCK, 512, 0, s>>>((float*)workspace, batch, is_actor ? 2 : 0, nb, is_actor, inv_count,
-                                                                                                                  grads, out2, opt);
+        static_assert(SAC_FUSED_KP <= 512, "sac_dw2_adam_role requests at most 8 k-steps per wave up front");
+        (void)n_small; (void)nets;
+        sac_dw2_adam_kernel<<<sac_dw2_blocks(is_actor), 512, 0, s>>>(sac_dw2_args_t{(float*)workspace, batch, is_actor ? 2 : 0, nb, is_actor, inv_count, grads, out2, opt});
         MI_LAUNCH_CHECK();
         return MI_OK;
     }
@@ -1188,6 +1121,136 @@ static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
+
+// ================================================ acting ========================================================================
+namespace rg_act {
+__global__ void __launch_bounds__(SA_THREADS)
+sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step, long long slots, long long learning_starts, float* __restrict__ obs_cur,
+               float* __restrict__ observations, float* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
+               const float* __restrict__ forced_actions, const float* __restrict__ forced_eps, const double* __restrict__ forced_resets,
+               mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep, int n_act, sac_dw2_args_t dw) {
+    __shared__ sac_smem sm;
+    // workgroups behind the acting ones: the critics' weight-gradient + Adam + polyak step owed from the last critic update (mi_sac_act_step_carry).  Acting reads the
+    // actor and the env only, the step touches the critics only: no dependency inside the launch; whoever needs the stepped critics sits behind the kernel boundary.
+    if ((int)blockIdx.x >= n_act) {
+        sac_dw2_adam_role(*reinterpret_cast<sac_dw2_smem*>(&sm), (int)blockIdx.x - n_act, dw.ws, dw.batch, dw.mat0, dw.n_slabs, dw.is_actor, dw.inv_count, dw.grads, dw.out2, dw.opt);
+        return;
+    }
+    const int N = e.n, row0 = blockIdx.x * SR;
+    const bool policy = !forced_actions && global_step >= learning_starts;   // block-uniform
+    if (policy) {
+        wstream ws; thin_t th; f32x4 acc[SA_NT];
+        issue_thin_actor(actor, th);
+        stream_prime<false>(actor + AC_W2, ws);
+        if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
+        float eps = 0.0f;
+        if (threadIdx.x < SR) {
+            const int g = row0 + threadIdx.x < N ? row0 + threadIdx.x : N - 1;
+            eps = forced_eps ? forced_eps[g] : keyed_normal(e.seed, (1ull << 40) + e.env_id_base + (uint64_t)g, (uint64_t)global_step);
+        }
+        __syncthreads();
+        layer1<3>(sm, th, sm.x, sm.b0);
+        __syncthreads();
+        actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, eps);
+    }
+    if (threadIdx.x < SR && row0 + threadIdx.x < N) {
+        const int g = row0 + threadIdx.x;
+        float a;
+        if (forced_actions) a = forced_actions[g];
+        else if (policy) a = sm.rv[threadIdx.x][6];
+        else {   // env.action_space.sample() (sac.py:139): uniform in [low, high), keyed
+            uint32_t r[4];
+            mi_philox(e.seed, e.env_id_base + (uint64_t)g, (uint64_t)global_step, STREAM_UNIF_ACT, r);
+            a = -SA_ACT_SCALE + 2.0f * SA_ACT_SCALE * ((float)(r[0] >> 8) * (1.0f / 16777216.0f));
+        }
+        const long long slot = global_step % slots, nslot = (global_step + 1) % slots;
+        actions[slot * N + g] = a;                                                        // sac.py:145
+        double th = e.x[g], thd = e.x_dot[g];
+        int elapsed = e.elapsed[g], eplen = e.ep_len[g];
+        float epret = e.ep_ret[g];
+        uint64_t episode = e.episode[g];
+        const pend_out r = pend_step_one(e, g, a, forced_resets ? forced_resets + 2 * (size_t)g : nullptr, th, thd, elapsed, epret, eplen, episode);
+        e.x[g] = th; e.x_dot[g] = thd; e.elapsed[g] = elapsed; e.ep_len[g] = eplen; e.ep_ret[g] = epret; e.episode[g] = episode;
+        e.step_ctr[g] += 1;
+        const size_t no = (size_t)(nslot * N + g);
+        observations[3 * no] = r.o0; observations[3 * no + 1] = r.o1; observations[3 * no + 2] = r.o2;   // :156 (reset obs where done)
+        rewards[no] = r.reward;                                                           // :157
+        terminated[no] = 0;                                                               // :158: done and not truncated == False for Pendulum
+        obs_cur[3 * (size_t)g] = r.o0; obs_cur[3 * (size_t)g + 1] = r.o1; obs_cur[3 * (size_t)g + 2] = r.o2;
+        if (r.done && episode_stats) {
+            atomicAdd(episode_stats, 1); atomicAdd(episode_stats + 1, r.fin_len);
+            if (max_ep > 0) { const int sl = atomicAdd(episode_stats + 3, 1); if (sl < max_ep) episodes[sl] = mi_episode_t{g, 0, r.fin_ret, r.fin_len}; }
+        }
+    }
+}
+}  // namespace rg_act
+
+__global__ void sac_zero4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
+
+static int sac_act_impl(void* handle, const float* actor, int64_t global_step, int64_t slots, int64_t learning_starts, float* obs_cur,
+                        float* observations, float* actions, float* rewards, uint8_t* terminated, const float* forced_actions,
+                        const float* forced_eps, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
+                        const sac_dw2_args_t* carry, void* stream) {
+    MI_CHECK_ARG(handle && actor && obs_cur && observations && actions && rewards && terminated, "NULL pointer");
+    mi_env* e = (mi_env*)handle;
+    MI_CHECK_ARG(e->kind == MI_ENV_PENDULUM_V1, "SAC path needs a Pendulum-v1 handle");
+    MI_CHECK_ARG(slots >= 2 && global_step >= 0 && max_ep >= 0 && (max_ep == 0 || episodes), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (episode_stats) { sac_zero4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    mi_prof_scope prof(MI_PROF_SAC_ACT, s);
+    const int n_act = (e->n + SR - 1) / SR;
+    static_assert(rg_act::SA_THREADS == 512, "the carried critic step (sac_dw2_adam_role) is written for 512-thread workgroups");
+    sac_dw2_args_t none; memset(&none, 0, sizeof(none));
+    rg_act::sac_act_kernel<<<n_act + (carry ? sac_dw2_blocks(0) : 0), rg_act::SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts,
+                                                                                                obs_cur, observations, actions, rewards, terminated, forced_actions, forced_eps,
+                                                                                                forced_resets, episodes, episode_stats, max_ep, n_act, carry ? *carry : none);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_step, int64_t slots, int64_t learning_starts, float* obs_cur,
+                               float* observations, float* actions, float* rewards, uint8_t* terminated, const float* forced_actions,
+                               const float* forced_eps, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
+                               void* stream) {
+    return sac_act_impl(handle, actor, global_step, slots, learning_starts, obs_cur, observations, actions, rewards, terminated, forced_actions, forced_eps, forced_resets,
+                        episodes, episode_stats, max_ep, nullptr, stream);
+}
+
+// ---- the critics' optimizer step DEFERRED to the next launch (round 4).  mi_sac_critic_update_deferred = mi_sac_critic_update_owed without its second launch (the
+// weight-gradient GEMM + gradient assembly + Adam + polyak): the row-group kernel leaves H1 / dZ2 / slabs in the workspace, and the step is owed until
+//   mi_sac_act_step_carry(..., step)   carries it on extra workgroups of the acting launch (which reads the actor and the env only: no dependency inside the launch), or
+//   mi_sac_critic_step(step)           runs it as the launch of its own that mi_sac_critic_update_owed would have made.
+// Either way the same workgroups do the same arithmetic: bit-identical to the undeferred call.  Nothing else may read or write the critics, their targets or their Adam
+// moments, or reuse the workspace, in between (deep_rl_amd.SACEngine settles the debt before any such access).
+static int sac_critic_step_args(const mi_sac_critic_step_t* st, sac_dw2_args_t* out) {
+    MI_CHECK_ARG(st && st->workspace && st->q && st->exp_avg && st->exp_avg_sq && st->grads && st->batch > 0 && st->step >= 1, "critic step: NULL pointer / bad batch or step");
+    const sac_opt_t opt = sac_make_opt(st->q, st->exp_avg, st->exp_avg_sq, st->tau >= 0.0f ? st->q_target : nullptr, st->step, st->lr, st->beta1, st->beta2, st->adam_eps, st->tau);
+    MI_CHECK_ARG(st->tau < 0.0f || st->q_target, "critic step: q_target is NULL but tau >= 0");
+    *out = sac_dw2_args_t{(float*)st->workspace, st->batch, 0, ws_kp(st->batch) / SR, 0, 1.0 / st->batch, st->grads, st->losses, opt};
+    return MI_OK;
+}
+extern "C" int mi_sac_critic_step(const mi_sac_critic_step_t* st, void* stream) {
+    sac_dw2_args_t a;
+    if (const int rc = sac_critic_step_args(st, &a)) return rc;
+    return sac_launch_grads(st->workspace, st->batch, 0, 1.0 / st->batch, st->grads, st->losses, a.opt, (hipStream_t)stream);
+}
+extern "C" int mi_sac_act_step_carry(void* handle, const float* actor, int64_t global_step, int64_t slots, int64_t learning_starts, float* obs_cur,
+                                     float* observations, float* actions, float* rewards, uint8_t* terminated, const float* forced_actions,
+                                     const float* forced_eps, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
+                                     const mi_sac_critic_step_t* step, void* stream) {
+    if (!step) return sac_act_impl(handle, actor, global_step, slots, learning_starts, obs_cur, observations, actions, rewards, terminated, forced_actions, forced_eps,
+                                   forced_resets, episodes, episode_stats, max_ep, nullptr, stream);
+    sac_dw2_args_t a;
+    if (const int rc = sac_critic_step_args(step, &a)) return rc;
+    if (ws_kp(step->batch) > SAC_FUSED_KP) {   // large batches: the step is two launches of its own (K-split GEMM, assembly); nothing to carry
+        if (const int rc = mi_sac_critic_step(step, stream)) return rc;
+        return sac_act_impl(handle, actor, global_step, slots, learning_starts, obs_cur, observations, actions, rewards, terminated, forced_actions, forced_eps, forced_resets,
+                            episodes, episode_stats, max_ep, nullptr, stream);
+    }
+    return sac_act_impl(handle, actor, global_step, slots, learning_starts, obs_cur, observations, actions, rewards, terminated, forced_actions, forced_eps, forced_resets,
+                        episodes, episode_stats, max_ep, &a, stream);
+}
+
 
 // How many sibling workgroups a row group gets.  Siblings WAIT for each other inside the launch, so every workgroup of the launch must be resident at once: these
 // kernels run one workgroup per CU (256 + 68..128 registers per lane), and the launch is kept to half the chip (row groups x roles + the owed-alpha workgroups
@@ -1330,7 +1393,7 @@ static int sac_check_owed(const mi_sac_owed_alpha_t* o, int batch) {
 static int sac_critic_impl(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
                            const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
                            uint64_t update_index, const float* alpha, float gamma, double inv_count, void* workspace, float* grads, float* losses,
-                           const sac_opt_t& opt, uint64_t sample_update, int64_t sample_upper, const sac_owed_t& ow_in, hipStream_t s) {
+                           const sac_opt_t& opt, uint64_t sample_update, int64_t sample_upper, const sac_owed_t& ow_in, hipStream_t s, bool defer_step = false) {
     const int nrg = ws_kp(batch) / SR;
     if (const int rc = sac_status_check("SAC critic update")) return rc;
     sac_owed_t ow = ow_in; ow.fault = g_sac_fault;
@@ -1341,6 +1404,7 @@ static int sac_critic_impl(float* q, float* q_target, const float* actor, const 
                                                            (int64_t*)idx, ow);
     }
     MI_LAUNCH_CHECK();
+    if (defer_step) return MI_OK;   // mi_sac_critic_update_deferred: the caller owes mi_sac_critic_step / mi_sac_act_step_carry
     return sac_launch_grads(workspace, batch, 0, inv_count, grads, losses, opt, s);
 }
 
@@ -1366,6 +1430,18 @@ extern "C" int mi_sac_critic_update_owed(float* q, float* q_target, const float*
     return sac_critic_impl(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
                            1.0 / batch, workspace, grads, losses, sac_make_opt(q, exp_avg, exp_avg_sq, tau >= 0.0f ? q_target : nullptr, step, lr, beta1, beta2, adam_eps, tau),
                            sample_update, sample_upper, sac_make_owed(owed, batch, seed, workspace), (hipStream_t)stream);
+}
+extern "C" int mi_sac_critic_update_deferred(const float* q, const float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                                             const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,
+                                             uint64_t update_index, const float* alpha, float gamma, void* workspace, uint64_t sample_update, int64_t sample_upper,
+                                             const mi_sac_owed_alpha_t* owed, void* stream) {
+    MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
+    MI_CHECK_ARG(q && q_target && actor && observations && actions && rewards && terminated && idx && alpha && workspace, "NULL pointer");
+    MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "bad sizes");
+    if (const int rc = sac_check_owed(owed, batch)) return rc;
+    return sac_critic_impl((float*)q, (float*)q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
+                           1.0 / batch, workspace, nullptr, nullptr, sac_no_opt(), sample_update, sample_upper, sac_make_owed(owed, batch, seed, workspace), (hipStream_t)stream,
+                           true);
 }
 extern "C" int mi_sac_critic_update(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
                                     const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed,

@@ -88,5 +88,6 @@ while global_step < total_timesteps:
     if global_step >= learning_starts:
         engine.train_step(policy_frequency, target_network_frequency)
 
+engine.flush()  # settle what is still owed (the last critic step rides on an acting launch that never comes, the last alpha step on an update launch)
 alpha = float(engine.alpha.item())  # :210 — read once here instead of once per actor update
 env.close()

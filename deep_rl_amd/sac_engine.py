@@ -17,6 +17,8 @@ from .agent import pack
 from .optim import Adam
 
 _OWE_ALPHA = os.environ.get("MIRL_SAC_OWE_ALPHA", "1") != "0"   # 0: every alpha step is a launch of its own (A/B, debugging)
+# 0: the critics' optimizer step is always the second launch of update_critic (A/B, debugging); 1: it is deferred and rides on the next acting launch (see update_critic)
+_DEFER_CRITIC = os.environ.get("MIRL_SAC_DEFER_CRITIC", "1") != "0"
 # diagnostics (tests/_rccl_world1_worker.py): walk the sharded branches even at world_size 1, so that RCCL really runs on a one-GPU box
 _FORCE_SHARDED = os.environ.get("MIRL_OFFPOLICY_SHARDED", "0") == "1"
 
@@ -32,11 +34,13 @@ class SACEngine:
         self.world_size, self.rank = D.world_size(process_group), D.rank(process_group)
         dev, S, Nn = self.device, self.slots, self.N
         # twin critics share one optimizer (sac.py:117): one flat buffer [2 * MI_SAC_Q_NPARAMS] each for online / target
-        self.q_flat = pack(qf1, qf2)
-        self.qt_flat = pack(qf1_target, qf2_target)
+        # (q_flat, qt_flat, q_grads, q_losses, q_optimizer are properties: reading them settles a critic step that is still owed, see update_critic)
+        self._q_flat = pack(qf1, qf2)
+        self._qt_flat = pack(qf1_target, qf2_target)
         self.qf1, self.qf2, self.qf1_target, self.qf2_target = qf1, qf2, qf1_target, qf2_target
         self.actor_optimizer = Adam(actor.flat, lr=policy_lr)                                  # sac.py:108
-        self.q_optimizer = Adam(self.q_flat, lr=q_lr)                                          # :117
+        self._q_optimizer = Adam(self._q_flat, lr=q_lr)                                        # :117
+        self._owed_critic = None     # N.SacCriticStep of a deferred critic step (mi_sac_critic_update_deferred), or None
         self.alpha_lr = float(q_lr if alpha_lr is None else alpha_lr)                          # :92
         self.target_entropy = float(-1.0 if target_entropy is None else target_entropy)        # :119 (-prod(action shape))
         # the entropy coefficient's state; an alpha step may be OWED (see update_alpha): every reader goes through the properties below, which settle it first
@@ -57,7 +61,7 @@ class SACEngine:
         self.terminated = torch.zeros((S, Nn), dtype=torch.uint8, device=dev)                  # :129 (bool)
         self.batch_inds = torch.zeros(self.batch_size, dtype=torch.int64, device=dev)
         self._qbuf = torch.zeros(2 * N.SAC_Q_NPARAMS + 2, dtype=torch.float32, device=dev)
-        self.q_grads, self.q_losses = self._qbuf[:2 * N.SAC_Q_NPARAMS], self._qbuf[2 * N.SAC_Q_NPARAMS:]
+        self._q_grads, self._q_losses = self._qbuf[:2 * N.SAC_Q_NPARAMS], self._qbuf[2 * N.SAC_Q_NPARAMS:]
         self._abuf = torch.zeros(N.SAC_ACTOR_NPARAMS + 2, dtype=torch.float32, device=dev)
         self.actor_grads, self.actor_out = self._abuf[:N.SAC_ACTOR_NPARAMS], self._abuf[N.SAC_ACTOR_NPARAMS:]   # out = {actor_loss, mean logp}
         self._alpha_out = torch.zeros(2, dtype=torch.float32, device=dev)                      # {alpha_loss, d/d log_alpha}
@@ -84,6 +88,29 @@ class SACEngine:
             return None
         return D.native_comm(self.pg)
 
+    # ---- the critics' state: reading it settles a deferred optimizer step first ----
+    def flush_critic(self):
+        """Run a deferred critic step now, as the launch of its own that update_critic would have made (mi_sac_critic_step)."""
+        st = self._owed_critic
+        if st is not None:
+            N.check(N.lib().mi_sac_critic_step(C.byref(st), self._s()), "mi_sac_critic_step")
+            self._owed_critic = None
+
+    def _critic_settled(self, t):
+        self.flush_critic()
+        return t
+
+    q_flat = property(lambda self: self._critic_settled(self._q_flat))
+    qt_flat = property(lambda self: self._critic_settled(self._qt_flat))
+    q_grads = property(lambda self: self._critic_settled(self._q_grads))
+    q_losses = property(lambda self: self._critic_settled(self._q_losses))
+    q_optimizer = property(lambda self: self._critic_settled(self._q_optimizer))
+
+    def flush(self):
+        """Settle everything that is owed (critic step, alpha step): the engine's tensors then hold what the reference's variables would."""
+        self.flush_critic()
+        self.flush_alpha()
+
     # ---- the entropy coefficient's state: reading it settles an owed alpha step first ----
     def _owed_struct(self):
         """-> (ctypes struct of the owed alpha step | None) for the NEXT counters.  Nothing is committed here: the C call may refuse before it launches anything
@@ -104,13 +131,16 @@ class SACEngine:
             self._owed = None
 
     def drop_owed(self):
-        """Forget a pending alpha debt and the stash (the state is about to be replaced wholesale: checkpoint.load)."""
+        """Forget a pending alpha debt, the stash and a deferred critic step (the state is about to be replaced wholesale: checkpoint.load)."""
         self._owed = None
         self._stash_fresh = False
+        self._owed_critic = None
 
     def flush_alpha(self):
         """Run an owed alpha step now (a launch of its own)."""
         o = self._owed_struct()
+        if o is not None:
+            self.flush_critic()      # (every launch but the acting one may use workspace regions a deferred critic step still reads)
         if o is not None:
             N.check(N.lib().mi_sac_alpha_step_owed(N.ptr(self.actor.flat), self.batch_size, self.env._seed, C.byref(o), N.ptr(self.workspace), self._s()),
                     "mi_sac_alpha_step_owed")
@@ -161,10 +191,13 @@ class SACEngine:
         fa = None if forced_actions is None else forced_actions.to(dev, torch.float32).reshape(self.N).contiguous()
         fe = None if forced_eps is None else forced_eps.to(dev, torch.float32).reshape(self.N).contiguous()
         fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
-        N.check(N.lib().mi_sac_act_step(
+        st = self._owed_critic    # a deferred critic step rides on this launch: acting reads the actor and the env only (mi_sac_act_step_carry)
+        N.check(N.lib().mi_sac_act_step_carry(
             self.env.handle, N.ptr(self.actor.flat), self.global_step, self.slots, self.learning_starts, N.ptr(self.observation),
             N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fe), N.ptr(fr),
-            N.ptr(self.episodes), N.ptr(self.episode_stats) if self.max_ep else None, self.max_ep, self._s()), "mi_sac_act_step")
+            N.ptr(self.episodes), N.ptr(self.episode_stats) if self.max_ep else None, self.max_ep, C.byref(st) if st is not None else None, self._s()),
+            "mi_sac_act_step_carry")
+        self._owed_critic = None
         self.global_step += 1
 
     def drain_episodes(self):
@@ -208,13 +241,27 @@ class SACEngine:
             if sample_in_launch and min(self.global_step, self.slots) * self.N == 0:   # 0 means "read batch_inds" to the launch
                 raise N.MiError("update_critic: the replay ring is empty (global_step == 0); act() before training")
             owed = self._owed_struct()       # an alpha step owed from the last actor update rides on this launch
-            N.check(N.lib().mi_sac_critic_update_owed(
-                N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
-                N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
-                self._key(self.update_index), N.ptr(self._alpha), self.gamma, N.ptr(self.workspace), N.ptr(self.q_grads), N.ptr(self.q_losses),
-                N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
-                self.tau if polyak else -1.0, self._key(self.update_index), min(self.global_step, self.slots) * self.N if sample_in_launch else 0,
-                C.byref(owed) if owed is not None else None, self._s()), "mi_sac_critic_update_owed")
+            upper = min(self.global_step, self.slots) * self.N if sample_in_launch else 0
+            if _DEFER_CRITIC:
+                # the row-group launch now, the optimizer step (dW2 GEMM + assembly + Adam + polyak) DEFERRED: the next act() carries it on workgroups of its own launch
+                # (the step touches the critics only, acting reads the actor and the env only), anything else that comes first settles it alone (flush_critic / the
+                # q_* properties).  One launch less on the chain of every iteration that is followed by an acting step; same arithmetic, same bits.
+                N.check(N.lib().mi_sac_critic_update_deferred(
+                    N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+                    N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
+                    self._key(self.update_index), N.ptr(self._alpha), self.gamma, N.ptr(self.workspace), self._key(self.update_index), upper,
+                    C.byref(owed) if owed is not None else None, self._s()), "mi_sac_critic_update_deferred")
+                self._owed_critic = N.SacCriticStep(N.ptr(self.workspace), self.batch_size, N.ptr(self._q_flat), N.ptr(self._qt_flat), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq),
+                                                    N.ptr(self._q_grads), N.ptr(self._q_losses), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                                                    self.tau if polyak else -1.0)
+            else:
+                N.check(N.lib().mi_sac_critic_update_owed(
+                    N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
+                    N.ptr(self.terminated), N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, N.ptr(e), self.env._seed,
+                    self._key(self.update_index), N.ptr(self._alpha), self.gamma, N.ptr(self.workspace), N.ptr(self.q_grads), N.ptr(self.q_losses),
+                    N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                    self.tau if polyak else -1.0, self._key(self.update_index), upper,
+                    C.byref(owed) if owed is not None else None, self._s()), "mi_sac_critic_update_owed")
             o.step_count += 1                # counters move only once the call has enqueued its launches (it may refuse with MI_ESTATE before)
             self._owed_commit(owed)
         elif self._comm() is not None:
@@ -276,6 +323,7 @@ class SACEngine:
 
     def update_alpha(self, eps=None):
         """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
+        self.flush_critic()          # the log-prob launch writes gradient slabs a deferred critic step would still read
         if eps is None and self._single() and self._stash_fresh and self._owed_fits and _OWE_ALPHA:
             # keyed draws, single process, right after a fused actor update: the step is OWED — the next row-group launch (actor or critic update) carries its
             # log-prob pass on workgroups of its own and hands alpha to its consumers in the launch; reading the state (or flush_alpha()) settles it alone

@@ -50,9 +50,9 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
-#define MI_VERSION 102
+#define MI_VERSION 103
 #define MI_PPO_NPARAMS 9155
 #define MI_PPO_ACTOR_NPARAMS 4610
 #define MI_OBS_DIM 4
@@ -405,6 +405,28 @@ int mi_sac_actor_update_owed(float* actor, const float* q, const float* observat
                              int64_t step, double lr, double beta1, double beta2, double adam_eps, const mi_sac_owed_alpha_t* owed, void* stream);
 int mi_sac_alpha_step_owed(const float* actor, int batch, uint64_t seed, const mi_sac_owed_alpha_t* owed, void* workspace, void* stream);
 int mi_sac_owed_alpha_fits(int batch);   /* 1 when a launch at this batch may carry an owed alpha step on the current device (half of its usable CUs stay free) */
+
+/* ---- the critics' optimizer step DEFERRED to the next launch.  mi_sac_critic_update_owed is two launches: the row-group kernel (forward, loss, backward: H1 / dZ2 / slabs
+ * into the workspace) and the step (weight-gradient GEMM + gradient assembly + Adam + polyak: sac.py:183-185,213-217).  The step touches the critics only, and the launch
+ * that follows a critic update in the loop of sac.py:137-217 is the NEXT acting step, which reads the actor and the env only — so the step can ride on extra workgroups of
+ * that launch instead of being a link of the launch chain:
+ *   mi_sac_critic_update_deferred   the first launch only (same arguments, same sampling contract; an alpha step owed from the last actor update rides on it as before);
+ *   mi_sac_act_step_carry(.., step) the acting launch + the owed step (step == NULL: plain mi_sac_act_step; padded batches > 512: the step's own two launches, then acting);
+ *   mi_sac_critic_step(step)        the step as the launch of its own (what an undeferred call would have made) — for anything else that comes next.
+ * The same workgroups do the same arithmetic in every form: bit-identical to mi_sac_critic_update_owed.  Between the deferred call and the step nothing may read or write the
+ * critics, their targets, their Adam moments or `grads` / `losses`, or use the workspace for another update.  step: 1-based Adam step; tau < 0: no polyak step. */
+typedef struct {
+    void* workspace; int32_t batch; float* q; float* q_target; float* exp_avg; float* exp_avg_sq; float* grads /* [2 MI_SAC_Q_NPARAMS] */; float* losses /* [2] */;
+    int64_t step; double lr, beta1, beta2, adam_eps; float tau;
+} mi_sac_critic_step_t;
+int mi_sac_critic_update_deferred(const float* q, const float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
+                                  const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed, uint64_t update_index,
+                                  const float* alpha, float gamma, void* workspace, uint64_t sample_update, int64_t sample_upper, const mi_sac_owed_alpha_t* owed,
+                                  void* stream);
+int mi_sac_critic_step(const mi_sac_critic_step_t* step, void* stream);
+int mi_sac_act_step_carry(void* handle, const float* actor, int64_t global_step, int64_t slots, int64_t learning_starts, float* obs_cur, float* observations,
+                          float* actions, float* rewards, uint8_t* terminated, const float* forced_actions, const float* forced_eps, const double* forced_resets,
+                          mi_episode_t* episodes, int32_t* episode_stats, int max_ep, const mi_sac_critic_step_t* step, void* stream);
 
 /* ---- waits between the workgroups of one SAC launch (sibling roles of a row group, the owed alpha step): every waiter only waits for workgroups that precede
  * it in dispatch order, and every spin is bounded (100 ms of wall clock).  A wait that runs out stores a code in a host-pinned status word and in a word on the

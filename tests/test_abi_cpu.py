@@ -36,6 +36,7 @@ def test_struct_layouts_match_header(N):
     assert C.sizeof(N.Episode) == 16
     assert C.sizeof(N.PPOBuffers) == 20 * 8 + 8 + 8  # 20 pointers + int32 (padded) + episode_stats_next
     assert C.sizeof(N.PPOHparams) == 4 * 4 + 8 + 6 * 4 + 4 * 8
+    assert C.sizeof(N.SacCriticStep) == 8 + 8 + 6 * 8 + 8 + 4 * 8 + 8   # pointer, int32 (padded), 6 pointers, int64, 4 doubles, float (padded)
     assert N.lib().mi_ppo_workspace_bytes() >= 512 * 4624 * 4
 
 

@@ -594,3 +594,69 @@ def test_owed_alpha_step_is_bit_identical_to_a_launch_of_its_own(dev, batch, mon
     assert torch.equal(a.actor.flat, b.actor.flat) and torch.equal(a.q_flat, b.q_flat) and torch.equal(a.qt_flat, b.qt_flat)
     assert torch.equal(a.actor_optimizer.exp_avg, b.actor_optimizer.exp_avg) and torch.equal(a.q_optimizer.exp_avg_sq, b.q_optimizer.exp_avg_sq)
     assert torch.equal(a.observations, b.observations) and torch.equal(a.actions, b.actions)
+
+
+@pytest.mark.parametrize("batch", [40, 256, 600])
+def test_deferred_critic_step_is_bit_identical_to_a_launch_of_its_own(dev, batch, monkeypatch):
+    """The critics' optimizer step (dW2 GEMM + assembly + Adam + polyak, sac.py:183-185,213-217) deferred and carried by the NEXT acting launch (mi_sac_critic_update_deferred
+    + mi_sac_act_step_carry) or settled alone when something else comes first (mi_sac_critic_step: the actor update of every second step, a read of the critics) against
+    the same training with the step as the second launch of every critic update: every parameter, target, optimizer moment, loss and the whole replay ring agree BIT FOR BIT
+    after 30 iterations (policy_frequency 2: both ways of settling occur), below (40, 256) and above (600: padded batch > 512, the step is the split-K pair of launches)
+    the fused-step limit."""
+    import deep_rl_amd as D
+    import deep_rl_amd.sac_engine as SE
+
+    def run(defer):
+        monkeypatch.setattr(SE, "_DEFER_CRITIC", defer)
+        env = D.make("Pendulum-v1", num_envs=48, device=dev, seed=9)
+        torch.manual_seed(9)
+        actor = D.Actor(env); q1 = D.SoftQNetwork(env); q2 = D.SoftQNetwork(env); q1t = D.SoftQNetwork(env); q2t = D.SoftQNetwork(env)
+        q1t.load_state_dict(q1.state_dict()); q2t.load_state_dict(q2.state_dict())
+        eng = D.SACEngine(env, actor, q1, q2, q1t, q2t, slots=40, batch_size=batch, learning_starts=4)
+        eng.reset()
+        carried = settled = 0
+        for _ in range(30):
+            carried += eng._owed_critic is not None      # a debt at this point rides on the acting launch
+            eng.act()
+            assert eng._owed_critic is None
+            if eng.global_step > 6:
+                eng.train_step()
+                settled += eng._owed_critic is None      # the actor update of this step settled it
+        return eng, carried, settled
+
+    a, carried, settled = run(True)
+    b, c0, _ = run(False)
+    assert carried > 5 and settled > 5 and c0 == 0, (carried, settled, c0)
+    assert a._owed_critic is not None                    # the last critic step is still owed ...
+    assert torch.equal(a.q_flat, b.q_flat) and a._owed_critic is None      # ... and reading the critics settles it
+    for name in ("qt_flat", "q_grads", "q_losses", "log_alpha", "alpha", "observations", "actions", "rewards"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.actor.flat, b.actor.flat) and torch.equal(a.actor_optimizer.exp_avg, b.actor_optimizer.exp_avg)
+    assert torch.equal(a.q_optimizer.exp_avg, b.q_optimizer.exp_avg) and torch.equal(a.q_optimizer.exp_avg_sq, b.q_optimizer.exp_avg_sq)
+    assert a.q_optimizer.step_count == b.q_optimizer.step_count and a.update_index == b.update_index
+
+
+def test_deferred_critic_step_is_settled_before_anything_else_uses_the_workspace(dev):
+    """update_critic(); update_alpha() — the log-prob launch writes gradient slabs the deferred step still has to read — and update_critic(); checkpoint: the engine settles
+    the debt first, so both orders give the bits of the undeferred engine."""
+    import deep_rl_amd.sac_engine as SE
+
+    outs = []
+    for defer in (True, False):
+        SE._DEFER_CRITIC = defer
+        try:
+            eng = _engine(dev, 32, 24, seed=4, batch_size=128, learning_starts=2)
+            eng.reset()
+            for _ in range(8):
+                eng.act()
+            eng.sample()
+            eng.update_critic(polyak=True)
+            eng.update_alpha()
+            eng.update_critic(polyak=True)
+            eng.update_actor()
+            eng.update_critic(polyak=False)
+            outs.append([t.clone() for t in (eng.q_flat, eng.qt_flat, eng.q_losses, eng.log_alpha, eng.actor.flat, eng.q_optimizer.exp_avg_sq)])
+        finally:
+            SE._DEFER_CRITIC = True
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
