@@ -601,7 +601,7 @@ def test_deferred_critic_step_is_bit_identical_to_a_launch_of_its_own(dev, batch
     """The critics' optimizer step (dW2 GEMM + assembly + Adam + polyak, sac.py:183-185,213-217) deferred and carried by the NEXT acting launch (mi_sac_critic_update_deferred
     + mi_sac_act_step_carry) or settled alone when something else comes first (mi_sac_critic_step: the actor update of every second step, a read of the critics) against
     the same training with the step as the second launch of every critic update: every parameter, target, optimizer moment, loss and the whole replay ring agree BIT FOR BIT
-    after 30 iterations (policy_frequency 2: both ways of settling occur), below (40, 256) and above (600: padded batch > 512, the step is the split-K pair of launches)
+    after 31 iterations (policy_frequency 2: both ways of settling occur), below (40, 256) and above (600: padded batch > 512, the step is the split-K pair of launches)
     the fused-step limit."""
     import deep_rl_amd as D
     import deep_rl_amd.sac_engine as SE
@@ -615,7 +615,7 @@ def test_deferred_critic_step_is_bit_identical_to_a_launch_of_its_own(dev, batch
         eng = D.SACEngine(env, actor, q1, q2, q1t, q2t, slots=40, batch_size=batch, learning_starts=4)
         eng.reset()
         carried = settled = 0
-        for _ in range(30):
+        for _ in range(31):                              # (an odd last step: no actor update behind the last critic update, its step stays owed)
             carried += eng._owed_critic is not None      # a debt at this point rides on the acting launch
             eng.act()
             assert eng._owed_critic is None
