@@ -250,7 +250,30 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
 // replicas) while the three forward waves evaluate the Q-network on it, and publishes them as records in LDS; after the step's one barrier every wave
 // derives the action from the partial sums and picks the chosen record — the forward waves only its observation.  The dynamics wave also draws the
 // exploration words one step ahead, keeps the episode bookkeeping and writes the ring.  Same keyed draws, same IEEE sequence per env: bit-identical
-// trajectories (tests/test_gpu_dqn.py runs unchanged).
+// trajectories (tests/test_gpu_dqn.py runs unchanged).  Round 4 (tools/dqn_act_stamps.py, -DDA_STAMPS): a step is 4,100 cycles at 2.23 GHz = 1.85 us, of which the forward
+// waves' chain is 3,450 (72 MFMAs = 2,304) + 170 at the barrier + 480 for the action and the chosen record; the dynamics wave waits 40 % of the step.  The launch is
+// 30.6 us by rocprof for an 18.5 us loop: 2.3 us of weight prologue, <= 0.5 us of start skew between XCDs, and the rest around the first entry and the last exit.
+// Nontemporal ring stores: +0.9 us per iteration; write-through (sc0 sc1) ring stores: -0.2 us, inside the noise — neither kept.
+#ifdef DA_STAMPS   // diagnostic build: where a forward wave (0) and the dynamics wave (3) of workgroup DA_STAMP_WG spend a step (s_memtime), tools/dqn_act_stamps.py
+#ifndef DA_STAMP_WG
+#define DA_STAMP_WG 100
+#endif
+__device__ unsigned long long da_stamp_dbg[2][8];
+__device__ unsigned long long da_mark_dbg[8][2][4][256];   // [forward wave 0 | dynamics wave][kernel entry, loop start, loop end, exit][workgroup]: s_memrealtime (100 MHz)
+#define DA_MARK(k) do { if (lane == 0 && (w == 0 || w == 3) && blockIdx.x < 256) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); \
+                        da_mark_dbg[(global_step / n_steps) & 7][w == 3][k][blockIdx.x] = rt_; } } while (0)
+extern "C" int mi_debug_dqn_act_marks(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(da_mark_dbg), sizeof(unsigned long long) * 8 * 2 * 4 * 256) == hipSuccess ? 0 : -2;
+}
+#define DA_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                         da_acc[k] += t_ - da_last; da_last = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int mi_debug_dqn_act_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(da_stamp_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+#else
+#define DA_STAMP(k) do {} while (0)
+#define DA_MARK(k) do {} while (0)
+#endif
 struct __attribute__((aligned(16))) da4_rec {
     float4 ob;                      // successor observation (the reset observation where the step ends the episode)
     double x, xd, th, thd;          // successor state (after the reset where done)
@@ -273,6 +296,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
     const bool phys = w == 3;
+    DA_MARK(0);
     const int N = e.n;
     const int i = blockIdx.x * DA_ENVS + j;
     const bool mine = i < N;
@@ -344,6 +368,13 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr0), "+v"(b30), "+v"(b31));
     __syncthreads();
     int a = 0;
+#ifdef DA_STAMPS
+    unsigned long long da_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, da_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(da_last) :: "memory");
+    const unsigned long long da_first = da_last;
+    unsigned long long da_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(da_rt0) :: "memory");
+#endif
     // bookkeeping of one committed step (dynamics wave, lane group 0): dqn.py:95, :106-108 and the episode statistics
     long long slot = global_step % slots;   // ring slot of the step being committed; advanced by compare-and-wrap (a 64-bit modulo per step is ~150 scalar instructions)
     auto commit = [&](int s, int act, const da4_rec& rc) {
@@ -365,6 +396,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
         }
         slot = nslot;
     };
+    DA_MARK(1);
     for (int s = 0; s < n_steps; ++s) {
         const int par = s & 1;
         if (!phys) {
@@ -398,8 +430,10 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
                 p1 += __shfl_xor(p1, 16); p1 += __shfl_xor(p1, 32);   //  post-barrier round trip are each ~1.5 us per launch SLOWER here)
                 if (lg == 0) { sm.qp[par][w][j][0] = p0; sm.qp[par][w][j][1] = p1; }
             }
+            DA_STAMP(0);
         } else {
             if (s > 0) commit(s - 1, a, sm.rec[par ^ 1][a][j]);
+            DA_STAMP(0);
             // both successors of the committed state: this lane group's action
             double nx = sx, nxd = sxd, nth = sth, nthd = sthd;
             int term;
@@ -429,9 +463,12 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
                 rc.elapsed = nel; rc.eplen = nlen; rc.epret = nret; rc.flags = (term ? 1 : 0) | (d ? 2 : 0);
                 rc.fin_len = fin_len; rc.fin_ret = fin_ret; rc.ep_lo = (unsigned)nep; rc.ep_hi = (unsigned)(nep >> 32);
             }
+            DA_STAMP(1);
             if (lg == 0 && s + 1 < n_steps) sm.expl[(s + 1) & 3][j] = draw(s + 1);
+            DA_STAMP(2);
         }
         __syncthreads();
+        DA_STAMP(3);
         // every wave: the action of step s (dqn.py:86-92)
         if (FORCED && forced_actions) a = (int)forced_actions[(size_t)s * N + g];
         else {
@@ -444,7 +481,20 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
             }
         }
         if (!phys) ob = sm.rec[par][a][j].ob;
+#ifdef DA_STAMPS
+        asm volatile("" :: "v"(ob.x), "v"(a));
+#endif
+        DA_STAMP(4);
     }
+    DA_MARK(2);
+#ifdef DA_STAMPS
+    if (blockIdx.x == DA_STAMP_WG && lane == 0 && (w == 0 || w == 3)) {
+        for (int k = 0; k < 5; ++k) da_stamp_dbg[w == 3][k] = da_acc[k];
+        unsigned long long da_rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(da_rt1) :: "memory");
+        da_stamp_dbg[w == 3][5] = da_last - da_first; da_stamp_dbg[w == 3][6] = (unsigned long long)n_steps; da_stamp_dbg[w == 3][7] = da_rt1 - da_rt0;   // [7]: 100 MHz ticks
+    }
+#endif
     if (phys) {
         commit(n_steps - 1, a, sm.rec[(n_steps - 1) & 1][a][j]);
         if (writer) {
@@ -454,6 +504,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
             if (episode_stats && st_cnt > 0) { atomicAdd(episode_stats, st_cnt); atomicAdd(episode_stats + 1, st_len); atomicMax(episode_stats + 2, st_max); }
         }
     }
+    DA_MARK(3);
 }
 
 // Negative result (round 2, measured, removed): the PPO rollout's lane = unit formulation on the 16-block 4x4x1 MFMA (4 envs per 2-wave workgroup,
