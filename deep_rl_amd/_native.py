@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
-ABI_VERSION = 103   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
+ABI_VERSION = 104   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
@@ -94,6 +94,7 @@ SIGNATURES = {
     "mi_dqn_td_grad": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _D, _VP, _VP, _VP, _VP]),
     "mi_ppo_perms_and_stats": (_I, [_U64, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "mi_ppo_rollout_gae": (_I, [_VP, _VP, _I] + [_VP] * 9 + [_I, _F, _F, _VP, _VP, _VP]),
+    "mi_env_episode_stats": (_I, [_VP, _VP, _VP]),
     "mi_env_state_bytes": (_SZ, [_VP]),
     "mi_env_export_state": (_I, [_VP, _VP, _VP]),
     "mi_env_import_state": (_I, [_VP, _VP, _VP]),

@@ -64,7 +64,16 @@ struct mi_env {
     int32_t* ep_len;
     uint64_t* episode;   // resets so far (index of the next reset-noise draw)
     uint64_t* step_ctr;  // actions sampled so far (index of the next action uniform)
+    // episode statistics WITHOUT same-address atomics: workgroup b of an acting / rollout launch stores {finished episodes, sum of their lengths, longest} at
+    // stats_part[4 b ..] with plain stores; mi_env_stats_reduce sums the stats_n slots of the last such launch on request.  (Agent-scope atomics on one address are
+    // performed one after the other at the memory side, ~8.5 ns each on an MI355X, and a launch is not over before the last one: 3 x 1024 of them kept
+    // rollout_q4_kernel open for 26 us, 3 x 256 dqn_act4_kernel for 9 us — round 4, tools/dqn_act_stamps.py, profiles/r04h_*.)
+    int32_t* stats_part;
+    int stats_cap, stats_n;   // slots allocated; slots written by the last launch that kept its statistics here (host-side bookkeeping, -1: none yet)
 };
+#define MI_STATS_PART_MIN 32   // launches of at least this many workgroups keep their statistics per workgroup (below it the few atomics are cheaper than a reduction)
+// sums the per-workgroup statistics of the last launch into out[0..3] = {episodes, sum of lengths, longest, 0} (device pointer; one small launch)
+int mi_env_stats_reduce(mi_env* e, int32_t* out, hipStream_t s);
 
 int mi_pend_reset_impl(mi_env* e, float* obs, const double* forced_state, hipStream_t s);
 int mi_rollout_gae_internal(void* handle, const float* params, int T, float* obs_cur, float* observations, float* values, int64_t* actions, float* log_probs,

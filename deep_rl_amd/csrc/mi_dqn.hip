@@ -106,7 +106,7 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
                dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
                int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
                const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
-               int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next) {
+               int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next, int32_t* __restrict__ stats_part) {
     __shared__ float qp[2][DA_WAVES][DA_ENVS][2];
     if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;   // the NEXT acting call's statistics (nobody else touches them during this launch)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
@@ -240,7 +240,13 @@ dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lon
         e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
         e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr;
         reinterpret_cast<float4*>(obs_cur)[g] = ob;
-        if (episode_stats && st_cnt > 0) { atomicAdd(episode_stats, st_cnt); atomicAdd(episode_stats + 1, st_len); atomicMax(episode_stats + 2, st_max); }
+    }
+    if ((episode_stats || stats_part) && w == 0) {   // one flush per workgroup (see dqn_act4_kernel)
+        int c = writer ? st_cnt : 0, l = writer ? st_len : 0, m = writer ? st_max : 0;
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
+        if (stats_part) { if (lane == 0) reinterpret_cast<int4*>(stats_part)[blockIdx.x] = make_int4(c, l, m, 0); }
+        else if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
     }
 }
 
@@ -270,6 +276,17 @@ extern "C" int mi_debug_dqn_act_marks(unsigned long long* out) {
 extern "C" int mi_debug_dqn_act_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(da_stamp_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
 }
+__device__ unsigned long long da_tiny_dbg[64][2];
+__global__ void da_tiny_kernel(int i) {   // a one-wave launch that only marks its entry and exit: put between two acting launches it splits their boundary into an end and a start
+    unsigned long long t0, t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    if (threadIdx.x == 0) { da_tiny_dbg[i & 63][0] = t0; da_tiny_dbg[i & 63][1] = t1; }
+}
+extern "C" int mi_debug_tiny_mark(int i, void* stream) { da_tiny_kernel<<<1, 64, 0, (hipStream_t)stream>>>(i); return hipGetLastError() == hipSuccess ? 0 : -2; }
+extern "C" int mi_debug_tiny_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(da_tiny_dbg), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -2;
+}
 #else
 #define DA_STAMP(k) do {} while (0)
 #define DA_MARK(k) do {} while (0)
@@ -291,7 +308,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
                 dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
                 int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
                 const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
-                int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next) {
+                int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next, int32_t* __restrict__ stats_part) {
     __shared__ da4_smem sm;
     if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
@@ -382,10 +399,13 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
         sx = rc.x; sxd = rc.xd; sth = rc.th; sthd = rc.thd; elapsed = rc.elapsed; eplen = rc.eplen; epret = rc.epret;
         episode = ((uint64_t)rc.ep_hi << 32) | rc.ep_lo;
         if (writer) {
-            actions[slot * N + g] = act;
-            reinterpret_cast<float4*>(observations)[nslot * N + g] = rc.ob;
-            rewards[nslot * N + g] = 1.0f;
-            terminated[nslot * N + g] = (uint8_t)(rc.flags & 1);
+#ifndef DA_ABLATE
+#define DA_ABLATE 0   // timing-only ablations of the stamp builds (results invalid): bit 0 no terminated store, 1 no rewards, 2 no actions, 3 no observations, 4 no final state
+#endif
+            if (!(DA_ABLATE & 4)) actions[slot * N + g] = act;
+            if (!(DA_ABLATE & 8)) reinterpret_cast<float4*>(observations)[nslot * N + g] = rc.ob;
+            if (!(DA_ABLATE & 2)) rewards[nslot * N + g] = 1.0f;
+            if (!(DA_ABLATE & 1)) terminated[nslot * N + g] = (uint8_t)(rc.flags & 1);
             if (rc.flags & 2) {
                 st_cnt += 1; st_len += rc.fin_len; st_max = rc.fin_len > st_max ? rc.fin_len : st_max;
                 if (EPLOG && max_ep > 0 && episode_stats) {
@@ -497,13 +517,43 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
 #endif
     if (phys) {
         commit(n_steps - 1, a, sm.rec[(n_steps - 1) & 1][a][j]);
+#if DA_ABLATE & 512
+        if (writer) e.x[g] = sx;
+#elif DA_ABLATE & 1024
+        if (writer) {   // the same stores into ring memory instead of the env slab
+            char* base = reinterpret_cast<char*>(observations) + (size_t)((slot + 3) % slots) * N * 16;
+            double* d0 = reinterpret_cast<double*>(base); const size_t n_ = (size_t)N;
+            d0[g] = sx; d0[n_ + g] = sxd; d0[2 * n_ + g] = sth; d0[3 * n_ + g] = sthd;
+            reinterpret_cast<uint64_t*>(d0 + 4 * n_)[g] = episode; reinterpret_cast<uint64_t*>(d0 + 5 * n_)[g] = stepctr0 + (uint64_t)n_steps;
+            int* i0 = reinterpret_cast<int*>(d0 + 6 * n_); i0[g] = elapsed; i0[n_ + g] = eplen; reinterpret_cast<float*>(i0 + 2 * n_)[g] = epret;
+        }
+#elif DA_ABLATE & 2048
         if (writer) {
-            e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
-            e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr0 + (uint64_t)n_steps;
-            reinterpret_cast<float4*>(obs_cur)[g] = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
-            if (episode_stats && st_cnt > 0) { atomicAdd(episode_stats, st_cnt); atomicAdd(episode_stats + 1, st_len); atomicMax(episode_stats + 2, st_max); }
+            e.x[g] = 1.0; e.x_dot[g] = 1.0; e.theta[g] = 0.01; e.theta_dot[g] = 0.01;
+            e.elapsed[g] = 3; e.ep_ret[g] = 3.0f; e.ep_len[g] = 3; e.episode[g] = 5; e.step_ctr[g] = 7;
+        }
+#else
+        if (writer && !(DA_ABLATE & 16)) {
+            if (!(DA_ABLATE & 32)) { e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd; }
+            if (!(DA_ABLATE & 128)) { e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; }
+            if (!(DA_ABLATE & 64)) { e.episode[g] = episode; e.step_ctr[g] = stepctr0 + (uint64_t)n_steps; }
+            if (!(DA_ABLATE & 256)) reinterpret_cast<float4*>(obs_cur)[g] = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
+        }
+#endif
+        // one flush per workgroup — and no atomics when the launch has many workgroups: same-address agent-scope atomics are performed one after the other at the
+        // memory side, and a launch is not over before the last of them (round 4, tools/dqn_act_stamps.py: 3 x 256 of them kept this launch open for 8.8 us after
+        // its last wave had left; the statistics then go to the workgroup's slot in the handle and are summed on request, mi_common.h)
+        if (episode_stats || stats_part) {
+            int c = writer ? st_cnt : 0, l = writer ? st_len : 0, m = writer ? st_max : 0;
+#pragma unroll
+            for (int sft = 1; sft < 16; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
+            if (stats_part) { if (lane == 0) reinterpret_cast<int4*>(stats_part)[blockIdx.x] = make_int4(c, l, m, 0); }
+            else if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
         }
     }
+#if defined(DA_STAMPS) && (DA_ABLATE & 4096)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the exit mark then includes the acknowledgement of this wave's stores
+#endif
     DA_MARK(3);
 }
 
@@ -524,7 +574,11 @@ static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t 
     MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
     mi_env* e = (mi_env*)handle;
     hipStream_t s = (hipStream_t)stream;
-    if (episode_stats && zero_now) { dqn_zero_stats_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    const bool forced = forced_actions || forced_resets, eplog = max_ep > 0 && episode_stats;
+    const int n_wg = (e->n + DA_ENVS - 1) / DA_ENVS;
+    // episode statistics: per workgroup in the handle when there is no buffer (mi_env_episode_stats) or when the launch is large (summed into the buffer right behind it)
+    const bool part = !eplog && (!episode_stats || n_wg >= MI_STATS_PART_MIN) && n_wg <= e->stats_cap;
+    if (episode_stats && !part && zero_now) { dqn_zero_stats_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
     // epsilon = max(slope * global_step + start_e, end_e) in the reference's double arithmetic (dqn.py:47,86), evaluated on
     // the host for the n_steps of this call and handed over by value (no allocation, no copy to enqueue)
     dqn_eps_tab tab;
@@ -533,8 +587,8 @@ static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t 
         const double ev = slope * (double)(global_step + k) + start_e;
         tab.v[k] = (float)(ev > end_e ? ev : end_e);
     }
+    {
     mi_prof_scope prof(MI_PROF_DQN_ACT, s);
-    const bool forced = forced_actions || forced_resets, eplog = max_ep > 0 && episode_stats;
 #ifdef DQN_ACT3   // A/B: the 3-wave form (every forward wave carries the dynamics)
     const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(64 * DA_WAVES);
 #define DA_KERNEL dqn_act_kernel
@@ -544,11 +598,14 @@ static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t 
 #endif
 #define DA_LAUNCH(F, L) DA_KERNEL<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
                                                                   obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes, \
-                                                                  episode_stats, max_ep, zero_next)
+                                                                  part ? nullptr : episode_stats, max_ep, zero_next, part ? e->stats_part : nullptr)
     if (forced) { if (eplog) DA_LAUNCH(true, true); else DA_LAUNCH(true, false); }
     else { if (eplog) DA_LAUNCH(false, true); else DA_LAUNCH(false, false); }
 #undef DA_LAUNCH
     MI_LAUNCH_CHECK();
+    }
+    if (part) { e->stats_n = n_wg; if (episode_stats) return mi_env_stats_reduce(e, episode_stats, s); }
+    else if (!episode_stats) e->stats_n = 0;
     return MI_OK;
 }
 

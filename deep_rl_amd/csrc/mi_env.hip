@@ -99,16 +99,24 @@ extern "C" int mi_env_create(int kind, int n_envs, uint64_t seed, uint64_t env_i
     // one slab: 4 f64 + 2 u64 + 2 i32 + 1 f32 per env
     char* slab = nullptr;
     const size_t bytes = n * (4 * 8 + 2 * 8 + 3 * 4);
-    if (hipMalloc(&slab, bytes) != hipSuccess) {
+#ifndef MI_ENV_SLAB_GRANULE
+#define MI_ENV_SLAB_GRANULE ((size_t)2 << 20)
+#endif
+    // (allocated in whole 2 MB granules so that the slab is mapped with large page-table fragments)
+    const int stats_cap = (n_envs + 3) / 4 + 1;   // the smallest workgroup of any acting kernel owns 4 envs (rollout_q4_kernel)
+    const size_t bytes_all = (bytes + 15) / 16 * 16 + (size_t)stats_cap * 16;
+    const size_t alloc = (bytes_all + MI_ENV_SLAB_GRANULE - 1) / MI_ENV_SLAB_GRANULE * MI_ENV_SLAB_GRANULE;
+    if (hipMalloc(&slab, alloc) != hipSuccess) {
         delete e;
-        mi_set_error("mi_env_create: hipMalloc(%zu) failed", bytes);
+        mi_set_error("mi_env_create: hipMalloc(%zu) failed", alloc);
         return MI_ENOMEM;
     }
-    MI_HIP(hipMemset(slab, 0, bytes));
+    MI_HIP(hipMemset(slab, 0, bytes_all));
     e->x = (double*)slab; e->x_dot = e->x + n; e->theta = e->x_dot + n; e->theta_dot = e->theta + n;
     e->episode = (uint64_t*)(e->theta_dot + n); e->step_ctr = e->episode + n;
     e->elapsed = (int32_t*)(e->step_ctr + n); e->ep_len = e->elapsed + n;
     e->ep_ret = (float*)(e->ep_len + n);
+    e->stats_part = (int32_t*)(slab + (bytes + 15) / 16 * 16); e->stats_cap = stats_cap; e->stats_n = -1;
     *handle = e;
     return MI_OK;
 }
@@ -133,6 +141,36 @@ extern "C" int mi_env_import_state(void* handle, const void* src, void* stream) 
     mi_env* e = (mi_env*)handle;
     MI_HIP(hipMemcpyAsync(e->x, src, mi_env_state_bytes(handle), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MI_OK;
+}
+
+// ---- episode statistics kept per workgroup (mi_common.h) --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) env_stats_reduce_kernel(const int32_t* __restrict__ part, int n, int32_t* __restrict__ out) {
+    __shared__ int sc[4], sl[4], sm[4];
+    int c = 0, l = 0, m = 0;
+    for (int b = threadIdx.x; b < n; b += 256) {
+        const int4 v = reinterpret_cast<const int4*>(part)[b];
+        c += v.x; l += v.y; m = v.z > m ? v.z : m;
+    }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
+    if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = c; sl[threadIdx.x >> 6] = l; sm[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (sc[0] + sc[1]) + (sc[2] + sc[3]); out[1] = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+        const int a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+        out[2] = a > b ? a : b; out[3] = 0;
+    }
+}
+int mi_env_stats_reduce(mi_env* e, int32_t* out, hipStream_t s) {
+    env_stats_reduce_kernel<<<1, 256, 0, s>>>(e->stats_part, e->stats_n > 0 ? e->stats_n : 0, out);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+extern "C" int mi_env_episode_stats(void* handle, int32_t* out, void* stream) {
+    MI_CHECK_ARG(handle && out, "NULL pointer");
+    mi_env* e = (mi_env*)handle;
+    if (e->stats_n < 0) { mi_set_error("mi_env_episode_stats: no acting / rollout call with episode_stats == NULL has run on this handle yet"); return MI_ESTATE; }
+    return mi_env_stats_reduce(e, out, (hipStream_t)stream);
 }
 
 extern "C" int mi_env_destroy(void* handle) {

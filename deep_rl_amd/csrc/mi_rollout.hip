@@ -165,7 +165,7 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                   const float* __restrict__ forced_uniforms, const double* __restrict__ forced_resets,
                   mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep,
                   float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n,
-                  int32_t* __restrict__ zero_i32) {
+                  int32_t* __restrict__ zero_i32, int32_t* __restrict__ stats_part) {
     __shared__ rq_smem sm;
 #ifdef RQ_STAMPS
     if (blockIdx.x == 517 && threadIdx.x == 0) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + 600] = rt_; }
@@ -319,11 +319,12 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
         if (lane == 0 && blockIdx.x < 1024) { for (int k = 0; k < 4; ++k) rq_stamp_dbg[blockIdx.x * 8 + k] = rq_acc[k]; }
 #endif
         __builtin_amdgcn_s_setprio(0);
-        if (episode_stats) {   // lanes 0..3: one flush per workgroup
+        if (episode_stats || stats_part) {   // lanes 0..3: one flush per workgroup
             int c = writer ? st_cnt : 0, l = writer ? st_len : 0, m = writer ? st_max : 0;
 #pragma unroll
             for (int sft = 1; sft < 4; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
-            if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
+            if (stats_part) { if (lane == 0) reinterpret_cast<int4*>(stats_part)[blockIdx.x] = make_int4(c, l, m, 0); }   // summed on request (mi_common.h: no atomics)
+            else if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
         }
         if (writer) {   // carry-over `observation` and env state for the next rollout
             e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
@@ -462,19 +463,26 @@ static int rollout_impl(void* handle, const float* params, int T, float* obs_cur
     MI_CHECK_ARG(max_ep >= 0 && (max_ep == 0 || episodes), "episodes buffer missing");
     mi_env* e = (mi_env*)handle;
     hipStream_t s = (hipStream_t)stream;
-    // statistics double-buffered by the caller (stats_next): episode_stats is zero on entry and this launch zeroes the other buffer — no reset launch
-    if (episode_stats && !stats_next) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
-    mi_prof_scope prof(MI_PROF_ROLLOUT, s);
     const bool forced = forced_actions || forced_uniforms || forced_resets, eplog = max_ep > 0 && episode_stats;
     const dim3 grid((e->n + RQ_ENVS - 1) / RQ_ENVS);
     const dim3 block(128);
+    // episode statistics: episode_stats == NULL keeps them per workgroup in the handle (mi_env_episode_stats sums them on request: no atomics, no launch); with a
+    // buffer, launches of >= MI_STATS_PART_MIN workgroups do the same and sum them into it right behind the launch, smaller ones (and the episode log) use atomics
+    const bool part = !eplog && (!episode_stats || (int)grid.x >= MI_STATS_PART_MIN) && (int)grid.x <= e->stats_cap;
+    // atomics: statistics double-buffered by the caller (stats_next): episode_stats is zero on entry and this launch zeroes the other buffer — no reset launch
+    if (episode_stats && !part && !stats_next) { zero_i32x4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
+    {
+        mi_prof_scope prof(MI_PROF_ROLLOUT, s);
 #define RQ_LAUNCH(F, L) rollout_q4_kernel<F, L><<<grid, block, 0, s>>>(*e, params, T, obs_cur, observations, values, actions, log_probs, rewards, dones, \
-                                                                     forced_actions, forced_uniforms, forced_resets, episodes, episode_stats, max_ep, \
-                                                                     advantages, returns, gamma, lam, zero_f64, zero_n, stats_next)
-    if (forced) { if (eplog) RQ_LAUNCH(true, true); else RQ_LAUNCH(true, false); }
-    else { if (eplog) RQ_LAUNCH(false, true); else RQ_LAUNCH(false, false); }
+                                                                     forced_actions, forced_uniforms, forced_resets, episodes, part ? nullptr : episode_stats, max_ep, \
+                                                                     advantages, returns, gamma, lam, zero_f64, zero_n, stats_next, part ? e->stats_part : nullptr)
+        if (forced) { if (eplog) RQ_LAUNCH(true, true); else RQ_LAUNCH(true, false); }
+        else { if (eplog) RQ_LAUNCH(false, true); else RQ_LAUNCH(false, false); }
 #undef RQ_LAUNCH
-    MI_LAUNCH_CHECK();
+        MI_LAUNCH_CHECK();
+    }
+    if (part) { e->stats_n = (int)grid.x; if (episode_stats) return mi_env_stats_reduce(e, episode_stats, s); }
+    else if (!episode_stats) e->stats_n = 0;
     return MI_OK;
 }
 

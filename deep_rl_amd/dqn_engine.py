@@ -39,7 +39,12 @@ class DQNEngine:
         self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
         self._stats2 = torch.zeros((2, 4), dtype=torch.int32, device=dev)   # double-buffered: an acting launch zeroes the NEXT call's statistics
         self._stats_i = 0
-        self.episode_stats = self._stats2[0]
+        self._stats_buf = self._stats2[0]
+        # without an episode log the statistics stay per workgroup inside the env handle (no atomics in the acting launch: -9 us at 4096 envs) and
+        # `episode_stats` sums them when somebody reads it (mi_env_episode_stats)
+        self._lazy_stats = self.max_ep == 0
+        self._stats_lazy = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._stats_ready, self._stats_any = False, False
         self.observation = None
         self.global_step = 0      # time steps taken (each advances every env once)
         self.update_index = 0
@@ -61,9 +66,27 @@ class DQNEngine:
         fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
         self._act_launch(self.q.flat, n_steps, fa, fr)
 
+    @property
+    def episode_stats(self):
+        """{finished episodes, sum of their lengths, longest, slots of the episode log} of the last act() call (device i32 [4])."""
+        if not self._lazy_stats:
+            return self._stats_buf
+        if not self._stats_ready and self._stats_any:
+            N.check(N.lib().mi_env_episode_stats(self.env.handle, N.ptr(self._stats_lazy), self._s()), "mi_env_episode_stats")
+            self._stats_ready = True
+        return self._stats_lazy
+
     def _act_launch(self, flat, n_steps, fa, fr):
+        if self._lazy_stats:
+            self._stats_ready, self._stats_any = False, True
+            N.check(N.lib().mi_dqn_act_steps(
+                self.env.handle, N.ptr(flat), int(n_steps), self.global_step, self.slots, self.learning_starts, self.start_e, self.end_e,
+                self.exploration_fraction, self.total_timesteps, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.actions),
+                N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fr), None, None, 0, self._s()), "mi_dqn_act_steps")
+            self.global_step += int(n_steps)
+            return
         cur, nxt = self._stats2[self._stats_i], self._stats2[self._stats_i ^ 1]
-        self.episode_stats = cur
+        self._stats_buf = cur
         N.check(N.lib().mi_dqn_act_steps2(
             self.env.handle, N.ptr(flat), int(n_steps), self.global_step, self.slots, self.learning_starts, self.start_e, self.end_e,
             self.exploration_fraction, self.total_timesteps, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.actions),

@@ -26,7 +26,8 @@ def it():
 for _ in range(50): it()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.iters): it()
+t_enq = time.perf_counter() - t0   # host time to ENQUEUE the loop: if it is the whole of dt the loop is host-bound, not GPU-bound
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({"variant": a.variant, "workload": "dqn.py CartPole-v1, %d envs, %d-slot ring (%d transitions), batch %d, train every 10 steps" % (a.envs, a.slots, a.envs * a.slots, a.batch),
-                  "env_steps_per_s": round(a.iters * 10 * a.envs / dt, 1), "updates_per_s": round(a.iters / dt, 1), "us_per_iteration": round(1e6 * dt / a.iters, 1),
+                  "env_steps_per_s": round(a.iters * 10 * a.envs / dt, 1), "updates_per_s": round(a.iters / dt, 1), "us_per_iteration": round(1e6 * dt / a.iters, 1), "host_enqueue_us_per_iteration": round(1e6 * t_enq / a.iters, 1),
                   "loss": float(eng.loss.item())}))

@@ -25,7 +25,8 @@ def it():
 for _ in range(60): it()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.iters): it()
+t_enq = time.perf_counter() - t0   # host time to ENQUEUE the loop: if it is the whole of dt the loop is host-bound, not GPU-bound
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({"workload": "sac.py Pendulum-v1, %d envs, %d-slot ring (%d transitions), batch %d, 1 critic + 1 actor + 1 alpha update per time step" % (a.envs, a.slots, a.envs * a.slots, a.batch),
-                  "env_steps_per_s": round(a.iters * a.envs / dt, 1), "updates_per_s": round(a.iters / dt, 1), "us_per_iteration": round(1e6 * dt / a.iters, 1),
+                  "env_steps_per_s": round(a.iters * a.envs / dt, 1), "updates_per_s": round(a.iters / dt, 1), "us_per_iteration": round(1e6 * dt / a.iters, 1), "host_enqueue_us_per_iteration": round(1e6 * t_enq / a.iters, 1),
                   "q_losses": eng.q_losses.tolist(), "alpha": float(eng.alpha)}))

@@ -42,3 +42,27 @@ for L in range(8):
     x = m[L] - m[L][:, 0].min()
     print("launch slot %d: entry by XCD (workgroup %% 8): %s | loop start mean %.2f | last exit %.2f us" % (
         L, " ".join("%.2f" % x[0, 0][k::8].mean() for k in range(8)), x[0, 1].mean(), x[:, 3].max()))
+# back-to-back acting launches only: the time between the last exit of one launch and the first entry of the next, by the same 100 MHz counter
+for _ in range(64): eng.act(10)
+torch.cuda.synchronize()
+assert fm(mk) == 0
+m = np.array(mk, dtype=np.float64).reshape(8, 2, 4, 256) / 100.0
+order = np.argsort(m[:, 0, 0].min(axis=1))
+for a, b in zip(order[:-1], order[1:]):
+    print("acting launch -> acting launch: span %.2f us, then %.2f us until the first entry of the next one (period %.2f)" % (
+        m[a][:, 3].max() - m[a][:, 0].min(), m[b][:, 0].min() - m[a][:, 3].max(), m[b][:, 0].min() - m[a][:, 0].min()))
+# the same with a one-wave marker launch between two acting launches: how much of the boundary is the END of the acting launch, how much the START of the next
+ft = N.lib().mi_debug_tiny_mark; ft.argtypes = [C.c_int, C.c_void_p]; ft.restype = C.c_int
+fr = N.lib().mi_debug_tiny_read; fr.argtypes = [C.c_void_p]; fr.restype = C.c_int
+for i in range(64):
+    eng.act(10); assert ft(eng.global_step // 10, N.stream_ptr(dev)) == 0
+torch.cuda.synchronize()
+tb = (C.c_ulonglong * 128)()
+assert fm(mk) == 0 and fr(tb) == 0
+m = np.array(mk, dtype=np.float64).reshape(8, 2, 4, 256) / 100.0
+tm = np.array(tb, dtype=np.float64).reshape(64, 2) / 100.0
+gs = eng.global_step // 10
+for L in range(gs - 6, gs):          # acting launch L ran in slot (L - 1) & 7 (its global_step / 10 before the call), the marker behind it carries index L
+    a, b = m[(L - 1) & 7], m[L & 7]
+    print("acting launch (span %.2f us) -> %.2f us -> marker launch (%.2f us) -> %.2f us -> first entry of the next acting launch" % (
+        a[:, 3].max() - a[:, 0].min(), tm[L & 63, 0] - a[:, 3].max(), tm[L & 63, 1] - tm[L & 63, 0], b[:, 0].min() - tm[L & 63, 1]))
