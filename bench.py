@@ -404,7 +404,7 @@ def sharded_route_leg(eng, one_update, timed_updates, u0, steps, dev, base_ms, b
       (a) with mi_ppo_test_assume_sharded(1): the owed optimizer steps recompute the clip coefficient from the 9,155 gradients (norm_parts = nullptr) — the prologue every
           rank of a sharded run executes;
       (b) the same on mi_ppo_update_sharded over a REAL one-rank RCCL communicator: 17 in-stream ncclAllReduce per update on top.
-    Deltas are against this run's headline window; per optimizer step = / 16.  Untimed for the headline: runs after it."""
+    Deltas are against a plain window timed right in front of the legs; per optimizer step = / 16.  Untimed for the headline: runs after it."""
     import socket
 
     import torch
@@ -413,7 +413,12 @@ def sharded_route_leg(eng, one_update, timed_updates, u0, steps, dev, base_ms, b
     import deep_rl_amd.engine as E
 
     out = {"note": "single GPU; (a) the world_size > 1 form of the owed clip + Adam step without a collective, (b) the same through mi_ppo_update_sharded on a one-rank RCCL "
-                   "communicator (17 in-stream all-reduces per update); deltas vs this run's headline window, per optimizer step = / 16"}
+                   "communicator (17 in-stream all-reduces per update); deltas vs a plain window timed right in front of the legs, per optimizer step = / 16"}
+    # the baseline of the deltas: one more plain window right here (same learning state, same clocks as the two legs behind it — the headline's first window is up to
+    # 10 us per update away from later ones, which is the size of the effect being measured)
+    dt0, prof0 = timed_updates(u0, steps)
+    base_ms, base_grad_us = 1e3 * dt0 / steps, 1e3 * prof0["grad"][0] / max(prof0["grad"][1], 1)
+    out["baseline"] = {"ms_per_step": round(base_ms, 4), "grad_kernel_avg_launch_us": round(base_grad_us, 2), "what": "a plain window of the same K updates right in front of the legs"}
     E.set_assume_sharded(True)
     try:
         for _ in range(2):
