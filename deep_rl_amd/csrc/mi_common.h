@@ -53,6 +53,37 @@ struct mi_prof_scope {
     ~mi_prof_scope() { mi_prof_mark(tag, true, s); }
 };
 
+// ---- the launches seen from inside (diagnostic build -DMI_INSIDE, tools/inside_view.py) ------------------------------------------------------------------------
+// Every wave of an instrumented kernel stores the 100 MHz wall clock (s_memrealtime) at its entry and at its exit (RAII: every return path), and mi_prof_mark puts a
+// one-wave marker launch in front of and behind every tagged launch.  Per tag the tool prints: marker -> first entry (start-up), first entry -> last exit (span), last
+// exit -> marker (how long the launch stays open after its last wave has left: memory-side atomics, write-backs ...).  rocprof, the counters and the stamp builds charge
+// all three to "the kernel".  One array per translation unit (no relocatable device code in this build): MI_INSIDE_EXPORT(tu) exports its reader.
+#ifdef MI_INSIDE
+#define MI_INSIDE_SLOTS 16384   // wave slots per tag
+static __device__ unsigned long long mi_inside_marks[18][2][MI_INSIDE_SLOTS];
+struct mi_inside_guard {
+    int tag;
+    __device__ __forceinline__ static void mark(int tag, int which) {
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            const unsigned slot = (blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            if (slot < MI_INSIDE_SLOTS) mi_inside_marks[tag][which][slot] = t;
+        }
+    }
+    __device__ __forceinline__ explicit mi_inside_guard(int t) : tag(t) { mark(tag, 0); }
+    __device__ __forceinline__ ~mi_inside_guard() { mark(tag, 1); }
+};
+#define MI_INSIDE_SCOPE(tag) mi_inside_guard mi_inside_guard_(tag)
+#define MI_INSIDE_EXPORT(tu) \
+    extern "C" int mi_debug_inside_##tu(unsigned long long* out, int clear) { \
+        if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(mi_inside_marks)) != hipSuccess) return -2; return hipMemset(p, 0, sizeof(mi_inside_marks)) == hipSuccess ? 0 : -2; } \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(mi_inside_marks), sizeof(mi_inside_marks)) == hipSuccess ? 0 : -2; }
+#else
+#define MI_INSIDE_SCOPE(tag) do {} while (0)
+#define MI_INSIDE_EXPORT(tu)
+#endif
+
 // ---- env handle ----------------------------------------------------------------------------------
 struct mi_env {
     int kind, n, device;   // kind 1 (Pendulum): x = theta, x_dot = theta_dot; theta / theta_dot arrays unused

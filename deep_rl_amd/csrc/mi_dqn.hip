@@ -310,6 +310,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
                 const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
                 int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next, int32_t* __restrict__ stats_part) {
     __shared__ da4_smem sm;
+    MI_INSIDE_SCOPE(MI_PROF_DQN_ACT);
     if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
     const bool phys = w == 3;
@@ -679,6 +680,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
               uint64_t sample_upper, int64_t* idx_out) {
     static_assert(R == 8 || R == 16, "the MFMA passes take the rows as R / 4 k-steps (dW2) and as (part of) a 16-column B operand");
     __shared__ td_smem<R> sm;
+    MI_INSIDE_SCOPE(MI_PROF_DQN_TD);
     const int t = threadIdx.x;
     const int n_groups = (batch + R - 1) / R;
     float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
@@ -943,6 +945,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, rbc2, eps; };
 __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
                                                          float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
+    MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < DQ_NP) {
         // the optimizer state is requested before the slabs, and the slabs 16 at a time with every load in flight at once (the kernel is one memory
@@ -980,6 +983,7 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
 #define DR_MIN_SLABS 64   // from this many slabs on
 __global__ void __launch_bounds__(DR_PARAMS * DR_GROUPS) dqn_reduce2_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
                                                                          float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
+    MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
     const int pl = threadIdx.x & (DR_PARAMS - 1), sg = threadIdx.x >> 6;
     const int pblocks = (DQ_NP + DR_PARAMS - 1) / DR_PARAMS;
     if ((int)blockIdx.x < pblocks) {
@@ -1594,3 +1598,5 @@ extern "C" int mi_per_update_priorities(float* priorities, const int64_t* idx, c
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
+
+MI_INSIDE_EXPORT(dqn)

@@ -260,7 +260,20 @@ static struct {
     size_t used = 0;              // events handed out
 } g_prof;
 
+#ifdef MI_INSIDE
+static __device__ unsigned long long mi_inside_marker[18][2][2];
+__global__ void mi_inside_marker_kernel(int tag, int end) {
+    unsigned long long t0, t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    if (threadIdx.x == 0) { mi_inside_marker[tag][end][0] = t0; mi_inside_marker[tag][end][1] = t1; }
+}
+extern "C" int mi_debug_inside_markers(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(mi_inside_marker), sizeof(mi_inside_marker)) == hipSuccess ? 0 : -2; }
+#endif
 void mi_prof_mark(int tag, bool end, hipStream_t s) {
+#ifdef MI_INSIDE
+    mi_inside_marker_kernel<<<1, 64, 0, s>>>(tag, end ? 1 : 0);
+#endif
     if (!g_prof.armed || !((g_prof.mask >> tag) & 1u)) return;
     if (!end) {
         if (g_prof.used + 2 > g_prof.ev.size()) return;  // pool exhausted: silently stop sampling

@@ -167,6 +167,7 @@ rollout_q4_kernel(mi_env e, const float* __restrict__ params, int T, float* __re
                   float* __restrict__ adv, float* __restrict__ returns, float gamma, float lam, double* __restrict__ zero_f64, int zero_n,
                   int32_t* __restrict__ zero_i32, int32_t* __restrict__ stats_part) {
     __shared__ rq_smem sm;
+    MI_INSIDE_SCOPE(MI_PROF_ROLLOUT);
 #ifdef RQ_STAMPS
     if (blockIdx.x == 517 && threadIdx.x == 0) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); rq_stamp_dbg[8192 + 600] = rt_; }
 #endif
@@ -574,3 +575,5 @@ extern "C" int mi_ppo_forward(const float* params, const float* obs, int n, floa
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
+
+MI_INSIDE_EXPORT(rollout)

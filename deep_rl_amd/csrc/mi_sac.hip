@@ -499,6 +499,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
                   uint64_t update, const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_, uint64_t sample_update, uint64_t sample_upper,
                   int64_t* idx_out, sac_owed_t ow) {
     __shared__ sac_smem sm;
+    MI_INSIDE_SCOPE(MI_PROF_SAC_CRITIC);
     const int bx = (int)blockIdx.x - ow.n_lp;   // row group; the owed alpha step's workgroups come FIRST in dispatch order (blockIdx.x < n_lp of row y = 0): everyone who waits for alpha is behind them
     if (bx < 0) {
         if (blockIdx.y == 0) sac_owed_alpha_role(sm, actor, batch, ws_, ow, (int)blockIdx.x);
@@ -630,6 +631,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
                  int batch, const float* __restrict__ eps, uint64_t seed, uint64_t update, const float* __restrict__ alpha_p, float invn,
                  float* __restrict__ ws_, int logp_only, sac_alpha_t al, sac_owed_t ow, int stash_slot) {
     __shared__ sac_smem sm;
+    MI_INSIDE_SCOPE(logp_only ? MI_PROF_SAC_LOGP : MI_PROF_SAC_ACTOR);
     const int bx = (int)blockIdx.x - ow.n_lp;   // row group; the owed alpha step's workgroups come first in dispatch order (see sac_critic_kernel)
     if (bx < 0) {
         if (blockIdx.y == 0) sac_owed_alpha_role(sm, actor, batch, ws_, ow, (int)blockIdx.x);
@@ -1084,6 +1086,7 @@ __device__ __forceinline__ void sac_dw2_adam_role(sac_dw2_smem& sm, const int bi
 }
 __global__ void __launch_bounds__(512) sac_dw2_adam_kernel(sac_dw2_args_t a) {
     __shared__ sac_dw2_smem sm;
+    MI_INSIDE_SCOPE(MI_PROF_SAC_GEMM);
     sac_dw2_adam_role(sm, (int)blockIdx.x, a.ws, a.batch, a.mat0, a.n_slabs, a.is_actor, a.inv_count, a.grads, a.out2, a.opt);
 }
 
@@ -1130,6 +1133,7 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
                const float* __restrict__ forced_actions, const float* __restrict__ forced_eps, const double* __restrict__ forced_resets,
                mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep, int n_act, sac_dw2_args_t dw) {
     __shared__ sac_smem sm;
+    MI_INSIDE_SCOPE(MI_PROF_SAC_ACT);
     // workgroups behind the acting ones: the critics' weight-gradient + Adam + polyak step owed from the last critic update (mi_sac_act_step_carry).  Acting reads the
     // actor and the env only, the step touches the critics only: no dependency inside the launch; whoever needs the stepped critics sits behind the kernel boundary.
     if ((int)blockIdx.x >= n_act) {
@@ -1662,3 +1666,5 @@ extern "C" int mi_polyak(float* target, const float* param, int n, float tau, vo
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
+
+MI_INSIDE_EXPORT(sac)

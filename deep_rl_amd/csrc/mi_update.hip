@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(256) adv_stats_kernel(const float* __restrict_
 struct ps_epochs_t { uint32_t k0[PS_MAX_EPOCHS], k1[PS_MAX_EPOCHS]; int32_t* out[PS_MAX_EPOCHS]; };   // blockIdx.y = epoch: all epochs of an update in one launch
 __global__ void __launch_bounds__(256) perm_stats_kernel(uint32_t n, uint32_t a, uint32_t b, ps_epochs_t ep, int mb, int n_mb,
                                                          const float* __restrict__ adv, double* __restrict__ sums_all) {
+    MI_INSIDE_SCOPE(MI_PROF_STATS);
     const uint32_t base = blockIdx.x * PS_PER_BLOCK;
     const uint32_t k0 = ep.k0[blockIdx.y], k1 = ep.k1[blockIdx.y];
     int32_t* __restrict__ out = ep.out[blockIdx.y];
@@ -507,6 +508,7 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 __global__ void __launch_bounds__(RED_PARAMS * RED_GROUPS)
 grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra, float ent_coef, float vf_coef, double inv_count,
                    float* __restrict__ grads, float* __restrict__ loss_terms, double* __restrict__ norm_parts) {
+    MI_INSIDE_SCOPE(MI_PROF_REDUCE);
     const int pblocks = (NPARAMS + RED_PARAMS - 1) / RED_PARAMS;
     if ((int)blockIdx.x < pblocks) {
         __shared__ float part[RED_GROUPS][RED_PARAMS];
@@ -660,6 +662,7 @@ __global__ void __launch_bounds__(512) clip_adam_kernel(const float* p_in, const
                                                          float w2, float step_size, float rbc2, float eps, float max_norm,
                                                          float* __restrict__ grad_norm, const double* __restrict__ norm_parts) {
     __shared__ double ws[4], sparts[256];
+    MI_INSIDE_SCOPE(MI_PROF_CLIP_ADAM);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 256 threads, or 512 for a PPO parameter vector (block_grad_norm's 8-wave branch when there are no block sums)
     const bool live = i < n;
     float pm = live ? m_in[i] : 0.0f, pv = live ? v_in[i] : 0.0f;
@@ -1080,3 +1083,5 @@ extern "C" int mi_test_tanh(const float* x, float* y, int n, void* stream) {
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
+
+MI_INSIDE_EXPORT(update)
