@@ -328,31 +328,33 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     dq_f32x4 b2v[2], w3v[2][2];
     float b30 = params[DQ_B3], b31 = params[DQ_B3 + 1];   // every wave derives the action
     if (!phys) {
+        // every request unconditional, from a clamped address, masked afterwards: a guarded load is a basic block of its own (42 of them, 21 with a scalar wait), this form
+        // is ~30 vector loads in flight at once.  120 = 30 x 4 and 84 = 21 x 4: a lane's four consecutive units are all inside or all outside.
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const int ua = 16 * t + j;
-            w1a[t] = ua < DQ_H1 ? params[DQ_W1 + 4 * ua + lg] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int u = 16 * t + 4 * lg + r; b1v[t][r] = u < DQ_H1 ? params[DQ_B1 + u] : 0.0f; }
+            const int ua = 16 * t + j, u0 = 16 * t + 4 * lg;
+            const float wv = params[DQ_W1 + 4 * (ua < DQ_H1 ? ua : DQ_H1 - 1) + lg];
+            const float4 bv = *reinterpret_cast<const float4*>(params + DQ_B1 + (u0 < DQ_H1 ? u0 : DQ_H1 - 4));
+            w1a[t] = ua < DQ_H1 ? wv : 0.0f;
+            b1v[t] = u0 < DQ_H1 ? dq_f32x4{bv.x, bv.y, bv.z, bv.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
-            const int row = 16 * (2 * w + T) + j;
+            const int row = 16 * (2 * w + T) + j, rowc = row < DQ_H2 ? row : DQ_H2 - 1;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int col = 16 * t + 4 * lg;
-                if (row < DQ_H2 && col < DQ_H1) {
-                    const float4 v = *reinterpret_cast<const float4*>(params + DQ_W2 + DQ_H1 * row + col);
-                    w2a[T][t][0] = v.x; w2a[T][t][1] = v.y; w2a[T][t][2] = v.z; w2a[T][t][3] = v.w;
-                } else { w2a[T][t][0] = w2a[T][t][1] = w2a[T][t][2] = w2a[T][t][3] = 0.0f; }
+                const float4 v = *reinterpret_cast<const float4*>(params + DQ_W2 + DQ_H1 * rowc + (col < DQ_H1 ? col : DQ_H1 - 4));
+                const bool in = row < DQ_H2 && col < DQ_H1;
+                w2a[T][t][0] = in ? v.x : 0.0f; w2a[T][t][1] = in ? v.y : 0.0f; w2a[T][t][2] = in ? v.z : 0.0f; w2a[T][t][3] = in ? v.w : 0.0f;
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * (2 * w + T) + 4 * lg + r;
-                b2v[T][r] = o < DQ_H2 ? params[DQ_B2 + o] : 0.0f;
-                w3v[T][0][r] = o < DQ_H2 ? params[DQ_W3 + o] : 0.0f;
-                w3v[T][1][r] = o < DQ_H2 ? params[DQ_W3 + DQ_H2 + o] : 0.0f;
-            }
+            const int o0 = 16 * (2 * w + T) + 4 * lg, oc = o0 < DQ_H2 ? o0 : DQ_H2 - 4;
+            const float4 bb = *reinterpret_cast<const float4*>(params + DQ_B2 + oc);
+            const float4 wa = *reinterpret_cast<const float4*>(params + DQ_W3 + oc), wb = *reinterpret_cast<const float4*>(params + DQ_W3 + DQ_H2 + oc);
+            const bool in = o0 < DQ_H2;
+            b2v[T] = in ? dq_f32x4{bb.x, bb.y, bb.z, bb.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            w3v[T][0] = in ? dq_f32x4{wa.x, wa.y, wa.z, wa.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            w3v[T][1] = in ? dq_f32x4{wb.x, wb.y, wb.z, wb.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     } else {
 #pragma unroll
@@ -386,6 +388,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr0), "+v"(b30), "+v"(b31));
     __syncthreads();
     int a = 0;
+    int ex = sm.expl[0][j];   // exploration word of the step about to run; the next step's is fetched together with the head sums behind the barrier (off the forward's chain)
 #ifdef DA_STAMPS
     unsigned long long da_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, da_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(da_last) :: "memory");
@@ -421,7 +424,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     for (int s = 0; s < n_steps; ++s) {
         const int par = s & 1;
         if (!phys) {
-            const bool explore = (FORCED && forced_actions) ? true : ((sm.expl[s & 3][j] & 1) != 0);
+            const bool explore = (FORCED && forced_actions) ? true : ((ex & 1) != 0);
             if (__any(!explore)) {  // skip the forward while every env of the group explores (the same envs in all three waves)
                 const float b0 = lg == 0 ? ob.x : lg == 1 ? ob.y : lg == 2 ? ob.z : ob.w;
                 dq_f32x4 h1[8];
@@ -493,13 +496,14 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
         // every wave: the action of step s (dqn.py:86-92)
         if (FORCED && forced_actions) a = (int)forced_actions[(size_t)s * N + g];
         else {
-            const int ex = sm.expl[s & 3][j];
+            const int exn = sm.expl[(s + 1) & 3][j];   // (drawn before this step's barrier; past the last step: never used)
             a = (ex >> 1) & 1;
             if (!(ex & 1)) {
                 const float q0 = ((sm.qp[par][0][j][0] + sm.qp[par][1][j][0]) + sm.qp[par][2][j][0]) + b30;
                 const float q1 = ((sm.qp[par][0][j][1] + sm.qp[par][1][j][1]) + sm.qp[par][2][j][1]) + b31;
                 a = q1 > q0 ? 1 : 0;                               // torch.argmax: first index on ties (dqn.py:92)
             }
+            ex = exn;
         }
         if (!phys) ob = sm.rec[par][a][j].ob;
 #ifdef DA_STAMPS
