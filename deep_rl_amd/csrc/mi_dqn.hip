@@ -403,13 +403,10 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
         sx = rc.x; sxd = rc.xd; sth = rc.th; sthd = rc.thd; elapsed = rc.elapsed; eplen = rc.eplen; epret = rc.epret;
         episode = ((uint64_t)rc.ep_hi << 32) | rc.ep_lo;
         if (writer) {
-#ifndef DA_ABLATE
-#define DA_ABLATE 0   // timing-only ablations of the stamp builds (results invalid): bit 0 no terminated store, 1 no rewards, 2 no actions, 3 no observations, 4 no final state
-#endif
-            if (!(DA_ABLATE & 4)) actions[slot * N + g] = act;
-            if (!(DA_ABLATE & 8)) reinterpret_cast<float4*>(observations)[nslot * N + g] = rc.ob;
-            if (!(DA_ABLATE & 2)) rewards[nslot * N + g] = 1.0f;
-            if (!(DA_ABLATE & 1)) terminated[nslot * N + g] = (uint8_t)(rc.flags & 1);
+            actions[slot * N + g] = act;
+            reinterpret_cast<float4*>(observations)[nslot * N + g] = rc.ob;
+            rewards[nslot * N + g] = 1.0f;
+            terminated[nslot * N + g] = (uint8_t)(rc.flags & 1);
             if (rc.flags & 2) {
                 st_cnt += 1; st_len += rc.fin_len; st_max = rc.fin_len > st_max ? rc.fin_len : st_max;
                 if (EPLOG && max_ep > 0 && episode_stats) {
@@ -522,29 +519,11 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
 #endif
     if (phys) {
         commit(n_steps - 1, a, sm.rec[(n_steps - 1) & 1][a][j]);
-#if DA_ABLATE & 512
-        if (writer) e.x[g] = sx;
-#elif DA_ABLATE & 1024
-        if (writer) {   // the same stores into ring memory instead of the env slab
-            char* base = reinterpret_cast<char*>(observations) + (size_t)((slot + 3) % slots) * N * 16;
-            double* d0 = reinterpret_cast<double*>(base); const size_t n_ = (size_t)N;
-            d0[g] = sx; d0[n_ + g] = sxd; d0[2 * n_ + g] = sth; d0[3 * n_ + g] = sthd;
-            reinterpret_cast<uint64_t*>(d0 + 4 * n_)[g] = episode; reinterpret_cast<uint64_t*>(d0 + 5 * n_)[g] = stepctr0 + (uint64_t)n_steps;
-            int* i0 = reinterpret_cast<int*>(d0 + 6 * n_); i0[g] = elapsed; i0[n_ + g] = eplen; reinterpret_cast<float*>(i0 + 2 * n_)[g] = epret;
-        }
-#elif DA_ABLATE & 2048
         if (writer) {
-            e.x[g] = 1.0; e.x_dot[g] = 1.0; e.theta[g] = 0.01; e.theta_dot[g] = 0.01;
-            e.elapsed[g] = 3; e.ep_ret[g] = 3.0f; e.ep_len[g] = 3; e.episode[g] = 5; e.step_ctr[g] = 7;
+            e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
+            e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr0 + (uint64_t)n_steps;
+            reinterpret_cast<float4*>(obs_cur)[g] = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
         }
-#else
-        if (writer && !(DA_ABLATE & 16)) {
-            if (!(DA_ABLATE & 32)) { e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd; }
-            if (!(DA_ABLATE & 128)) { e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; }
-            if (!(DA_ABLATE & 64)) { e.episode[g] = episode; e.step_ctr[g] = stepctr0 + (uint64_t)n_steps; }
-            if (!(DA_ABLATE & 256)) reinterpret_cast<float4*>(obs_cur)[g] = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
-        }
-#endif
         // one flush per workgroup — and no atomics when the launch has many workgroups: same-address agent-scope atomics are performed one after the other at the
         // memory side, and a launch is not over before the last of them (round 4, tools/dqn_act_stamps.py: 3 x 256 of them kept this launch open for 8.8 us after
         // its last wave had left; the statistics then go to the workgroup's slot in the handle and are summed on request, mi_common.h)
@@ -556,9 +535,6 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
             else if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
         }
     }
-#if defined(DA_STAMPS) && (DA_ABLATE & 4096)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the exit mark then includes the acknowledgement of this wave's stores
-#endif
     DA_MARK(3);
 }
 
