@@ -96,19 +96,14 @@ extern "C" int mi_env_create(int kind, int n_envs, uint64_t seed, uint64_t env_i
     e->kind = kind; e->n = n_envs; e->seed = seed; e->env_id_base = env_id_base;
     MI_HIP(hipGetDevice(&e->device));
     const size_t n = (size_t)n_envs;
-    // one slab: 4 f64 + 2 u64 + 2 i32 + 1 f32 per env
+    // one slab: 4 f64 + 2 u64 + 2 i32 + 1 f32 per env, and behind them the per-workgroup episode statistics (mi_common.h)
     char* slab = nullptr;
     const size_t bytes = n * (4 * 8 + 2 * 8 + 3 * 4);
-#ifndef MI_ENV_SLAB_GRANULE
-#define MI_ENV_SLAB_GRANULE ((size_t)2 << 20)
-#endif
-    // (allocated in whole 2 MB granules so that the slab is mapped with large page-table fragments)
     const int stats_cap = (n_envs + 3) / 4 + 1;   // the smallest workgroup of any acting kernel owns 4 envs (rollout_q4_kernel)
     const size_t bytes_all = (bytes + 15) / 16 * 16 + (size_t)stats_cap * 16;
-    const size_t alloc = (bytes_all + MI_ENV_SLAB_GRANULE - 1) / MI_ENV_SLAB_GRANULE * MI_ENV_SLAB_GRANULE;
-    if (hipMalloc(&slab, alloc) != hipSuccess) {
+    if (hipMalloc(&slab, bytes_all) != hipSuccess) {
         delete e;
-        mi_set_error("mi_env_create: hipMalloc(%zu) failed", alloc);
+        mi_set_error("mi_env_create: hipMalloc(%zu) failed", bytes_all);
         return MI_ENOMEM;
     }
     MI_HIP(hipMemset(slab, 0, bytes_all));
