@@ -1126,6 +1126,10 @@ static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv
 }
 
 // ================================================ acting ========================================================================
+// (Round 4, measured, not kept: requesting the row's env state before the forward instead of behind it.  In front of the actor's own requests: +1 us per launch — loads
+// return in order, the first weight tiles wait behind seven state loads; behind them: no change, 84.6 - 84.7 against 84.2 - 84.6 us per iteration — the tail of the launch
+// is the fp64 step itself, not its loads.  Running the action-independent half of the step (fmod, sin) on the stepping wave ahead of the first barrier: +0.7 us, every
+// wave of the workgroup waits for it there.)
 namespace rg_act {
 __global__ void __launch_bounds__(SA_THREADS)
 sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step, long long slots, long long learning_starts, float* __restrict__ obs_cur,
