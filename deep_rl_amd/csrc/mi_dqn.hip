@@ -712,11 +712,14 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         const int T = 3 * (mw & 1) + T3, u2 = 16 * T + mj;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+            // (unconditional from a clamped address, masked afterwards: a guarded load is a basic block of its own — ~90 of them in this prologue, round 4)
             const int k = 16 * c + 4 * mlg;
-            wA[T3][c] = (u2 < DQ_H2 && k < DQ_H1) ? *reinterpret_cast<const f32x4_t*>(mp + DQ_W2 + DQ_H1 * u2 + k) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(mp + DQ_W2 + DQ_H1 * (u2 < DQ_H2 ? u2 : DQ_H2 - 1) + (k < DQ_H1 ? k : DQ_H1 - 4));
+            wA[T3][c] = (u2 < DQ_H2 && k < DQ_H1) ? v : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int o = 16 * T + 4 * mlg + r; bias2[T3][r] = o < DQ_H2 ? mp[DQ_B2 + o] : 0.0f; }
+        const int o0 = 16 * T + 4 * mlg;   // 84 = 21 x 4: a lane's four units are all inside or all outside
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(mp + DQ_B2 + (o0 < DQ_H2 ? o0 : DQ_H2 - 4));
+        bias2[T3] = o0 < DQ_H2 ? bv : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
     }
     float wa1[2][21];   // the dh1 pass's A operands (W2 read column-wise)
     if ((int)blockIdx.x < n_groups) gather_group((int)blockIdx.x, i_cur);
@@ -724,15 +727,20 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 #pragma unroll
     for (int s2 = 0; s2 < 21; ++s2)
 #pragma unroll
-        for (int U2 = 0; U2 < 2; ++U2) { const int k = 16 * (2 * mw + U2) + mj; wa1[U2][s2] = k < DQ_H1 ? params[DQ_W2 + DQ_H1 * (4 * s2 + mlg) + k] : 0.0f; }
+        for (int U2 = 0; U2 < 2; ++U2) {
+            const int k = 16 * (2 * mw + U2) + mj;
+            const float v = params[DQ_W2 + DQ_H1 * (4 * s2 + mlg) + (k < DQ_H1 ? k : DQ_H1 - 1)];
+            wa1[U2][s2] = k < DQ_H1 ? v : 0.0f;
+        }
     // thin parameters: layer 1 of the thread's (net, unit), the online head's column of thread j < 84; both heads into LDS for the forward dot products
     const int net = t >> 7, u = t & 127;                 // threads 0..127: online net, 128..255: target net
     const float* p = net ? target_params : params;
-    float4 w1v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float b1v = 0.0f;
-    if (u < DQ_H1) { w1v = *reinterpret_cast<const float4*>(p + DQ_W1 + 4 * u); b1v = p[DQ_B1 + u]; }
-    float w30 = 0.0f, w31 = 0.0f;
-    if (t < DQ_H2) { w30 = params[DQ_W3 + t]; w31 = params[DQ_W3 + DQ_H2 + t]; }
+    const int uc = u < DQ_H1 ? u : DQ_H1 - 1, tc = t < DQ_H2 ? t : DQ_H2 - 1;
+    float4 w1v = *reinterpret_cast<const float4*>(p + DQ_W1 + 4 * uc);
+    float b1v = p[DQ_B1 + uc];
+    if (u >= DQ_H1) { w1v = make_float4(0.0f, 0.0f, 0.0f, 0.0f); b1v = 0.0f; }
+    float w30 = params[DQ_W3 + tc], w31 = params[DQ_W3 + DQ_H2 + tc];
+    if (t >= DQ_H2) { w30 = 0.0f; w31 = 0.0f; }
     for (int i = t; i < 2 * 2 * DQ_H2; i += 256) { const int n3 = i / (2 * DQ_H2), rem = i % (2 * DQ_H2); (&sm.w3[n3][0][0])[rem] = (n3 ? target_params : params)[DQ_W3 + rem]; }
     if (t < 4) sm.b3[t >> 1][t & 1] = ((t >> 1) ? target_params : params)[DQ_B3 + (t & 1)];
     // gradient accumulators over the workgroup's groups
