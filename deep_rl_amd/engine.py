@@ -140,6 +140,10 @@ class PPOEngine:
     def episode_summary_async(self, pinned):
         """Non-blocking copy of {episodes, sum of lengths, longest, -} of the last rollout into a pinned host tensor
         (read it after the next sync point; CartPole return == length)."""
+        if self._lazy_stats and self._stats_any and pinned.is_pinned() and pinned.dtype == torch.int32 and pinned.numel() >= 4 and pinned.is_contiguous():
+            # the sum of the per-workgroup statistics is written straight into the pinned host tensor (device-visible at the same address): no copy behind it
+            N.check(N.lib().mi_env_episode_stats(self.env.handle, pinned.data_ptr(), self._s()), "mi_env_episode_stats")
+            return
         pinned.copy_(self.episode_stats, non_blocking=True)
 
     def rollout_gae(self):

@@ -84,7 +84,8 @@ size_t mi_env_state_bytes(void* handle);
 int mi_env_export_state(void* handle, void* dst, void* stream);
 int mi_env_import_state(void* handle, const void* src, void* stream);
 /* Episode statistics of the LAST rollout / acting call on this handle that was given episode_stats == NULL (mi_ppo_rollout*, mi_ppo_update*, mi_dqn_act_steps):
- * out dev i32 [4] = {finished episodes, sum of their lengths, longest, 0}, one small launch on `stream`.  Such a call keeps the statistics per workgroup inside the
+ * out i32 [4] (device memory, or pinned host memory the device can write: a training loop reads the summary without a copy behind the launch) = {finished episodes,
+ * sum of their lengths, longest, 0}, one small launch on `stream`.  Such a call keeps the statistics per workgroup inside the
  * handle with plain stores instead of accumulating them with atomics: agent-scope atomics on one address are performed one after the other at the memory side
  * (~8.5 ns each) and a launch is not over before the last one — 26 us per 4096-env rollout, 9 us per DQN acting launch.  With a buffer the calls still fill it before
  * they return (large launches: per-workgroup statistics summed by a small launch right behind; small launches and the episode log: atomics).
