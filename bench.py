@@ -39,7 +39,8 @@ BYTES_PER_ENV_STEP = 292                         # rollout 40 + env state 72 + G
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
 REFERENCE_PY_STEPS_PER_S = 886.0                 # the unmodified reference ppo.py, torch CPU, 1 thread, build container
-PREWARM_UPDATES = 60                             # ~90 ms of throwaway updates before the W warm-up steps: the GPU's clocks have ramped by then (see main)
+PREWARM_UPDATES = 60
+PROF_EVERY = 10   # the timed windows bracket grad_kernel's launches with HIP events in every 10th update (see timed_updates)                             # ~90 ms of throwaway updates before the W warm-up steps: the GPU's clocks have ramped by then (see main)
 
 
 def usable_cpus():
@@ -526,10 +527,15 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
-        N.prof_begin(n * 16 + 16, tags=["grad"])  # only the dominant kernel is bracketed inside the timed region
+        # Only the dominant kernel is bracketed inside the timed region, and only in every PROF_EVERY-th update (its 16 launches): a pair of HIP events around EVERY
+        # launch of a 70 us kernel costs the loop it measures 0.098 ms per update = 7.5 % (tools/prof_overhead.py: 1.411 ms with all 320 launches of 20 updates
+        # bracketed, 1.312 ms with none, the same 70.2 - 70.5 us per launch either way) - until round 4 the headline carried that.
+        N.prof_begin((n // PROF_EVERY + 1) * 16 + 16, tags=["grad"])
         t0 = time.perf_counter()
-        for u in range(u0, u0 + n):
+        for k, u in enumerate(range(u0, u0 + n)):
+            N.prof_pause(k % PROF_EVERY != 0)
             one_update(min(u, num_updates - 1))
+        N.prof_pause(False)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -610,7 +616,9 @@ def main():
                        "collectives": "none (single process)" if world == 1 else ("RCCL direct (mi_ppo_update_sharded: one C call per update, 17 in-stream all-reduces)" if eng_native else "torch.distributed (host-sequenced, 17 all-reduces per update)")},
             "roofline": {"bound": "mfma", "kernel": "grad_kernel_f32", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "flops_per_launch": flops_per_launch, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "launches": g_n},
+                         "flops_per_launch": flops_per_launch, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "launches": g_n,
+                         "sampling": "HIP events around the 16 launches of every %d-th update of the timed window (a pair around every launch costs the window 7.5 %%: "
+                                     "tools/prof_overhead.py); launches = the bracketed ones" % PROF_EVERY},
             "hbm_roofline": {"algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                              "achieved_GBps_per_gpu": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9, 2), "peak_GBps": PEAK_HBM_GBS,
                              "frac": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9 / PEAK_HBM_GBS, 6)},

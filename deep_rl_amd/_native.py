@@ -144,6 +144,7 @@ SIGNATURES = {
     "mi_test_tanh": (_I, [_VP, _VP, _I, _VP]),
     "mi_prof_begin": (_I, [_I, _U32]),
     "mi_prof_end": (_I, [C.POINTER(_F), C.POINTER(C.c_int32)]),
+    "mi_prof_pause": (_I, [_I]),
     "mi_timer_create": (_I, [C.POINTER(_VP)]),
     "mi_timer_destroy": (_I, [_VP]),
     "mi_timer_start": (_I, [_VP, _VP]),
@@ -222,6 +223,11 @@ def prof_begin(max_launches, tags=None):
     for t in (tags or PROF_TAGS):
         mask |= 1 << PROF_TAGS.index(t)
     check(lib().mi_prof_begin(int(max_launches), mask), "mi_prof_begin")
+
+
+def prof_pause(paused):
+    """Stop / resume the sampling between prof_begin and prof_end."""
+    check(lib().mi_prof_pause(1 if paused else 0), "mi_prof_pause")
 
 
 def prof_end():

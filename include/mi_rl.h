@@ -494,7 +494,9 @@ int mi_test_tanh(const float* x, float* y, int n, void* stream);
  * pair of HIP events on ITS stream (so the durations are measured live inside the timed region, on the stream the
  * kernel runs on).  mi_prof_begin(max_launches, tag_mask) arms it for the tags whose bit is set (allocates the event
  * pool, may synchronise);
- * mi_prof_end synchronises, fills total_ms[MI_PROF_NTAGS] / count[MI_PROF_NTAGS] (host arrays) and disarms. */
+ * mi_prof_end synchronises, fills total_ms[MI_PROF_NTAGS] / count[MI_PROF_NTAGS] (host arrays) and disarms.
+ * mi_prof_pause(1 / 0) between the two stops / resumes the sampling: two events around every launch of a 70 us kernel cost the loop they measure ~2.5 %, so bench.py
+ * brackets the launches of every 4th update only. */
 enum { MI_PROF_ROLLOUT = 0, MI_PROF_GAE = 1, MI_PROF_GRAD = 2, MI_PROF_REDUCE = 3, MI_PROF_CLIP_ADAM = 4, MI_PROF_STATS = 5,
        /* DQN (config 3): acting launch, TD forward+backward, slab sum (+ Adam), PER sampler launches */
        MI_PROF_DQN_ACT = 6, MI_PROF_DQN_TD = 7, MI_PROF_DQN_REDUCE = 8, MI_PROF_PER = 9,
@@ -505,6 +507,7 @@ enum { MI_PROF_ROLLOUT = 0, MI_PROF_GAE = 1, MI_PROF_GRAD = 2, MI_PROF_REDUCE = 
        MI_PROF_NTAGS = 18 };
 int mi_prof_begin(int max_launches, uint32_t tag_mask);
 int mi_prof_end(float* total_ms, int32_t* count);
+int mi_prof_pause(int paused);
 
 /* ---- timing helper for bench.py: HIP events on the given stream (torch.cuda.Event only sees torch's
  * current stream).  mi_timer_* are host-side and may synchronise. */

@@ -147,7 +147,7 @@ def test_bench_contract_line():
     assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 3 * 128 * 4096 / (3 * d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0 and r["launches"] == 3 * 16
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0 and r["launches"] == 16 and "every 10-th update" in r["sampling"]   # 3 timed updates: the launches of the first one are bracketed
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert "static" in r["traffic_source"]                        # roofline.traffic comes from committed PMC passes, and the line says so
@@ -184,7 +184,7 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["params_finite"] is True
     assert abs(d["value"] - 2 * 2 * 128 * 4096 / (2 * d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]      # whole-job aggregate over both ranks
-    assert "x2" in d["config"]["parallelism"] and d["roofline"]["launches"] == 2 * 16
+    assert "x2" in d["config"]["parallelism"] and d["roofline"]["launches"] == 16
     c = d["collectives"]
     assert c["per_update"] == 17 and c["world_size"] == 2 and "gloo" in c["carrier"] and c["grad_allreduce"]["bytes"] == 4 * 9159
     assert c["back_to_back"]["us_per_allreduce_grad"] > 0 and c["back_to_back"]["us_per_allreduce_stats"] > 0
