@@ -89,3 +89,28 @@ def test_statistics_before_any_call_are_an_error_not_garbage(dev):
     rc = N.lib().mi_env_episode_stats(env.handle, N.ptr(out), N.stream_ptr(dev))
     assert rc == -4 and b"episode_stats == NULL" in N.lib().mi_last_error()       # MI_ESTATE
     assert N.lib().mi_env_episode_stats(None, N.ptr(out), None) == -1                  # MI_EINVAL
+
+
+def test_profiler_brackets_only_what_it_is_asked_to(dev):
+    """bench.py's live roofline figure: mi_prof_begin arms the in-library HIP-event profiler for the tagged kernels, mi_prof_pause stops / resumes the sampling in
+    between (the timed windows bracket the gradient launches of every 10th update only: a pair of events around every launch costs the window 7.5 %), mi_prof_end
+    reports totals and counts of the bracketed launches alone."""
+    from deep_rl_amd import _native as N
+
+    eng = _ppo(dev, 256, 0, T=16)
+    for _ in range(2):
+        eng.update()
+    N.prof_begin(64, tags=["grad", "rollout"])
+    eng.update()                      # bracketed: 16 gradient launches + 1 rollout
+    N.prof_pause(True)
+    eng.update(); eng.update()        # not bracketed
+    N.prof_pause(False)
+    eng.update()                      # bracketed again
+    p = N.prof_end()
+    assert p["grad"][1] == 32 and p["rollout"][1] == 2 and p["reduce"][1] == 0
+    assert 0.0 < p["grad"][0] / 32 < 1.0 and 0.0 < p["rollout"][0]          # ms per launch: sane
+    eng.update()                      # disarmed: nothing recorded, nothing breaks
+    N.prof_begin(8, tags=["grad"])
+    N.prof_pause(True)
+    eng.update()
+    assert N.prof_end()["grad"][1] == 0
