@@ -489,6 +489,21 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        # a multi-rank run that blocks (a rank lost in communicator set-up, a collective one rank never joins) must not sit on an 8-GPU node until the driver's own
+        # limit: after MIRL_BENCH_WATCHDOG_S seconds (default 900; the whole run takes ~1 minute) every rank says where it is and leaves with code 124
+        import faulthandler
+        import threading
+
+        def _give_up():
+            sys.stderr.write("bench.py: rank %d of %d still running after the watchdog's limit: giving up (stacks follow)\n" % (rank, world))
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+            os._exit(124)
+
+        _wd = threading.Timer(float(os.environ.get("MIRL_BENCH_WATCHDOG_S", "900")), _give_up)
+        _wd.daemon = True
+        _wd.start()
 
     # Clock ramp, reported as `prewarm` in the line: a fresh process runs its first ~80 ms of GPU work at ramping clocks (tools/rollout_ab.py: 202 us per rollout for the
     # first 40 launches, 188 us afterwards, whatever the build), which is longer than W = 5 warm-up updates (7 ms) and put the first timed window of a short run 1.2 - 1.8 %
