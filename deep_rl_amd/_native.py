@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
-ABI_VERSION = 104   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
+ABI_VERSION = 105   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
@@ -86,6 +86,11 @@ SIGNATURES = {
     "mi_comm_destroy": (_I, [_VP]),
     "mi_comm_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "mi_comm_allreduce_sum": (_I, [_VP, _VP, _SZ, _I, _VP]),
+    "mi_comm_p2p_alloc": (_I, [_I, _I, _SZ, C.POINTER(_VP), _VP]),
+    "mi_comm_p2p_connect": (_I, [_VP, _VP]),
+    "mi_comm_p2p_synthetic": (_I, [_I, _SZ, C.POINTER(_VP)]),
+    "mi_comm_check": (_I, [_VP]),
+    "mi_comm_carrier": (_I, [_VP]),
     "mi_dqn_forward": (_I, [_VP, _VP, _I, _VP, _VP]),
     "mi_dqn_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP]),
     "mi_dqn_act_steps2": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP, _VP]),

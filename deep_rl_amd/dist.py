@@ -7,8 +7,9 @@ data-path collective besides these:
   * the flat gradient (+ 4 loss terms), each rank's share already scaled by 1/(world*mb) (ppo.py:189-192)
 Messages are <= 36.6 KB: latency-bound, one fused buffer per collective, in-stream, no bucketing.
 
-Two carriers: (1) libmirl's own RCCL communicator (`native_comm`, csrc/mi_comm.hip, direct rccl.h) — the production path: the whole
-sharded update is ONE C call (mi_ppo_update_sharded) with the collectives enqueued between its launches; (2) `torch.distributed`
+Carriers: (1) libmirl's own communicator (`native_comm`, csrc/mi_comm.hip) — the production path: the whole sharded update is ONE C call
+(mi_ppo_update_sharded) with the collectives enqueued between its launches — either RCCL (direct rccl.h; default) or, with MIRL_COMM=p2p, the
+one-shot peer-to-peer exchange over hipIpc-mapped inboxes (rank-ordered sum, works with two ranks on one device); (2) `torch.distributed`
 (`allreduce_sum_`) — the host-sequenced path, kept for gloo (CPU tests, two ranks on one GPU) and as the A/B reference.
 Diagnostics on a one-GPU box: MIRL_FORCE_PG=1 makes a single process join a (world_size 1) process group so that RCCL really runs;
 MIRL_FORCE_COLLECTIVES=1 makes `allreduce_sum_` issue its collective even at world_size 1.
@@ -85,8 +86,15 @@ def check_replicas(tensors, group=None, what="replicated state"):
     if world_size(group) == 1:
         return
     c = state_checksum(tensors)
-    pair = torch.stack([c, -c])
+    bad = 0
+    try:   # a wait of the P2P carrier that ran out on ANY rank (its buffers then hold local shares) is reported on every rank through the same exchange
+        check_native_comm(group)
+    except MiError as e:
+        bad, why = 1, str(e)
+    pair = torch.stack([c, -c, torch.full_like(c, bad)])
     dist.all_reduce(pair, op=dist.ReduceOp.MAX, group=group)
+    if int(pair[2].item()):
+        raise MiError("a collective of libmirl's P2P carrier timed out on %s" % (("this rank (%d): %s" % (rank(group), why)) if bad else "another rank"))
     hi, lo = int(pair[0].item()), -int(pair[1].item())
     if hi != lo:
         raise MiError("replica divergence: %s differs across ranks (checksum of rank %d: %016x; min %016x, max %016x over %d ranks) — the replicas no longer "
@@ -96,34 +104,80 @@ def check_replicas(tensors, group=None, what="replicated state"):
 _native_comms = {}
 
 
+def carrier():
+    """MIRL_COMM: "rccl" (default — libmirl's own RCCL communicator; needs an NCCL process group, one device per rank) or "p2p" (the one-shot exchange over
+    hipIpc-mapped inboxes, csrc/mi_comm.hip; any process group — the handles travel through it — and any placement, two ranks on one device included)."""
+    c = os.environ.get("MIRL_COMM", "rccl").lower()
+    if c not in ("rccl", "p2p"):
+        raise MiError("MIRL_COMM=%r: known carriers are rccl and p2p" % c)
+    return c
+
+
+def _agree(ok, group):
+    """MIN over the ranks of a 0 / 1 flag (every rank takes the one-call route or none does)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item())
+
+
+def _create_rccl(group):
+    from . import _native as N
+
+    ident = (C.c_char * 128)()
+    ok = 1
+    if dist.get_rank(group) == 0:
+        ok = 1 if N.lib().mi_comm_unique_id(ident) == 0 else 0
+    box = [bytes(ident.raw), ok]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ident.raw, ok = box[0], box[1]
+    h = C.c_void_p()
+    err = ""
+    if ok and N.lib().mi_comm_create(ident, dist.get_world_size(group), dist.get_rank(group), C.byref(h)) != 0:
+        ok, err = 0, N.lib().mi_last_error().decode()
+    return h, ok, err
+
+
+def _create_p2p(group):
+    """Every rank allocates its inbox, the 64-byte hipIpcMemHandle_t of all ranks travel through the process group, every rank maps its peers' inboxes."""
+    from . import _native as N
+
+    world, rk = dist.get_world_size(group), dist.get_rank(group)
+    max_bytes = int(os.environ.get("MIRL_P2P_MAX_BYTES", str(1 << 20)))   # SAC's twin-critic gradient is 539 KB, PPO's 36.6 KB
+    h, mine = C.c_void_p(), (C.c_char * 64)()
+    ok, err = 1, ""
+    if N.lib().mi_comm_p2p_alloc(world, rk, max_bytes, C.byref(h), mine) != 0:
+        ok, err = 0, N.lib().mi_last_error().decode()
+    boxes = [None] * world
+    dist.all_gather_object(boxes, (bytes(mine.raw), ok), group=group)
+    if ok and all(b[1] for b in boxes):
+        if N.lib().mi_comm_p2p_connect(h, b"".join(b[0] for b in boxes)) != 0:
+            ok, err = 0, N.lib().mi_last_error().decode()
+    elif ok:
+        ok, err = 0, "a peer could not allocate its inbox"
+    return h, ok, err
+
+
 def native_comm(group=None):
-    """libmirl's RCCL communicator for `group` (created collectively on first use) or None when there is no process group, its backend
-    is not nccl (gloo runs keep the host-sequenced path), MIRL_NATIVE_COMM=0, or the creation failed on ANY rank (the ranks agree on
-    that through the process group, so either all of them take the one-call path or all of them fall back).
-    Rank 0 draws the ncclUniqueId, the group broadcasts it."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl" or os.environ.get("MIRL_NATIVE_COMM", "1") == "0":
+    """libmirl's communicator for `group` (created collectively on first use) or None when there is no process group, MIRL_NATIVE_COMM=0, the carrier is RCCL and
+    the backend is not nccl (gloo runs keep the host-sequenced path), or the creation failed on ANY rank (the ranks agree on that through the process group, so either
+    all of them take the one-call path or all of them fall back).  RCCL: rank 0 draws the ncclUniqueId, the group broadcasts it.  P2P (MIRL_COMM=p2p): see _create_p2p."""
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("MIRL_NATIVE_COMM", "1") == "0":
         return None
-    key = id(group) if group is not None else 0
+    which = carrier()
+    if which == "rccl" and dist.get_backend(group) != "nccl":
+        return None
+    key = (id(group) if group is not None else 0, which)
     if key not in _native_comms:
         import sys
 
         from . import _native as N
 
-        ident = (C.c_char * 128)()
-        ok = 1
-        if dist.get_rank(group) == 0:
-            ok = 1 if N.lib().mi_comm_unique_id(ident) == 0 else 0
-        box = [bytes(ident.raw), ok]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident.raw, ok = box[0], box[1]
-        h = C.c_void_p()
-        if ok and N.lib().mi_comm_create(ident, dist.get_world_size(group), dist.get_rank(group), C.byref(h)) != 0:
-            ok, err = 0, N.lib().mi_last_error().decode()
-            print("deep_rl_amd: mi_comm_create failed on rank %d (%s): falling back to torch.distributed collectives" % (dist.get_rank(group), err), file=sys.stderr)
-        import torch as _t
-        flag = _t.tensor([ok], dtype=_t.int32, device=_t.device("cuda", _t.cuda.current_device()))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()) == 0:
+        h, ok, err = _create_p2p(group) if which == "p2p" else _create_rccl(group)
+        if not ok:
+            print("deep_rl_amd: creating the %s communicator failed on rank %d (%s): falling back to torch.distributed collectives" % (which, dist.get_rank(group), err),
+                  file=sys.stderr)
+        if _agree(ok, group) == 0:
             if h.value:
                 N.lib().mi_comm_destroy(h)
             _native_comms[key] = None
@@ -132,12 +186,25 @@ def native_comm(group=None):
     return _native_comms[key]
 
 
-def destroy_native_comms():
+def check_native_comm(group=None):
+    """Host-synchronising: raise MiError when a wait of the P2P carrier ran out on this rank (mi_comm_check); no-op without a communicator or on RCCL."""
     from . import _native as N
 
-    for h in _native_comms.values():
-        if h is not None:
-            N.lib().mi_comm_destroy(h)
+    for (g, _), h in _native_comms.items():
+        if h is not None and g == (id(group) if group is not None else 0):
+            N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+
+
+def destroy_native_comms():
+    """Collective when a P2P communicator exists: a barrier in front (a peer may still be storing into this rank's inbox)."""
+    from . import _native as N
+
+    live = [h for h in _native_comms.values() if h is not None]
+    if live and dist.is_available() and dist.is_initialized() and any(N.lib().mi_comm_carrier(h) == 1 for h in live):
+        torch.cuda.synchronize()
+        dist.barrier()
+    for h in live:
+        N.lib().mi_comm_destroy(h)
     _native_comms.clear()
 
 

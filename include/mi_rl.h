@@ -50,9 +50,9 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
-#define MI_VERSION 104
+#define MI_VERSION 105
 #define MI_PPO_NPARAMS 9155
 #define MI_PPO_ACTOR_NPARAMS 4610
 #define MI_OBS_DIM 4
@@ -224,6 +224,28 @@ int mi_comm_destroy(void* comm);
  * (ncclCommCount; -1 if the entry point is missing).  Any out pointer may be NULL. */
 int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version, int* comm_count);
 int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stream);
+/* The second carrier behind the same handle: a ONE-SHOT peer-to-peer all-reduce over hipIpc-mapped inboxes (round 5).  Every rank owns an inbox
+ * [2 parities][world][max_bytes] (+ one flag word per parity, rank and workgroup) in uncached device memory, mapped into every peer.  One all-reduce = ONE launch:
+ * store the local share into slot (parity, rank) of every rank's inbox, publish the sequence number, wait (bounded: MIRL_P2P_TIMEOUT_MS, default 10,000) for the
+ * world's sequence numbers in the own inbox, sum the world's slots IN RANK ORDER -> bitwise the same result on every rank by construction, for any world size
+ * (a ring's grouping depends on the rank); at world 2 also bitwise RCCL's / gloo's a + b.  Works with two ranks on ONE device (RCCL refuses that), which is how
+ * a one-GPU box runs the one-call *_sharded routes at world_size 2 (tests/test_gpu_p2p.py).  world_size <= 8 (one node).
+ *   mi_comm_p2p_alloc    allocates this rank's inbox on the CURRENT device for messages of <= max_bytes and writes its 64-byte hipIpcMemHandle_t; the caller ships the
+ *                        handles of all ranks to all ranks (torch.distributed all_gather / file / MPI) ...
+ *   mi_comm_p2p_connect  ... and hands them over in rank order (world_size * 64 bytes): maps the peers' inboxes.  The handle then works wherever an RCCL one does
+ *                        (mi_comm_allreduce_sum, mi_*_sharded).  All collectives of one communicator must be enqueued on streams ordered with each other, by every rank
+ *                        in the same order.  Put a barrier in front of mi_comm_destroy: a peer may still be storing into this rank's inbox.
+ *   mi_comm_p2p_synthetic  ONE process plays world_size ranks into its own inbox (slot 0 = its share, the others zeros: results unchanged): the stores, flags,
+ *                        waits and the world-slot sum of a world_size-rank exchange minus the links — for timing on a one-GPU box (bench.py `collectives`).
+ *   mi_comm_check        host-synchronising.  MI_OK, or MI_ESTATE when a wait ran out: that all-reduce and every later one on the communicator left the LOCAL share in
+ *                        its buffer (a launch never spins beyond its budget, later launches return at once).  Always MI_OK for RCCL.
+ *   mi_comm_carrier      0 = RCCL, 1 = P2P. */
+#define MI_COMM_IPC_BYTES 64
+int mi_comm_p2p_alloc(int world_size, int rank, size_t max_bytes, void** comm, void* ipc_handle64);
+int mi_comm_p2p_connect(void* comm, const void* ipc_handles);
+int mi_comm_p2p_synthetic(int world_size, size_t max_bytes, void** comm);
+int mi_comm_check(void* comm);
+int mi_comm_carrier(void* comm);
 int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* comm, void* stream);
 /* TEST HOOK (process-wide; 0 = off): mi_ppo_update / mi_ppo_update_sharded behave as at world_size > 1 in everything but the collective — the owed optimizer steps
  * recompute the clip coefficient from the (all-reduced) gradient itself instead of reading the slab sum's block sums, the one branch a single-GPU run never takes.

@@ -7,7 +7,9 @@ exchange between backward and optimizer.step()).
       mi_sac_alpha_step_sharded with the in-stream ncclAllReduce on libmirl's own RCCL communicator; then the same work again on the host-sequenced route
       (MIRL_NATIVE_COMM=0: *_grad launch, torch.distributed all-reduce over RCCL, Adam launch) — at world_size 2 a SUM all-reduce is a + b on both ranks whatever the
       algorithm, so the two routes must agree bit for bit;
-  backend gloo (both ranks on cuda:0): the host-sequenced route, so that the harness and the comparison below run every round on the one-GPU box.
+  backend gloo (both ranks on cuda:0): the host-sequenced route, so that the harness and the comparison below run every round on the one-GPU box;
+  MIRL_COMM=p2p with either backend: the ONE-CALL routes on libmirl's peer-to-peer carrier — with gloo and both ranks on cuda:0 this is how the one-GPU box runs them
+      at world_size 2.
 Each rank dumps its final state to OUT_DIR/off_rank<r>.npz; the TEST process compares rank against rank (bitwise), route against route (bitwise) and, for DQN and SAC
 with caller-supplied batches and noise, against a single process that owns all 2*NL envs and takes the union batch."""
 import os
@@ -94,8 +96,11 @@ def run_all():
 
 st = run_all()
 native = bool(st["dqn_native"][0]) and bool(st["sac_native"][0])
-assert native == (backend == "nccl"), "backend %s: one-call RCCL routes %s" % (backend, native)
-if native:   # host-sequenced route over torch's RCCL all-reduces: bit-identical at world_size 2
+p2p = DD.carrier() == "p2p"    # MIRL_COMM=p2p: the one-call routes on the peer-to-peer carrier, whatever the process group
+assert native == (backend == "nccl" or p2p), "backend %s, carrier %s: one-call routes %s" % (backend, DD.carrier(), native)
+if native:
+    DD.check_native_comm()
+if native:   # host-sequenced route over torch.distributed all-reduces (RCCL, or gloo under the P2P carrier): bit-identical at world_size 2
     os.environ["MIRL_NATIVE_COMM"] = "0"
     st2 = run_all()
     os.environ["MIRL_NATIVE_COMM"] = "1"
@@ -107,4 +112,4 @@ torch.distributed.barrier()
 DD.destroy_native_comms()
 torch.distributed.destroy_process_group()
 if rank == 0:
-    print("OFFPOLICY_WORKER_OK backend=%s native=%d" % (backend, int(native)))
+    print("OFFPOLICY_WORKER_OK backend=%s native=%d carrier=%s" % (backend, int(native), DD.carrier()))

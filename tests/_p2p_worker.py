@@ -1,0 +1,89 @@
+"""Worker of tests/test_gpu_p2p.py — one rank of a world_size-2 job started by torch.distributed.run, BOTH ranks on cuda:0 (or one per GPU when there are two),
+process group gloo (it only carries the IPC handles and the test's own comparisons), MIRL_COMM=p2p.
+
+The raw collective of libmirl's P2P carrier (csrc/mi_comm.hip: mi_comm_p2p_alloc / _connect, mi_comm_allreduce_sum): the exchange that stands between backward and
+the optimizer step in the sharded form of reference ppo.py:189-192 / dqn.py:131-133 / sac.py:185-210.
+  * f32 and f64 messages of the sizes the engines send (48 doubles, 9,159 / 10,936 / 134,660 floats, 1 float) and ragged / unaligned ones, 40 back-to-back rounds each
+    (both parities, no host synchronisation in between): bitwise the gloo SUM all-reduce of the same data and bitwise the other rank's result;
+  * a peer that never arrives: the wait runs out (MIRL_P2P_TIMEOUT_MS), the buffer keeps the local share, mi_comm_check says which rank was missing."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import deep_rl_amd.dist as DD  # noqa: E402
+from deep_rl_amd import _native as N  # noqa: E402
+
+assert os.environ.get("MIRL_COMM") == "p2p"
+rank, world, local_rank = DD.init_from_env("gloo")
+assert world == 2
+dev = torch.device("cuda", local_rank if torch.cuda.device_count() >= 2 else 0)
+torch.cuda.set_device(dev)
+comm = DD.native_comm()
+assert comm is not None, "the P2P communicator could not be created (hipIpc between two processes on this device?)"
+L = N.lib()
+assert L.mi_comm_carrier(comm) == 1
+ws, rk, ver, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+N.check(L.mi_comm_info(comm, C.byref(ws), C.byref(rk), C.byref(ver), C.byref(cnt)), "mi_comm_info")
+assert (ws.value, rk.value, ver.value, cnt.value) == (2, rank, 0, 2)
+s = N.stream_ptr(dev)
+
+ROUNDS = 40
+gen = torch.Generator(device="cpu").manual_seed(100 + rank)
+for dtype, sizes in ((torch.float32, (1, 3, 9159, 10936, 134660, 1024, 4097)), (torch.float64, (48, 1, 7, 2050))):
+    for n in sizes:
+        for off in (0, 1):   # off 1: a buffer that is not 16-byte aligned (the scalar instantiation)
+            host = torch.randn(ROUNDS, n + off, generator=gen, dtype=dtype) * (10.0 ** torch.randint(-3, 4, (ROUNDS, 1), generator=gen).to(dtype))
+            mine = host.to(dev)
+            want = mine.clone()
+            dist.all_reduce(want)                      # gloo: a + b on both ranks
+            got = mine.clone()
+            for r in range(ROUNDS):                    # back to back on one stream, no host synchronisation
+                N.check(L.mi_comm_allreduce_sum(comm, got[r, off:].data_ptr(), n, 0 if dtype == torch.float32 else 1, s), "mi_comm_allreduce_sum")
+            torch.cuda.synchronize()
+            N.check(L.mi_comm_check(comm), "mi_comm_check")
+            assert torch.equal(got[:, off:], want[:, off:]), (dtype, n, off, (got[:, off:] - want[:, off:]).abs().max().item())
+            if off:
+                assert torch.equal(got[:, 0], mine[:, 0])   # the element in front of the message was not touched
+            other = got.clone()
+            dist.all_reduce(other)                     # 2 x the result iff both ranks hold the same bits
+            assert torch.equal(other[:, off:], got[:, off:] * 2)
+torch.cuda.synchronize()
+dist.barrier()
+
+# a message larger than the slots is refused up front
+big = torch.zeros((1 << 20) // 4 + 64, dtype=torch.float32, device=dev)
+assert L.mi_comm_allreduce_sum(comm, big.data_ptr(), big.numel(), 0, s) == -1 and b"does not fit" in L.mi_last_error()
+
+# a peer that never arrives: rank 0 enqueues an all-reduce that rank 1 does not
+os.environ["MIRL_P2P_TIMEOUT_MS"] = "300"
+h, mine = C.c_void_p(), (C.c_char * 64)()
+N.check(L.mi_comm_p2p_alloc(2, rank, 4096, C.byref(h), mine), "mi_comm_p2p_alloc")
+boxes = [None, None]
+dist.all_gather_object(boxes, bytes(mine.raw))
+N.check(L.mi_comm_p2p_connect(h, b"".join(boxes)), "mi_comm_p2p_connect")
+x = torch.arange(100, dtype=torch.float32, device=dev) + 1
+if rank == 0:
+    N.check(L.mi_comm_allreduce_sum(h, x.data_ptr(), 100, 0, s), "mi_comm_allreduce_sum")
+    torch.cuda.synchronize()
+    assert L.mi_comm_check(h) == -4 and b"never arrived: 1" in L.mi_last_error(), L.mi_last_error()
+    assert torch.equal(x, torch.arange(100, dtype=torch.float32, device=dev) + 1)      # the local share, untouched
+    N.check(L.mi_comm_allreduce_sum(h, x.data_ptr(), 100, 0, s), "mi_comm_allreduce_sum")   # later launches return at once
+    torch.cuda.synchronize()
+    assert L.mi_comm_check(h) == -4
+else:
+    assert L.mi_comm_check(h) == 0
+dist.barrier()
+L.mi_comm_destroy(h)
+
+dist.barrier()
+DD.destroy_native_comms()
+dist.destroy_process_group()
+if rank == 0:
+    print("P2P_WORKER_OK")

@@ -3,7 +3,9 @@
   backend nccl (needs >= 2 GPUs, one per rank): PPOEngine.update() takes the ONE-CALL route, mi_ppo_update_sharded with 17 in-stream ncclAllReduce
       per update on libmirl's own RCCL communicator (reference ppo.py:189-192: backward -> [gradient exchange] -> clip_grad_norm_ -> step);
   backend gloo (both ranks on cuda:0): the host-sequenced route over the same launches — run on the one-GPU box so that the comparison
-      harness below is itself exercised every round.
+      harness below is itself exercised every round;
+  MIRL_COMM=p2p with either backend: the ONE-CALL route on libmirl's peer-to-peer carrier (hipIpc-mapped inboxes, rank-ordered sum) — with gloo and both ranks on
+      cuda:0 this is how the one-GPU box runs mi_ppo_update_sharded at world_size 2.
 
 Each rank owns NL envs (global ids [rank*NL, (rank+1)*NL)), runs UPDATES whole updates and dumps its final state to OUT_DIR/rank<r>.npz; the TEST process
 (no process group: an engine built inside a rank would join the ranks' collectives) then plays the single process that owns all 2*NL envs — the explicit
@@ -62,15 +64,19 @@ def state(eng):
 
 eng, params0 = run_rank()
 native = DD.native_comm(eng.pg) is not None
-assert native == (backend == "nccl"), "backend %s: native RCCL route %s" % (backend, native)
+p2p = DD.carrier() == "p2p"    # MIRL_COMM=p2p: the one-call route on the peer-to-peer carrier, whatever the process group (gloo with both ranks on cuda:0 included)
+assert native == (backend == "nccl" or p2p), "backend %s, carrier %s: one-call route %s" % (backend, DD.carrier(), native)
 if native:
     ws, rk, ver, cnt = N.C.c_int(), N.C.c_int(), N.C.c_int(), N.C.c_int()
     N.check(N.lib().mi_comm_info(DD.native_comm(eng.pg), N.C.byref(ws), N.C.byref(rk), N.C.byref(ver), N.C.byref(cnt)), "mi_comm_info")
-    assert ws.value == 2 and rk.value == rank and cnt.value == 2 and ver.value > 0
+    assert ws.value == 2 and rk.value == rank and cnt.value == 2 and (ver.value == 0 if p2p else ver.value > 0)
+    assert N.lib().mi_comm_carrier(DD.native_comm(eng.pg)) == int(p2p)
+    DD.check_native_comm(eng.pg)   # no wait of the P2P carrier ran out
+    eng.check_replicas()
 st = state(eng)
 st["params0"] = params0
 st["native"] = np.array([int(native)])
-if native:   # the host-sequenced route over torch's RCCL all-reduces, from the same initial parameters: bit-identical at world_size 2
+if native:   # the host-sequenced route over torch.distributed all-reduces (RCCL, or gloo under the P2P carrier), from the same initial parameters: bit-identical at world_size 2
     E._FORCE_SHARDED_SEQUENCE = True
     eng2, _ = run_rank(params0)
     E._FORCE_SHARDED_SEQUENCE = False
@@ -78,9 +84,7 @@ if native:   # the host-sequenced route over torch's RCCL all-reduces, from the 
         st["seq_" + k] = v
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **st)
 torch.distributed.barrier()
-
-torch.distributed.barrier()
 DD.destroy_native_comms()
 torch.distributed.destroy_process_group()
 if rank == 0:
-    print("SHARDED_WORKER_OK backend=%s native=%d" % (backend, int(native)))
+    print("SHARDED_WORKER_OK backend=%s native=%d carrier=%s" % (backend, int(native), DD.carrier()))

@@ -1,0 +1,144 @@
+"""The peer-to-peer carrier of libmirl's communicator (csrc/mi_comm.hip; MIRL_COMM=p2p) — and, through it, the production ONE-CALL sharded routes at world_size 2 on
+the one GPU this box has (until round 5 mi_ppo_update_sharded, mi_dqn_td_update_sharded, mi_sac_{critic,actor}_update_sharded and
+mi_sac_alpha_step_sharded had only ever run at world_size 1, because RCCL refuses two ranks on one device).  The exchange they carry stands between backward and the
+optimizer step of reference ppo.py:189-192, dqn.py:131-133 (per.py:147-153), sac.py:185-210.
+
+  test_synthetic_world_*                 one process plays 1 / 2 / 4 / 8 ranks into its own inbox (slot 0 = its share, the others zeros): every message size the
+                                         engines send comes back bit for bit, f32 and f64, aligned or not, 50 back-to-back launches (both parities).
+  test_two_ranks_one_gpu_p2p_collective  two PROCESSES on cuda:0, inboxes exchanged with hipIpcGetMemHandle / hipIpcOpenMemHandle: bitwise gloo's a + b, rank == rank,
+                                         the bounded wait when a peer never arrives (tests/_p2p_worker.py).
+  test_two_ranks_one_gpu_p2p_ppo         PPOEngine.update() on mi_ppo_update_sharded, two ranks on cuda:0, two whole updates: rank == rank bitwise, == the
+                                         host-sequenced route over gloo bitwise, == the single process with union minibatches at the tolerances of test_gpu_multigpu.py.
+  test_two_ranks_one_gpu_p2p_offpolicy   the same for DQNEngine, PERDQNEngine, SACEngine on their one-call routes (MIRL_CHECK_REPLICAS=2 inside the worker).
+  test_two_gpus_p2p_*                    the same two workers with one rank per GPU and an NCCL process group (skip below 2 GPUs)."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _need_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_synthetic_world_allreduce_is_identity(world):
+    torch = _need_gpu()
+    from deep_rl_amd import _native as N
+
+    dev = torch.device("cuda", 0)
+    L, s = N.lib(), N.stream_ptr(dev)
+    h = C.c_void_p()
+    N.check(L.mi_comm_p2p_synthetic(world, 1 << 20, C.byref(h)), "mi_comm_p2p_synthetic")
+    try:
+        assert L.mi_comm_carrier(h) == 1
+        ws, rk, ver, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        N.check(L.mi_comm_info(h, C.byref(ws), C.byref(rk), C.byref(ver), C.byref(cnt)), "mi_comm_info")
+        assert (ws.value, rk.value, ver.value, cnt.value) == (world, 0, 0, world)
+        gen = torch.Generator(device="cpu").manual_seed(world)
+        for dtype, sizes in ((torch.float32, (1, 5, 1023, 1024, 1025, 9159, 10936, 67331, 134660, 262144)), (torch.float64, (1, 48, 513, 131072))):
+            for n in sizes:
+                for off in (0, 1):
+                    x = (torch.randn(n + off + 3, generator=gen, dtype=dtype) * 100).to(dev)
+                    x[x == 0] = 1.0                   # x + 0 == x bit for bit except for -0
+                    y = x.clone()
+                    for _ in range(50):
+                        N.check(L.mi_comm_allreduce_sum(h, y[off:].data_ptr(), n, 0 if dtype == torch.float32 else 1, s), "mi_comm_allreduce_sum")
+                    torch.cuda.synchronize()
+                    assert torch.equal(x, y), (dtype, n, off)
+        N.check(L.mi_comm_check(h), "mi_comm_check")
+        big = torch.zeros((1 << 20) // 4 + 4, dtype=torch.float32, device=dev)
+        assert L.mi_comm_allreduce_sum(h, big.data_ptr(), big.numel(), 0, s) == -1
+    finally:
+        L.mi_comm_destroy(h)
+
+
+def _launch(worker, env_extra, timeout=600):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", MIRL_COMM="p2p", **env_extra)
+    # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                           os.path.join(ROOT, "tests", worker)], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_two_ranks_one_gpu_p2p_collective():
+    _need_gpu()
+    out = _launch("_p2p_worker.py", {})
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "P2P_WORKER_OK" in out.stdout, out.stdout[-2000:]
+
+
+def _ppo(backend):
+    import tempfile
+
+    import test_gpu_multigpu as M
+
+    with tempfile.TemporaryDirectory() as tmp:
+        out = _launch("_sharded_update_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL="64"))
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        assert "SHARDED_WORKER_OK backend=%s native=1 carrier=p2p" % backend in out.stdout, out.stdout[-2000:]
+        r0, r1 = dict(np.load(os.path.join(tmp, "rank0.npz"))), dict(np.load(os.path.join(tmp, "rank1.npz")))
+    assert int(r0["native"][0]) == 1 and int(r1["native"][0]) == 1     # mi_ppo_update_sharded really was the route
+    M._check(r0, r1, M._single_process(r0["params0"], 64), 64)
+    # ONE C call with the in-stream peer-to-peer all-reduces == host-sequenced launches with torch.distributed all-reduces in between, bit for bit (a + b on both ranks)
+    for rk in (r0, r1):
+        for k in ("params", "exp_avg", "exp_avg_sq", "grads", "loss_terms", "grad_norm", "observations", "advantages"):
+            assert np.array_equal(rk[k], rk["seq_" + k]), k
+        # the per-minibatch advantage sums are fp64 ATOMIC adds of workgroup partials (mi_adv_stats): two runs of the same launch may differ in the last bits of the
+        # fp64 sum (never in the f32 mean / std derived from it — the bitwise-equal gradients above)
+        assert np.allclose(rk["adv_sums"], rk["seq_adv_sums"], rtol=1e-12, atol=0.0)
+
+
+def _offpolicy(backend):
+    import tempfile
+
+    import test_gpu_multigpu as M
+
+    with tempfile.TemporaryDirectory() as tmp:
+        out = _launch("_offpolicy_sharded_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp), timeout=900)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        assert "OFFPOLICY_WORKER_OK backend=%s native=1 carrier=p2p" % backend in out.stdout, out.stdout[-2000:]
+        r0, r1 = dict(np.load(os.path.join(tmp, "off_rank0.npz"))), dict(np.load(os.path.join(tmp, "off_rank1.npz")))
+    assert int(r0["dqn_native"][0]) == 1 and int(r0["sac_native"][0]) == 1
+    M._check_off(r0, r1, M._off_single_process(r0))
+    for rk in (r0, r1):
+        seq = [k for k in rk if k.startswith("seq_") and not k.endswith("_native")]
+        assert len(seq) > 20
+        for k in seq:
+            assert np.array_equal(rk[k], rk[k[4:]]), k
+
+
+def test_two_ranks_one_gpu_p2p_ppo():
+    _need_gpu()
+    _ppo("gloo")
+
+
+def test_two_ranks_one_gpu_p2p_offpolicy():
+    _need_gpu()
+    _offpolicy("gloo")
+
+
+def test_two_gpus_p2p_ppo():
+    if _need_gpu().cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs; the one-GPU variant above runs the same worker with both ranks on cuda:0")
+    _ppo("nccl")
+
+
+def test_two_gpus_p2p_offpolicy():
+    if _need_gpu().cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs; the one-GPU variant above runs the same worker with both ranks on cuda:0")
+    _offpolicy("nccl")
