@@ -39,8 +39,8 @@ BYTES_PER_ENV_STEP = 292                         # rollout 40 + env state 72 + G
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
 PEAK_HBM_GBS = 8000.0
 REFERENCE_PY_STEPS_PER_S = 886.0                 # the unmodified reference ppo.py, torch CPU, 1 thread, build container
-PREWARM_UPDATES = 60
-PROF_EVERY = 10   # the timed windows bracket grad_kernel's launches with HIP events in every 10th update (see timed_updates)                             # ~90 ms of throwaway updates before the W warm-up steps: the GPU's clocks have ramped by then (see main)
+PREWARM_UPDATES = 60   # ~90 ms of throwaway updates on a scratch engine before the W warm-up steps: the GPU's clocks have ramped by then (see main)
+PROF_EVERY = 10        # the timed windows bracket grad_kernel's launches with HIP events in every 10th update only (see timed_updates)
 
 
 def usable_cpus():
@@ -310,6 +310,20 @@ def cpu_baseline_sac(actor0, q0, envs, slots, batch, min_seconds):
             "sample": "%d loop iterations (1 step x %d envs + critic / actor / alpha update each) in %.1f s, C oracle, OpenMP over envs / rows" % (gs, envs, dt)}
 
 
+def kernel_device_durations(window_ms):
+    """Per-kernel DEVICE time per update from the committed rocprofv3 kernel trace of the headline command (profiles/latest_kernel_durations.json, written by
+    tools/make_latest_durations.py): sum of End - Start of each kernel's launches between two rollouts, the update's span and launch_gaps = span - sum, all from ONE
+    profiled run so that they add up.  Static (not measured by this run) and labelled so; this run's own window stands beside it."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "latest_kernel_durations.json")))
+        return {"kernels": {n: v["ms_per_update"] for n, v in d["ppo_update"].items()}, "sum_ms": d["sum_ms"], "span_ms_profiled": d["span_ms"], "launch_gaps_ms": d["launch_gaps_ms"],
+                "launches_per_update": d.get("launches_per_update"), "this_run_window_ms": round(window_ms, 4),
+                "source": "%s, build %s, %s updates averaged — static: device durations, span and gaps of the SAME profiled run (they add up; HIP-event brackets cannot)"
+                          % (d.get("source", "?"), d.get("build", "?"), d.get("updates_averaged", "?"))}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": "profiles/latest_kernel_durations.json: %s" % ex}
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` with N > 1: start the N ranks as a child process and relay rank 0's line.  The parent makes no GPU call
     and never replaces itself (a process that has initialised HIP must not exec; this one has not even imported torch)."""
@@ -360,7 +374,8 @@ def collective_diagnostics(eng, comm, world, dev, breakdown, n_break):
         if comm is not None:
             ws, rk, ver, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
             N.check(N.lib().mi_comm_info(comm, C.byref(ws), C.byref(rk), C.byref(ver), C.byref(cnt)), "mi_comm_info")
-            out["carrier"] = "RCCL direct (rccl.h via libmirl mi_comm, in-stream ncclAllReduce inside ONE C call per update)"
+            out["carrier"] = ("P2P (libmirl mi_comm over hipIpc-mapped inboxes: one launch per all-reduce, rank-ordered sum, inside ONE C call per update)"
+                              if N.lib().mi_comm_carrier(comm) == 1 else "RCCL direct (rccl.h via libmirl mi_comm, in-stream ncclAllReduce inside ONE C call per update)")
             out["rccl_version"] = ver.value
             out["rccl_comm_count"] = cnt.value
             g, st = breakdown.get("comm_grad", (0.0, 0)), breakdown.get("comm_stats", (0.0, 0))
@@ -400,6 +415,74 @@ def collective_diagnostics(eng, comm, world, dev, breakdown, n_break):
     return out
 
 
+def carrier_legs(eng, world, dev, one_update, timed_updates, u0, steps):
+    """The same K updates on EACH carrier of libmirl's communicator: RCCL (in-stream ncclAllReduce) and P2P (one launch per all-reduce over
+    hipIpc-mapped inboxes, rank-ordered sum).  Per carrier: a plain timed window, a short window with HIP events around every in-stream collective (in_update: includes
+    the wait for the slowest rank), 200 back-to-back all-reduces on an idle stream, and whether the replicas are still bitwise identical afterwards.  Runs AFTER the
+    headline measurement; every step is collective and agreed on, a failing carrier costs its own entry only."""
+    import ctypes as C
+
+    import torch
+
+    import deep_rl_amd.dist as DD
+    import deep_rl_amd.engine as E
+    from deep_rl_amd import _native as N
+
+    res = {}
+    for which in ("rccl", "p2p"):
+        entry = {}
+        try:
+            comm = DD.native_comm(eng.pg, which=which)
+        except Exception as ex:  # noqa: BLE001
+            comm, entry = None, {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if comm is None:
+            entry.setdefault("error", "no %s communicator (process group %s)" % (which, torch.distributed.get_backend()))
+            res[which] = entry
+            continue
+        try:
+            DD.use_comm(comm)
+            E._FORCE_NATIVE_SHARDED = True
+            for _ in range(2):
+                one_update(u0)
+            dt, _ = timed_updates(u0, steps)
+            n_ev = min(steps, 10)
+            _, prof = timed_updates(u0, n_ev, prof_every=1, tags=("comm_grad", "comm_stats", "reduce"))
+            g, st, rd = prof["comm_grad"], prof["comm_stats"], prof["reduce"]
+            entry = {"ms_per_step": round(1e3 * dt / steps, 4),
+                     "in_update": {"us_per_allreduce_grad": round(1e3 * g[0] / max(g[1], 1), 2) if g[1] else None, "us_per_allreduce_stats": round(1e3 * st[0] / max(st[1], 1), 2),
+                                   "us_per_slab_sum": round(1e3 * rd[0] / max(rd[1], 1), 2), "ms_per_update": round((g[0] + st[0] + rd[0]) / n_ev, 4), "samples": [g[1], st[1], rd[1]],
+                                   "note": "p2p: the gradient all-reduce happens INSIDE the slab-sum launch (us_per_slab_sum includes the exchange and the wait for the slowest "
+                                           "rank; no all-reduce launch); rccl: slab sum, then an in-stream ncclAllReduce"}}
+            buf = torch.zeros(N.NPARAMS + 4, device=dev)
+            for _ in range(20):
+                N.check(N.lib().mi_comm_allreduce_sum(comm, N.ptr(buf), buf.numel(), 0, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+            torch.cuda.synchronize(); torch.distributed.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                N.check(N.lib().mi_comm_allreduce_sum(comm, N.ptr(buf), buf.numel(), 0, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+            torch.cuda.synchronize()
+            entry["back_to_back_us_per_allreduce_grad"] = round(1e6 * (time.perf_counter() - t0) / 200, 2)
+            try:
+                if world > 1:
+                    eng.check_replicas()
+                else:
+                    DD.check_native_comm(eng.pg)
+                    N.check(N.lib().mi_comm_check(comm), "mi_comm_check")
+                entry["replicas_identical"] = True
+            except Exception as ex:  # noqa: BLE001
+                entry["replicas_identical"] = False
+                entry["error"] = "%s: %s" % (type(ex).__name__, ex)
+        except Exception as ex:  # noqa: BLE001
+            entry["error"] = "%s: %s" % (type(ex).__name__, ex)
+        finally:
+            E._FORCE_NATIVE_SHARDED = False
+            DD.use_comm(None)
+        res[which] = entry
+    res["note"] = ("in_update: HIP events around each in-stream all-reduce inside the update (includes the wait for the slowest rank = the exposed cost); back_to_back: 200 "
+                   "all-reduces of the 9,159-float gradient buffer on an idle stream, wall clock / 200, this rank; the headline window runs on MIRL_COMM (default rccl)")
+    return res
+
+
 def sharded_route_leg(eng, one_update, timed_updates, u0, steps, dev, base_ms, base_grad_us):
     """What the launches that ONLY a multi-GPU run takes cost, measured on this one GPU (VERDICT r03 missing #2): the same K updates
       (a) with mi_ppo_test_assume_sharded(1): the owed optimizer steps recompute the clip coefficient from the 9,155 gradients (norm_parts = nullptr) — the prologue every
@@ -429,6 +512,49 @@ def sharded_route_leg(eng, one_update, timed_updates, u0, steps, dev, base_ms, b
         out["assume_sharded"] = {"ms_per_step": round(1e3 * dt / steps, 4), "grad_kernel_avg_launch_us": round(g_us, 2),
                                  "delta_us_per_update": round(1e3 * (1e3 * dt / steps - base_ms), 1), "delta_us_per_optimizer_step": round(1e3 * (1e3 * dt / steps - base_ms) / 16, 2),
                                  "grad_kernel_delta_us": round(g_us - base_grad_us, 2)}
+        # (c) the P2P carrier with world = 2 / 4 / 8 SYNTHETIC ranks (mi_comm_p2p_synthetic: this process stores its share into slot 0 and zeros into the other world - 1
+        # slots of its own inbox, publishes and polls world flags, sums world slots — results unchanged): what the one-launch exchange costs per optimizer step before a byte
+        # crosses xGMI, and how it grows with the number of slots summed
+        import ctypes as C
+
+        from deep_rl_amd import _native as N
+
+        p2p = {"note": "mi_ppo_update_sharded on the P2P carrier, ONE process playing `world` ranks into its own inbox: grad_reduce_kernel stores each summed gradient element "
+                       "as a line into `world` slots, polls `world` lines and adds them in rank order (no launch per all-reduce, no link traffic here); the one stats all-reduce per "
+                       "update is a launch of its own; back_to_back = 200 stand-alone all-reduces of the 9,159-float buffer on an idle stream, wall clock / 200"}
+        for w in (2, 4, 8):
+            h = C.c_void_p()
+            try:
+                N.check(N.lib().mi_comm_p2p_synthetic(w, 1 << 20, C.byref(h)), "mi_comm_p2p_synthetic")
+                DD.use_comm(h)
+                E.set_assume_sharded(False)   # on this carrier grad_reduce_kernel exchanges the gradient itself: the owed steps take the single-rank branch by design
+                E._FORCE_NATIVE_SHARDED = True
+                for _ in range(2):
+                    one_update(u0)
+                dt, prof = timed_updates(u0, steps)
+                E._FORCE_NATIVE_SHARDED = False
+                buf = torch.zeros(N.NPARAMS + 4, device=dev)
+                for _ in range(20):
+                    N.check(N.lib().mi_comm_allreduce_sum(h, N.ptr(buf), buf.numel(), 0, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    N.check(N.lib().mi_comm_allreduce_sum(h, N.ptr(buf), buf.numel(), 0, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+                torch.cuda.synchronize()
+                b2b = 1e6 * (time.perf_counter() - t0) / 200
+                N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+                p2p["world%d" % w] = {"ms_per_step": round(1e3 * dt / steps, 4), "delta_us_per_update": round(1e3 * (1e3 * dt / steps - base_ms), 1),
+                                      "delta_us_per_optimizer_step": round(1e3 * (1e3 * dt / steps - base_ms) / 16, 2), "back_to_back_us_per_allreduce": round(b2b, 2)}
+            except Exception as ex:  # noqa: BLE001
+                p2p["world%d" % w] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            finally:
+                E._FORCE_NATIVE_SHARDED = False
+                E.set_assume_sharded(True)
+                DD.use_comm(None)
+                if h.value:
+                    torch.cuda.synchronize()
+                    N.lib().mi_comm_destroy(h)
+        out["p2p_synthetic"] = p2p
         made_pg = False
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             with socket.socket() as sk:
@@ -473,6 +599,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
+    # stdout carries exactly ONE line, the JSON line: anything a library prints there (RCCL's version banner at communicator creation goes to C stdout) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -536,8 +667,8 @@ def main():
         eng.update()
         eng.episode_summary_async(stats_host)  # what a training loop reads per update; no host sync
 
-    def timed_updates(u0, n):
-        """n updates bracketed by barrier + synchronize on both sides; -> (seconds, MAX over ranks; grad_kernel's in-library HIP-event profile)"""
+    def timed_updates(u0, n, prof_every=PROF_EVERY, tags=("grad",)):
+        """n updates bracketed by barrier + synchronize on both sides; -> (seconds, MAX over ranks; the in-library HIP-event profile of `tags` in every prof_every-th update)"""
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -546,11 +677,11 @@ def main():
         # launch of a 70 us kernel costs the loop it measures 0.098 ms per update = 7.5 % (tools/prof_overhead.py: 1.411 ms with all 320 launches of 20 updates
         # bracketed, 1.312 ms with none, the same 70.2 - 70.5 us per launch either way) - until round 4 the headline carried that.
         # (the bracketed updates sit inside the window — the 6th, 16th, ... — not right behind the synchronisation that opens it)
-        N.prof_begin((n // PROF_EVERY + 1) * 16 + 16, tags=["grad"])
-        phase = min(PROF_EVERY // 2, n - 1)
+        N.prof_begin((n // prof_every + 1) * 20 * len(tags) + 16, tags=list(tags))
+        phase = min(prof_every // 2, n - 1)
         t0 = time.perf_counter()
         for k, u in enumerate(range(u0, u0 + n)):
-            N.prof_pause(k % PROF_EVERY != phase)
+            N.prof_pause(k % prof_every != phase)
             one_update(min(u, num_updates - 1))
         N.prof_pause(False)
         torch.cuda.synchronize()
@@ -573,6 +704,11 @@ def main():
     if not args.single_window:
         for _ in range(2):
             windows.append(timed_updates(num_updates, args.steps)[0])
+
+    # the round-1..3 methodology beside it: one more window with a pair of HIP events around EVERY gradient launch of EVERY update
+    dt_all = None
+    if not args.single_window:
+        dt_all = timed_updates(num_updates, args.steps, prof_every=1)[0]
 
     # beside it, never instead of it: the same K updates with the split-bf16 experiment switched on (include/mi_rl.h, mi_ppo_set_contraction)
     variant = None
@@ -611,6 +747,12 @@ def main():
             collectives = collective_diagnostics(eng, comm, world, dev, breakdown, n_break)
         except Exception as ex:  # noqa: BLE001
             collectives = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if collectives is not None and "error" not in collectives and os.environ.get("MIRL_BENCH_CARRIER_LEGS", "1") != "0":
+            try:
+                collectives["carriers"] = carrier_legs(eng, world, dev, one_update, timed_updates, num_updates - 1, args.steps)
+            except Exception as ex:  # noqa: BLE001
+                collectives["carriers"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            collectives["rccl_env"] = _dist.apply_rccl_env() or None
     finite = bool(torch.isfinite(agent.flat).all().item())
     ep = stats_host.tolist()
     if rank == 0:
@@ -630,7 +772,7 @@ def main():
             "config": {"workload": "ppo.py CartPole-v1, %d envs/GPU x %d steps per update, 4 epochs x 4 minibatches of %d rows, "
                                    "2x64-tanh actor+critic (9155 params), on-device env.step + GAE + fwd/bwd + clip + Adam" % (ENVS_PER_GPU, T, mb),
                        "envs_per_gpu": ENVS_PER_GPU, "num_steps": T, "minibatch_rows": mb, "parallelism": "env-sharded x%d, grad all-reduce" % world,
-                       "collectives": "none (single process)" if world == 1 else ("RCCL direct (mi_ppo_update_sharded: one C call per update, 17 in-stream all-reduces)" if eng_native else "torch.distributed (host-sequenced, 17 all-reduces per update)")},
+                       "collectives": "none (single process)" if world == 1 else (("%s (mi_ppo_update_sharded: one C call per update, 17 in-stream all-reduces)" % ("P2P over hipIpc inboxes" if _dist.carrier() == "p2p" else "RCCL direct")) if eng_native else "torch.distributed (host-sequenced, 17 all-reduces per update)")},
             "roofline": {"bound": "mfma", "kernel": "grad_kernel_f32", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_launch, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "launches": g_n,
@@ -639,7 +781,16 @@ def main():
             "hbm_roofline": {"algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                              "achieved_GBps_per_gpu": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9, 2), "peak_GBps": PEAK_HBM_GBS,
                              "frac": round(BYTES_PER_ENV_STEP * steps_per_s / world / 1e9 / PEAK_HBM_GBS, 6)},
-            "kernel_ms_per_update": {k: round(v[0] / n_break, 4) for k, v in breakdown.items() if v[1]},
+            "kernel_ms_per_update_bracketed": dict({k: round(v[0] / n_break, 4) for k, v in breakdown.items() if v[1]},
+                                                   note="HIP events around EVERY tagged launch in an untimed pass of %d updates: each figure carries its own event overhead "
+                                                        "(~3 us per launch); the sum exceeds the timed window by construction — use kernel_device_ms_per_update for a sum" % n_break),
+            "kernel_device_ms_per_update": kernel_device_durations(1e3 * dt / args.steps),
+            "methodology": {"prewarm_updates": prewarm_updates, "events": "HIP events around grad_kernel's 16 launches of every %d-th update of the timed windows" % PROF_EVERY,
+                            "protocol_changed_in": "r04 (rounds 1-3: no prewarm, events around every launch of every update; BASELINE.md section 3 names neither)",
+                            "ms_per_step_all_launches_bracketed": None if dt_all is None else round(1e3 * dt_all / args.steps, 4),
+                            "value_all_launches_bracketed": None if dt_all is None else round(env_steps / dt_all, 1),
+                            "note": "the r01-r03 style figure (a pair of events around every gradient launch) from one more window of the same K updates right behind the "
+                                    "repeat windows; compare BENCH_r01..r03 with this key, BENCH_r04.. with `value`"},
             "last_rollout": {"episodes": ep[0], "mean_return": round(ep[1] / max(ep[0], 1), 2), "max_return": ep[2]},
             "params_finite": finite,
             "prewarm": {"updates": prewarm_updates, "what": "throwaway engine of the same shape, run and discarded BEFORE the engine that is measured is built (clock ramp of a fresh "
@@ -673,7 +824,7 @@ def main():
             # "(also a scaled batch, stated)" — NOT the reference's batch: the same loops with batch 4,096, where the update kernels are throughputs, not fixed latencies
             out["config3_dqn_scaled"] = dict(bench_dqn(dev, iters=150, cpu_seconds=min(cs, 2.0), batch=4096), scaled="batch 4096 instead of the reference's 128 (dqn.py:46)")
             out["config4_sac_scaled"] = dict(bench_sac(dev, iters=150, cpu_seconds=min(cs, 2.0), batch=4096), scaled="batch 4096 instead of the reference's 256 (sac.py:85)")
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
         torch.distributed.barrier()
         from deep_rl_amd.dist import destroy_native_comms

@@ -2,9 +2,10 @@
 // enqueued IN-STREAM between the kernels of mi_ppo_update_sharded & co., so a whole sharded outer update is ONE C call with no Python between launches.
 // Two carriers behind one handle (reference ppo.py:189-192, dqn.py:131-133, sac.py:185-210 with the gradient exchange between backward and the optimizer step):
 //   RCCL  (mi_comm_create; default)       straight on rccl.h, one communicator per process (one process per GPU).
-//   P2P   (mi_comm_p2p_alloc / _connect)  a one-shot exchange over hipIpc-mapped inboxes: every rank stores its share into its slot of EVERY rank's inbox, publishes a
-//         sequence number, waits for the world's sequence numbers in its own inbox and sums the slots IN RANK ORDER — one launch per all-reduce, no ring, and the
-//         same bits on every rank by construction (a ring's grouping depends on the rank).  Also the only carrier that takes two ranks on ONE device (RCCL refuses).
+//   P2P   (mi_comm_p2p_alloc / _connect)  a one-shot exchange over hipIpc-mapped inboxes: every rank stores its share — every 32-bit word together with the
+//         all-reduce's sequence number in ONE 8-byte line — into its slot of EVERY rank's inbox, polls the world's lines in its own inbox and sums them IN RANK
+//         ORDER: one launch per all-reduce, no ring, no fence, the same bits on every rank by construction (a ring's grouping depends on the rank).  Also the only
+//         carrier that takes two ranks on ONE device (RCCL refuses).
 //
 // RCCL is bound at run time (dlopen), not at link time: libmirl.so stays loadable on a CPU-only box and single-GPU runs never touch
 // it.  The instance already living in the process (torch's bundled librccl.so) is preferred, so both talk to the same transport.
@@ -60,13 +61,12 @@ static int rccl_bind() {
     } while (0)
 
 // ---- the P2P carrier's inbox (device memory of its owner, mapped into every peer with hipIpcOpenMemHandle) ------------------------------------------------------
-//   [flags u32 [2 parities][P2P_MAX_WORLD][P2P_MAX_GROUPS]] [status u32 ... padded to P2P_HDR_BYTES] [data [2 parities][world][cap bytes]]
-// flag (parity, r, g) = sequence number of the last all-reduce whose workgroup g of rank r has stored its chunk into slot (parity, r) of THIS inbox.
-#define P2P_MAX_WORLD 8
+//   [status u32, padded to P2P_HDR_BYTES] [lines u64 [2 parities][world][cap / 4]]
+// A LINE is one 8-byte word {payload word (low), sequence number (high)}, stored and loaded as ONE 8-byte access: the payload carries its own "arrived" flag, so an
+// all-reduce needs no fence, no separate flag and no second round trip (the LL protocol idea).  Line i of slot (parity, r) = 32-bit word i of rank r's message.
 #define P2P_MAX_GROUPS 64
 #define P2P_THREADS 256
-#define P2P_FLAG_WORDS (2 * P2P_MAX_WORLD * P2P_MAX_GROUPS)
-#define P2P_HDR_BYTES (P2P_FLAG_WORDS * 4 + 256)
+#define P2P_HDR_BYTES 256
 enum { CARRIER_RCCL = 0, CARRIER_P2P = 1 };
 
 struct mi_comm {
@@ -112,88 +112,49 @@ extern "C" int mi_comm_create(const void* id128, int world_size, int rank, void*
 }
 
 // ================================================================ the P2P carrier ================================================================
-struct p2p_args_t {
-    char* peer[P2P_MAX_WORLD];
-    unsigned long long budget;
-    size_t cap;
-    uint32_t seq;
-    int world, rank, synthetic;
-};
-__device__ __forceinline__ uint32_t* p2p_flag(char* box, int parity, int r, int g) { return reinterpret_cast<uint32_t*>(box) + (parity * P2P_MAX_WORLD + r) * P2P_MAX_GROUPS + g; }
-__device__ __forceinline__ uint32_t* p2p_status(char* box) { return reinterpret_cast<uint32_t*>(box) + P2P_FLAG_WORDS; }
-__device__ __forceinline__ char* p2p_slot(char* box, int parity, int r, int world, size_t cap) { return box + P2P_HDR_BYTES + ((size_t)parity * world + r) * cap; }
-__device__ __forceinline__ unsigned long long p2p_clock() {
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
+// One launch = one all-reduce; a thread owns elements e = its global id, + the grid's threads, ...: it stores each of them as lines into slot (parity, rank) of EVERY
+// rank's inbox (all stores of the launch go out before the first load), then polls the SAME lines of every rank's slot in its own inbox — all WORLD loads of an
+// element in flight together — and writes the sum in RANK ORDER back to buf.  No barrier, no fence, no flag word: a thread waits for nothing but its peers' stores of its
+// own elements, which depend on no wait — no deadlock whatever the residency (two ranks time-sharing one device included).  Two parities: rank A reaches all-reduce
+// k + 2 only after B has stored k + 1, i.e. after B's launch k — the reader of parity k & 1 — is over (launches of one stream run in order; all collectives of a
+// communicator must be enqueued on streams ordered with each other, in the same order on every rank).
+// The wait is bounded (budget: MIRL_P2P_TIMEOUT_MS, default 10 s): a peer that never arrives sets the status word, the elements concerned keep the LOCAL share, later
+// launches give up after 64 polls, and mi_comm_check reports MI_ESTATE.
+template <typename T, int WORLD>
+__global__ void __launch_bounds__(P2P_THREADS) p2p_allreduce_kernel(p2p_args_t a, T* __restrict__ buf, size_t n) {
+    constexpr int W = ll_elem<T>::W;
+    const size_t gtid = (size_t)blockIdx.x * P2P_THREADS + threadIdx.x, nthreads = (size_t)gridDim.x * P2P_THREADS;
+    // 1. publish
+    for (size_t e = gtid; e < n; e += nthreads) {
+        uint32_t w[W];
+        ll_elem<T>::split(buf[e], w);
+#pragma unroll
+        for (int d = 0; d < WORLD; ++d)
+#pragma unroll
+            for (int k = 0; k < W; ++k) ll_store_nowait(a.dst[d] + e * W + k, (a.zeros >> d) & 1 ? 0u : w[k], a.seq);
+    }
+    // 2. poll the world's lines of the own elements, 3. sum in rank order
+    for (size_t e = gtid; e < n; e += nthreads) {
+        uint64_t v[WORLD][W];
+        if (!ll_gather<WORLD, W>(a, e * W, v)) continue;   // the element keeps the local share
+        T acc = ll_elem<T>::join(v[0]);
+#pragma unroll
+        for (int r = 1; r < WORLD; ++r) acc += ll_elem<T>::join(v[r]);
+        buf[e] = acc;
+    }
 }
 
-// One launch = one all-reduce.  Workgroup g owns elements [g * per, (g + 1) * per): it stores them into slot (parity, rank) of every rank's inbox, publishes the
-// sequence number (one flag per peer and workgroup), waits for the world's flags of ITS chunk in its own inbox and writes the rank-ordered sum back to buf.  A
-// workgroup never waits for anything but peers' stores of the same chunk, which do not depend on any wait: no deadlock whatever the residency (two ranks on one
-// device included).  Two parities: rank A reaches all-reduce k + 2 only after B has published k + 1, i.e. after B's launch k — the reader of parity k & 1 — is over
-// (launches of one stream run in order; all collectives of a communicator must be enqueued on streams ordered with each other).
-// The wait is bounded (budget, default 10 s): a peer that never arrives sets the status word, the launch leaves buf = the local share, every later launch on this
-// communicator returns at once, and mi_comm_check / the next enqueue's host-side check report MI_ESTATE.
-template <typename T, int V>
-__global__ void __launch_bounds__(P2P_THREADS) p2p_allreduce_kernel(p2p_args_t a, T* __restrict__ buf, size_t n, size_t per) {
-    typedef T vec_t __attribute__((ext_vector_type(V)));
-    __shared__ int s_bad;
-    const int tid = threadIdx.x, g = blockIdx.x, parity = a.seq & 1;
-    char* const mine = a.peer[a.synthetic ? 0 : a.rank];
-    if (tid == 0) s_bad = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    __syncthreads();
-    if (s_bad) return;
-    const size_t lo = (size_t)g * per, hi = lo + per < n ? lo + per : n;   // per is a multiple of V, buf is V-aligned
-    // 1. publish
-    for (int d = 0; d < a.world; ++d) {
-        const int p = a.rank + d < a.world ? a.rank + d : a.rank + d - a.world;   // start with the own inbox, then rank + 1 ...: the peers' links are used side by side
-        const bool zeros = a.synthetic && p != 0;
-        T* dst = reinterpret_cast<T*>(p2p_slot(a.peer[p], parity, a.synthetic ? p : a.rank, a.world, a.cap));
-        for (size_t i = lo + (size_t)tid * V; i < hi; i += (size_t)P2P_THREADS * V) {
-            if (i + V <= hi) {
-                vec_t v = *reinterpret_cast<const vec_t*>(buf + i);
-                if (zeros) v = vec_t(0);
-                *reinterpret_cast<vec_t*>(dst + i) = v;
-            } else {
-                for (size_t k = i; k < hi; ++k) dst[k] = zeros ? T(0) : buf[k];
-            }
-        }
-    }
-    __threadfence_system();   // this thread's stores are visible system-wide before ...
-    __syncthreads();          // ... any flag of this workgroup is
-    if (tid < a.world) __hip_atomic_store(p2p_flag(a.peer[tid], parity, a.synthetic ? tid : a.rank, g), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // 2. wait for the world's chunk g
-    if (tid < a.world) {
-        const uint32_t* f = p2p_flag(mine, parity, tid, g);
-        const unsigned long long t0 = p2p_clock();
-        uint32_t spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 31) == 0 && (p2p_clock() - t0 > a.budget || __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_fetch_or(p2p_status(mine), 1u | (1u << (8 + tid)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bit 8 + r: rank r never arrived
-                s_bad = 1;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    if (s_bad) return;
-    __threadfence_system();   // acquire for every thread's loads below
-    // 3. the sum, in rank order on every rank
-    for (size_t i = lo + (size_t)tid * V; i < hi; i += (size_t)P2P_THREADS * V) {
-        if (i + V <= hi) {
-            vec_t acc = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(p2p_slot(mine, parity, 0, a.world, a.cap)) + i));
-            for (int r = 1; r < a.world; ++r)
-                acc += __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(p2p_slot(mine, parity, r, a.world, a.cap)) + i));
-            *reinterpret_cast<vec_t*>(buf + i) = acc;
-        } else {
-            for (size_t k = i; k < hi; ++k) {
-                T acc = __builtin_nontemporal_load(reinterpret_cast<const T*>(p2p_slot(mine, parity, 0, a.world, a.cap)) + k);
-                for (int r = 1; r < a.world; ++r) acc += __builtin_nontemporal_load(reinterpret_cast<const T*>(p2p_slot(mine, parity, r, a.world, a.cap)) + k);
-                buf[k] = acc;
-            }
-        }
+template <typename T>
+static void p2p_launch(int world, unsigned groups, hipStream_t s, const p2p_args_t& a, T* buf, size_t n) {
+    switch (world) {
+        case 1: p2p_allreduce_kernel<T, 1><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
+        case 2: p2p_allreduce_kernel<T, 2><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
+        case 3: p2p_allreduce_kernel<T, 3><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
+        case 4: p2p_allreduce_kernel<T, 4><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
+        case 5: p2p_allreduce_kernel<T, 5><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
+        case 6: p2p_allreduce_kernel<T, 6><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
+        case 7: p2p_allreduce_kernel<T, 7><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
+        default: p2p_allreduce_kernel<T, 8><<<groups, P2P_THREADS, 0, s>>>(a, buf, n); break;
     }
 }
 
@@ -207,7 +168,7 @@ static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm
     c->budget = ms * 100000ull;   // s_memrealtime: 100 MHz
     hipError_t e = hipGetDevice(&c->device);
     if (e != hipSuccess) { mi_set_error("mi_comm_p2p: hipGetDevice failed: %s", hipGetErrorString(e)); free(c); return MI_EHIP; }
-    const size_t bytes = P2P_HDR_BYTES + 2 * (size_t)world * c->cap;
+    const size_t bytes = P2P_HDR_BYTES + 2 * (size_t)world * 2 * c->cap;   // 2 parities x world slots x (cap payload bytes as 8-byte lines)
     // uncached (or at least fine-grained) device memory: a peer's stores over xGMI must not meet stale lines in the owner's L2 while the owner polls inside a kernel
     const unsigned kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, hipDeviceMallocDefault};
     const char* want = getenv("MIRL_P2P_MEM");   // "uncached" | "finegrained" | "plain": start of the fallback chain (diagnostic)
@@ -283,30 +244,38 @@ extern "C" int mi_comm_p2p_synthetic(int world_size, size_t max_bytes, void** ou
     return MI_OK;
 }
 
-static int p2p_allreduce(mi_comm* c, void* buf, size_t n, int dtype, hipStream_t s) {
-    const size_t esz = dtype ? 8 : 4;
+int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world_out) {
+    mi_comm* c = (mi_comm*)comm;
+    if (!c || c->carrier != CARRIER_P2P) { mi_set_error("mi_comm: not a P2P communicator"); return MI_EINVAL; }
     if (!c->connected) { mi_set_error("mi_comm (p2p): all-reduce before mi_comm_p2p_connect"); return MI_ESTATE; }
-    if (n * esz > c->cap) { mi_set_error("mi_comm (p2p): a %zu-byte message does not fit the %zu-byte slots (max_bytes of mi_comm_p2p_alloc)", n * esz, c->cap); return MI_EINVAL; }
-    const bool vec = ((uintptr_t)buf & 15) == 0;
-    const size_t V = vec ? 16 / esz : 1;
-    // >= 1024 elements per workgroup (one 16-byte vector per thread and pass), at most P2P_MAX_GROUPS workgroups
-    size_t groups = (n + 1023) / 1024;
-    if (groups > P2P_MAX_GROUPS) groups = P2P_MAX_GROUPS;
-    size_t per = (n + groups - 1) / groups;
-    per = (per + V - 1) / V * V;
-    groups = (n + per - 1) / per;
-    p2p_args_t a;
-    for (int r = 0; r < P2P_MAX_WORLD; ++r) a.peer[r] = r < c->world ? c->peer[r] : nullptr;
-    a.budget = c->budget; a.cap = c->cap; a.world = c->world; a.rank = c->rank; a.synthetic = c->synthetic;
+    if (n_words * 4 > c->cap) { mi_set_error("mi_comm (p2p): a %zu-byte message does not fit the %zu-byte slots (max_bytes of mi_comm_p2p_alloc)", n_words * 4, c->cap); return MI_EINVAL; }
     if (++c->seq == 0) c->seq = 1;   // 0 is the cleared inbox
-    a.seq = c->seq;
-    if (dtype) {
-        if (vec) p2p_allreduce_kernel<double, 2><<<(unsigned)groups, P2P_THREADS, 0, s>>>(a, (double*)buf, n, per);
-        else p2p_allreduce_kernel<double, 1><<<(unsigned)groups, P2P_THREADS, 0, s>>>(a, (double*)buf, n, per);
-    } else {
-        if (vec) p2p_allreduce_kernel<float, 4><<<(unsigned)groups, P2P_THREADS, 0, s>>>(a, (float*)buf, n, per);
-        else p2p_allreduce_kernel<float, 1><<<(unsigned)groups, P2P_THREADS, 0, s>>>(a, (float*)buf, n, per);
+    memset(a, 0, sizeof(*a));
+    const int parity = c->seq & 1, world = c->world;
+    auto slot = [&](char* box, int r) { return reinterpret_cast<uint64_t*>(box + P2P_HDR_BYTES + ((size_t)parity * world + r) * 2 * c->cap); };
+    for (int d = 0; d < world; ++d) {
+        const int p = (c->rank + d) % world;
+        a->dst[d] = slot(c->peer[p], c->synthetic ? p : c->rank);
+        if (c->synthetic && p != 0) a->zeros |= 1u << d;
+        a->src[d] = slot(c->inbox, d);
     }
+    a->mine = c->inbox; a->budget = c->budget; a->seq = c->seq;
+    if (world_out) *world_out = world;
+    return MI_OK;
+}
+
+bool mi_comm_is_p2p(void* comm) { return comm && ((mi_comm*)comm)->carrier == CARRIER_P2P; }
+
+static int p2p_allreduce(mi_comm* c, void* buf, size_t n, int dtype, hipStream_t s) {
+    p2p_args_t a;
+    int world = 1;
+    int rc = mi_comm_p2p_next(c, n * (dtype ? 2 : 1), &a, &world);
+    if (rc) return rc;
+    // two elements per thread while that gives <= P2P_MAX_GROUPS workgroups (PPO's 9,159 floats: 18 workgroups), more beyond (SAC's 134,660: 9 per thread)
+    size_t groups = (n + 2 * P2P_THREADS - 1) / (2 * P2P_THREADS);
+    if (groups > P2P_MAX_GROUPS) groups = P2P_MAX_GROUPS;
+    if (dtype) p2p_launch<double>(world, (unsigned)groups, s, a, (double*)buf, n);
+    else p2p_launch<float>(world, (unsigned)groups, s, a, (float*)buf, n);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -317,12 +286,12 @@ extern "C" int mi_comm_check(void* comm) {
     mi_comm* c = (mi_comm*)comm;
     if (c->carrier != CARRIER_P2P) return MI_OK;
     uint32_t st = 0;
-    MI_HIP(hipMemcpy(&st, c->inbox + (size_t)P2P_FLAG_WORDS * 4, 4, hipMemcpyDeviceToHost));
+    MI_HIP(hipMemcpy(&st, c->inbox, 4, hipMemcpyDeviceToHost));
     if (st) {
         char who[64]; int k = 0;
         for (int r = 0; r < c->world; ++r) if (st & (1u << (8 + r))) k += snprintf(who + k, sizeof(who) - k, " %d", r);
-        mi_set_error("mi_comm (p2p), rank %d: a wait ran out (MIRL_P2P_TIMEOUT_MS); ranks that never arrived:%s — the buffers of that and every later all-reduce hold "
-                     "the LOCAL share only", c->rank, k ? who : " ?");
+        mi_set_error("mi_comm (p2p), rank %d: a wait ran out (MIRL_P2P_TIMEOUT_MS); ranks that never arrived:%s — elements of that and every later all-reduce hold "
+                     "the LOCAL share", c->rank, k ? who : " ?");
         return MI_ESTATE;
     }
     return MI_OK;
@@ -347,7 +316,7 @@ extern "C" int mi_comm_destroy(void* comm) {
 extern "C" int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version, int* comm_count) {
     MI_CHECK_ARG(comm != nullptr, "comm is NULL");
     mi_comm* c = (mi_comm*)comm;
-    if (world_size) *world_size = c->world;
+    if (world_size) *world_size = c->synthetic ? 1 : c->world;   // a synthetic communicator is ONE rank (the caller's arithmetic is the single-rank one) playing comm_count ranks
     if (rank) *rank = c->rank;
     if (c->carrier == CARRIER_P2P) {   // no RCCL behind it: version 0, count = the inboxes mapped
         if (rccl_version) *rccl_version = 0;

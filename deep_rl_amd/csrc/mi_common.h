@@ -113,6 +113,87 @@ int mi_rollout_gae_internal(void* handle, const float* params, int T, float* obs
 
 int mi_comm_allreduce_impl(void* comm, void* buf, size_t n, int dtype /* 0 f32, 1 f64 */, hipStream_t s);   // mi_comm.hip
 
+// ---- the P2P carrier's line protocol (mi_comm.hip; also spoken by grad_reduce_kernel, which exchanges the gradient it has just summed without a launch of its own) ----
+// A LINE is one 8-byte word {payload word (low), sequence number of the all-reduce (high)}, stored and loaded as ONE 8-byte access: the payload carries its own
+// "arrived" flag, so an exchange needs no fence, no flag word and no second round trip.  Line i of slot (parity, r) of an inbox = 32-bit word i of rank r's message.
+#define P2P_MAX_WORLD 8
+struct p2p_args_t {          // everything resolved on the host: the kernel does no address arithmetic beyond "+ element"
+    uint64_t* dst[P2P_MAX_WORLD];         // d-th target: slot (parity, this rank) of rank (rank + d) % world's inbox — the own inbox first, then rank + 1 ...: the links are used side by side
+    const uint64_t* src[P2P_MAX_WORLD];   // slot (parity, r) of the OWN inbox, r in rank order
+    char* mine;                           // own inbox (status word)
+    unsigned long long budget;
+    uint32_t seq;
+    uint32_t zeros;                       // bit d: target d receives zeros (synthetic communicator: the ranks this process plays besides its own)
+};
+__device__ __forceinline__ uint32_t* p2p_status(char* box) { return reinterpret_cast<uint32_t*>(box); }
+__device__ __forceinline__ unsigned long long p2p_clock() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+// system-scope 8-byte accesses, written through to the owner's memory / read past every cache (sc0 sc1), issued WITHOUT a wait: a thread puts all its stores, then all
+// the loads of an element, in flight together (the compiler's own system-scope atomics wait for each one: 8 dependent round trips at world 8)
+__device__ __forceinline__ void ll_store_nowait(uint64_t* p, uint32_t w, uint32_t seq) {
+    const uint64_t v = ((uint64_t)seq << 32) | w;
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint64_t ll_load_nowait(const uint64_t* p) {
+    uint64_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ll_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void ll_pin(uint64_t& v) { asm volatile("" : "+v"(v)); }   // every use of a loaded value sits behind this point, which sits behind ll_wait_loads()
+
+// Gathers the W lines of one element from every rank's slot in the own inbox: all WORLD * W loads in flight together, re-issued TOGETHER until every line carries the
+// all-reduce's sequence number (polling them one after the other costs a memory round trip per rank).  false when the budget ran out (or an earlier wait on this
+// communicator did): the status word then names the ranks whose lines never arrived (bit 8 + r).
+template <int WORLD, int W>
+__device__ __forceinline__ bool ll_gather(const p2p_args_t& x, size_t line, uint64_t (&v)[WORLD][W]) {
+    unsigned long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+#pragma unroll
+        for (int r = 0; r < WORLD; ++r)
+#pragma unroll
+            for (int k = 0; k < W; ++k) v[r][k] = ll_load_nowait(x.src[r] + line + k);
+        ll_wait_loads();
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < WORLD; ++r)
+#pragma unroll
+            for (int k = 0; k < W; ++k) { ll_pin(v[r][k]); all = all && (uint32_t)(v[r][k] >> 32) == x.seq; }
+        if (all) return true;
+        if (spins == 0) t0 = p2p_clock();
+        if ((spins & 63) == 63 && (p2p_clock() - t0 > x.budget || __hip_atomic_load(p2p_status(x.mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            uint32_t missing = 1u;
+#pragma unroll
+            for (int r = 0; r < WORLD; ++r)
+#pragma unroll
+                for (int k = 0; k < W; ++k) if ((uint32_t)(v[r][k] >> 32) != x.seq) missing |= 1u << (8 + r);
+            __hip_atomic_fetch_or(p2p_status(x.mine), missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <typename T> struct ll_elem;   // an element as W payload words
+template <> struct ll_elem<float> {
+    static constexpr int W = 1;
+    static __device__ __forceinline__ void split(float x, uint32_t* w) { w[0] = __float_as_uint(x); }
+    static __device__ __forceinline__ float join(const uint64_t* v) { return __uint_as_float((uint32_t)v[0]); }
+};
+template <> struct ll_elem<double> {
+    static constexpr int W = 2;
+    static __device__ __forceinline__ void split(double x, uint32_t* w) { const uint64_t b = (uint64_t)__double_as_longlong(x); w[0] = (uint32_t)b; w[1] = (uint32_t)(b >> 32); }
+    static __device__ __forceinline__ double join(const uint64_t* v) { return __longlong_as_double((long long)(((uint64_t)(uint32_t)v[1] << 32) | (uint32_t)v[0])); }
+};
+
+// Fills `a` for the NEXT all-reduce of `n_words` 32-bit words on a P2P communicator (advances its sequence number: the caller MUST launch exactly one kernel that
+// publishes and consumes those lines on every rank); MI_EINVAL when the message does not fit, MI_ESTATE when the communicator is not connected.
+int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world);
+bool mi_comm_is_p2p(void* comm);
+
 // ---- RNG contract (include/mi_rl.h) ----------------------------------------------------------------
 #define STREAM_RESET 0u
 #define STREAM_ACTION 1u

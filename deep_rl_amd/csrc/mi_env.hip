@@ -295,10 +295,10 @@ extern "C" int mi_prof_begin(int max_launches, uint32_t tag_mask) {
 }
 
 // pause / resume the sampling between mi_prof_begin and mi_prof_end (a measurement that brackets EVERY launch of a 70 us kernel with two events costs the loop it
-// measures ~2.5 %: bench.py samples the launches of every 4th update)
+// measures 7.5 %, tools/prof_overhead.py: bench.py samples the launches of every 10th update)
 extern "C" int mi_prof_pause(int paused) {
     if (g_prof.ev.empty()) return MI_OK;
-    if ((g_prof.used & 1) != 0) return MI_OK;   // between a begin and an end mark: leave it
+    if ((g_prof.used & 1) != 0) return MI_OK;   // between a begin and an end mark (only reachable from a second host thread while a C call is inside a tagged scope): leave it
     g_prof.armed = !paused;
     return MI_OK;
 }

@@ -503,11 +503,33 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 // 1024 threads = 64 consecutive slab positions x 16 slab groups: every wave reads 256 contiguous bytes per slab, 16 independent
 // loads per lane, then the 16 group sums are added in group order through LDS.  Slab positions inside a net's W2 range are in
 // accumulator-fragment order (grad_body's exit reduction); the store maps them back to W2[o][i].
+// WORLD > 0 (sharded run on the P2P carrier, csrc/mi_comm.hip): the all-reduce of {gradient, loss terms} (ppo.py:189 -> :191 with the exchange in between) happens HERE,
+// without a launch of its own — the lane that has just summed element p stores it as a line into slot (parity, rank) of every rank's inbox, polls the WORLD lines of p in
+// its own inbox and adds them in RANK ORDER (the same bits on every rank), so `grads`, `loss_terms` and the block sums of squares come out ALL-REDUCED and the next
+// gradient launch's owed clip + Adam takes the single-rank branch.  Only wave 0 of a 1,024-thread workgroup waits, for peers' stores that depend on no wait; 145 small
+// workgroups never fill the chip, so two ranks time-sharing one device cannot starve each other.  A peer that never arrives: bounded wait, status word, the local share.
+template <int WORLD>
+__device__ __forceinline__ float p2p_exchange(const p2p_args_t& x, int line, float t) {
+    if constexpr (WORLD > 0) {
+#pragma unroll
+        for (int d = 0; d < WORLD; ++d) ll_store_nowait(x.dst[d] + line, (x.zeros >> d) & 1 ? 0u : __float_as_uint(t), x.seq);
+        uint64_t v[WORLD][1];
+        if (!ll_gather<WORLD, 1>(x, (size_t)line, v)) return t;
+        float acc = __uint_as_float((uint32_t)v[0][0]);
+#pragma unroll
+        for (int r = 1; r < WORLD; ++r) acc += __uint_as_float((uint32_t)v[r][0]);
+        return acc;
+    } else {
+        return t;
+    }
+}
+
 #define RED_PARAMS 64
 #define RED_GROUPS 16
+template <int WORLD>
 __global__ void __launch_bounds__(RED_PARAMS * RED_GROUPS)
 grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra, float ent_coef, float vf_coef, double inv_count,
-                   float* __restrict__ grads, float* __restrict__ loss_terms, double* __restrict__ norm_parts) {
+                   float* __restrict__ grads, float* __restrict__ loss_terms, double* __restrict__ norm_parts, const p2p_args_t x) {
     MI_INSIDE_SCOPE(MI_PROF_REDUCE);
     const int pblocks = (NPARAMS + RED_PARAMS - 1) / RED_PARAMS;
     if ((int)blockIdx.x < pblocks) {
@@ -538,6 +560,7 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra,
             if (p < NPARAMS) {
 #pragma unroll
                 for (int k = 0; k < RED_GROUPS; ++k) t += part[k][pl];
+                t = p2p_exchange<WORLD>(x, p, t);   // line p = slab position p on every rank
                 grads[ppo_slab_to_param(p)] = t;
             }
             // block sum of squares for the next launch's clip coefficient (block_grad_norm's s_b: same butterfly, same element -> lane map)
@@ -559,9 +582,13 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra,
         if (threadIdx.x == 0 && loss_terms) {
             double PG = 0.0, EN = 0.0, VL = 0.0;
             for (int k = 0; k < 16; ++k) { PG += t[0][k]; EN += t[1][k]; VL += t[2][k]; }
-            const float t0 = (float)(PG * inv_count), t1 = (float)(EN * inv_count), t2 = (float)(0.5 * VL * inv_count);
-            loss_terms[0] = t0; loss_terms[1] = t1; loss_terms[2] = t2;
-            loss_terms[3] = t0 - ent_coef * t1 + t2 * vf_coef;  // ppo.py:187
+            float t0 = (float)(PG * inv_count), t1 = (float)(EN * inv_count), t2 = (float)(0.5 * VL * inv_count);
+            float t3 = t0 - ent_coef * t1 + t2 * vf_coef;  // ppo.py:187
+            if constexpr (WORLD > 0) {   // the four shares travel as lines NPARAMS .. NPARAMS + 3, each summed in rank order like a gradient element (what the one-buffer all-reduce did)
+                t0 = p2p_exchange<WORLD>(x, NPARAMS + 0, t0); t1 = p2p_exchange<WORLD>(x, NPARAMS + 1, t1);
+                t2 = p2p_exchange<WORLD>(x, NPARAMS + 2, t2); t3 = p2p_exchange<WORLD>(x, NPARAMS + 3, t3);
+            }
+            loss_terms[0] = t0; loss_terms[1] = t1; loss_terms[2] = t2; loss_terms[3] = t3;
         }
     }
 }
@@ -608,10 +635,17 @@ static int g_assume_sharded = 0;
 extern "C" int mi_ppo_test_assume_sharded(int on) { g_assume_sharded = on ? 1 : 0; return MI_OK; }
 
 // gradient launch + slab sum.  `pend.grads != nullptr`: the launch first applies the owed optimizer step (see grad_pending_t).
+template <int WORLD>
+static void grad_reduce_launch(hipStream_t s, const float* workspace, int blocks, int extra, float ent_coef, float vf_coef, double inv_count, float* grads, float* loss_terms,
+                               double* norm_parts, const p2p_args_t& x) {
+    grad_reduce_kernel<WORLD><<<NORM_BLOCKS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>(workspace, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, norm_parts, x);
+}
+
+// p2p != nullptr: the slab sum also all-reduces {grads, loss_terms} over the P2P carrier (mi_comm_p2p_next is drawn here: exactly one exchange per call, on every rank)
 static int ppo_grad_launch(const float* params, const grad_pending_t& pend, const float* observations, const int64_t* actions, const float* log_probs,
                            const float* advantages, const float* returns, const float* values, const int32_t* idx, int mb, const double* adv_sums,
                            float clip_coef, float ent_coef, float vf_coef, double inv_count, void* workspace, float* grads, float* loss_terms,
-                           hipStream_t s) {
+                           hipStream_t s, void* p2p = nullptr) {
     int blocks = grad_blocks();
     // small minibatches: no point launching blocks that would only write zero slabs
     const int tiles = (mb + TROWS - 1) / TROWS;
@@ -632,8 +666,27 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
     {
         mi_prof_scope prof(MI_PROF_REDUCE, s);
         static_assert((NPARAMS + RED_PARAMS - 1) / RED_PARAMS == NORM_BLOCKS && RED_PARAMS == 64, "one norm block per reduction workgroup");
-        grad_reduce_kernel<<<NORM_BLOCKS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>((const float*)workspace, blocks, extra, ent_coef, vf_coef, inv_count,
-                                                                     grads, loss_terms, ws_norm_parts(workspace));
+        p2p_args_t x;
+        memset(&x, 0, sizeof(x));
+        int world = 0;
+        if (p2p) {
+            if (loss_terms != grads + NPARAMS) { mi_set_error("ppo_grad_launch: the P2P exchange needs loss_terms == grads + MI_PPO_NPARAMS"); return MI_EINVAL; }
+            int rc = mi_comm_p2p_next(p2p, (size_t)NPARAMS + 4, &x, &world);
+            if (rc) return rc;
+        }
+        const float* ws = (const float*)workspace;
+        double* np = ws_norm_parts(workspace);
+        switch (world) {
+            case 0: grad_reduce_launch<0>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 1: grad_reduce_launch<1>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 2: grad_reduce_launch<2>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 3: grad_reduce_launch<3>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 4: grad_reduce_launch<4>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 5: grad_reduce_launch<5>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 6: grad_reduce_launch<6>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 7: grad_reduce_launch<7>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            default: grad_reduce_launch<8>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+        }
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -835,7 +888,10 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
     MI_CHECK_ARG(B % hp->n_minibatch == 0, "T*N must be divisible by n_minibatch");
     const int mb = B / hp->n_minibatch;
     const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass; their fp64 accumulators are zeroed by the rollout launch
-    const bool sharded_norm = world > 1 || g_assume_sharded != 0;
+    // P2P carrier: grad_reduce_kernel itself exchanges {gradient, loss terms} (no launch per all-reduce) and its block sums of squares are those of the ALL-REDUCED
+    // gradient, so the owed steps take the single-rank branch; RCCL: an in-stream ncclAllReduce behind every slab sum, the norm recomputed from the gradient
+    const bool p2p = comm != nullptr && mi_comm_is_p2p(comm);
+    const bool sharded_norm = (world > 1 && !p2p) || g_assume_sharded != 0;
     int rc = mi_rollout_gae_internal(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
                                      b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns,
                                      fused ? b->adv_sums : nullptr, 3 * hp->n_minibatch * hp->update_epochs, b->episode_stats_next, stream);
@@ -892,9 +948,9 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
             }
             rc = ppo_grad_launch(owed ? nullptr : cur.p, pend, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
                                  perm + (size_t)k * mb, mb, sums + 3 * k, hp->clip_coef, hp->ent_coef, hp->vf_coef, 1.0 / ((double)mb * world), b->workspace, b->grads,
-                                 b->loss_terms, s);
+                                 b->loss_terms, s, p2p ? comm : nullptr);
             if (rc) return rc;
-            if (comm) {   // gradient shares (already scaled by 1/(world*mb)) + the 4 loss-term shares: one SUM all-reduce (ppo.py:189 -> :191)
+            if (comm && !p2p) {   // gradient shares (already scaled by 1/(world*mb)) + the 4 loss-term shares: one SUM all-reduce (ppo.py:189 -> :191)
                 mi_prof_scope prof(MI_PROF_COMM_GRAD, s);
                 rc = mi_comm_allreduce_impl(comm, b->grads, (size_t)NPARAMS + 4, 0, s);
                 if (rc) return rc;

@@ -27,11 +27,28 @@ _FORCE_PG = os.environ.get("MIRL_FORCE_PG", "0") == "1"
 _FORCE_COLLECTIVES = os.environ.get("MIRL_FORCE_COLLECTIVES", "0") == "1"
 
 
+_rccl_env = {}
+
+
+def apply_rccl_env():
+    """MIRL_RCCL_ENV="NCCL_PROTO=LL,NCCL_MIN_NCHANNELS=1,NCCL_MAX_NCHANNELS=1": RCCL's small-message knobs for the path's 36.6 KB all-reduces, set in this process'
+    environment before any communicator exists (only NCCL_* / RCCL_* names are accepted).  Returns what was set (bench.py records it in its line)."""
+    spec = os.environ.get("MIRL_RCCL_ENV", "")
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        k, sep, v = item.partition("=")
+        if not sep or not (k.startswith("NCCL_") or k.startswith("RCCL_")):
+            raise MiError("MIRL_RCCL_ENV: %r is not NCCL_*=value / RCCL_*=value" % item)
+        os.environ[k] = v
+        _rccl_env[k] = v
+    return dict(_rccl_env)
+
+
 def init_from_env(backend=None):
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).
     Returns (rank, world_size, local_rank); a single process needs no process group."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    apply_rccl_env()
     if (world > 1 or _FORCE_PG) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -158,13 +175,27 @@ def _create_p2p(group):
     return h, ok, err
 
 
-def native_comm(group=None):
+_override = None
+
+
+def use_comm(handle):
+    """Make `handle` (a libmirl communicator the caller created: mi_comm_p2p_synthetic, or another carrier's from native_comm(group, which)) the one every engine's
+    one-call route takes from here on; None restores the default.  bench.py's carrier legs."""
+    global _override
+    _override = handle
+
+
+def native_comm(group=None, which=None):
     """libmirl's communicator for `group` (created collectively on first use) or None when there is no process group, MIRL_NATIVE_COMM=0, the carrier is RCCL and
     the backend is not nccl (gloo runs keep the host-sequenced path), or the creation failed on ANY rank (the ranks agree on that through the process group, so either
     all of them take the one-call path or all of them fall back).  RCCL: rank 0 draws the ncclUniqueId, the group broadcasts it.  P2P (MIRL_COMM=p2p): see _create_p2p."""
-    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("MIRL_NATIVE_COMM", "1") == "0":
+    if os.environ.get("MIRL_NATIVE_COMM", "1") == "0":
         return None
-    which = carrier()
+    if _override is not None and which is None:
+        return _override
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    which = which or carrier()
     if which == "rccl" and dist.get_backend(group) != "nccl":
         return None
     key = (id(group) if group is not None else 0, which)

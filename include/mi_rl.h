@@ -236,7 +236,8 @@ int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stre
  *                        (mi_comm_allreduce_sum, mi_*_sharded).  All collectives of one communicator must be enqueued on streams ordered with each other, by every rank
  *                        in the same order.  Put a barrier in front of mi_comm_destroy: a peer may still be storing into this rank's inbox.
  *   mi_comm_p2p_synthetic  ONE process plays world_size ranks into its own inbox (slot 0 = its share, the others zeros: results unchanged): the stores, flags,
- *                        waits and the world-slot sum of a world_size-rank exchange minus the links — for timing on a one-GPU box (bench.py `collectives`).
+ *                        waits and the world-slot sum of a world_size-rank exchange minus the links — for timing on a one-GPU box (bench.py `sharded_route`).
+ *                        mi_comm_info reports world_size 1 (the sharded calls scale their shares by 1 / world_size: it IS one rank) and comm_count = the ranks played.
  *   mi_comm_check        host-synchronising.  MI_OK, or MI_ESTATE when a wait ran out: that all-reduce and every later one on the communicator left the LOCAL share in
  *                        its buffer (a launch never spins beyond its budget, later launches return at once).  Always MI_OK for RCCL.
  *   mi_comm_carrier      0 = RCCL, 1 = P2P. */
@@ -517,8 +518,8 @@ int mi_test_tanh(const float* x, float* y, int n, void* stream);
  * kernel runs on).  mi_prof_begin(max_launches, tag_mask) arms it for the tags whose bit is set (allocates the event
  * pool, may synchronise);
  * mi_prof_end synchronises, fills total_ms[MI_PROF_NTAGS] / count[MI_PROF_NTAGS] (host arrays) and disarms.
- * mi_prof_pause(1 / 0) between the two stops / resumes the sampling: two events around every launch of a 70 us kernel cost the loop they measure ~2.5 %, so bench.py
- * brackets the launches of every 4th update only. */
+ * mi_prof_pause(1 / 0) between the two stops / resumes the sampling: two events around every launch of a 70 us kernel cost the loop they measure 7.5 % (tools/prof_overhead.py:
+ * 1.411 ms per update with all launches bracketed, 1.335 with every 4th update's, 1.312 with none), so bench.py brackets the launches of every 10th update only. */
 enum { MI_PROF_ROLLOUT = 0, MI_PROF_GAE = 1, MI_PROF_GRAD = 2, MI_PROF_REDUCE = 3, MI_PROF_CLIP_ADAM = 4, MI_PROF_STATS = 5,
        /* DQN (config 3): acting launch, TD forward+backward, slab sum (+ Adam), PER sampler launches */
        MI_PROF_DQN_ACT = 6, MI_PROF_DQN_TD = 7, MI_PROF_DQN_REDUCE = 8, MI_PROF_PER = 9,

@@ -46,7 +46,7 @@ def test_synthetic_world_allreduce_is_identity(world):
         assert L.mi_comm_carrier(h) == 1
         ws, rk, ver, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         N.check(L.mi_comm_info(h, C.byref(ws), C.byref(rk), C.byref(ver), C.byref(cnt)), "mi_comm_info")
-        assert (ws.value, rk.value, ver.value, cnt.value) == (world, 0, 0, world)
+        assert (ws.value, rk.value, ver.value, cnt.value) == (1, 0, 0, world)   # ONE rank playing `world` of them
         gen = torch.Generator(device="cpu").manual_seed(world)
         for dtype, sizes in ((torch.float32, (1, 5, 1023, 1024, 1025, 9159, 10936, 67331, 134660, 262144)), (torch.float64, (1, 48, 513, 131072))):
             for n in sizes:

@@ -156,6 +156,15 @@ def test_bench_contract_line():
     sr = d["sharded_route"]                                       # the launches only a multi-GPU run takes, timed on this GPU (hook + real one-rank RCCL)
     assert "error" not in sr and "error" not in sr["rccl_world1"], sr
     assert sr["assume_sharded"]["ms_per_step"] > 0 and sr["rccl_world1"]["ms_per_step"] > 0 and "delta_us_per_optimizer_step" in sr["assume_sharded"]
+    ps = sr["p2p_synthetic"]                                      # the P2P carrier's one-launch exchange with 2 / 4 / 8 synthetic ranks (round 5)
+    for w in (2, 4, 8):
+        assert "error" not in ps["world%d" % w], ps
+        assert ps["world%d" % w]["ms_per_step"] > 0 and ps["world%d" % w]["back_to_back_us_per_allreduce"] > 0
+    m = d["methodology"]                                          # rounds 1-3 and rounds 4+ measured differently: both figures live in one line
+    assert m["prewarm_updates"] == 60 and m["protocol_changed_in"].startswith("r04") and m["ms_per_step_all_launches_bracketed"] > 0
+    kd = d["kernel_device_ms_per_update"]                         # device durations + span + gaps of ONE profiled run: they add up (weak #8)
+    assert "error" not in kd and abs(kd["sum_ms"] + kd["launch_gaps_ms"] - kd["span_ms_profiled"]) < 1e-3 and "static" in kd["source"]
+    assert "kernel_ms_per_update" not in d and "note" in d["kernel_ms_per_update_bracketed"]
     n1 = d["cpu_baseline_n1"]                                     # the oracle at the reference's own shape (1 env, 1 thread)
     assert n1["cores"] == 1 and n1["value"] > 0 and n1["reference_python_env_steps_per_s"] == 886.0
     for key, kern in (("config3_dqn", "dqn_act4_kernel"), ("config4_sac", "sac_critic_kernel")):   # BASELINE configs[2] / [3] ride on the same line
@@ -188,6 +197,11 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     c = d["collectives"]
     assert c["per_update"] == 17 and c["world_size"] == 2 and "gloo" in c["carrier"] and c["grad_allreduce"]["bytes"] == 4 * 9159
     assert c["back_to_back"]["us_per_allreduce_grad"] > 0 and c["back_to_back"]["us_per_allreduce_stats"] > 0
+    # the per-carrier legs (round 5): RCCL cannot exist under gloo / two ranks on one device; the P2P carrier runs the ONE-CALL route with both ranks on cuda:0
+    k = c["carriers"]
+    assert "error" in k["rccl"] and "error" not in k["p2p"], k
+    assert k["p2p"]["ms_per_step"] > 0 and k["p2p"]["replicas_identical"] is True and k["p2p"]["in_update"]["samples"] == [0, 2, 32]   # no all-reduce launch per step: the exchange rides in the 32 slab sums
+    assert k["p2p"]["back_to_back_us_per_allreduce_grad"] > 0
 
 
 def test_bench_native_rccl_diagnostics_at_world_size_1():
@@ -214,6 +228,9 @@ def test_bench_native_rccl_diagnostics_at_world_size_1():
     assert "error" not in c, c
     assert "RCCL direct" in c["carrier"] and c["rccl_version"] > 0 and c["rccl_comm_count"] == 1 and c["world_size"] == 1
     assert c["back_to_back"]["us_per_allreduce_grad"] > 0 and c["back_to_back"]["us_per_allreduce_stats"] > 0 and "in_update" in c
+    k = c["carriers"]                                             # both carriers at world_size 1 (a one-rank P2P communicator needs no peer)
+    for which in ("rccl", "p2p"):
+        assert "error" not in k[which] and k[which]["ms_per_step"] > 0 and k[which]["replicas_identical"] is True, k
 
 
 def test_bench_self_launch_propagates_failure():
