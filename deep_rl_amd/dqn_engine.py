@@ -34,7 +34,7 @@ class DQNEngine:
         self._gradbuf = torch.zeros(N.DQN_NPARAMS + 2, dtype=torch.float32, device=dev)
         self.grads = self._gradbuf[:N.DQN_NPARAMS]
         self.loss = self._gradbuf[N.DQN_NPARAMS:N.DQN_NPARAMS + 1]
-        self.workspace = torch.empty(N.lib().mi_dqn_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)
+        self.workspace = torch.zeros(N.lib().mi_dqn_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)   # zero-filled once: the one-launch TD update's slab lines (include/mi_rl.h)
         self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (1024 if Nn <= 8 else 0))
         self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
         self._stats2 = torch.zeros((2, 4), dtype=torch.int32, device=dev)   # double-buffered: an acting launch zeroes the NEXT call's statistics
@@ -140,7 +140,6 @@ class DQNEngine:
             self.sample(indices)
         if fusable:
             o = self.optimizer
-            o.step_count += 1
             w, td = self._row_weights()
             upper = min(self.global_step, self.slots) * self.N if in_kernel_sampling else 0
             if in_kernel_sampling and upper == 0:   # upper == 0 means "read batch_inds" to the launch: an empty ring must not train on stale indices
@@ -148,19 +147,20 @@ class DQNEngine:
             N.check(N.lib().mi_dqn_td_update(
                 N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
                 N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self.grads),
-                N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                 self.env._seed, self.update_index, upper, self._s()), "mi_dqn_td_update")
+            o.step_count += 1   # committed only once the call has accepted the step (it refuses with MI_ESTATE after a timed-out one-launch update)
             self._after_td()
         elif self._native_sharded():
             # sharded, NCCL process group: ONE C call — TD share, slab sum, in-stream RCCL all-reduce of {grads, loss}, clip + Adam (mi_dqn_td_update_sharded)
             o = self.optimizer
-            o.step_count += 1
             w, td = self._row_weights()
             N.check(N.lib().mi_dqn_td_update_sharded(
                 N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
                 N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self._gradbuf),
-                N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], float(g["max_grad_norm"]),
+                N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], float(g["max_grad_norm"]),
                 N.ptr(o.grad_norm), D.native_comm(self.pg), self._s()), "mi_dqn_td_update_sharded")
+            o.step_count += 1
             self._after_td()
         else:
             self.td_grad()
