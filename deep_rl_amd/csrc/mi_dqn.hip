@@ -635,28 +635,6 @@ extern "C" int mi_dqn_sample(uint64_t seed, uint64_t update_index, int64_t upper
 #define TD_R 8                 // rows per group of the small-batch form; also the granule of mi_dqn_workspace_bytes
 #define TD_MAX_BLOCKS 256      // workgroups (= slabs) per launch at most: one per CU of an MI355X
 #define TD_SLAB (DQ_NP + 2)   // + loss
-// optimizer.step() riding on a gradient launch (torch Adam without clipping, dqn.py:68,133)
-struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, rbc2, eps; };
-// ---- the small-grid form (round 5): TD gradient + slab sum + Adam in ONE launch.  At the reference's batch of 128 the TD launch is 16 workgroups writing 16 slabs,
-// and the launch behind it exists to add 16 x 43 KB and step 10,934 parameters: a kernel boundary plus a start-up for 5 us of work.  Instead every workgroup writes its
-// slab as before, makes it visible device-wide (release fence: this XCD's L2 written back), publishes the launch's TAG in its flag word, waits for the n flags of the
-// launch (thread k polls flag k), and then sums 1 / n of the parameter range over the n slabs in dqn_reduce_kernel's order and expression tree (bit-identical) and steps
-// what it has summed.  (First form of this round: every slab element stored together with the tag in one 8-byte write-through word and polled itself — no fence, but 52
-// scattered 8-byte write-through stores per thread took 7 us against 1 us for the cached 16-byte stores: profiles/r05_dqn_td_stamps.txt.)  A workgroup waits only for
-// other workgroups' flags, which depend on no wait; n <= TD_FUSED_MAX_SLABS workgroups of 256 threads are co-resident on any device this library runs on, and a chip
-// shared with other work only delays them.  The wait is bounded all the same (100 ms): a workgroup that never publishes stalls EVERY consumer (each needs every slab), so
-// no parameter is stepped; the launch records the fault in a device word (later fused launches withhold their step) and in a host-pinned status word that the next
-// mi_dqn_td_update returns as MI_ESTATE (mi_dqn_check / mi_dqn_clear_error).
-#define TD_FUSED_MAX_SLABS 32
-#define DQN_SPIN_TICKS 10000000ull   // 100 ms of s_memrealtime
-struct dqn_fused_t { dqn_opt_t opt; float* grads; float* loss; double inv_count; uint32_t tag; int fault; };
-__device__ unsigned int* dqn_status_word;   // device pointer of the host-pinned status word (per device: dqn_status_init)
-__device__ unsigned int dqn_fault_word;     // != 0: a fused launch on this device timed out; cleared by mi_dqn_clear_error
-__device__ __noinline__ void dqn_timeout() {
-    __hip_atomic_store(&dqn_fault_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int* p = dqn_status_word;
-    if (p) __hip_atomic_store(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 template <int R>
 struct __attribute__((aligned(16))) td_smem {
     float x[2][R][4];          // [0] obs, [1] next obs
@@ -673,26 +651,17 @@ struct __attribute__((aligned(16))) td_smem {
     float rw[R], live[R];      // reward and (not terminated) of the successor row
 };
 
-#ifdef TD_STAMPS   // diagnostic build: wall-clock marks (s_memrealtime, 100 MHz) of thread 0 of every workgroup at the phase boundaries of the one-launch form (tools/dqn_td_stamps.py)
-__device__ unsigned long long td_stamp_dbg[TD_FUSED_MAX_SLABS][8];
-#define TD_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < TD_FUSED_MAX_SLABS) td_stamp_dbg[blockIdx.x][k] = p2p_clock(); } while (0)
-extern "C" int mi_debug_td_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(td_stamp_dbg), sizeof(td_stamp_dbg)) == hipSuccess ? 0 : -2; }
-#else
-#define TD_MARK(k) do {} while (0)
-#endif
-
-template <int R, bool FUSED>
+template <int R>
 __global__ void __launch_bounds__(256)
 dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target_params, const float* __restrict__ observations,
               const int64_t* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
               const int64_t* idx /* may alias idx_out: no __restrict__ */, int batch, int n_envs, long long slots, float gamma, float invn,
               float* __restrict__ workspace, const float* __restrict__ row_w, float* __restrict__ td_abs, uint64_t sample_seed, uint64_t sample_update,
-              uint64_t sample_upper, int64_t* idx_out, const dqn_fused_t fz) {
+              uint64_t sample_upper, int64_t* idx_out) {
     static_assert(R == 8 || R == 16, "the MFMA passes take the rows as R / 4 k-steps (dW2) and as (part of) a 16-column B operand");
     __shared__ td_smem<R> sm;
     MI_INSIDE_SCOPE(MI_PROF_DQN_TD);
     const int t = threadIdx.x;
-    TD_MARK(0);
     const int n_groups = (batch + R - 1) / R;
     float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
     // The batch rows of a group: thread (net nt = t / 4R, row r, component k = t & 3) < 8R derives row r's index ITSELF (the four threads of a row repeat the draw or
@@ -937,7 +906,6 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         }
         if (nxt_grp < n_groups) { __syncthreads(); gather_group(nxt_grp, i_nxt); }
     }
-    TD_MARK(1);
     // ---- the workgroup's slab: every gradient element once ----
     if (t < DQ_H2) { part[DQ_W3 + t] = g30; part[DQ_W3 + DQ_H2 + t] = g31; part[DQ_B2 + t] = gb2; }
     else if (t < DQ_H2 + 2) part[DQ_B3 + (t - DQ_H2)] = g30;
@@ -958,93 +926,11 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         part[DQ_B1 + t] = gb1;
         *reinterpret_cast<float4*>(part + DQ_W1 + 4 * t) = make_float4(gw1[0], gw1[1], gw1[2], gw1[3]);
     }
-    TD_MARK(2);
-    if constexpr (FUSED) {
-        // ---- publish the slab, wait for the launch's n slabs ----
-        __shared__ int s_ok;
-        const int n_slabs = gridDim.x;
-        unsigned long long* const flags = reinterpret_cast<unsigned long long*>(workspace + (size_t)n_slabs * TD_SLAB + ((n_slabs * TD_SLAB) & 1));   // 8-byte aligned, behind the slabs
-        if (t == 0) s_ok = 1;
-        // this workgroup's share of the parameters: <= TD_Q per thread and pass; the optimizer state of the first pass is requested BEFORE the wait (it depends on no other
-        // workgroup), so that behind the flags there is ONE round of slab loads
-        constexpr int TD_Q = 3;   // 16 workgroups (the reference's batch): 684 parameters per workgroup = one pass
-        const int chunk = (DQ_NP + n_slabs - 1) / n_slabs;
-        const int lo = blockIdx.x * chunk, hi = lo + chunk < DQ_NP ? lo + chunk : DQ_NP;
-        float pi[TD_Q], mi[TD_Q], vi[TD_Q];
-#pragma unroll
-        for (int q = 0; q < TD_Q; ++q) {
-            const int pp = lo + t + 256 * q < hi ? lo + t + 256 * q : lo;
-            pi[q] = fz.opt.params[pp]; mi[q] = fz.opt.m[pp]; vi[q] = fz.opt.v[pp];
-        }
-        __threadfence();      // this thread's slab stores are visible device-wide (the XCD's L2 written back) ...
-        __syncthreads();      // ... for every thread of the workgroup, before ...
-        if (t == 0 && !(fz.fault && blockIdx.x == 0))   // (TEST HOOK, mi_dqn_test_fault: workgroup 0 never publishes)
-            __hip_atomic_store(flags + blockIdx.x, (unsigned long long)fz.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the flag says so (relaxed: the fence above is the release — a release store would write the L2 back a second time)
-        if (t < n_slabs) {
-            const unsigned long long t0 = p2p_clock();
-            for (uint32_t spins = 1; __hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)fz.tag; ++spins) {   // (relaxed: ONE acquire fence behind the barrier, not an L2 invalidation per poll)
-                __builtin_amdgcn_s_sleep(1);
-                if ((spins & 15) == 0 && p2p_clock() - t0 > DQN_SPIN_TICKS) { dqn_timeout(); s_ok = 0; break; }
-            }
-        }
-        __syncthreads();
-        TD_MARK(3);
-        if (s_ok) {
-            __threadfence();  // acquire for every thread: no stale line of another workgroup's slab in this XCD's L2
-            // ---- slab sum + optimizer.step() of this workgroup's share of the parameters: dqn_reduce_kernel's arithmetic, element for element ----
-            const bool withheld = __hip_atomic_load(&dqn_fault_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // an earlier launch on this device timed out
-            for (int p0 = lo + t; p0 < hi; p0 += TD_Q * 256) {
-                if (p0 != lo + t) {   // later passes (fewer than 16 workgroups): their optimizer state now
-#pragma unroll
-                    for (int q = 0; q < TD_Q; ++q) {
-                        const int pp = p0 + 256 * q < hi ? p0 + 256 * q : lo;
-                        pi[q] = fz.opt.params[pp]; mi[q] = fz.opt.m[pp]; vi[q] = fz.opt.v[pp];
-                    }
-                }
-                float acc[TD_Q][4];   // accumulator b & 3 takes slab b, then (0 + 1) + (2 + 3): dqn_reduce_kernel's order
-#pragma unroll
-                for (int q = 0; q < TD_Q; ++q) { acc[q][0] = 0.0f; acc[q][1] = 0.0f; acc[q][2] = 0.0f; acc[q][3] = 0.0f; }
-                int b = 0;
-                for (; b + 16 <= n_slabs; b += 16) {   // TD_Q x 16 loads in flight
-                    float x[TD_Q][16];
-#pragma unroll
-                    for (int q = 0; q < TD_Q; ++q) {
-                        const int pp = p0 + 256 * q < hi ? p0 + 256 * q : lo;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) x[q][k] = workspace[(size_t)(b + k) * TD_SLAB + pp];
-                    }
-#pragma unroll
-                    for (int q = 0; q < TD_Q; ++q)
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) acc[q][k & 3] += x[q][k];
-                }
-                for (; b < n_slabs; ++b)
-#pragma unroll
-                    for (int q = 0; q < TD_Q; ++q) acc[q][b & 3] += workspace[(size_t)b * TD_SLAB + (p0 + 256 * q < hi ? p0 + 256 * q : lo)];
-#pragma unroll
-                for (int q = 0; q < TD_Q; ++q) {
-                    const int pp = p0 + 256 * q;
-                    if (pp >= hi) continue;
-                    const float g = (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
-                    fz.grads[pp] = g;
-                    if (!withheld) {   // the formula of clip_adam_kernel at coef = 1 (max_norm = inf), bit for bit (mi_adam_elem)
-                        fz.opt.params[pp] = mi_adam_elem(pi[q], g, mi[q], vi[q], fz.opt.w1, fz.opt.b2, fz.opt.w2, fz.opt.step_size, fz.opt.rbc2, fz.opt.eps);
-                        fz.opt.m[pp] = mi[q]; fz.opt.v[pp] = vi[q];
-                    }
-                }
-            }
-            if ((int)blockIdx.x == n_slabs - 1 && t == 255 && fz.loss) {   // the slab losses, in slab order (f64), by a thread of the workgroup with the shortest share
-                double l = 0.0;
-                for (int b = 0; b < n_slabs; ++b) l += workspace[(size_t)b * TD_SLAB + DQ_NP];
-                fz.loss[0] = (float)(l * fz.inv_count);
-            }
-        }
-        TD_MARK(4);
-    }
 }
 
 // grads[p] = sum over workgroup slabs in slab order; loss = sum of the slab losses * inv_count.  With `opt.params` set the same launch applies
 // optimizer.step() (torch Adam without clipping, dqn.py:68,133) to the element it has just summed: no launch of its own in single-process runs.
+struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, rbc2, eps; };
 __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
                                                          float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
     MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
@@ -1135,62 +1021,10 @@ __global__ void __launch_bounds__(DR_PARAMS * DR_GROUPS) dqn_reduce2_kernel(cons
 }
 
 extern "C" size_t mi_dqn_workspace_bytes(int batch) {
-    const size_t slabs = (size_t)((batch + TD_R - 1) / TD_R);
-    return (slabs * TD_SLAB + 2) * sizeof(float) + (slabs <= TD_FUSED_MAX_SLABS ? slabs * sizeof(unsigned long long) : 0);   // + the one-launch form's flag words behind the slabs
+    return (size_t)((batch + TD_R - 1) / TD_R) * TD_SLAB * sizeof(float);
 }
 
 static dqn_opt_t dqn_no_opt() { dqn_opt_t o; memset(&o, 0, sizeof(o)); return o; }
-
-// ---- the fused small-grid form: switch, launch tags, fault plumbing (include/mi_rl.h "mi_dqn_check") ----
-static int g_dqn_fused = 1;            // mi_dqn_set_fused_step: 0 = always the two-launch form (A/B, bit-identical)
-static int g_dqn_fault_inject = 0;     // mi_dqn_test_fault
-static uint32_t g_dqn_tag = 0;         // one tag per fused launch of this process (0 is never used: a zero-filled workspace holds no valid line)
-static unsigned int* g_dqn_status_host = nullptr;
-static bool g_dqn_status_dev[64] = {};
-static int dqn_status_init() {
-    int dev = 0;
-    MI_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (g_dqn_status_host && g_dqn_status_dev[dev]) return MI_OK;
-    if (!g_dqn_status_host) {
-        unsigned int* h = nullptr;
-        MI_HIP(hipHostMalloc((void**)&h, 64, hipHostMallocMapped | hipHostMallocPortable));
-        h[0] = 0u;
-        g_dqn_status_host = h;
-    }
-    unsigned int* d = nullptr;
-    MI_HIP(hipHostGetDevicePointer((void**)&d, g_dqn_status_host, 0));
-    MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dqn_status_word), &d, sizeof(d)));   // the CURRENT device's copy of the symbol
-    g_dqn_status_dev[dev] = true;
-    return MI_OK;
-}
-static int dqn_status_check(const char* who) {
-    if (const int rc = dqn_status_init()) return rc;
-    if (__atomic_load_n(g_dqn_status_host, __ATOMIC_RELAXED)) {
-        mi_set_error("%s: an earlier fused TD update of this process timed out waiting for a workgroup's gradient slab (not stored within 100 ms): that update's optimizer "
-                     "step was not applied (every consumer needs every slab) and none has been since; call mi_dqn_clear_error to go on", who);
-        return MI_ESTATE;
-    }
-    return MI_OK;
-}
-extern "C" int mi_dqn_check(void* stream, int wait) {
-    if (wait) MI_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return dqn_status_check("mi_dqn_check");
-}
-extern "C" int mi_dqn_clear_error(void* stream) {
-    if (const int rc = dqn_status_init()) return rc;
-    const unsigned int zero = 0u;
-    MI_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(dqn_fault_word), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, (hipStream_t)stream));
-    MI_HIP(hipStreamSynchronize((hipStream_t)stream));
-    __atomic_store_n(g_dqn_status_host, 0u, __ATOMIC_RELAXED);
-    return MI_OK;
-}
-extern "C" int mi_dqn_test_fault(int mode) {
-    MI_CHECK_ARG(mode == 0 || mode == 1, "mode: 1 = workgroup 0 of a fused TD update never stores its slab, 0 = off");
-    g_dqn_fault_inject = mode;
-    return MI_OK;
-}
-extern "C" int mi_dqn_set_fused_step(int on) { g_dqn_fused = on ? 1 : 0; return MI_OK; }
 
 static int dqn_td_impl(const float* params, const float* target_params, const float* observations, const int64_t* actions,
                        const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
@@ -1205,30 +1039,16 @@ static int dqn_td_impl(const float* params, const float* target_params, const fl
     const int groups8 = (batch + TD_R - 1) / TD_R, groups16 = (batch + 15) / 16;
     const bool wide = groups8 > TD_MAX_BLOCKS;
     const int blocks = wide ? (groups16 < TD_MAX_BLOCKS ? groups16 : TD_MAX_BLOCKS) : groups8;
-    dqn_fused_t fz;
-    memset(&fz, 0, sizeof(fz));
-    // small grids of a single-process run: ONE launch (see dqn_fused_t); everything else: gradient launch + slab-sum launch
-    if (opt.params && !wide && blocks <= TD_FUSED_MAX_SLABS && g_dqn_fused) {
-        if (const int rc = dqn_status_check("mi_dqn_td_update")) return rc;
-        if (++g_dqn_tag == 0) g_dqn_tag = 1;
-        fz.opt = opt; fz.grads = grads; fz.loss = loss; fz.inv_count = inv_count; fz.tag = g_dqn_tag; fz.fault = g_dqn_fault_inject;
-        mi_prof_scope prof(MI_PROF_DQN_TD, s);
-        dqn_td_kernel<TD_R, true><<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
-                                                         (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update,
-                                                         (uint64_t)sample_upper, (int64_t*)idx, fz);
-        MI_LAUNCH_CHECK();
-        return MI_OK;
-    }
     {
         mi_prof_scope prof(MI_PROF_DQN_TD, s);
         if (wide)
-            dqn_td_kernel<16, false><<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
-                                                            (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update,
-                                                            (uint64_t)sample_upper, (int64_t*)idx, fz);
+            dqn_td_kernel<16><<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
+                                                     (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update,
+                                                     (uint64_t)sample_upper, (int64_t*)idx);
         else
-            dqn_td_kernel<TD_R, false><<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
-                                                              (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update,
-                                                              (uint64_t)sample_upper, (int64_t*)idx, fz);
+            dqn_td_kernel<TD_R><<<blocks, 256, 0, s>>>(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs,
+                                                       (long long)slots, gamma, (float)inv_count, (float*)workspace, weights, td_abs, sample_seed, sample_update,
+                                                       (uint64_t)sample_upper, (int64_t*)idx);
     }
     MI_LAUNCH_CHECK();
     {

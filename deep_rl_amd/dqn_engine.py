@@ -34,7 +34,7 @@ class DQNEngine:
         self._gradbuf = torch.zeros(N.DQN_NPARAMS + 2, dtype=torch.float32, device=dev)
         self.grads = self._gradbuf[:N.DQN_NPARAMS]
         self.loss = self._gradbuf[N.DQN_NPARAMS:N.DQN_NPARAMS + 1]
-        self.workspace = torch.zeros(N.lib().mi_dqn_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)   # zero-filled once: the one-launch TD update's slab lines (include/mi_rl.h)
+        self.workspace = torch.empty(N.lib().mi_dqn_workspace_bytes(self.batch_size), dtype=torch.uint8, device=dev)
         self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (1024 if Nn <= 8 else 0))
         self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
         self._stats2 = torch.zeros((2, 4), dtype=torch.int32, device=dev)   # double-buffered: an acting launch zeroes the NEXT call's statistics
@@ -149,7 +149,7 @@ class DQNEngine:
                 N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self.grads),
                 N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
                 self.env._seed, self.update_index, upper, self._s()), "mi_dqn_td_update")
-            o.step_count += 1   # committed only once the call has accepted the step (it refuses with MI_ESTATE after a timed-out one-launch update)
+            o.step_count += 1   # committed only once the call has accepted the step
             self._after_td()
         elif self._native_sharded():
             # sharded, NCCL process group: ONE C call — TD share, slab sum, in-stream RCCL all-reduce of {grads, loss}, clip + Adam (mi_dqn_td_update_sharded)

@@ -50,7 +50,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier; mi_dqn_check / _clear_error / _test_fault / _set_fused_step and the flag words behind the DQN workspace of small batches).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
 #define MI_VERSION 105
 #define MI_PPO_NPARAMS 9155
@@ -294,22 +294,12 @@ int mi_dqn_td_grad(const float* params, const float* target_params, const float*
 /* single-process fusion: the same two launches, the second of which also applies optimizer.step() (torch Adam, no clipping) to every
  * gradient element it has just summed — bit-identical to mi_dqn_td_grad (or mi_per_td_grad when weights / td_abs are given) followed by
  * mi_clip_adam with max_norm = +inf.  inv_count = 1 / batch.  sample_upper > 0: the TD launch draws idx itself (the mi_dqn_sample contract
- * with (sample_seed, sample_update), bit-identical) and stores it in idx — no sampling launch either; 0: idx is an input. 
- * Round 5, small grids (batch <= 256 = 32 workgroups; the reference's 128 is 16): ONE launch — every workgroup writes its gradient slab, publishes the launch's tag in a
- * flag word behind the slabs, waits for the n flags and then sums and steps 1 / n of the parameters in the two-launch form's order (bit-identical; mi_dqn_set_fused_step(0) keeps the two launches for the A/B).  Its waits for
- * the other workgroups' slabs are bounded (100 ms); one that runs out leaves the parameters unstepped, and the NEXT mi_dqn_td_update returns MI_ESTATE:
- *   mi_dqn_check(stream, wait)   wait != 0: synchronise `stream` first.  MI_OK or MI_ESTATE.      mi_dqn_clear_error(stream)   clears the fault (synchronises).
- *   mi_dqn_test_fault(1)         TEST HOOK: workgroup 0 of a fused update never stores its slab.   mi_dqn_set_fused_step(on)    process-wide, default 1.
- * The workspace must be ZERO-FILLED once before its first use (a flag is valid when it equals the launch's tag, which is never 0). */
+ * with (sample_seed, sample_update), bit-identical) and stores it in idx — no sampling launch either; 0: idx is an input. */
 int mi_dqn_td_update(float* params, const float* target_params, const float* observations, const int64_t* actions,
                      const float* rewards, const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots,
                      float gamma, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, float* exp_avg, float* exp_avg_sq,
                      int64_t step, double lr, double beta1, double beta2, double eps, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper,
                      void* stream);
-int mi_dqn_check(void* stream, int wait);
-int mi_dqn_clear_error(void* stream);
-int mi_dqn_test_fault(int mode);
-int mi_dqn_set_fused_step(int on);
 /* sharded runs (one process per GPU), ONE call per optimisation step (dqn.py:118-133 with the gradient exchange between backward and step): TD gradient
  * share scaled by 1 / (world * batch), slab sum, in-stream RCCL SUM all-reduce of gradbuf = dev f32 [MI_DQN_NPARAMS + 2] {grads, loss, pad}, then mi_clip_adam(max_norm,
  * grad_norm nullable).  weights / td_abs: PER row weights and |td| out (nullable together).  The same launches as mi_dqn_td_grad (mi_per_td_grad) + caller all-reduce +

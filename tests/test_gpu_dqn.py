@@ -341,73 +341,3 @@ def test_fused_td_update_equals_grad_then_adam(dev, R):
         assert torch.equal(f.q.flat, u.q.flat) and torch.equal(f.optimizer.exp_avg_sq, u.optimizer.exp_avg_sq)
         if kind == "per":
             assert torch.equal(f.priorities, u.priorities) and torch.equal(f.max_priority, u.max_priority)
-
-
-@pytest.mark.parametrize("kind", ["dqn", "per"])
-def test_one_launch_td_update_equals_two_launch_form_bitwise(dev, R, kind):
-    """Round 5: at small grids mi_dqn_td_update is ONE launch — TD gradient, slab lines, slab sum and Adam — instead of two.  Same summation order,
-    same expression tree: 20 chained updates agree bit for bit with the two-launch form (mi_dqn_set_fused_step(0)) at every batch size up to 32 workgroups (8 ... 256,
-    ragged ones included); 264 rows (33 workgroups) take the two-launch form either way.  dqn.py:116-133 / per.py:124-153."""
-    import deep_rl_amd as D
-    from deep_rl_amd import _native as N
-
-    for batch in (8, 100, 128, 256, 264):
-        out = []
-        for fused in (1, 0):
-            N.check(N.lib().mi_dqn_set_fused_step(fused), "mi_dqn_set_fused_step")
-            try:
-                env = D.make("CartPole-v1", num_envs=64, device=dev, seed=9)
-                torch.manual_seed(9)
-                q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
-                Eng = D.DQNEngine if kind == "dqn" else D.PERDQNEngine
-                eng = Eng(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=64, batch_size=batch, learning_starts=0, total_timesteps=2000, max_episodes_logged=0)
-                eng.reset()
-                eng.act(30)
-                for it in range(20):
-                    eng.act(1)
-                    eng.train_step()
-                    if it % 7 == 6:
-                        eng.sync_target()
-                torch.cuda.synchronize()
-                N.check(N.lib().mi_dqn_check(N.stream_ptr(dev), 1), "mi_dqn_check")
-                st = [eng.q.flat.clone(), eng.optimizer.exp_avg.clone(), eng.optimizer.exp_avg_sq.clone(), eng.grads.clone(), eng.loss.clone(), eng.batch_inds.clone()]
-                if kind == "per":
-                    st += [eng.priorities.clone(), eng.max_priority.clone()]
-                out.append(st)
-            finally:
-                N.check(N.lib().mi_dqn_set_fused_step(1), "mi_dqn_set_fused_step")
-        for a, b in zip(*out):
-            assert torch.equal(a, b), (kind, batch)
-        assert torch.isfinite(out[0][0]).all()
-
-
-def test_one_launch_td_update_bounded_wait(dev, R):
-    """A workgroup that never stores its slab (mi_dqn_test_fault): every consumer's wait runs out after 100 ms, NO parameter is stepped, the next update call returns
-    MI_ESTATE, later launches withhold their step, and after mi_dqn_clear_error training goes on from the untouched state."""
-    import deep_rl_amd as D
-    from deep_rl_amd import _native as N
-
-    L, s = N.lib(), N.stream_ptr(dev)
-    eng = _engine(dev, 32, 64, seed=4, batch_size=128, learning_starts=0, total_timesteps=2000, max_episodes_logged=0)
-    eng.reset(); eng.act(40)
-    eng.train_step()
-    torch.cuda.synchronize()
-    p0, m0, steps0 = eng.q.flat.clone(), eng.optimizer.exp_avg.clone(), eng.optimizer.step_count
-    try:
-        N.check(L.mi_dqn_test_fault(1), "mi_dqn_test_fault")
-        eng.train_step()                                      # enqueued: the launch itself discovers the missing slab
-        torch.cuda.synchronize()
-        N.check(L.mi_dqn_test_fault(0), "mi_dqn_test_fault")
-        assert L.mi_dqn_check(s, 1) == -4 and b"timed out" in L.mi_last_error()
-        assert torch.equal(eng.q.flat, p0) and torch.equal(eng.optimizer.exp_avg, m0)        # nothing was stepped
-        with pytest.raises(N.MiError):
-            eng.train_step()                                  # refused up front (a plain host read of the status word)
-    finally:
-        L.mi_dqn_test_fault(0)
-        N.check(L.mi_dqn_clear_error(s), "mi_dqn_clear_error")
-    assert L.mi_dqn_check(s, 0) == 0
-    assert eng.optimizer.step_count == steps0 + 1              # the faulted update's step number was spent; the refused call committed nothing
-    eng.optimizer.step_count = steps0
-    eng.train_step()
-    torch.cuda.synchronize()
-    assert not torch.equal(eng.q.flat, p0) and torch.isfinite(eng.q.flat).all()
