@@ -74,6 +74,7 @@ SIGNATURES = {
     "mi_ppo_workspace_bytes": (_SZ, []),
     "mi_ppo_set_contraction": (_I, [_I]),
     "mi_ppo_get_contraction": (_I, []),
+    "mi_test_contraction": (_I, [_I, _VP, _VP, _I, _VP, _VP]),
     "mi_ppo_minibatch_grad": (_I, [_VP] * 8 + [_I, _VP, _F, _F, _F, _D, _VP, _VP, _VP, _VP]),
     "mi_clip_adam": (_I, [_VP, _VP, _VP, _VP, _I, _I64, _D, _D, _D, _D, _F, _VP, _VP]),
     "mi_explained_var": (_I, [_VP, _VP, _SZ, _VP, _VP]),

@@ -1128,6 +1128,39 @@ extern "C" int mi_selftest_mfma(int32_t* report, float* dump, void* stream) {
     return MI_OK;
 }
 
+// TEST HOOK (include/mi_rl.h, mi_test_contraction): D[16][16] = A[16][K] . B[K][16] by ONE wave with exactly the building blocks of the gradient kernels' 64 x 64
+// contractions — mode F32: v_mfma_f32_16x16x4_f32, K / 4 chained k-steps (grad_kernel_f32); mode BF16X3: both operands through split8 (three bf16 parts), six products
+// per 32 k-slots through bx_mac on v_mfma_f32_16x16x32_bf16 (grad_kernel_bx) — so that the variant's error bound can be tested on adversarial operands.
+__global__ void __launch_bounds__(64) contraction_kernel(int mode, const float* __restrict__ A, const float* __restrict__ B, int K, float* __restrict__ D) {
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (mode == MI_CONTRACTION_F32) {
+        for (int s = 0; s < K / 4; ++s) acc = mfma16(A[j * K + 4 * s + g], B[(4 * s + g) * 16 + j], acc);   // A lane (i = j, k = 4s + g), B lane (k = 4s + g, col j)
+    } else {
+        for (int h = 0; h < K / 32; ++h) {   // lane holds A[j][32h + 8g + e], B[32h + 8g + e][j], e = 0..7
+            f32x4 a0, a1, b0, b1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] = A[j * K + 32 * h + 8 * g + e]; a1[e] = A[j * K + 32 * h + 8 * g + 4 + e];
+                b0[e] = B[(32 * h + 8 * g + e) * 16 + j]; b1[e] = B[(32 * h + 8 * g + 4 + e) * 16 + j];
+            }
+            const bx_parts ap = split8(a0, a1), bp = split8(b0, b1);
+            acc = bx_mac(ap.p, bp, acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + j] = acc[r];   // D register r = D[4g + r][j]
+}
+
+extern "C" int mi_test_contraction(int mode, const float* A, const float* B, int K, float* D, void* stream) {
+    MI_CHECK_ARG(mode == MI_CONTRACTION_F32 || mode == MI_CONTRACTION_BF16X3, "mode must be MI_CONTRACTION_F32 or MI_CONTRACTION_BF16X3");
+    MI_CHECK_ARG(A && B && D, "NULL pointer");
+    MI_CHECK_ARG(K >= 32 && K % 32 == 0 && K <= 4096, "K must be a multiple of 32 in [32, 4096]");
+    contraction_kernel<<<1, 64, 0, (hipStream_t)stream>>>(mode, A, B, K, D);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
 __global__ void __launch_bounds__(256) tanh_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = mi_tanhf(x[i]);

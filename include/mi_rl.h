@@ -50,7 +50,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier; mi_test_contraction).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
 #define MI_VERSION 105
 #define MI_PPO_NPARAMS 9155
@@ -164,6 +164,19 @@ int mi_ppo_minibatch_grad(const float* params, const float* observations, const 
 enum { MI_CONTRACTION_F32 = 0, MI_CONTRACTION_BF16X3 = 1 };
 int mi_ppo_set_contraction(int mode);
 int mi_ppo_get_contraction(void);
+/* SPECIFIED ERROR BOUND of MI_CONTRACTION_BF16X3 (round 5; an opt-in mode, never the headline).  For one contraction y = sum_k a_k b_k over K terms, finite f32
+ * operands, no overflow of |a_k b_k| or of the sum:
+ *     | y_bf16x3 - y_exact |  <=  MI_BF16X3_REL_BOUND * max(1, K / 64) * sum_k |a_k| |b_k|  +  K * MI_BF16X3_ABS_FLOOR          (K = 64 in the gradient kernels)
+ * — a bound relative to the sum of ABSOLUTE products, as for any floating-point dot product (cancellation in the result is not the variant's: the exact f32 MFMA
+ * path obeys the same form with 2^-24 (K / 4 + 1) in place of the constant), from: split residual <= 2^-27 |x|, dropped part products (mid.lo, lo.mid, lo.lo)
+ * <= 2^-25 |a b|, f32 accumulation of 6 K / 32 matrix instructions.  The absolute floor covers operands and products in the subnormal range, where a bf16 part
+ * or an MFMA product may be flushed.  tests/test_gpu_bf16x3_bound.py drives mi_test_contraction — the gradient kernels' own split and multiply-accumulate code on one
+ * 16 x K x 16 tile — with operands spanning 2^+-20 per element, cancelling pairs, subnormals and exact integers, and prints the worst observed ratio (round 5, K = 64:
+ * 2^-21.2 for bf16x3 against 2^-21.5 for the exact-f32 MFMA path on the same operands). */
+#define MI_BF16X3_REL_BOUND 9.5367431640625e-07   /* 2^-20 */
+#define MI_BF16X3_ABS_FLOOR 1.1754943508222875e-38 /* 2^-126 */
+/* TEST HOOK: D dev f32 [16][16] = A dev f32 [16][K] . B dev f32 [K][16] computed by one wave with the building blocks of the selected mode (K a multiple of 32) */
+int mi_test_contraction(int mode, const float* A, const float* B, int K, float* D, void* stream);
 
 /* ---- clip_grad_norm_(max_norm) + Adam step (ppo.py:191-192, torch single-tensor Adam).
  * step is 1-based.  grad_norm dev f32 [1] nullable: receives the pre-clip total norm. */
