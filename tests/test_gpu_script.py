@@ -165,6 +165,8 @@ def test_bench_contract_line():
     kd = d["kernel_device_ms_per_update"]                         # device durations + span + gaps of ONE profiled run: they add up (weak #8)
     assert "error" not in kd and abs(kd["sum_ms"] + kd["launch_gaps_ms"] - kd["span_ms_profiled"]) < 1e-3 and "static" in kd["source"]
     assert "kernel_ms_per_update" not in d and "note" in d["kernel_ms_per_update_bracketed"]
+    vr = d["variant_bf16x3"]["roofline"]                          # the opt-in mode's own roofline against the BF16 matrix peak, executed and algorithmic
+    assert vr["peak"] == 2516.8 and 0 < vr["frac_algorithmic"] < vr["frac"] < 1 and "error_bound" in d["variant_bf16x3"]
     n1 = d["cpu_baseline_n1"]                                     # the oracle at the reference's own shape (1 env, 1 thread)
     assert n1["cores"] == 1 and n1["value"] > 0 and n1["reference_python_env_steps_per_s"] == 886.0
     for key, kern in (("config3_dqn", "dqn_act4_kernel"), ("config4_sac", "sac_critic_kernel")):   # BASELINE configs[2] / [3] ride on the same line
