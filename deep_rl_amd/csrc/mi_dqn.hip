@@ -1,6 +1,6 @@
 // mi_dqn.hip — the DQN hot path of reference deep_rl/dqn.py on the device:
 //   dqn_forward_kernel   QNetwork.forward 4->120->84->2 ReLU                                   (dqn.py:24-36)
-//   dqn_act_kernel       n_steps x {epsilon-greedy, env.step + auto-reset, ring store} per env (dqn.py:84-108)
+//   dqn_act4_kernel      n_steps x {epsilon-greedy, env.step + auto-reset, ring store} per env (dqn.py:84-108)
 //   dqn_sample_kernel    batch_inds = randint(upper, size=batch)                               (dqn.py:116)
 //   dqn_td_kernel        gather, target max, TD target, MSE loss, backward                      (dqn.py:118-128)
 //   dqn_reduce_kernel    fixed-order sum of the per-workgroup partial gradients
@@ -84,174 +84,21 @@ extern "C" int mi_dqn_forward(const float* params, const float* obs, int n, floa
 struct dqn_eps_tab { float v[DQN_MAX_STEPS_PER_CALL]; };  // epsilon(global_step + k), passed by value
 
 // ---- acting: n_steps iterations of {epsilon-greedy, env.step + auto-reset, ring store} in one launch (the online net is frozen
-// between two updates).  A workgroup of 3 waves owns 16 envs; the forward runs on v_mfma_f32_16x16x4_f32 in the [unit][env] orientation
-// with EVERY weight resident in registers as an A operand for the whole launch (wave w owns output tiles 2w, 2w+1 of layer 2):
+// between two updates).  A workgroup owns 16 envs: THREE forward waves run the Q-network on v_mfma_f32_16x16x4_f32 in the [unit][env] orientation
+// with EVERY weight resident in registers as an A operand for the whole launch (forward wave w owns output tiles 2w, 2w+1 of layer 2):
 //   layer 1  D1[unit][env] = W1[unit][0..3] . obs[env][0..3]            one k-step per 16-unit tile (8 tiles, 120 units padded to 128)
 //   layer 2  D2[out][env] += W2[out][u] * h1[u][env]                    the layer-1 accumulators ARE the B operands: accumulator
 //            register r of tile t in lane group g is unit 16 t + 4 g + r, so k-step (t, r) contracts over g with A = W2[out][16 t + 4 g + r]
 //   layer 3  two dot products over the wave's 32 units, summed across lane groups (2 shuffles) and across the 3 waves (LDS, one barrier)
-// All 64 lanes of every wave carry the fp64 state of env (lane & 15) and step it redundantly (same IEEE sequence => same bits), so the
-// observation never has to be exchanged; wave 0, lane group 0 writes the ring.  72 MFMAs per wave and step.
+// and a FOURTH wave steps the fp64 dynamics (below).  72 MFMAs per forward wave and step.  (The 3-wave form of rounds 1 - 3, in which every forward wave carried
+// the dynamics redundantly, lost the A/B in round 4 and left the source in round 5: docs/LEDGER.md.)
 #define DA_ENVS 16
-#define DA_WAVES 3
 typedef float dq_f32x4 __attribute__((ext_vector_type(4)));
 typedef dq_f32x4 f32x4_t;
 #define DQ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // FORCED (parity mode: forced_actions / forced_resets may be given) and EPLOG (per-episode list kept) are separate instantiations, not
 // run-time branches: a conditional global load or returning atomic inside the step loop makes the compiler place s_waitcnt vmcnt(0) at
 // the join, executed on EVERY step, where it waits for all of the wave's outstanding ring stores (mi_rollout.hip, rollout_q4_kernel).
-template <bool FORCED, bool EPLOG>
-__global__ void __launch_bounds__(64 * DA_WAVES)
-dqn_act_kernel(mi_env e, const float* __restrict__ params, int n_steps, long long global_step, long long slots, long long learning_starts,
-               dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
-               int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
-               const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
-               int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next, int32_t* __restrict__ stats_part) {
-    __shared__ float qp[2][DA_WAVES][DA_ENVS][2];
-    if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;   // the NEXT acting call's statistics (nobody else touches them during this launch)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
-    const int N = e.n;
-    const int i = blockIdx.x * DA_ENVS + j;
-    const bool mine = i < N, writer = mine && w == 0 && lg == 0;
-    const int g = mine ? i : N - 1;
-    // ---- resident operands ----
-    float w1a[8];
-    dq_f32x4 b1v[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int ua = 16 * t + j;
-        w1a[t] = ua < DQ_H1 ? params[DQ_W1 + 4 * ua + lg] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int u = 16 * t + 4 * lg + r; b1v[t][r] = u < DQ_H1 ? params[DQ_B1 + u] : 0.0f; }
-    }
-    float w2a[2][8][4];
-    dq_f32x4 b2v[2], w3v[2][2];
-#pragma unroll
-    for (int T = 0; T < 2; ++T) {
-        const int row = 16 * (2 * w + T) + j;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int col = 16 * t + 4 * lg;
-            if (row < DQ_H2 && col < DQ_H1) {      // 120 = 7.5 tiles: a lane's 4 columns are all inside or all outside
-                const float4 v = *reinterpret_cast<const float4*>(params + DQ_W2 + DQ_H1 * row + col);
-                w2a[T][t][0] = v.x; w2a[T][t][1] = v.y; w2a[T][t][2] = v.z; w2a[T][t][3] = v.w;
-            } else { w2a[T][t][0] = w2a[T][t][1] = w2a[T][t][2] = w2a[T][t][3] = 0.0f; }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 16 * (2 * w + T) + 4 * lg + r;
-            b2v[T][r] = o < DQ_H2 ? params[DQ_B2 + o] : 0.0f;
-            w3v[T][0][r] = o < DQ_H2 ? params[DQ_W3 + o] : 0.0f;
-            w3v[T][1][r] = o < DQ_H2 ? params[DQ_W3 + DQ_H2 + o] : 0.0f;
-        }
-    }
-    const float b30 = params[DQ_B3], b31 = params[DQ_B3 + 1];
-    // ---- env state (every lane group holds a copy) ----
-    double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
-    int elapsed = e.elapsed[g], eplen = e.ep_len[g];
-    float epret = e.ep_ret[g];
-    uint64_t episode = e.episode[g], stepctr = e.step_ctr[g];
-    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
-    int st_cnt = 0, st_len = 0, st_max = 0, par = 0;
-    // every value loaded so far is consumed here: no load is pending when the loop starts (it would become a vmcnt wait inside the body)
-    asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr));
-    long long slot = global_step % slots;
-    for (int s = 0; s < n_steps; ++s) {
-        const long long gs = global_step + s, nslot = slot + 1 == slots ? 0 : slot + 1;   // (no 64-bit modulo per step)
-        int a;
-        if (FORCED && forced_actions) a = (int)forced_actions[(size_t)s * N + g];
-        else {
-            uint32_t r[4];
-            mi_philox(e.seed, e.env_id_base + (uint64_t)g, stepctr, STREAM_EXPLORE, r);
-            const float u = mi_u32_to_uniform(r[0]);
-            const bool explore = gs < learning_starts || u < eps.v[s];
-            a = (int)(r[1] & 1u);
-            if (__any(!explore)) {  // skip the forward while every env of the group explores (same envs in all three waves: block-uniform)
-                const float b0 = lg == 0 ? ob.x : lg == 1 ? ob.y : lg == 2 ? ob.z : ob.w;
-                dq_f32x4 h1[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    h1[t] = DQ_MFMA(w1a[t], b0, b1v[t]);          // the bias enters as the accumulator
-#pragma unroll
-                    for (int r2 = 0; r2 < 4; ++r2) h1[t][r2] = fmaxf(h1[t][r2], 0.0f);
-                }
-                dq_f32x4 h2[2] = {b2v[0], b2v[1]};
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int r2 = 0; r2 < 4; ++r2) {
-                        h2[0] = DQ_MFMA(w2a[0][t][r2], h1[t][r2], h2[0]);
-                        h2[1] = DQ_MFMA(w2a[1][t][r2], h1[t][r2], h2[1]);
-                    }
-                float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-                for (int T = 0; T < 2; ++T)
-#pragma unroll
-                    for (int r2 = 0; r2 < 4; ++r2) {
-                        const float hv = fmaxf(h2[T][r2], 0.0f);
-                        p0 = __builtin_fmaf(w3v[T][0][r2], hv, p0); p1 = __builtin_fmaf(w3v[T][1][r2], hv, p1);
-                    }
-                p0 += __shfl_xor(p0, 16); p0 += __shfl_xor(p0, 32);
-                p1 += __shfl_xor(p1, 16); p1 += __shfl_xor(p1, 32);
-                if (lg == 0) { qp[par][w][j][0] = p0; qp[par][w][j][1] = p1; }
-                __syncthreads();
-                const float q0 = ((qp[par][0][j][0] + qp[par][1][j][0]) + qp[par][2][j][0]) + b30;
-                const float q1 = ((qp[par][0][j][1] + qp[par][1][j][1]) + qp[par][2][j][1]) + b31;
-                par ^= 1;                                          // the other buffer next time: one barrier per step is enough
-                if (!explore) a = q1 > q0 ? 1 : 0;                 // torch.argmax: first index on ties (dqn.py:92)
-            }
-        }
-        stepctr += 1;
-        if (writer) actions[slot * N + g] = a;                                   // dqn.py:95
-        int term;
-        mi_cartpole_step(sx, sxd, sth, sthd, a, term);
-        elapsed += 1;
-        const bool trunc = !term && elapsed >= CP_MAX_STEPS;
-        const bool d = term || trunc;
-        epret += 1.0f; eplen += 1;
-        if (d) {
-            if (writer) {
-                st_cnt += 1; st_len += eplen; st_max = eplen > st_max ? eplen : st_max;
-                if (EPLOG && max_ep > 0 && episode_stats) {
-                    const int sl = atomicAdd(episode_stats + 3, 1);
-                    if (sl < max_ep) episodes[sl] = mi_episode_t{g, s, epret, eplen};
-                }
-            }
-            epret = 0.0f; eplen = 0; elapsed = 0;
-            double rs[4];
-            if (FORCED && forced_resets) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) rs[k] = forced_resets[4 * ((size_t)s * N + g) + k];
-            } else {
-                mi_reset_noise(e.seed, e.env_id_base + (uint64_t)g, episode, rs);
-            }
-            episode += 1;
-            sx = rs[0]; sxd = rs[1]; sth = rs[2]; sthd = rs[3];
-        }
-        ob = make_float4((float)sx, (float)sxd, (float)sth, (float)sthd);
-        if (writer) {
-            reinterpret_cast<float4*>(observations)[nslot * N + g] = ob;       // dqn.py:106 (the reset obs where done)
-            rewards[nslot * N + g] = 1.0f;                                     // :107
-            terminated[nslot * N + g] = (uint8_t)(term ? 1 : 0);               // :108: done and not TimeLimit.truncated
-        }
-        slot = nslot;
-    }
-    if (writer) {
-        e.x[g] = sx; e.x_dot[g] = sxd; e.theta[g] = sth; e.theta_dot[g] = sthd;
-        e.elapsed[g] = elapsed; e.ep_ret[g] = epret; e.ep_len[g] = eplen; e.episode[g] = episode; e.step_ctr[g] = stepctr;
-        reinterpret_cast<float4*>(obs_cur)[g] = ob;
-    }
-    if ((episode_stats || stats_part) && w == 0) {   // one flush per workgroup (see dqn_act4_kernel)
-        int c = writer ? st_cnt : 0, l = writer ? st_len : 0, m = writer ? st_max : 0;
-#pragma unroll
-        for (int sft = 1; sft < 16; sft <<= 1) { c += __shfl_xor(c, sft); l += __shfl_xor(l, sft); const int mo = __shfl_xor(m, sft); m = mo > m ? mo : m; }
-        if (stats_part) { if (lane == 0) reinterpret_cast<int4*>(stats_part)[blockIdx.x] = make_int4(c, l, m, 0); }
-        else if (lane == 0 && c > 0) { atomicAdd(episode_stats, c); atomicAdd(episode_stats + 1, l); atomicMax(episode_stats + 2, m); }
-    }
-}
-
-// ---- the same contract with a FOURTH wave: acting at 3 waves per 16 envs leaves one SIMD of every CU idle and spends 1.07 us of every 3.5 us step on the fp64
-// dynamics, carried redundantly by all three forward waves (timing-only ablations: no dynamics 57.6 -> 46.9 us per 10-step iteration, no forward -> 41.5).
 // CartPole has two actions, so the dynamics wave computes BOTH successors of the current state (lane groups 0 / 1 take action 0 / 1, groups 2 / 3 idle
 // replicas) while the three forward waves evaluate the Q-network on it, and publishes them as records in LDS; after the step's one barrier every wave
 // derives the action from the partial sums and picks the chosen record — the forward waves only its observation.  The dynamics wave also draws the
@@ -321,7 +168,7 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     const int g = mine ? i : N - 1;
     const int la = lg & 1;                                  // dynamics wave: the action this lane group speculates on
     const bool writer = phys && mine && lg == 0;
-    // ---- forward waves: resident operands (as in dqn_act_kernel) ----
+    // ---- forward waves: resident operands ----
     float w1a[8];
     dq_f32x4 b1v[8];
     float w2a[2][8][4];
@@ -570,14 +417,8 @@ static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t 
     }
     {
     mi_prof_scope prof(MI_PROF_DQN_ACT, s);
-#ifdef DQN_ACT3   // A/B: the 3-wave form (every forward wave carries the dynamics)
-    const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(64 * DA_WAVES);
-#define DA_KERNEL dqn_act_kernel
-#else
     const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(256);
-#define DA_KERNEL dqn_act4_kernel
-#endif
-#define DA_LAUNCH(F, L) DA_KERNEL<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
+#define DA_LAUNCH(F, L) dqn_act4_kernel<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
                                                                   obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes, \
                                                                   part ? nullptr : episode_stats, max_ep, zero_next, part ? e->stats_part : nullptr)
     if (forced) { if (eplog) DA_LAUNCH(true, true); else DA_LAUNCH(true, false); }

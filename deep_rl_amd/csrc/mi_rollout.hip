@@ -37,9 +37,7 @@
 #define RQ_RING (RQ_GAE_T + 1)
 #define RQ_UNI_BLOCKS (RQ_GAE_T / 4 + 2)   // Philox blocks (4 steps each) a launch of <= RQ_GAE_T steps can touch, whatever its first step's phase
 
-#ifndef RQ_CHAINS
 #define RQ_CHAINS 4   // independent accumulator chains of layer 2 (k mod RQ_CHAINS); 8 measured no faster: the wave is issue-bound, not MFMA-latency-bound
-#endif
 template <int K>
 struct rq_layer2 {   // k-steps K..63
     static __device__ __forceinline__ void run(const float (&w2)[HID], const rq_f32x4& tr, rq_f32x4 (&acc)[RQ_CHAINS]) {

@@ -141,20 +141,13 @@ int mi_pend_step_ex_impl(mi_env* e, const float* actions, const double* forced_r
 // Waves per row-group workgroup (round 4, measured: profiles/r04_sac_waves.txt).  TWO waves per SIMD, each owning two of the sixteen 16-unit output tiles of a pass, let one
 // wave's MFMAs cover the other's weight-stream waits — which pays on a kernel that is ONE pass long (acting: 15.0 -> 13.6 us: its stream starts cold) and not on the
 // multi-pass update kernels, whose later passes are requested three stages ahead anyway while every one of their ~20 barriers gets dearer with eight waves (critic 31.1 ->
-// 31.4 us, actor 37.0 -> 38.3 us).  So: 8 for the single-pass kernels, 4 for the update kernels; -DSA_WAVES=8 / -DSA_WAVES_ACT=4 build the other forms for A/B.
-#ifndef SA_WAVES
+// 31.4 us, actor 37.0 -> 38.3 us).  So: 8 for the single-pass kernels, 4 for the update kernels (the build switches for the other two forms left the source in round 5).
 #define SA_WAVES 4
-#endif
-#ifndef SA_WAVES_ACT
 #define SA_WAVES_ACT 8
-#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define L2_STAGES 8       // 256 reduction indices in stages of 32
 #define L2_NBUF 4         // ring of stage buffers (8 stages = 0 mod 4: every pass starts at slot 0)
 #define L2_AHEAD 3        // stages in flight ahead of the MFMAs
-#ifndef SAC_EXP
-#define SAC_EXP 0         // diagnostics (wrong results): 1 = stream only the first pass's first stages (MFMA-only time)
-#endif
 // keyed standard normal (production mode): Box-Muller on two Philox words
 __device__ __forceinline__ float keyed_normal(uint64_t seed, uint64_t tag_update, uint64_t row) {
     uint32_t r[4];

@@ -193,23 +193,15 @@ extern "C" int mi_adv_stats(const float* advantages, const int32_t* idx, int mb,
 #define GRAD_WAVES 8        // ONE 512-thread workgroup per CU: two waves per SIMD share one staged copy of the weights
 #define GRAD_WPS 2          // waves per SIMD the kernel is built for
 #define GRAD_OCC (GRAD_WPS * 4 / GRAD_WAVES)   // workgroups per CU
-// GRAD_ANTISYM (round 4, default 1): the actor tiles evaluate ONE head, d = l0 - l1 (mi_grad_kernel.inc); 0 = both heads, the round-3 form (A/B build).
-#ifndef GRAD_ANTISYM
-#define GRAD_ANTISYM 1
-#endif
+// The actor tiles evaluate ONE head, d = l0 - l1 (mi_grad_kernel.inc; round 4).
 // GRAD_OLD_SHARE: of every 16 tile rounds, how many go to the first-dispatched ("older") half of the waves (age arbitration: the older wave of a SIMD wins every issue
-// conflict).  Measured per launch with GRAD_ANTISYM (profiles/r04_grad_ab.txt): 9: 71.6, 10: 71.0, 11: 70.4, 12: 71.9, 13: 73.3 us.
-#ifndef GRAD_OLD_SHARE
-#define GRAD_OLD_SHARE (GRAD_ANTISYM ? 11 : 10)
-#endif
+// conflict).  Measured per launch (profiles/r04_grad_ab.txt): 9: 71.6, 10: 71.0, 11: 70.4, 12: 71.9, 13: 73.3 us.
+#define GRAD_OLD_SHARE 11
 #define GRAD_ROLE_BIT 3     // which blockIdx bit selects actor / critic (bit 0 would pin one net per XCD)
-// GRAD_ACTOR_EXTRA: per 128 workgroups, how many more serve the actor than the critic (negative: the critic gets more).  The minibatch is 8,192 tiles per net = exactly 16
-// per SIMD at 128 : 128 workgroups; any other split leaves some SIMDs with a 17th tile (+6 % on their CU), so it only pays when one net's tile costs > 6 % more: round 3's
-// two-head actor tile (835 against 725 instructions) ran best at +2; with GRAD_ANTISYM the two tiles cost the same (740 / 725) and 0 is best (-2: 74.2, -1: 74.2, 0: 71.0,
-// +1: 73.1, +2: 73.1 us per launch).
-#ifndef GRAD_ACTOR_EXTRA
-#define GRAD_ACTOR_EXTRA (GRAD_ANTISYM ? 0 : 2)
-#endif
+// Both nets get the same number of workgroups: the minibatch is 8,192 tiles per net = exactly 16 per SIMD at 128 : 128 workgroups, and any other split leaves some SIMDs
+// with a 17th tile (+6 % on their CU) — with the one-head actor tile the two tiles cost the same (740 / 725 instructions), and 0 extra actor workgroups per 128 measured
+// best (-2: 74.2, -1: 74.2, 0: 71.0, +1: 73.1, +2: 73.1 us; the two-head tile of rounds 1 - 3 ran best at +2).  The A/B switches for both (and for the two-head tile)
+// left the source in round 5: docs/LEDGER.md has the numbers and the commit.
 #define TROWS 16
 #define PART_STRIDE 4624
 #define PART_LOSS 4610
@@ -360,11 +352,7 @@ __device__ __forceinline__ float block_grad_norm(const float* __restrict__ grads
     double S = 0.0;
     if (parts) {
         if (t < 256) for (int b = t; b < nb; b += 256) S += parts[b];
-#ifdef NORM_SHARDED_GENERIC   // A/B build: the sharded gradient launch walks the generic branch below (what it did until round 4)
-    } else if (false) {
-#else
     } else if (n == NPARAMS && nw == 8) {
-#endif
         // The sharded gradient launch (8 waves, the all-reduced PPO gradient, no block sums): the SAME tree, evaluated with a quarter of the instructions.  Wave w owns
         // blocks w + 8k, k < 18 (144 = 18 x 8): all 18 loads in flight before the first add, then the butterflies' xor-32 and xor-16 stages on PAIRS of blocks (one
         // swap + one add serves two blocks: each half / row of the wave keeps one of them), which leaves 5 values for the four in-row stages instead of 18 for all six.
@@ -434,28 +422,12 @@ struct grad_pending_t {
     float w1, b2, w2, step_size, rbc2, eps, max_norm;
 };
 
-// Which net a slab / workgroup serves.  Slab index vb: even = actor, odd = critic, except that the first `extra` critic slabs serve the actor too: an
-// actor tile costs ~3.5 % more than a critic tile (the policy loss), and with one workgroup per CU that is a per-CU imbalance, so the actor gets
-// `extra` more CUs (130 : 126 at 256).  ri = index within the role (the order grad_reduce_kernel sums in), nr = workgroups of that role.
+// Which net a slab / workgroup serves.  Slab index vb: even = actor, odd = critic.  ri = index within the role (the order grad_reduce_kernel sums in), nr = workgroups of that role.
 struct grad_role_t { int role, ri, nr; };
-// extra > 0: the actor gets `extra` of the odd (critic) slabs as well; extra < 0: the critic gets -extra of the even (actor) slabs; |extra| < n_blocks / 2
-__host__ __device__ inline grad_role_t grad_role(unsigned vb, int n_blocks, int extra) {
-    const int half = n_blocks >> 1, k = (int)(vb >> 1);
-    if (extra >= 0) {
-        if ((vb & 1u) == 0) return grad_role_t{0, k, half + extra};
-        if (k < extra) return grad_role_t{0, half + k, half + extra};
-        return grad_role_t{1, k - extra, half - extra};
-    }
-    const int e = -extra;
-    if ((vb & 1u) != 0) return grad_role_t{1, k, half + e};
-    if (k < e) return grad_role_t{1, half + k, half + e};
-    return grad_role_t{0, k - e, half - e};
+__host__ __device__ inline grad_role_t grad_role(unsigned vb, int n_blocks) {
+    return grad_role_t{(int)(vb & 1u), (int)(vb >> 1), n_blocks >> 1};
 }
-__host__ __device__ inline int grad_slab(int role, int ri, int n_blocks, int extra) {   // inverse: the slab of workgroup ri of a role
-    const int half = n_blocks >> 1;
-    if (extra >= 0) return role == 0 ? (ri < half ? 2 * ri : 2 * (ri - half) + 1) : 2 * (ri + extra) + 1;
-    return role == 1 ? (ri < half ? 2 * ri + 1 : 2 * (ri - half)) : 2 * (ri - extra);
-}
+__host__ __device__ inline int grad_slab(int role, int ri) { return 2 * ri + role; }   // inverse: the slab of workgroup ri of a role
 
 struct row_in {
     float x;          // observation component g of the row (lane (j,g))
@@ -528,7 +500,7 @@ __device__ __forceinline__ float p2p_exchange(const p2p_args_t& x, int line, flo
 #define RED_GROUPS 16
 template <int WORLD>
 __global__ void __launch_bounds__(RED_PARAMS * RED_GROUPS)
-grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra, float ent_coef, float vf_coef, double inv_count,
+grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_coef, float vf_coef, double inv_count,
                    float* __restrict__ grads, float* __restrict__ loss_terms, double* __restrict__ norm_parts, const p2p_args_t x) {
     MI_INSIDE_SCOPE(MI_PROF_REDUCE);
     const int pblocks = (NPARAMS + RED_PARAMS - 1) / RED_PARAMS;
@@ -541,16 +513,16 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra,
         const int off = p - (role ? C_BASE : 0);   // slab position within the net
         if (p < NPARAMS) {
             const float* src = workspace + off;
-            const int nr = role == 0 ? (n_blocks >> 1) + extra : (n_blocks >> 1) - extra;
+            const int nr = n_blocks >> 1;
             if (nr <= 9 * RED_GROUPS) {   // the full grid (130 / 126 slabs per net): every load of the thread in flight at once, summed in workgroup order
                 float v[9];
 #pragma unroll
-                for (int u = 0; u < 9; ++u) { const int k = sg + RED_GROUPS * u; v[u] = k < nr ? src[(size_t)grad_slab(role, k, n_blocks, extra) * PART_STRIDE] : 0.0f; }
+                for (int u = 0; u < 9; ++u) { const int k = sg + RED_GROUPS * u; v[u] = k < nr ? src[(size_t)grad_slab(role, k) * PART_STRIDE] : 0.0f; }
 #pragma unroll
                 for (int u = 0; u < 9; ++u) if (sg + RED_GROUPS * u < nr) acc += v[u];
             } else {
 #pragma unroll 4
-                for (int k = sg; k < nr; k += RED_GROUPS) acc += src[(size_t)grad_slab(role, k, n_blocks, extra) * PART_STRIDE];
+                for (int k = sg; k < nr; k += RED_GROUPS) acc += src[(size_t)grad_slab(role, k) * PART_STRIDE];
             }
         }
         part[sg][pl] = acc;
@@ -572,7 +544,7 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, int extra,
         double pg = 0.0, en = 0.0, vl = 0.0;
         for (int b = threadIdx.x; b < n_blocks; b += RED_PARAMS * RED_GROUPS) {
             const float* s = workspace + (size_t)b * PART_STRIDE + PART_LOSS;
-            if (grad_role((unsigned)b, n_blocks, extra).role == 0) { pg += s[0]; en += s[1]; } else { vl += s[0]; }
+            if (grad_role((unsigned)b, n_blocks).role == 0) { pg += s[0]; en += s[1]; } else { vl += s[0]; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { pg += __shfl_xor(pg, o); en += __shfl_xor(en, o); vl += __shfl_xor(vl, o); }
@@ -636,9 +608,9 @@ extern "C" int mi_ppo_test_assume_sharded(int on) { g_assume_sharded = on ? 1 : 
 
 // gradient launch + slab sum.  `pend.grads != nullptr`: the launch first applies the owed optimizer step (see grad_pending_t).
 template <int WORLD>
-static void grad_reduce_launch(hipStream_t s, const float* workspace, int blocks, int extra, float ent_coef, float vf_coef, double inv_count, float* grads, float* loss_terms,
+static void grad_reduce_launch(hipStream_t s, const float* workspace, int blocks, float ent_coef, float vf_coef, double inv_count, float* grads, float* loss_terms,
                                double* norm_parts, const p2p_args_t& x) {
-    grad_reduce_kernel<WORLD><<<NORM_BLOCKS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>(workspace, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, norm_parts, x);
+    grad_reduce_kernel<WORLD><<<NORM_BLOCKS + 1, RED_PARAMS * RED_GROUPS, 0, s>>>(workspace, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, norm_parts, x);
 }
 
 // p2p != nullptr: the slab sum also all-reduces {grads, loss_terms} over the P2P carrier (mi_comm_p2p_next is drawn here: exactly one exchange per call, on every rank)
@@ -651,16 +623,14 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
     const int tiles = (mb + TROWS - 1) / TROWS;
     const int need = 2 * ((tiles + GRAD_WAVES - 1) / GRAD_WAVES);
     if (need < blocks) blocks = need;  // (the role swizzle falls back to identity when the grid is not a multiple of 2^(bit+1))
-    // full grids: the actor gets GRAD_ACTOR_EXTRA of every 128 workgroups more than the critic (see grad_role)
-    const int extra = (blocks == grad_blocks() && blocks >= 128) ? GRAD_ACTOR_EXTRA * (blocks / 128) / 2 : 0;
     {
         mi_prof_scope prof(MI_PROF_GRAD, s);
         if (g_contraction == MI_CONTRACTION_BF16X3)
             grad_kernel_bx<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb,
-                                                              adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace, extra);
+                                                              adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace);
         else
             grad_kernel_f32<<<blocks, 64 * GRAD_WAVES, 0, s>>>(params, pend, observations, actions, log_probs, advantages, returns, values, idx, mb,
-                                                               adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace, extra);
+                                                               adv_sums, clip_coef, ent_coef, vf_coef, (float)inv_count, (float*)workspace);
     }
     MI_LAUNCH_CHECK();
     {
@@ -677,15 +647,15 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
         const float* ws = (const float*)workspace;
         double* np = ws_norm_parts(workspace);
         switch (world) {
-            case 0: grad_reduce_launch<0>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            case 1: grad_reduce_launch<1>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            case 2: grad_reduce_launch<2>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            case 3: grad_reduce_launch<3>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            case 4: grad_reduce_launch<4>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            case 5: grad_reduce_launch<5>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            case 6: grad_reduce_launch<6>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            case 7: grad_reduce_launch<7>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
-            default: grad_reduce_launch<8>(s, ws, blocks, extra, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 0: grad_reduce_launch<0>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 1: grad_reduce_launch<1>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 2: grad_reduce_launch<2>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 3: grad_reduce_launch<3>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 4: grad_reduce_launch<4>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 5: grad_reduce_launch<5>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 6: grad_reduce_launch<6>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            case 7: grad_reduce_launch<7>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
+            default: grad_reduce_launch<8>(s, ws, blocks, ent_coef, vf_coef, inv_count, grads, loss_terms, np, x); break;
         }
     }
     MI_LAUNCH_CHECK();

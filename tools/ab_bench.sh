@@ -8,6 +8,6 @@ for so in "$@"; do
   b=$(timeout 300 python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
-print('%.1fM steps/s  %.2f ms/upd  grad %.1f us (%.1f%% mfma)  %s' % (d['value']/1e6, d['ms_per_step'], d['roofline']['avg_launch_us'], 100*d['roofline']['frac'], d['kernel_ms_per_update']))")
+print('%.1fM steps/s  %.2f ms/upd  grad %.1f us (%.1f%% mfma)  %s' % (d['value']/1e6, d['ms_per_step'], d['roofline']['avg_launch_us'], 100*d['roofline']['frac'], {k: v for k, v in d['kernel_ms_per_update_bracketed'].items() if k != 'note'}))")
   echo "$so | $r | $b"
 done

@@ -9,7 +9,7 @@ for r in $(seq 1 $REPS); do
     b=$(timeout 300 python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --headline-only 2>/dev/null | grep '^{"metric"' | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
-print('%s ms/upd  grad %.2f us (%.4f of peak)  %s' % (d['timed_windows']['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac'], d['kernel_ms_per_update']))")
+print('%s ms/upd  grad %.2f us (%.4f of peak)  %s' % (d['timed_windows']['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac'], {k: v for k, v in d['kernel_ms_per_update_bracketed'].items() if k != 'note'}))")
     echo "round $r | $so | $b"
   done
 done
