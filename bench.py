@@ -259,6 +259,8 @@ def bench_sac(dev, iters=400, cpu_seconds=3.0, batch=256):
            "value": round(iters * envs / dt, 1), "unit": "env-steps/s", "updates_per_s": round(iters / dt, 1), "ms_per_step": round(1e3 * dt / iters, 5),
            "step": "1 env step of every env + critic update + polyak + actor update + alpha update", "dtype": "f32",
            "kernel_us": {k: round(v, 2) for k, v in us.items()}, "kernel_us_per_step": per_it,
+           "kernel_us_note": "sac_act includes the critics' deferred optimizer step (dW2 GEMM + Adam + polyak on extra workgroups of the acting launch: MIRL_SAC_DEFER_CRITIC=1, "
+                             "the default), which therefore does not appear under sac_gemm",
            "roofline": {"bound": "mfma", "kernel": "sac_critic_kernel", "achieved": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12, 3),
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(critic_flops / (us["sac_critic"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                         "traffic": cr_traffic, "traffic_source": cr_src, "flops_per_launch": critic_flops, "avg_launch_us": round(us["sac_critic"], 2),

@@ -1134,6 +1134,7 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
     // workgroups behind the acting ones: the critics' weight-gradient + Adam + polyak step owed from the last critic update (mi_sac_act_step_carry).  Acting reads the
     // actor and the env only, the step touches the critics only: no dependency inside the launch; whoever needs the stepped critics sits behind the kernel boundary.
     if ((int)blockIdx.x >= n_act) {
+        static_assert(sizeof(sac_smem) >= sizeof(sac_dw2_smem) && alignof(sac_smem) >= alignof(sac_dw2_smem), "the carried critic step reuses the acting kernel's LDS block");
         sac_dw2_adam_role(*reinterpret_cast<sac_dw2_smem*>(&sm), (int)blockIdx.x - n_act, dw.ws, dw.batch, dw.mat0, dw.n_slabs, dw.is_actor, dw.inv_count, dw.grads, dw.out2, dw.opt);
         return;
     }
@@ -1188,14 +1189,22 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
 
 __global__ void sac_zero4_kernel(int32_t* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0; }
 
+// the acting arguments, checked BEFORE anything is enqueued: mi_sac_act_step_carry must not launch (or carry) the owed critic step and then refuse the acting call —
+// the caller would keep the debt and apply the same Adam + polyak step a second time
+static int sac_act_check(void* handle, const float* actor, int64_t global_step, int64_t slots, const float* obs_cur, const float* observations, const float* actions,
+                         const float* rewards, const uint8_t* terminated, const mi_episode_t* episodes, int max_ep) {
+    MI_CHECK_ARG(handle && actor && obs_cur && observations && actions && rewards && terminated, "NULL pointer");
+    MI_CHECK_ARG(((mi_env*)handle)->kind == MI_ENV_PENDULUM_V1, "SAC path needs a Pendulum-v1 handle");
+    MI_CHECK_ARG(slots >= 2 && global_step >= 0 && max_ep >= 0 && (max_ep == 0 || episodes), "bad arguments");
+    return MI_OK;
+}
+
 static int sac_act_impl(void* handle, const float* actor, int64_t global_step, int64_t slots, int64_t learning_starts, float* obs_cur,
                         float* observations, float* actions, float* rewards, uint8_t* terminated, const float* forced_actions,
                         const float* forced_eps, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
                         const sac_dw2_args_t* carry, void* stream) {
-    MI_CHECK_ARG(handle && actor && obs_cur && observations && actions && rewards && terminated, "NULL pointer");
+    if (const int rc = sac_act_check(handle, actor, global_step, slots, obs_cur, observations, actions, rewards, terminated, episodes, max_ep)) return rc;
     mi_env* e = (mi_env*)handle;
-    MI_CHECK_ARG(e->kind == MI_ENV_PENDULUM_V1, "SAC path needs a Pendulum-v1 handle");
-    MI_CHECK_ARG(slots >= 2 && global_step >= 0 && max_ep >= 0 && (max_ep == 0 || episodes), "bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (episode_stats) { sac_zero4_kernel<<<1, 64, 0, s>>>(episode_stats); MI_LAUNCH_CHECK(); }
     mi_prof_scope prof(MI_PROF_SAC_ACT, s);
@@ -1243,6 +1252,7 @@ extern "C" int mi_sac_act_step_carry(void* handle, const float* actor, int64_t g
                                    forced_resets, episodes, episode_stats, max_ep, nullptr, stream);
     sac_dw2_args_t a;
     if (const int rc = sac_critic_step_args(step, &a)) return rc;
+    if (const int rc = sac_act_check(handle, actor, global_step, slots, obs_cur, observations, actions, rewards, terminated, episodes, max_ep)) return rc;   // nothing enqueued yet
     if (ws_kp(step->batch) > SAC_FUSED_KP) {   // large batches: the step is two launches of its own (K-split GEMM, assembly); nothing to carry
         if (const int rc = mi_sac_critic_step(step, stream)) return rc;
         return sac_act_impl(handle, actor, global_step, slots, learning_starts, obs_cur, observations, actions, rewards, terminated, forced_actions, forced_eps, forced_resets,

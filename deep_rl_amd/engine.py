@@ -92,7 +92,10 @@ class PPOEngine:
     # ---- pieces of one outer update ----------------------------------------------------------------
     @property
     def episode_stats(self):
-        """{finished episodes, sum of their lengths, longest, slots of the episode log} of the last rollout (device i32 [4])."""
+        """{finished episodes, sum of their lengths, longest, slots of the episode log} of the last rollout (device i32 [4]).
+        Single-owner, single-stream contract: without an episode log the property hands back ONE persistent tensor that the next read after the next
+        rollout overwrites (clone it to keep an update's numbers), and the launch that sums the per-workgroup statistics is ordered behind the rollout through torch's
+        current stream only — read it on the stream the rollout ran on."""
         if not self._lazy_stats:
             return self._stats2[self._stats_cur]
         if not self._stats_ready and self._stats_any:
@@ -139,8 +142,14 @@ class PPOEngine:
 
     def episode_summary_async(self, pinned):
         """Non-blocking copy of {episodes, sum of lengths, longest, -} of the last rollout into a pinned host tensor
-        (read it after the next sync point; CartPole return == length)."""
-        if self._lazy_stats and self._stats_any and pinned.is_pinned() and pinned.dtype == torch.int32 and pinned.numel() >= 4 and pinned.is_contiguous():
+        (read it after the next sync point; CartPole return == length).  Same single-stream contract as `episode_stats`.  The direct route below lets the device
+        kernel write into `pinned.data_ptr()`: that holds for tensors torch itself pinned (`.pin_memory()` / hipHostMalloc: mapped at the same address on the device);
+        memory pinned some other way (hipHostRegister of a foreign allocation) need not be — pass `direct=False` for such tensors."""
+        self._episode_summary(pinned, True)
+
+    def _episode_summary(self, pinned, direct):
+        ok = direct and self._lazy_stats and self._stats_any and pinned.is_pinned() and pinned.dtype == torch.int32 and pinned.numel() >= 4 and pinned.is_contiguous()
+        if ok:
             # the sum of the per-workgroup statistics is written straight into the pinned host tensor (device-visible at the same address): no copy behind it
             N.check(N.lib().mi_env_episode_stats(self.env.handle, pinned.data_ptr(), self._s()), "mi_env_episode_stats")
             return

@@ -536,7 +536,9 @@ int mi_test_tanh(const float* x, float* y, int n, void* stream);
 enum { MI_PROF_ROLLOUT = 0, MI_PROF_GAE = 1, MI_PROF_GRAD = 2, MI_PROF_REDUCE = 3, MI_PROF_CLIP_ADAM = 4, MI_PROF_STATS = 5,
        /* DQN (config 3): acting launch, TD forward+backward, slab sum (+ Adam), PER sampler launches */
        MI_PROF_DQN_ACT = 6, MI_PROF_DQN_TD = 7, MI_PROF_DQN_REDUCE = 8, MI_PROF_PER = 9,
-       /* SAC (config 4): acting launch, row-group critic / actor kernels, dW2 GEMM, assembly (+ Adam + polyak), log-prob + alpha */
+       /* SAC (config 4): acting launch, row-group critic / actor kernels, dW2 GEMM, assembly (+ Adam + polyak), log-prob + alpha.  NOTE: with the critics' optimizer
+        * step deferred (mi_sac_act_step_carry; the engines' default) MI_PROF_SAC_ACT also covers the carried dW2 + Adam + polyak workgroups, which then do not
+        * appear under MI_PROF_SAC_GEMM; on the P2P carrier the gradient all-reduce runs inside MI_PROF_REDUCE and MI_PROF_COMM_GRAD stays empty */
        MI_PROF_SAC_ACT = 10, MI_PROF_SAC_CRITIC = 11, MI_PROF_SAC_ACTOR = 12, MI_PROF_SAC_GEMM = 13, MI_PROF_SAC_ASSEMBLE = 14, MI_PROF_SAC_LOGP = 15,
        /* the in-stream collectives of mi_ppo_update_sharded: the 9,159-float gradient all-reduce (16 per update), the advantage-statistics all-reduce (1) */
        MI_PROF_COMM_GRAD = 16, MI_PROF_COMM_STATS = 17,
