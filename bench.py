@@ -821,7 +821,7 @@ def main():
             # its OWN roofline, against the bf16 matrix peak: the three 64 x 64 contractions per net (49,152 of the 53,376 algorithmic FLOP per row) run as SIX bf16 part
             # products each, so the matrix pipe executes 6 x their FLOP as bf16 — the honest fraction of the bf16 peak is small, and the algorithmic one smaller still
             v_us = 1e3 * vg_ms / max(vg_n, 1)
-            contraction_flops = 3 * 2 * 64 * 64 * 2 * 2 * mb          # layer 2 forward, dh1, dW2: 2 x 64 x 64 FLOP each, both nets, per row
+            contraction_flops = 3 * (2 * 64 * 64) * 2 * mb            # layer 2 forward, dh1, dW2: 2 x 64 x 64 FLOP each per row, both nets = 49,152 of the 53,376 per row
             executed_bf16 = 6 * contraction_flops
             out["variant_bf16x3"]["roofline"] = {
                 "bound": "mfma", "kernel": "grad_kernel_bx", "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "peak_what": "dense bf16 MFMA (16 x the f32 MFMA peak)",
