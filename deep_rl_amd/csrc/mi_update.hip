@@ -551,16 +551,24 @@ grad_reduce_kernel(const float* __restrict__ workspace, int n_blocks, float ent_
         __shared__ double t[3][16];
         if ((threadIdx.x & 63) == 0) { t[0][threadIdx.x >> 6] = pg; t[1][threadIdx.x >> 6] = en; t[2][threadIdx.x >> 6] = vl; }
         __syncthreads();
-        if (threadIdx.x == 0 && loss_terms) {
+        if constexpr (WORLD > 0) {
+            // the four shares travel as lines NPARAMS .. NPARAMS + 3, each summed in rank order like a gradient element (what the one-buffer all-reduce did): lanes 0 .. 3
+            // exchange one term each, side by side (one thread doing the four in turn put four memory round trips on this workgroup, the launch's longest)
+            __shared__ float lt[4];
+            if (threadIdx.x == 0) {
+                double PG = 0.0, EN = 0.0, VL = 0.0;
+                for (int k = 0; k < 16; ++k) { PG += t[0][k]; EN += t[1][k]; VL += t[2][k]; }
+                const float t0 = (float)(PG * inv_count), t1 = (float)(EN * inv_count), t2 = (float)(0.5 * VL * inv_count);
+                lt[0] = t0; lt[1] = t1; lt[2] = t2; lt[3] = t0 - ent_coef * t1 + t2 * vf_coef;  // ppo.py:187
+            }
+            __syncthreads();
+            if (threadIdx.x < 4 && loss_terms) loss_terms[threadIdx.x] = p2p_exchange<WORLD>(x, NPARAMS + (int)threadIdx.x, lt[threadIdx.x]);
+        } else if (threadIdx.x == 0 && loss_terms) {
             double PG = 0.0, EN = 0.0, VL = 0.0;
             for (int k = 0; k < 16; ++k) { PG += t[0][k]; EN += t[1][k]; VL += t[2][k]; }
-            float t0 = (float)(PG * inv_count), t1 = (float)(EN * inv_count), t2 = (float)(0.5 * VL * inv_count);
-            float t3 = t0 - ent_coef * t1 + t2 * vf_coef;  // ppo.py:187
-            if constexpr (WORLD > 0) {   // the four shares travel as lines NPARAMS .. NPARAMS + 3, each summed in rank order like a gradient element (what the one-buffer all-reduce did)
-                t0 = p2p_exchange<WORLD>(x, NPARAMS + 0, t0); t1 = p2p_exchange<WORLD>(x, NPARAMS + 1, t1);
-                t2 = p2p_exchange<WORLD>(x, NPARAMS + 2, t2); t3 = p2p_exchange<WORLD>(x, NPARAMS + 3, t3);
-            }
-            loss_terms[0] = t0; loss_terms[1] = t1; loss_terms[2] = t2; loss_terms[3] = t3;
+            const float t0 = (float)(PG * inv_count), t1 = (float)(EN * inv_count), t2 = (float)(0.5 * VL * inv_count);
+            loss_terms[0] = t0; loss_terms[1] = t1; loss_terms[2] = t2;
+            loss_terms[3] = t0 - ent_coef * t1 + t2 * vf_coef;  // ppo.py:187
         }
     }
 }

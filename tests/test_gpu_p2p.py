@@ -5,6 +5,7 @@ optimizer step of reference ppo.py:189-192, dqn.py:131-133 (per.py:147-153), sac
 
   test_synthetic_world_*                 one process plays 1 / 2 / 4 / 8 ranks into its own inbox (slot 0 = its share, the others zeros): every message size the
                                          engines send comes back bit for bit, f32 and f64, aligned or not, 50 back-to-back launches (both parities).
+  test_ppo_update_on_synthetic_ranks_*   mi_ppo_update_sharded with grad_reduce_kernel's in-launch exchange at 1 .. 8 synthetic ranks == mi_ppo_update, exactly.
   test_two_ranks_one_gpu_p2p_collective  two PROCESSES on cuda:0, inboxes exchanged with hipIpcGetMemHandle / hipIpcOpenMemHandle: bitwise gloo's a + b, rank == rank,
                                          the bounded wait when a peer never arrives (tests/_p2p_worker.py).
   test_two_ranks_one_gpu_p2p_ppo         PPOEngine.update() on mi_ppo_update_sharded, two ranks on cuda:0, two whole updates: rank == rank bitwise, == the
@@ -63,6 +64,50 @@ def test_synthetic_world_allreduce_is_identity(world):
         assert L.mi_comm_allreduce_sum(h, big.data_ptr(), big.numel(), 0, s) == -1
     finally:
         L.mi_comm_destroy(h)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_ppo_update_on_synthetic_ranks_equals_plain_update(world):
+    """mi_ppo_update_sharded on the P2P carrier with `world` synthetic ranks (slot 0 = this process's share, the others zeros) against mi_ppo_update: grad_reduce_kernel's
+    in-launch exchange — every instantiation 1 .. 8 of it — must return each gradient element and loss term unchanged (x + 0 + ... + 0 in rank order), so parameters, both
+    Adam moments, the last gradient, the loss terms and the clip norm agree exactly after 2 updates x 16 optimizer steps, at 64 envs (small grid) and 512 envs (full grid)."""
+    torch = _need_gpu()
+    import deep_rl_amd as D
+    import deep_rl_amd.dist as DD
+    import deep_rl_amd.engine as E
+    from deep_rl_amd import _native as N
+
+    dev = torch.device("cuda", 0)
+    for n_envs in (64, 512):
+        out = []
+        for synthetic in (False, True):
+            h = C.c_void_p()
+            if synthetic:
+                N.check(N.lib().mi_comm_p2p_synthetic(world, 1 << 16, C.byref(h)), "mi_comm_p2p_synthetic")
+                DD.use_comm(h)
+                E._FORCE_NATIVE_SHARDED = True
+            try:
+                env = D.make("CartPole-v1", num_envs=n_envs, device=dev, seed=21)
+                torch.manual_seed(21)
+                agent = D.ActorCritic(env)
+                opt = D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
+                eng = D.PPOEngine(env, agent, opt, num_steps=128)
+                eng.reset()
+                for _ in range(2):
+                    eng.update()
+                torch.cuda.synchronize()
+                if synthetic:
+                    N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+                out.append([t.clone() for t in (agent.flat, opt.exp_avg, opt.exp_avg_sq, eng.grads, eng.loss_terms, opt.grad_norm, eng.advantages)])
+            finally:
+                E._FORCE_NATIVE_SHARDED = False
+                DD.use_comm(None)
+                if h.value:
+                    torch.cuda.synchronize()
+                    N.lib().mi_comm_destroy(h)
+        for a, b in zip(*out):
+            assert torch.equal(a, b), (world, n_envs)
+        assert torch.isfinite(out[0][0]).all()
 
 
 def _launch(worker, env_extra, timeout=600):
