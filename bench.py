@@ -708,6 +708,16 @@ def main():
         for _ in range(2):
             windows.append(timed_updates(num_updates, args.steps)[0])
 
+    # a sharded headline is only worth its number if the exchange really happened: right behind the timed windows, no wait of the carrier may have run out on any rank
+    # and the replicas must still be bitwise identical (one MAX all-reduce of a checksum; host-synchronising, outside the timed region)
+    headline_exchange = None
+    if world > 1:
+        try:
+            eng.check_replicas()
+            headline_exchange = {"replicas_identical": True}
+        except Exception as ex:  # noqa: BLE001
+            headline_exchange = {"replicas_identical": False, "error": "%s: %s" % (type(ex).__name__, ex)}
+
     # the round-1..3 methodology beside it: one more window with a pair of HIP events around EVERY gradient launch of EVERY update
     dt_all = None
     if not args.single_window:
@@ -807,6 +817,8 @@ def main():
         if sharded is not None:
             out["sharded_route"] = sharded
         if collectives is not None:
+            if headline_exchange is not None:
+                collectives["headline_exchange"] = headline_exchange
             out["collectives"] = collectives
         if variant is not None:
             v_dt, v_prof = variant

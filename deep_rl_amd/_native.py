@@ -92,6 +92,7 @@ SIGNATURES = {
     "mi_comm_p2p_synthetic": (_I, [_I, _SZ, C.POINTER(_VP)]),
     "mi_comm_check": (_I, [_VP]),
     "mi_comm_carrier": (_I, [_VP]),
+    "mi_comm_p2p_set_colocated": (_I, [_VP, _I]),
     "mi_dqn_forward": (_I, [_VP, _VP, _I, _VP, _VP]),
     "mi_dqn_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP]),
     "mi_dqn_act_steps2": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP, _VP]),

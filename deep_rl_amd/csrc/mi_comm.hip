@@ -83,6 +83,7 @@ struct mi_comm {
     int mem_kind;                  // 0 uncached, 1 fine-grained, 2 plain device memory
     unsigned long long budget;     // wait budget in 100 MHz ticks
     int connected;
+    int colocated;                 // ranks of this communicator that share this rank's DEVICE (1 = one rank per GPU, the production placement)
 };
 
 extern "C" int mi_comm_unique_id(void* id128) {
@@ -161,7 +162,7 @@ static void p2p_launch(int world, unsigned groups, hipStream_t s, const p2p_args
 static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm** out) {
     mi_comm* c = (mi_comm*)calloc(1, sizeof(mi_comm));
     if (!c) { mi_set_error("mi_comm_p2p: out of host memory"); return MI_ENOMEM; }
-    c->carrier = CARRIER_P2P; c->world = world; c->rank = rank; c->synthetic = synthetic;
+    c->carrier = CARRIER_P2P; c->world = world; c->rank = rank; c->synthetic = synthetic; c->colocated = 1;
     c->cap = (max_bytes + 255) & ~(size_t)255;
     unsigned long long ms = 10000;
     if (const char* e = getenv("MIRL_P2P_TIMEOUT_MS")) { const long long v = atoll(e); if (v > 0) ms = (unsigned long long)v; }
@@ -265,6 +266,23 @@ int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world_out) 
 }
 
 bool mi_comm_is_p2p(void* comm) { return comm && ((mi_comm*)comm)->carrier == CARRIER_P2P; }
+
+// May a kernel of 145 x 1,024 threads (grad_reduce_kernel) spin-wait for its peers' exchange?  One rank per device: always.  Ranks SHARING a device (test placements):
+// every waiting rank holds 145 workgroups' worth of wave slots and registers while it spins, and a peer's gradient launch needs whole CUs (512 VGPRs per SIMD lane): two
+// ranks leave it 111 CUs, from three waiting ranks on the chip is full of waiters and the rank they wait for cannot be scheduled — a (bounded) deadlock, seen with 8 ranks
+// x 4096 envs on one MI355X.  More than two colocated ranks therefore take the stand-alone all-reduce launch (18 small workgroups per rank).  MIRL_P2P_FUSED=0 / 1 overrides.
+bool mi_comm_p2p_fused_ok(void* comm) {
+    if (!mi_comm_is_p2p(comm)) return false;
+    if (const char* e = getenv("MIRL_P2P_FUSED")) return atoi(e) != 0;
+    return ((mi_comm*)comm)->colocated <= 2;
+}
+
+extern "C" int mi_comm_p2p_set_colocated(void* comm, int ranks_on_this_device) {
+    MI_CHECK_ARG(mi_comm_is_p2p(comm), "not a P2P communicator");
+    MI_CHECK_ARG(ranks_on_this_device >= 1 && ranks_on_this_device <= ((mi_comm*)comm)->world, "ranks_on_this_device must be in [1, world_size]");
+    ((mi_comm*)comm)->colocated = ranks_on_this_device;
+    return MI_OK;
+}
 
 static int p2p_allreduce(mi_comm* c, void* buf, size_t n, int dtype, hipStream_t s) {
     p2p_args_t a;

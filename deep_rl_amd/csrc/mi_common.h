@@ -193,6 +193,7 @@ template <> struct ll_elem<double> {
 // publishes and consumes those lines on every rank); MI_EINVAL when the message does not fit, MI_ESTATE when the communicator is not connected.
 int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world);
 bool mi_comm_is_p2p(void* comm);
+bool mi_comm_p2p_fused_ok(void* comm);   // grad_reduce_kernel may carry the exchange (false when more than two ranks share this device: see mi_comm.hip)
 
 // ---- RNG contract (include/mi_rl.h) ----------------------------------------------------------------
 #define STREAM_RESET 0u

@@ -868,7 +868,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
     const bool fused = (mb % PS_PER_BLOCK) == 0;  // perm + stats in one pass; their fp64 accumulators are zeroed by the rollout launch
     // P2P carrier: grad_reduce_kernel itself exchanges {gradient, loss terms} (no launch per all-reduce) and its block sums of squares are those of the ALL-REDUCED
     // gradient, so the owed steps take the single-rank branch; RCCL: an in-stream ncclAllReduce behind every slab sum, the norm recomputed from the gradient
-    const bool p2p = comm != nullptr && mi_comm_is_p2p(comm);
+    const bool p2p = comm != nullptr && mi_comm_p2p_fused_ok(comm);   // (a P2P communicator shared by > 2 ranks of one device: the stand-alone launch, as on RCCL)
     const bool sharded_norm = (world > 1 && !p2p) || g_assume_sharded != 0;
     int rc = mi_rollout_gae_internal(handle, b->params, hp->T, b->obs_cur, b->observations, b->values, b->actions, b->log_probs, b->rewards,
                                      b->dones, b->episodes, b->episode_stats, b->max_ep, hp->gamma, hp->gae_lambda, b->advantages, b->returns,

@@ -165,11 +165,20 @@ def _create_p2p(group):
     ok, err = 1, ""
     if N.lib().mi_comm_p2p_alloc(world, rk, max_bytes, C.byref(h), mine) != 0:
         ok, err = 0, N.lib().mi_last_error().decode()
+    import socket
+
+    dev = torch.cuda.current_device()
+    try:
+        where = (socket.gethostname(), str(torch.cuda.get_device_properties(dev).uuid))
+    except Exception:  # noqa: BLE001  (no uuid on this torch: the index — right on one node, where CUDA_VISIBLE_DEVICES-style remapping is the launcher's business)
+        where = (socket.gethostname(), str(dev))
     boxes = [None] * world
-    dist.all_gather_object(boxes, (bytes(mine.raw), ok), group=group)
+    dist.all_gather_object(boxes, (bytes(mine.raw), ok, where), group=group)
     if ok and all(b[1] for b in boxes):
         if N.lib().mi_comm_p2p_connect(h, b"".join(b[0] for b in boxes)) != 0:
             ok, err = 0, N.lib().mi_last_error().decode()
+        else:   # ranks sharing this rank's device (test placements): > 2 of them take the stand-alone all-reduce launch (csrc/mi_comm.hip: mi_comm_p2p_fused_ok)
+            N.check(N.lib().mi_comm_p2p_set_colocated(h, sum(1 for b in boxes if b[2] == where)), "mi_comm_p2p_set_colocated")
     elif ok:
         ok, err = 0, "a peer could not allocate its inbox"
     return h, ok, err

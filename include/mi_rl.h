@@ -50,7 +50,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier; mi_test_contraction).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier, mi_comm_p2p_set_colocated; mi_test_contraction).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
 #define MI_VERSION 105
 #define MI_PPO_NPARAMS 9155
@@ -260,6 +260,10 @@ int mi_comm_p2p_connect(void* comm, const void* ipc_handles);
 int mi_comm_p2p_synthetic(int world_size, size_t max_bytes, void** comm);
 int mi_comm_check(void* comm);
 int mi_comm_carrier(void* comm);
+/* How many ranks of the communicator share THIS rank's device (default 1 = one rank per GPU).  With more than two, mi_ppo_update_sharded takes a stand-alone launch per
+ * all-reduce instead of the exchange inside the slab sum: three or more ranks spin-waiting in 145 x 1,024-thread workgroups fill the chip, and the rank they wait for cannot be
+ * scheduled (test placements only; MIRL_P2P_FUSED=0 / 1 overrides).  deep_rl_amd.dist derives the count from the ranks' (host, device uuid). */
+int mi_comm_p2p_set_colocated(void* comm, int ranks_on_this_device);
 int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* comm, void* stream);
 /* TEST HOOK (process-wide; 0 = off): mi_ppo_update / mi_ppo_update_sharded behave as at world_size > 1 in everything but the collective — the owed optimizer steps
  * recompute the clip coefficient from the (all-reduced) gradient itself instead of reading the slab sum's block sums, the one branch a single-GPU run never takes.

@@ -30,7 +30,7 @@ T, NL, UPDATES, SEED = 128, int(os.environ.get("MIRL_TEST_NL", "64")), 2, 11
 backend = os.environ["MIRL_TEST_BACKEND"]
 out_dir = os.environ["MIRL_TEST_OUT"]
 rank, world, local_rank = DD.init_from_env(backend)
-assert world == 2
+assert world == int(os.environ.get("MIRL_TEST_WORLD", "2"))
 dev = torch.device("cuda", local_rank if backend == "nccl" else 0)
 torch.cuda.set_device(dev)
 
@@ -69,7 +69,7 @@ assert native == (backend == "nccl" or p2p), "backend %s, carrier %s: one-call r
 if native:
     ws, rk, ver, cnt = N.C.c_int(), N.C.c_int(), N.C.c_int(), N.C.c_int()
     N.check(N.lib().mi_comm_info(DD.native_comm(eng.pg), N.C.byref(ws), N.C.byref(rk), N.C.byref(ver), N.C.byref(cnt)), "mi_comm_info")
-    assert ws.value == 2 and rk.value == rank and cnt.value == 2 and (ver.value == 0 if p2p else ver.value > 0)
+    assert ws.value == world and rk.value == rank and cnt.value == world and (ver.value == 0 if p2p else ver.value > 0)
     assert N.lib().mi_comm_carrier(DD.native_comm(eng.pg)) == int(p2p)
     DD.check_native_comm(eng.pg)   # no wait of the P2P carrier ran out
     eng.check_replicas()

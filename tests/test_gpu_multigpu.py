@@ -41,16 +41,16 @@ def _run(backend, nl):
 T, UPDATES, SEED = 128, 2, 11
 
 
-def _single_process(params0, nl):
-    """One process that owns all 2 * nl envs: the explicit launch sequence with the UNION minibatches (each rank draws the same keyed permutation of its LOCAL rows;
-    local row t * nl + e of rank r is row t * (2 nl) + r * nl + e here)."""
+def _single_process(params0, nl, world=2):
+    """One process that owns all world * nl envs: the explicit launch sequence with the UNION minibatches (each rank draws the same keyed permutation of its LOCAL rows;
+    local row t * nl + e of rank r is row t * (world nl) + r * nl + e here)."""
     import torch
 
     import deep_rl_amd as D
     from deep_rl_amd import _native as N
 
     dev = torch.device("cuda", 0)
-    env = D.make("CartPole-v1", num_envs=2 * nl, device=dev, seed=SEED)
+    env = D.make("CartPole-v1", num_envs=world * nl, device=dev, seed=SEED)
     torch.manual_seed(SEED)
     agent = D.ActorCritic(env)
     big = D.PPOEngine(env, agent, D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5), num_steps=T)
@@ -66,10 +66,10 @@ def _single_process(params0, nl):
             local = scratch.cpu().numpy().astype(np.int64)
             for k in range(big.n_minibatch):
                 part = local[k * mb:(k + 1) * mb]
-                union = np.concatenate([(part // nl) * (2 * nl) + r * nl + part % nl for r in range(2)]).astype(np.int32)
-                big.perm[:2 * mb].copy_(torch.from_numpy(union).to(dev))
-                big.adv_stats(mb=2 * mb, n_mb=1)
-                big.minibatch_grad(0, mb=2 * mb)
+                union = np.concatenate([(part // nl) * (world * nl) + r * nl + part % nl for r in range(world)]).astype(np.int32)
+                big.perm[:world * mb].copy_(torch.from_numpy(union).to(dev))
+                big.adv_stats(mb=world * mb, n_mb=1)
+                big.minibatch_grad(0, mb=world * mb)
                 big.optimizer_step()
         big.update_index += 1
     torch.cuda.synchronize()

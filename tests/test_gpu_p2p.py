@@ -11,7 +11,8 @@ optimizer step of reference ppo.py:189-192, dqn.py:131-133 (per.py:147-153), sac
   test_two_ranks_one_gpu_p2p_ppo         PPOEngine.update() on mi_ppo_update_sharded, two ranks on cuda:0, two whole updates: rank == rank bitwise, == the
                                          host-sequenced route over gloo bitwise, == the single process with union minibatches at the tolerances of test_gpu_multigpu.py.
   test_two_ranks_one_gpu_p2p_offpolicy   the same for DQNEngine, PERDQNEngine, SACEngine on their one-call routes (MIRL_CHECK_REPLICAS=2 inside the worker).
-  test_two_gpus_p2p_*                    the same two workers with one rank per GPU and an NCCL process group (skip below 2 GPUs)."""
+  test_two_gpus_p2p_*                    the same two workers with one rank per GPU and an NCCL process group (skip below 2 GPUs).
+  test_eight_ranks_one_gpu_p2p_ppo       EIGHT processes on cuda:0 (BASELINE config 5's rank count): the 8-rank exchange between real processes, all ranks bitwise equal."""
 import ctypes as C
 import os
 import socket
@@ -110,13 +111,13 @@ def test_ppo_update_on_synthetic_ranks_equals_plain_update(world):
         assert torch.isfinite(out[0][0]).all()
 
 
-def _launch(worker, env_extra, timeout=600):
+def _launch(worker, env_extra, timeout=600, nproc=2):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", MIRL_COMM="p2p", **env_extra)
     # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP)
-    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
                            os.path.join(ROOT, "tests", worker)], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
 
 
@@ -187,3 +188,42 @@ def test_two_gpus_p2p_offpolicy():
     if _need_gpu().cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs; the one-GPU variant above runs the same worker with both ranks on cuda:0")
     _offpolicy("nccl")
+
+
+@pytest.mark.parametrize("fused", ["1", ""])
+def test_eight_ranks_one_gpu_p2p_ppo(fused):
+    """(fused = "1": MIRL_P2P_FUSED=1 forces the exchange inside grad_reduce_kernel although eight ranks share the device — safe at this size, the grids are tiny; "": the
+    placement rule of csrc/mi_comm.hip applies — more than two colocated ranks take the stand-alone all-reduce launch — which is what lets `bench.py --gpus 8` run with all
+    eight ranks on one GPU at 4096 envs each, where eight waiting slab-sum grids would fill the chip.)
+    BASELINE config 5's rank count on the one GPU this box has: EIGHT processes on cuda:0, every one mapping the other seven inboxes (hipIpc), PPOEngine.update() on
+    mi_ppo_update_sharded with grad_reduce_kernel's 8-rank exchange, two whole updates at 32 envs per rank.  All eight ranks end with bitwise the same parameters, moments,
+    gradient, loss terms and clip norm (rank-ordered sum: identical by construction, here checked); against the host-sequenced route over gloo — whose 8-rank SUM uses
+    another grouping — and against one process that owns all 256 envs with union minibatches, at the tolerances of the two-rank test (ppo.py:189-192)."""
+    _need_gpu()
+    import tempfile
+
+    import test_gpu_multigpu as M
+
+    W, NL = 8, 32
+    with tempfile.TemporaryDirectory() as tmp:
+        extra = dict(MIRL_TEST_BACKEND="gloo", MIRL_TEST_OUT=tmp, MIRL_TEST_NL=str(NL), MIRL_TEST_WORLD=str(W))
+        if fused:
+            extra["MIRL_P2P_FUSED"] = fused
+        out = _launch("_sharded_update_worker.py", extra, timeout=900, nproc=W)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        assert "SHARDED_WORKER_OK backend=gloo native=1 carrier=p2p" in out.stdout, out.stdout[-2000:]
+        rk = [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(W)]
+    for r in range(1, W):
+        for k in ("params0", "params", "exp_avg", "exp_avg_sq", "grads", "loss_terms", "grad_norm"):
+            assert np.array_equal(rk[0][k], rk[r][k]), (k, r)
+        assert np.allclose(rk[0]["adv_sums"], rk[r]["adv_sums"], rtol=1e-12, atol=0.0)
+        assert int(rk[r]["native"][0]) == 1
+    assert np.isfinite(rk[0]["params"]).all() and not np.array_equal(rk[0]["params"], rk[0]["params0"])
+    # the host-sequenced route (gloo's own summation order over 8 ranks) and the single process with union minibatches: f32 re-association only
+    big = M._single_process(rk[0]["params0"], NL, world=W)
+    for ref in (rk[0]["seq_params"], big["params"]):
+        assert np.abs(rk[0]["params"] - ref).max() < 2e-5, np.abs(rk[0]["params"] - ref).max()
+    assert np.allclose(rk[0]["loss_terms"], big["loss_terms"], rtol=5e-3, atol=1e-4)
+    assert abs(float(rk[0]["grad_norm"][0]) - float(big["grad_norm"][0])) < 5e-3 * float(big["grad_norm"][0])
+    for r in range(W):   # env sharding: the first rollout's trajectories are the matching columns of the big run (the second runs on parameters that differ in the last bits)
+        assert rk[r]["observations"].shape == big["observations"][:, r * NL:(r + 1) * NL].shape
