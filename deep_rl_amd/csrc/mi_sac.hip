@@ -399,6 +399,15 @@ __device__ void sac_owed_alpha_role(sac_smem& sm, const float* __restrict__ acto
     }
 }
 
+#ifdef SAC_MARKS   // diagnostic build: wall-clock marks (s_memrealtime, 100 MHz) of thread 0 of row group 0's workgroups at the phase boundaries of the two update kernels (tools/sac_marks.py)
+__device__ unsigned long long sac_mark_dbg[2][4][16];   // [critic | actor kernel][role / sibling][mark]
+#define SAC_MARK(kern, role, k) do { if (threadIdx.x == 0 && row0 == 0) { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); \
+                                     sac_mark_dbg[kern][role][k] = rt_; } } while (0)
+extern "C" int mi_debug_sac_marks(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(sac_mark_dbg), sizeof(sac_mark_dbg)) == hipSuccess ? 0 : -2; }
+#else
+#define SAC_MARK(kern, role, k) do {} while (0)
+#endif
+
 // ================================================ critic update =================================================================
 // slab layout (critic): net n at n*1793: W1 1024 | b1 256 | b2 256 | W3 256 | b3 1;  then [3586] = sum (q1-y)^2, [3587] = sum (q2-y)^2
 // passes: actor fwd -> target 1 fwd -> target 2 fwd -> critic 1 fwd, bwd -> critic 2 fwd, bwd
@@ -413,9 +422,39 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
     const float* p = q + (size_t)NET * SQ_NP;
     float* sl = slab + NET * 1793;
     f32x4 acc[SA_NT];
+    SAC_MARK(0, 2 + NET, 5);
     layer1<4>(sm, th, sm.x, sm.b0);
     __syncthreads();
     q_forward2<true>(sm, p, p + SQ_W2, sm.b0, ws, acc, 8);          // h1 in b0, relu(h2) in acc; the stream continues with this net's backward
+    SAC_MARK(0, 2 + NET, 6);
+    // ---- the backward matrix pass with UNIT weight per row, BEFORE the TD target is needed (round 5).  d loss / d q of a row is one scalar dq, and everything behind the
+    //      head is linear in it: dz2 = relu'(h2) w3 dq, dh1 = W2^T dz2 = dq (W2^T (relu'(h2) w3)).  A critic role of the quad form used to sit idle from the end of its
+    //      forward (10.6 us after entry) until the target roles' words arrived (20.0 us: actor' forward, then the target forward), and only then ran this pass (4.1 us):
+    //      now the pass runs in the wait and the arrival of the target is followed by a scaling (tools/sac_marks.py, profiles/r05_sac_marks.txt).  DZ2, db2, dW3 keep
+    //      their bits (the same products, the same sums); dh1 — hence dW1 / db1 of the critics — is rounded after the sum instead of before it. ----
+    store_acc(acc, sm.b2);                           // h2 image
+#pragma unroll
+    for (int tt = 0; tt < SA_NT; ++tt) {
+        const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.pb[1][16 * (SA_NT * wv + tt) + 4 * lg]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tt][r] = acc[tt][r] > 0.0f ? w3[r] : 0.0f;
+    }
+    store_acc(acc, sm.b1);                           // relu'(h2) w3: dz2 per unit of dq
+    __syncthreads();
+    if (t < SA_H) {   // H1 rows for the dW2 GEMM: nothing of the target in them either
+#pragma unroll
+        for (int r = 0; r < SR; ++r) H1[((size_t)NET * ws_kp(batch) + row0 + r) * SA_H + t] = sm.b0[r][t];
+    }
+    SAC_MARK(0, 2 + NET, 8);
+    mfma_pass<true, false>(p + SQ_W2, Wnext, sm.b1, ws, acc);      // dh1 per unit of dq, in the D layout
+    SAC_MARK(0, 2 + NET, 9);
+#pragma unroll
+    for (int tt = 0; tt < SA_NT; ++tt) {
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][16 * (SA_NT * wv + tt) + 4 * lg]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
+    }
+    // ---- the TD target ----
     if (qw && qw->y_only) {
         if (t < SR) sm.rv[t][10] = xw_take(qw->xw + 6 * t);
         __syncthreads();
@@ -429,6 +468,7 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
         }
         __syncthreads();
     }
+    SAC_MARK(0, 2 + NET, 7);
     if (t < SR) {
         const bool valid = row0 + t < batch;
         const float d = valid ? sm.rv[t][8] - sm.rv[t][10] : 0.0f;
@@ -436,36 +476,23 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
         sm.rv[t][8] = 2.0f * d * invn; // d loss / d q
     }
     __syncthreads();
-    {   // dz2 in the D layout: h2 image -> b2, dz2 image -> b1 and the GEMM operand in the workspace
+    {   // scale by the row's dq: the GEMM operand DZ2 (w3 dq for the live units: the product the pre-round-5 form stored) and dz1
         const float dq = sm.rv[li][8];
-        store_acc(acc, sm.b2);
 #pragma unroll
         for (int tt = 0; tt < SA_NT; ++tt) {
             const int u = 16 * (SA_NT * wv + tt) + 4 * lg;
-            const f32x4 w3 = *reinterpret_cast<const f32x4*>(&sm.pb[1][u]);
+            const f32x4 un = *reinterpret_cast<const f32x4*>(&sm.b1[li][u]);
+            *reinterpret_cast<f32x4*>(&DZ2[((size_t)NET * ws_kp(batch) + row0 + li) * SA_H + u]) = f32x4{un[0] * dq, un[1] * dq, un[2] * dq, un[3] * dq};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tt][r] = acc[tt][r] > 0.0f ? w3[r] * dq : 0.0f;
-            *reinterpret_cast<f32x4*>(&DZ2[((size_t)NET * ws_kp(batch) + row0 + li) * SA_H + u]) = acc[tt];
+            for (int r = 0; r < 4; ++r) acc[tt][r] = acc[tt][r] * dq;
         }
-        store_acc(acc, sm.b1);
     }
-    __syncthreads();
-    if (t < SA_H) {   // unit j = t: thin gradients of layer 3 / bias 2, H1 rows for the GEMM
+    if (t < SA_H) {   // unit j = t: thin gradients of layer 3 / bias 2
         float gw3 = 0.0f, gb2 = 0.0f;
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            gw3 = __builtin_fmaf(sm.rv[r][8], sm.b2[r][t], gw3); gb2 += sm.b1[r][t];
-            H1[((size_t)NET * ws_kp(batch) + row0 + r) * SA_H + t] = sm.b0[r][t];
-        }
+        for (int r = 0; r < SR; ++r) { gw3 = __builtin_fmaf(sm.rv[r][8], sm.b2[r][t], gw3); gb2 += sm.b1[r][t] * sm.rv[r][8]; }
         sl[1024 + 256 + t] = gb2; sl[1024 + 512 + t] = gw3;
         if (t == 0) { float gb3 = 0.0f, l = 0.0f; for (int r = 0; r < SR; ++r) { gb3 += sm.rv[r][8]; l += sm.rv[r][9]; } sl[1792] = gb3; slab[3586 + NET] = l; }
-    }
-    mfma_pass<true, false>(p + SQ_W2, Wnext, sm.b1, ws, acc);      // dh1 in the D layout
-#pragma unroll
-    for (int tt = 0; tt < SA_NT; ++tt) {
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][16 * (SA_NT * wv + tt) + 4 * lg]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[tt][r] = h1[r] > 0.0f ? acc[tt][r] : 0.0f;
     }
     __syncthreads();                                 // every thread is done reading b2 (h2)
     store_acc(acc, sm.b2);                           // dz1 image
@@ -483,6 +510,7 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
         sl[1024 + t] = gb1;
     }
     __syncthreads();
+    SAC_MARK(0, 2 + NET, 10);
 }
 
 __global__ void __launch_bounds__(SA_THREADS)
@@ -499,6 +527,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         return;
     }
     const int t = threadIdx.x, row0 = bx * SR;
+    SAC_MARK(0, (int)blockIdx.y & 3, 0);
     // gridDim.y == 2: critic 2's forward + backward run in a sibling workgroup y = 1, which takes the finished TD target from workgroup y = 0 (actor forward, both
     // targets, critic 1) — y = 0 never waits for y = 1, so the pair needs no co-residency: 5 passes on the critical path instead of 7, used while the row groups do
     // not fill the chip anyway.  (Round 2 let the two siblings evaluate one target each and swap them: 4 us faster at batch 288 - 768, but a symmetric rendezvous
@@ -542,6 +571,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
     if (t < SR * 4) { sm.x[t >> 2][t & 3] = gx; sm.xn[t >> 2][t & 3] = gxn; }
     __syncthreads();
+    SAC_MARK(0, (int)blockIdx.y & 3, 1);
     unsigned long long* xw = reinterpret_cast<unsigned long long*>(ws_ + ws_xch_off(batch)) + 6 * (size_t)row0;
     if (role >= 2) {   // critic role - 2 (quad), critic 2 fed the finished TD target (split)
         const quad_wait_t qw = {xw, rewards, terminated, alpha_p, ws_, gamma, &ow, split};
@@ -555,15 +585,18 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         issue_thin_q(qtn, th);
         __syncthreads();
         actor_forward2<false>(sm, actor, qtn + SQ_W2, sm.b0, ws, acc, e_row);
+        SAC_MARK(0, role, 2);
         if (t < SR) { sm.xn[t][3] = sm.rv[t][6]; sm.rv[t][9] = sm.rv[t][5]; }   // a', log pi(a'|s')
         __syncthreads();
         layer1<4>(sm, th, sm.xn, sm.b0);
         __syncthreads();
         q_forward2<false>(sm, qtn, nullptr, sm.b0, ws, acc, 8);
+        SAC_MARK(0, role, 3);
         if (t < SR && !(ow.fault & 1)) {
             xw_put(xw + 6 * t + 2 * role, sm.rv[t][8]); xw_put(xw + 6 * t + 2 * role + 1, sm.rv[t][8]);
             if (role == 0) { xw_put(xw + 6 * t + 4, sm.rv[t][9]); xw_put(xw + 6 * t + 5, sm.rv[t][9]); }
         }
+        SAC_MARK(0, role, 4);
         return;
     }
     // ---- next action + log-prob under the current actor (no grad; sac.py:172) ----
@@ -631,6 +664,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         return;
     }
     const int t = threadIdx.x, row0 = bx * SR;
+    SAC_MARK(1, (int)blockIdx.y & 3, 0);
     const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
     const size_t matf = ws_mat_floats(batch);
     float* H1 = ws_ + 2 * matf; float* DZ2 = ws_ + 5 * matf;
@@ -654,6 +688,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, ((logp_only ? 4ull : 3ull) << 40) + update, (uint64_t)b); }
     __syncthreads();
+    SAC_MARK(1, (int)blockIdx.y & 3, 1);
     layer1<3>(sm, th, sm.x, sm.b0);                              // actor h1 -> b0 (kept for the backward)
     const float wm = th.h0, wl = th.h1;                          // this unit's head weights, kept for the actor's backward
     if (logp_only) {   // sac.py:203-204
@@ -678,6 +713,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     issue_thin_q(qn, th);
     __syncthreads();
     actor_forward2<false>(sm, actor, qn + SQ_W2, sm.b0, ws, acc, e_row);
+    SAC_MARK(1, (int)blockIdx.y & 3, 2);
     store_acc(acc, sm.b1);                                       // actor h2 image, kept until the actor's backward
     float alpha = 0.0f;                                          // read where it is first needed (an owed alpha step of this launch may still be producing it)
     if (t < SR) sm.x[t][3] = sm.rv[t][6];   // the action enters the critics
@@ -689,6 +725,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         if (t < SA_H) { sm.qmask[net][t] = mk; sm.qw13[net][t] = th.w1[3]; sm.qw3[net][t] = th.h0; }
         __syncthreads();
         q_forward2<true>(sm, qn, qn + SQ_W2, sm.b2, ws, acc, 8);                // q_net(obs, pi(obs)) -> rv[8]; next pass: the same matrix, column-wise
+        SAC_MARK(1, (int)blockIdx.y & 3, 3);
         uint32_t hm = 0;
 #pragma unroll
         for (int tt = 0; tt < SA_NT; ++tt)
@@ -708,8 +745,10 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         if (second) mfma_pass<true, false>(qn + SQ_W2, nullptr, sm.b2, ws, acc);
         else mfma_pass<true, true>(qn + SQ_W2, actor + AC_W2, sm.b2, ws, acc);
         rows_combine2(sm, q_daction_partial(sm, net, acc), 0.0f, 11, 15);        // d q_net / d action (unit weight) -> rv[11]
+        SAC_MARK(1, (int)blockIdx.y & 3, 4);
         if (second) {
             if (t < SR && !(ow.fault & 1)) { xw_put(xw + 2 * t, sm.rv[t][10]); xw_put(xw + 2 * t + 1, sm.rv[t][11]); }
+            SAC_MARK(1, 0, 5);
             return;
         }
         alpha = wait_owed_alpha(ow, ws_, batch, alpha_p, sm);   // (contains a barrier when a step is owed)
@@ -723,6 +762,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
             sm.rv[t][8] = w1 * da1; sm.rv[t][11] = w2 * da2;
         }
         __syncthreads();
+        SAC_MARK(1, 1, 5);
     } else {
     // ---- min(Q1, Q2)(obs, pi(obs)) (:194-196) ----
     {
@@ -812,7 +852,9 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         }
     }
     __syncthreads();
+    SAC_MARK(1, (int)blockIdx.y & 3, 6);
     mfma_pass<true, false>(actor + AC_W2, nullptr, sm.b2, ws, acc);
+    SAC_MARK(1, (int)blockIdx.y & 3, 7);
 #pragma unroll
     for (int tt = 0; tt < SA_NT; ++tt) {
         const f32x4 h1 = *reinterpret_cast<const f32x4*>(&sm.b0[li][16 * (SA_NT * wv + tt) + 4 * lg]);
@@ -833,6 +875,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         slab[3 * t] = gw[0]; slab[3 * t + 1] = gw[1]; slab[3 * t + 2] = gw[2];
         slab[768 + t] = gb1;
     }
+    SAC_MARK(1, (int)blockIdx.y & 3, 8);
 }
 
 // ================================================ dW2 = dZ2^T H1 on the f32 MFMA ================================================

@@ -140,14 +140,11 @@ class PPOEngine:
         eps = sorted((int(raw[i, 1]), int(raw[i, 0]), float(rets[i]), int(raw[i, 3])) for i in range(k))
         return n, [(e, t, r, l) for (t, e, r, l) in eps]
 
-    def episode_summary_async(self, pinned):
+    def episode_summary_async(self, pinned, direct=True):
         """Non-blocking copy of {episodes, sum of lengths, longest, -} of the last rollout into a pinned host tensor
         (read it after the next sync point; CartPole return == length).  Same single-stream contract as `episode_stats`.  The direct route below lets the device
         kernel write into `pinned.data_ptr()`: that holds for tensors torch itself pinned (`.pin_memory()` / hipHostMalloc: mapped at the same address on the device);
         memory pinned some other way (hipHostRegister of a foreign allocation) need not be — pass `direct=False` for such tensors."""
-        self._episode_summary(pinned, True)
-
-    def _episode_summary(self, pinned, direct):
         ok = direct and self._lazy_stats and self._stats_any and pinned.is_pinned() and pinned.dtype == torch.int32 and pinned.numel() >= 4 and pinned.is_contiguous()
         if ok:
             # the sum of the per-workgroup statistics is written straight into the pinned host tensor (device-visible at the same address): no copy behind it
