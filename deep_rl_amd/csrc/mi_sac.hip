@@ -156,6 +156,24 @@ __device__ __forceinline__ float keyed_normal(uint64_t seed, uint64_t tag_update
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
+#ifdef SAC_MARKS   // diagnostic build (tools/sac_marks.py): besides the phase marks below, a fine trace of the building blocks — thread 0 of a workgroup whose smem carries a trace slot
+                   // appends {tag, s_memrealtime} at the end of every building block (layer 1, matrix pass, bias + head partial, cross-wave combine, row scalars)
+__device__ unsigned long long sac_fine_dbg[4][64][2];
+#define SAC_FINE_FIELDS int fine_slot, fine_n;
+#define SAC_FINE(sm, tag) do { if (threadIdx.x == 0 && (unsigned)(sm).fine_slot < 4u && (unsigned)(sm).fine_n < 64u) {   /* (kernels that never set the slot hold garbage there: bounds only) */ \
+                                unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); \
+                                sac_fine_dbg[(sm).fine_slot][(sm).fine_n][0] = (tag); sac_fine_dbg[(sm).fine_slot][(sm).fine_n][1] = rt_; (sm).fine_n = (sm).fine_n + 1; } } while (0)
+#define SAC_FINE_INIT(sm, slot) do { if (threadIdx.x == 0) { (sm).fine_slot = (slot); (sm).fine_n = 0; } } while (0)
+extern "C" int mi_debug_sac_fine(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(sac_fine_dbg), sizeof(sac_fine_dbg)) == hipSuccess ? 0 : -2; }
+#else
+#define SAC_FINE_FIELDS
+#define SAC_FINE(sm, tag) do {} while (0)
+#define SAC_FINE_INIT(sm, slot) do {} while (0)
+#endif
+#ifndef SAC_FWD_AS_BWD
+#define SAC_FWD_AS_BWD 0   // TIMING-ONLY experiment (wrong results): forward passes fetch their stages with the backward pass's access pattern (what a transposed copy of the matrix would allow)
+#endif
+
 namespace rg_act {
 #define SA_W SA_WAVES_ACT
 #include "mi_sac_rowgroup.inc"
@@ -527,6 +545,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         return;
     }
     const int t = threadIdx.x, row0 = bx * SR;
+    SAC_FINE_INIT(sm, bx == 0 && (blockIdx.y == 0 || blockIdx.y == 2) ? (blockIdx.y == 0 ? 0 : 1) : -1);   // target role 0, critic role 2
     SAC_MARK(0, (int)blockIdx.y & 3, 0);
     // gridDim.y == 2: critic 2's forward + backward run in a sibling workgroup y = 1, which takes the finished TD target from workgroup y = 0 (actor forward, both
     // targets, critic 1) — y = 0 never waits for y = 1, so the pair needs no co-residency: 5 passes on the critical path instead of 7, used while the row groups do
@@ -664,6 +683,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         return;
     }
     const int t = threadIdx.x, row0 = bx * SR;
+    SAC_FINE_INIT(sm, bx == 0 ? 2 + (int)(blockIdx.y & 1) : -1);   // 2: critic 2's sibling (y = 0), 3: main (y = 1)
     SAC_MARK(1, (int)blockIdx.y & 3, 0);
     const int lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
     const size_t matf = ws_mat_floats(batch);

@@ -29,3 +29,14 @@ for k, name in enumerate(("sac_critic_kernel", "sac_actor_kernel")):
         row = m[k, role]
         if (row > 0).any():
             print("  role %d: " % role + "  ".join("%d:%.2f" % (i, (v - t0) / 100.0) for i, v in enumerate(row) if v > 0))
+
+fb = (C.c_ulonglong * (4 * 64 * 2))()
+if hasattr(L, "mi_debug_sac_fine") and L.mi_debug_sac_fine(fb) == 0:
+    f = np.array(fb, dtype=np.uint64).reshape(4, 64, 2).astype(np.int64)
+    tags = {1: "layer1", 2: "pass>", 3: "pass<", 4: "bias+head", 5: "combine", 6: "q-bias", 7: "row-scalars"}
+    for slot, name in enumerate(("critic kernel, target role 0", "critic kernel, critic role 2", "actor kernel, sibling", "actor kernel, main")):
+        rows = [(int(a), int(b)) for a, b in f[slot] if b > 0]
+        if rows:
+            t0 = rows[0][1]
+            print("fine trace, %s (us since its first block end; tag = block that just ended):" % name)
+            print("   " + "  ".join("%s:%.2f" % (tags.get(a, str(a)), (b - t0) / 100.0) for a, b in rows))
