@@ -137,6 +137,10 @@ SIGNATURES = {
     "mi_sac_critic_step": (_I, [_VP, _VP]),
     "mi_sac_act_step_carry": (_I, [_VP, _VP, _I64, _I64, _I64] + [_VP] * 10 + [_I, _VP, _VP]),
     "mi_sac_owed_alpha_fits": (_I, [_I]),
+    "mi_sac_shadow_set": (_I, [_VP, _I, _VP]),
+    "mi_sac_shadow_refresh": (_I, [_VP, _VP]),
+    "mi_sac_shadow_invalidate": (_I, [_VP]),
+    "mi_sac_shadow_valid": (_I, [_VP]),
     "mi_sac_check": (_I, [_VP, _I]),
     "mi_sac_clear_error": (_I, [_VP, _I, _VP]),
     "mi_sac_set_max_cus": (_I, [_I]),

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(SA_THREADS) sac_actor_sample_kernel(const floa
     __syncthreads();
     layer1<3>(sm, th, sm.x, sm.b0);
     __syncthreads();
-    actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e);
+    actor_forward2<false>(sm, actor, actor + AC_W2, nullptr, sm.b0, ws, acc, e);
     if (threadIdx.x < SR && row0 + threadIdx.x < n) { action[row0 + threadIdx.x] = sm.rv[threadIdx.x][6]; if (logp) logp[row0 + threadIdx.x] = sm.rv[threadIdx.x][5]; }
 }
 }  // namespace rg_act
@@ -399,7 +399,7 @@ __device__ void sac_owed_alpha_role(sac_smem& sm, const float* __restrict__ acto
     __syncthreads();
     layer1<3>(sm, th, sm.x, sm.b0);
     __syncthreads();
-    actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e_row);
+    actor_forward2<false>(sm, actor, actor + AC_W2, nullptr, sm.b0, ws, acc, e_row);
     if (t == 0) { float s = 0.0f; for (int r = 0; r < SR; ++r) s += row0 + r < batch ? sm.rv[r][5] : 0.0f; part[rg] = s; }
     if (t == 0) { __threadfence(); sm.cur[0] = atomicAdd(ow.al.ticket, 1u) == (unsigned)ow.n_lp - 1 ? 1 : 0; }
     __syncthreads();
@@ -426,14 +426,19 @@ extern "C" int mi_debug_sac_marks(unsigned long long* out) { return hipMemcpyFro
 #define SAC_MARK(kern, role, k) do {} while (0)
 #endif
 
+// ---- transposed copies of the layer-2 matrices (mi_sac_shadow_*, round 5): kernels instantiated with TR stream every FORWARD pass from them (q_forward2 / actor_forward2, FT) ----
+struct sac_wt_t { const float* actor; const float* q; const float* qt; };   // actor^T [65536], critics^T [2][65536], targets^T [2][65536]; members a kernel does not stream may be null
+#define SA_MAT (SA_H * SA_H)
+
 // ================================================ critic update =================================================================
 // slab layout (critic): net n at n*1793: W1 1024 | b1 256 | b2 256 | W3 256 | b3 1;  then [3586] = sum (q1-y)^2, [3587] = sum (q2-y)^2
 // passes: actor fwd -> target 1 fwd -> target 2 fwd -> critic 1 fwd, bwd -> critic 2 fwd, bwd
 // the TD target's ingredients arriving from the target workgroups of a four-workgroup row group (see sac_critic_kernel)
 // y_only: the sibling already formed the TD target (two-workgroup row groups): ONE word per row
 struct quad_wait_t { unsigned long long* xw; const float* rewards; const uint8_t* terminated; const float* alpha_p; float* ws_; float gamma; const sac_owed_t* ow; bool y_only; };
-template <int NET>
-__device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __restrict__ q, const float* __restrict__ Wnext, wstream& ws, const thin_t& th,
+template <int NET, bool TR>
+__device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __restrict__ q, const float* __restrict__ Wfwd /* this critic's layer-2 matrix as the forward pass streams it */,
+                                                  const float* __restrict__ Wnext /* the matrix of the pass behind the backward (streamed as a forward pass: TR form if TR) */, wstream& ws, const thin_t& th,
                                                   int batch, int row0, float invn, float* __restrict__ H1, float* __restrict__ DZ2, float* __restrict__ slab,
                                                   const quad_wait_t* qw = nullptr) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lg = lane >> 4;
@@ -443,7 +448,7 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
     SAC_MARK(0, 2 + NET, 5);
     layer1<4>(sm, th, sm.x, sm.b0);
     __syncthreads();
-    q_forward2<true>(sm, p, p + SQ_W2, sm.b0, ws, acc, 8);          // h1 in b0, relu(h2) in acc; the stream continues with this net's backward
+    q_forward2<true, TR>(sm, p, Wfwd, p + SQ_W2, sm.b0, ws, acc, 8);          // h1 in b0, relu(h2) in acc; the stream continues with this net's backward
     SAC_MARK(0, 2 + NET, 6);
     // ---- the backward matrix pass with UNIT weight per row, BEFORE the TD target is needed (round 5).  d loss / d q of a row is one scalar dq, and everything behind the
     //      head is linear in it: dz2 = relu'(h2) w3 dq, dh1 = W2^T dz2 = dq (W2^T (relu'(h2) w3)).  A critic role of the quad form used to sit idle from the end of its
@@ -464,7 +469,7 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
         for (int r = 0; r < SR; ++r) H1[((size_t)NET * ws_kp(batch) + row0 + r) * SA_H + t] = sm.b0[r][t];
     }
     SAC_MARK(0, 2 + NET, 8);
-    mfma_pass<true, false>(p + SQ_W2, Wnext, sm.b1, ws, acc);      // dh1 per unit of dq, in the D layout
+    mfma_pass<true, TR>(p + SQ_W2, Wnext, sm.b1, ws, acc);      // dh1 per unit of dq, in the D layout
     SAC_MARK(0, 2 + NET, 9);
 #pragma unroll
     for (int tt = 0; tt < SA_NT; ++tt) {
@@ -531,14 +536,18 @@ __device__ __forceinline__ void critic_net_update(sac_smem& sm, const float* __r
     SAC_MARK(0, 2 + NET, 10);
 }
 
+template <bool TR>
 __global__ void __launch_bounds__(SA_THREADS)
 sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, const float* __restrict__ actor, const float* __restrict__ observations,
                   const float* __restrict__ actions, const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
                   const int64_t* idx /* may alias idx_out: no __restrict__ */, int batch, int n_envs, long long slots, const float* __restrict__ eps, uint64_t seed,
                   uint64_t update, const float* __restrict__ alpha_p, float gamma, float invn, float* __restrict__ ws_, uint64_t sample_update, uint64_t sample_upper,
-                  int64_t* idx_out, sac_owed_t ow) {
+                  int64_t* idx_out, sac_owed_t ow, sac_wt_t wt) {
     __shared__ sac_smem sm;
     MI_INSIDE_SCOPE(MI_PROF_SAC_CRITIC);
+    const float* const AW = TR ? wt.actor : actor + AC_W2;                                    // the matrices as this kernel's FORWARD passes stream them
+    const float* const QW0 = TR ? wt.q : q + SQ_W2, * const QW1 = TR ? wt.q + SA_MAT : q + SQ_NP + SQ_W2;
+    const float* const QTW0 = TR ? wt.qt : qt + SQ_W2, * const QTW1 = TR ? wt.qt + SA_MAT : qt + SQ_NP + SQ_W2;
     const int bx = (int)blockIdx.x - ow.n_lp;   // row group; the owed alpha step's workgroups come FIRST in dispatch order (blockIdx.x < n_lp of row y = 0): everyone who waits for alpha is behind them
     if (bx < 0) {
         if (blockIdx.y == 0) sac_owed_alpha_role(sm, actor, batch, ws_, ow, (int)blockIdx.x);
@@ -585,7 +594,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         gxn = k < 3 ? observations[3 * nx + k] : 0.0f;
         if (k == 0) { sm.cur[r] = i; sm.nxt[r] = nx; }
     }
-    stream_prime<false>(role >= 2 ? q + (role - 2) * SQ_NP + SQ_W2 : actor + AC_W2, ws);
+    stream_prime<TR>(role >= 2 ? (role == 2 ? QW0 : QW1) : AW, ws);
     float e_row = 0.0f;
     if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
     if (t < SR * 4) { sm.x[t >> 2][t & 3] = gx; sm.xn[t >> 2][t & 3] = gxn; }
@@ -594,8 +603,8 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     unsigned long long* xw = reinterpret_cast<unsigned long long*>(ws_ + ws_xch_off(batch)) + 6 * (size_t)row0;
     if (role >= 2) {   // critic role - 2 (quad), critic 2 fed the finished TD target (split)
         const quad_wait_t qw = {xw, rewards, terminated, alpha_p, ws_, gamma, &ow, split};
-        if (role == 2) critic_net_update<0>(sm, q, nullptr, ws, th, batch, row0, invn, H1, DZ2, slab, &qw);
-        else critic_net_update<1>(sm, q, nullptr, ws, th, batch, row0, invn, H1, DZ2, slab, &qw);
+        if (role == 2) critic_net_update<0, TR>(sm, q, QW0, nullptr, ws, th, batch, row0, invn, H1, DZ2, slab, &qw);
+        else critic_net_update<1, TR>(sm, q, QW1, nullptr, ws, th, batch, row0, invn, H1, DZ2, slab, &qw);
         return;
     }
     if (quad) {
@@ -603,13 +612,13 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         layer1<3>(sm, th, sm.xn, sm.b0);
         issue_thin_q(qtn, th);
         __syncthreads();
-        actor_forward2<false>(sm, actor, qtn + SQ_W2, sm.b0, ws, acc, e_row);
+        actor_forward2<TR, TR>(sm, actor, AW, role ? QTW1 : QTW0, sm.b0, ws, acc, e_row);
         SAC_MARK(0, role, 2);
         if (t < SR) { sm.xn[t][3] = sm.rv[t][6]; sm.rv[t][9] = sm.rv[t][5]; }   // a', log pi(a'|s')
         __syncthreads();
         layer1<4>(sm, th, sm.xn, sm.b0);
         __syncthreads();
-        q_forward2<false>(sm, qtn, nullptr, sm.b0, ws, acc, 8);
+        q_forward2<false, TR>(sm, qtn, role ? QTW1 : QTW0, nullptr, sm.b0, ws, acc, 8);
         SAC_MARK(0, role, 3);
         if (t < SR && !(ow.fault & 1)) {
             xw_put(xw + 6 * t + 2 * role, sm.rv[t][8]); xw_put(xw + 6 * t + 2 * role + 1, sm.rv[t][8]);
@@ -622,21 +631,21 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     layer1<3>(sm, th, sm.xn, sm.b0);
     issue_thin_q(qt, th);
     __syncthreads();
-    actor_forward2<false>(sm, actor, qt + SQ_W2, sm.b0, ws, acc, e_row);
+    actor_forward2<TR, TR>(sm, actor, AW, QTW0, sm.b0, ws, acc, e_row);
     if (t < SR) { sm.xn[t][3] = sm.rv[t][6]; sm.rv[t][9] = sm.rv[t][5]; }   // a', log pi(a'|s')
     __syncthreads();
     // ---- target critics (:173-174) ----
     layer1<4>(sm, th, sm.xn, sm.b0);
     issue_thin_q(qt + SQ_NP, th);
     __syncthreads();
-    q_forward2<false>(sm, qt, qt + SQ_NP + SQ_W2, sm.b0, ws, acc, 8);
+    q_forward2<TR, TR>(sm, qt, QTW0, QTW1, sm.b0, ws, acc, 8);
     if (t < SR) sm.rv[t][10] = sm.rv[t][8];
     __syncthreads();
     layer1<4>(sm, th, sm.xn, sm.b0);
     issue_thin_q(q, th);
     if (!split) issue_thin_q(q + SQ_NP, th2);
     __syncthreads();
-    q_forward2<false>(sm, qt + SQ_NP, q + SQ_W2, sm.b0, ws, acc, 8);
+    q_forward2<TR, TR>(sm, qt + SQ_NP, QTW1, QW0, sm.b0, ws, acc, 8);
     const float alpha_now = wait_owed_alpha(ow, ws_, batch, alpha_p, sm);
     if (t < SR) {
         const float alpha = alpha_now;
@@ -646,8 +655,8 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     }
     __syncthreads();
     // ---- the two critics on (obs, action): forward, loss, backward (:179-185) ----
-    critic_net_update<0>(sm, q, split ? nullptr : q + SQ_NP + SQ_W2, ws, th, batch, row0, invn, H1, DZ2, slab);
-    if (!split) critic_net_update<1>(sm, q, nullptr, ws, th2, batch, row0, invn, H1, DZ2, slab);
+    critic_net_update<0, TR>(sm, q, QW0, split ? nullptr : QW1, ws, th, batch, row0, invn, H1, DZ2, slab);
+    if (!split) critic_net_update<1, TR>(sm, q, QW1, nullptr, ws, th2, batch, row0, invn, H1, DZ2, slab);
 }
 
 // ================================================ actor update ==================================================================
@@ -671,11 +680,14 @@ __device__ __forceinline__ float q_daction_partial(const sac_smem& sm, int net, 
     return v;
 }
 
+template <bool TR>
 __global__ void __launch_bounds__(SA_THREADS)
 sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, const float* __restrict__ observations, const int64_t* __restrict__ idx,
                  int batch, const float* __restrict__ eps, uint64_t seed, uint64_t update, const float* __restrict__ alpha_p, float invn,
-                 float* __restrict__ ws_, int logp_only, sac_alpha_t al, sac_owed_t ow, int stash_slot) {
+                 float* __restrict__ ws_, int logp_only, sac_alpha_t al, sac_owed_t ow, int stash_slot, sac_wt_t wt) {
     __shared__ sac_smem sm;
+    const float* const AW = TR ? wt.actor : actor + AC_W2;                                    // the matrices as this kernel's FORWARD passes stream them
+    const float* const QW0 = TR ? wt.q : q + SQ_W2, * const QW1 = TR ? wt.q + SA_MAT : q + SQ_NP + SQ_W2;
     MI_INSIDE_SCOPE(logp_only ? MI_PROF_SAC_LOGP : MI_PROF_SAC_ACTOR);
     const int bx = (int)blockIdx.x - ow.n_lp;   // row group; the owed alpha step's workgroups come first in dispatch order (see sac_critic_kernel)
     if (bx < 0) {
@@ -698,7 +710,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     issue_thin_actor(actor, th);
     float gv = 0.0f;
     if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; gv = observations[3 * idx[b] + k]; }
-    stream_prime<false>(actor + AC_W2, ws);   // (after the row requests: loads return in order)
+    stream_prime<TR>(AW, ws);   // (after the row requests: loads return in order)
     if (t < SR * 3) {
         const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1;
         sm.x[r][k] = gv;
@@ -713,7 +725,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     const float wm = th.h0, wl = th.h1;                          // this unit's head weights, kept for the actor's backward
     if (logp_only) {   // sac.py:203-204
         __syncthreads();
-        actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, e_row);
+        actor_forward2<false, TR>(sm, actor, AW, nullptr, sm.b0, ws, acc, e_row);
         if (t == 0) { float s = 0.0f; for (int r = 0; r < SR; ++r) s += row0 + r < batch ? sm.rv[r][5] : 0.0f; slab[1795] = s; slab[1794] = 0.0f; }
         if (!al.ticket) return;
         if (t == 0) { __threadfence(); sm.cur[0] = atomicAdd(al.ticket, 1u) == gridDim.x - 1 ? 1 : 0; }
@@ -732,7 +744,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     const float* qn = q + (second ? SQ_NP : 0);
     issue_thin_q(qn, th);
     __syncthreads();
-    actor_forward2<false>(sm, actor, qn + SQ_W2, sm.b0, ws, acc, e_row);
+    actor_forward2<TR, TR>(sm, actor, AW, second ? QW1 : QW0, sm.b0, ws, acc, e_row);
     SAC_MARK(1, (int)blockIdx.y & 3, 2);
     store_acc(acc, sm.b1);                                       // actor h2 image, kept until the actor's backward
     float alpha = 0.0f;                                          // read where it is first needed (an owed alpha step of this launch may still be producing it)
@@ -744,7 +756,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
         if (t < SA_H) { sm.qmask[net][t] = mk; sm.qw13[net][t] = th.w1[3]; sm.qw3[net][t] = th.h0; }
         __syncthreads();
-        q_forward2<true>(sm, qn, qn + SQ_W2, sm.b2, ws, acc, 8);                // q_net(obs, pi(obs)) -> rv[8]; next pass: the same matrix, column-wise
+        q_forward2<true, TR>(sm, qn, second ? QW1 : QW0, qn + SQ_W2, sm.b2, ws, acc, 8);                // q_net(obs, pi(obs)) -> rv[8]; next pass: the same matrix, column-wise
         SAC_MARK(1, (int)blockIdx.y & 3, 3);
         uint32_t hm = 0;
 #pragma unroll
@@ -790,7 +802,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         if (t < SA_H) { sm.qmask[0][t] = mk; sm.qw13[0][t] = th.w1[3]; sm.qw3[0][t] = th.h0; }
         issue_thin_q(q + SQ_NP, th);
         __syncthreads();
-        q_forward2<false>(sm, q, q + SQ_NP + SQ_W2, sm.b2, ws, acc, 8);
+        q_forward2<TR, TR>(sm, q, QW0, QW1, sm.b2, ws, acc, 8);
         h2mask[0] = 0;
 #pragma unroll
         for (int tt = 0; tt < SA_NT; ++tt)
@@ -803,7 +815,7 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
         const uint32_t mk = layer1<4>(sm, th, sm.x, sm.b2);
         if (t < SA_H) { sm.qmask[1][t] = mk; sm.qw13[1][t] = th.w1[3]; sm.qw3[1][t] = th.h0; }
         __syncthreads();
-        q_forward2<true>(sm, q + SQ_NP, q + SQ_W2, sm.b2, ws, acc, 8);
+        q_forward2<true, TR>(sm, q + SQ_NP, QW1, q + SQ_W2, sm.b2, ws, acc, 8);
         h2mask[1] = 0;
 #pragma unroll
         for (int tt = 0; tt < SA_NT; ++tt)
@@ -967,7 +979,15 @@ __global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(float* __restrict__ w
 // fixed-order sum of the GEMM's K-split partials; (c) the two loss scalars.  With `opt.params` set, the same launch also applies the Adam
 // step to every element it has just assembled and (critics) the polyak step of the target copy: optimizer.step() and the target update
 // (sac.py:185,213-217) cost no launch of their own.
-struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, rbc2, eps, tau; };
+struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, rbc2, eps, tau;
+                   float* params_t; float* target_t; int is_actor; };   // transposed layer-2 copies of params / target (nullable: not registered or not valid), kept in step by sac_apply
+// flat parameter index -> index into the transposed layer-2 copy ([net][k][unit]), -1 outside the layer-2 matrices
+__device__ __forceinline__ int sac_t_index(int is_actor, int i) {
+    const int net = is_actor ? 0 : (i >= SQ_NP ? 1 : 0);
+    const int l = i - net * SQ_NP - (is_actor ? AC_W2 : SQ_W2);
+    if (l < 0 || l >= SA_H * SA_H) return -1;
+    return net * (SA_H * SA_H) + (l & (SA_H - 1)) * SA_H + (l >> 8);
+}
 // the element's optimizer state is requested BEFORE its gradient is summed (sac_state_load), so the launch is one memory latency deep, not two
 struct sac_state_t { float p, m, v, t; unsigned fault; };   // fault: the device's fault word, requested with the state (set by an EARLIER launch: a plain load)
 __device__ __forceinline__ sac_state_t sac_state_load(const sac_opt_t& o, int i) {
@@ -980,7 +1000,12 @@ __device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g, sa
     const float p = mi_adam_elem(s.p, g, s.m, s.v, o.w1, o.b2, o.w2, o.step_size, o.rbc2, o.eps);
     o.m[i] = s.m; o.v[i] = s.v;
     o.params[i] = p;
-    if (o.target) o.target[i] = o.tau * p + (1.0f - o.tau) * s.t;
+    const float tn = o.tau * p + (1.0f - o.tau) * s.t;
+    if (o.target) o.target[i] = tn;
+    if (o.params_t) {
+        const int ti = sac_t_index(o.is_actor, i);
+        if (ti >= 0) { o.params_t[ti] = p; if (o.target && o.target_t) o.target_t[ti] = tn; }
+    }
 }
 #define RED_SMALL_PER_BLOCK 64
 // (a) + (c) for the 64 thin elements of block `blk`: threads 0..255 of the workgroup (4 slab groups x 64 elements); contains one __syncthreads
@@ -1146,9 +1171,67 @@ __global__ void __launch_bounds__(512) sac_dw2_adam_kernel(sac_dw2_args_t a) {
     sac_dw2_adam_role(sm, (int)blockIdx.x, a.ws, a.batch, a.mat0, a.n_slabs, a.is_actor, a.inv_count, a.grads, a.out2, a.opt);
 }
 
+// ---- transposed layer-2 copies ("shadows"), include/mi_rl.h mi_sac_shadow_*.  A registry keyed by the flat parameter vector's device pointer: the caller owns both buffers,
+//      registers the pair, refreshes it (one transpose launch) whenever it has written the parameters behind the library's back, and the library (a) streams every forward
+//      pass of the acting / update launches from valid shadows, (b) keeps them in step wherever ITS fused optimizer steps write a layer-2 element (sac_apply), (c) marks a
+//      shadow invalid wherever one of its other writers (mi_adam, mi_polyak, mi_clip_adam) touches the vector.  An invalid or missing shadow only means the old access pattern.
+struct sac_shadow_ent { const float* base; float* t; int is_actor; bool valid; };
+#define SAC_MAX_SHADOWS 32
+static sac_shadow_ent g_shadow[SAC_MAX_SHADOWS];
+static int g_nshadow = 0;
+static sac_shadow_ent* shadow_find(const float* base) {
+    for (int k = 0; k < g_nshadow; ++k) if (g_shadow[k].base == base) return &g_shadow[k];
+    return nullptr;
+}
+static float* shadow_valid(const float* base) { sac_shadow_ent* e = base ? shadow_find(base) : nullptr; return (e && e->valid) ? e->t : nullptr; }
+extern "C" int mi_sac_shadow_set(const float* params, int is_actor, float* shadow) {
+    MI_CHECK_ARG(params != nullptr && (is_actor == 0 || is_actor == 1), "params is NULL / is_actor must be 0 (the two critics' flat vector) or 1 (the actor's)");
+    sac_shadow_ent* e = shadow_find(params);
+    if (!shadow) {   // drop
+        if (e) { *e = g_shadow[g_nshadow - 1]; --g_nshadow; }
+        return MI_OK;
+    }
+    if (!e) {
+        if (g_nshadow == SAC_MAX_SHADOWS) { mi_set_error("mi_sac_shadow_set: more than %d parameter vectors registered", SAC_MAX_SHADOWS); return MI_ESTATE; }
+        e = &g_shadow[g_nshadow++];
+    }
+    e->base = params; e->t = shadow; e->is_actor = is_actor; e->valid = false;   // valid after mi_sac_shadow_refresh
+    return MI_OK;
+}
+extern "C" int mi_sac_shadow_invalidate(const float* params) {   // NULL: every registered vector
+    for (int k = 0; k < g_nshadow; ++k) if (!params || g_shadow[k].base == params) g_shadow[k].valid = false;
+    return MI_OK;
+}
+static void shadow_invalidate_range(const float* p, size_t n) {   // a library writer that does not maintain shadows touched [p, p + n)
+    for (int k = 0; k < g_nshadow; ++k) if (g_shadow[k].base >= p && g_shadow[k].base < p + n) g_shadow[k].valid = false;
+}
+// t[m][k][u] = W_m[u][k]: 32 x 32 tiles through LDS, both sides coalesced
+__global__ void __launch_bounds__(256) sac_transpose_kernel(const float* __restrict__ params, int is_actor, float* __restrict__ t) {
+    __shared__ float tile[32][33];
+    const int m = blockIdx.z;
+    const float* W = params + (is_actor ? AC_W2 : m * SQ_NP + SQ_W2);
+    const int u0 = 32 * blockIdx.y, k0 = 32 * blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = W[(size_t)(u0 + r) * SA_H + k0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) t[(size_t)m * SA_H * SA_H + (size_t)(k0 + r) * SA_H + u0 + tx] = tile[tx][r];
+}
+extern "C" int mi_sac_shadow_refresh(const float* params, void* stream) {
+    sac_shadow_ent* e = params ? shadow_find(params) : nullptr;
+    MI_CHECK_ARG(e != nullptr, "params is not a registered parameter vector (mi_sac_shadow_set)");
+    sac_transpose_kernel<<<dim3(SA_H / 32, SA_H / 32, e->is_actor ? 1 : 2), 256, 0, (hipStream_t)stream>>>(params, e->is_actor, e->t);
+    MI_LAUNCH_CHECK();
+    e->valid = true;
+    return MI_OK;
+}
+extern "C" int mi_sac_shadow_valid(const float* params) { return shadow_valid(params) ? 1 : 0; }
+
 static sac_opt_t sac_no_opt() { sac_opt_t o; memset(&o, 0, sizeof(o)); return o; }
-static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, int64_t step, double lr, double beta1, double beta2, double eps, float tau) {
+static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, int64_t step, double lr, double beta1, double beta2, double eps, float tau, int is_actor) {
     sac_opt_t o;
+    o.params_t = shadow_valid(params); o.target_t = target ? shadow_valid(target) : nullptr; o.is_actor = is_actor;
+    if (target && o.target_t && !o.params_t) { (void)mi_sac_shadow_invalidate(target); o.target_t = nullptr; }   // the step would move the target without its shadow
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     o.params = params; o.m = m; o.v = v; o.target = target;
     o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2); o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps; o.tau = tau;
@@ -1187,11 +1270,12 @@ static int sac_launch_grads(void* workspace, int batch, int is_actor, double inv
 // is the fp64 step itself, not its loads.  Running the action-independent half of the step (fmod, sin) on the stepping wave ahead of the first barrier: +0.7 us, every
 // wave of the workgroup waits for it there.)
 namespace rg_act {
+template <bool TR>
 __global__ void __launch_bounds__(SA_THREADS)
 sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step, long long slots, long long learning_starts, float* __restrict__ obs_cur,
                float* __restrict__ observations, float* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
                const float* __restrict__ forced_actions, const float* __restrict__ forced_eps, const double* __restrict__ forced_resets,
-               mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep, int n_act, sac_dw2_args_t dw) {
+               mi_episode_t* __restrict__ episodes, int32_t* __restrict__ episode_stats, int max_ep, int n_act, sac_dw2_args_t dw, const float* __restrict__ actor_t) {
     __shared__ sac_smem sm;
     MI_INSIDE_SCOPE(MI_PROF_SAC_ACT);
     // workgroups behind the acting ones: the critics' weight-gradient + Adam + polyak step owed from the last critic update (mi_sac_act_step_carry).  Acting reads the
@@ -1206,7 +1290,8 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
     if (policy) {
         wstream ws; thin_t th; f32x4 acc[SA_NT];
         issue_thin_actor(actor, th);
-        stream_prime<false>(actor + AC_W2, ws);
+        const float* const AW = TR ? actor_t : actor + AC_W2;
+        stream_prime<TR>(AW, ws);
         if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
         float eps = 0.0f;
         if (threadIdx.x < SR) {
@@ -1216,7 +1301,7 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
         __syncthreads();
         layer1<3>(sm, th, sm.x, sm.b0);
         __syncthreads();
-        actor_forward2<false>(sm, actor, nullptr, sm.b0, ws, acc, eps);
+        actor_forward2<false, TR>(sm, actor, AW, nullptr, sm.b0, ws, acc, eps);
     }
     if (threadIdx.x < SR && row0 + threadIdx.x < N) {
         const int g = row0 + threadIdx.x;
@@ -1274,9 +1359,14 @@ static int sac_act_impl(void* handle, const float* actor, int64_t global_step, i
     const int n_act = (e->n + SR - 1) / SR;
     static_assert(rg_act::SA_THREADS == 512, "the carried critic step (sac_dw2_adam_role) is written for 512-thread workgroups");
     sac_dw2_args_t none; memset(&none, 0, sizeof(none));
-    rg_act::sac_act_kernel<<<n_act + (carry ? sac_dw2_blocks(0) : 0), rg_act::SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts,
-                                                                                                obs_cur, observations, actions, rewards, terminated, forced_actions, forced_eps,
-                                                                                                forced_resets, episodes, episode_stats, max_ep, n_act, carry ? *carry : none);
+    const float* actor_t = shadow_valid(actor);
+    const unsigned grid = n_act + (carry ? sac_dw2_blocks(0) : 0);
+    if (actor_t)
+        rg_act::sac_act_kernel<true><<<grid, rg_act::SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations, actions, rewards,
+                                                                          terminated, forced_actions, forced_eps, forced_resets, episodes, episode_stats, max_ep, n_act, carry ? *carry : none, actor_t);
+    else
+        rg_act::sac_act_kernel<false><<<grid, rg_act::SA_THREADS, 0, s>>>(*e, actor, (long long)global_step, (long long)slots, (long long)learning_starts, obs_cur, observations, actions, rewards,
+                                                                           terminated, forced_actions, forced_eps, forced_resets, episodes, episode_stats, max_ep, n_act, carry ? *carry : none, nullptr);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -1297,7 +1387,7 @@ extern "C" int mi_sac_act_step(void* handle, const float* actor, int64_t global_
 // moments, or reuse the workspace, in between (deep_rl_amd.SACEngine settles the debt before any such access).
 static int sac_critic_step_args(const mi_sac_critic_step_t* st, sac_dw2_args_t* out) {
     MI_CHECK_ARG(st && st->workspace && st->q && st->exp_avg && st->exp_avg_sq && st->grads && st->batch > 0 && st->step >= 1, "critic step: NULL pointer / bad batch or step");
-    const sac_opt_t opt = sac_make_opt(st->q, st->exp_avg, st->exp_avg_sq, st->tau >= 0.0f ? st->q_target : nullptr, st->step, st->lr, st->beta1, st->beta2, st->adam_eps, st->tau);
+    const sac_opt_t opt = sac_make_opt(st->q, st->exp_avg, st->exp_avg_sq, st->tau >= 0.0f ? st->q_target : nullptr, st->step, st->lr, st->beta1, st->beta2, st->adam_eps, st->tau, 0);
     MI_CHECK_ARG(st->tau < 0.0f || st->q_target, "critic step: q_target is NULL but tau >= 0");
     *out = sac_dw2_args_t{(float*)st->workspace, st->batch, 0, ws_kp(st->batch) / SR, 0, 1.0 / st->batch, st->grads, st->losses, opt};
     return MI_OK;
@@ -1473,9 +1563,14 @@ static int sac_critic_impl(float* q, float* q_target, const float* actor, const 
     sac_owed_t ow = ow_in; ow.fault = g_sac_fault;
     {
         mi_prof_scope prof(MI_PROF_SAC_CRITIC, s);
-        sac_critic_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 4)), SA_THREADS, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps,
-                                                           seed, update_index, alpha, gamma, (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper,
-                                                           (int64_t*)idx, ow);
+        const sac_wt_t wt = {shadow_valid(actor), shadow_valid(q), shadow_valid(q_target)};
+        const dim3 grid(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 4));
+        if (wt.actor && wt.q && wt.qt)
+            sac_critic_kernel<true><<<grid, SA_THREADS, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps, seed, update_index, alpha, gamma,
+                                                                (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper, (int64_t*)idx, ow, wt);
+        else
+            sac_critic_kernel<false><<<grid, SA_THREADS, 0, s>>>(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, (long long)slots, eps, seed, update_index, alpha, gamma,
+                                                                 (float)inv_count, (float*)workspace, sample_update, (uint64_t)sample_upper, (int64_t*)idx, ow, sac_wt_t{});
     }
     MI_LAUNCH_CHECK();
     if (defer_step) return MI_OK;   // mi_sac_critic_update_deferred: the caller owes mi_sac_critic_step / mi_sac_act_step_carry
@@ -1502,7 +1597,7 @@ extern "C" int mi_sac_critic_update_owed(float* q, float* q_target, const float*
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2 && step >= 1, "bad sizes");
     if (const int rc = sac_check_owed(owed, batch)) return rc;
     return sac_critic_impl(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
-                           1.0 / batch, workspace, grads, losses, sac_make_opt(q, exp_avg, exp_avg_sq, tau >= 0.0f ? q_target : nullptr, step, lr, beta1, beta2, adam_eps, tau),
+                           1.0 / batch, workspace, grads, losses, sac_make_opt(q, exp_avg, exp_avg_sq, tau >= 0.0f ? q_target : nullptr, step, lr, beta1, beta2, adam_eps, tau, 0),
                            sample_update, sample_upper, sac_make_owed(owed, batch, seed, workspace), (hipStream_t)stream);
 }
 extern "C" int mi_sac_critic_update_deferred(const float* q, const float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
@@ -1535,8 +1630,14 @@ static int sac_actor_impl(float* actor, const float* q, const float* observation
         mi_prof_scope prof(MI_PROF_SAC_ACTOR, s);
         const int nrg = ws_kp(batch) / SR;
         // the batch observations go to the stash slot that a debt carried by THIS launch does not read (no debt: slot 0)
-        sac_actor_kernel<<<dim3(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 2)), SA_THREADS, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count,
-                                                                                 (float*)workspace, 0, sac_alpha_t{}, ow, ow.n_lp ? (ow.slot ^ 1) : 0);
+        const sac_wt_t wt = {shadow_valid(actor), shadow_valid(q), nullptr};
+        const dim3 grid(nrg + ow.n_lp, sac_roles(nrg, ow.n_lp, 2));
+        if (wt.actor && wt.q)
+            sac_actor_kernel<true><<<grid, SA_THREADS, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0, sac_alpha_t{}, ow,
+                                                               ow.n_lp ? (ow.slot ^ 1) : 0, wt);
+        else
+            sac_actor_kernel<false><<<grid, SA_THREADS, 0, s>>>(actor, q, observations, idx, batch, eps, seed, update_index, alpha, (float)inv_count, (float*)workspace, 0, sac_alpha_t{}, ow,
+                                                                ow.n_lp ? (ow.slot ^ 1) : 0, sac_wt_t{});
     }
     MI_LAUNCH_CHECK();
     return sac_launch_grads(workspace, batch, 1, inv_count, grads, out, opt, s);
@@ -1557,7 +1658,7 @@ extern "C" int mi_sac_actor_update_owed(float* actor, const float* q, const floa
     MI_CHECK_ARG(batch > 0 && step >= 1, "bad sizes");
     if (const int rc = sac_check_owed(owed, batch)) return rc;
     return sac_actor_impl(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / batch, workspace, grads, out,
-                          sac_make_opt(actor, exp_avg, exp_avg_sq, nullptr, step, lr, beta1, beta2, adam_eps, 0.0f), sac_make_owed(owed, batch, seed, workspace),
+                          sac_make_opt(actor, exp_avg, exp_avg_sq, nullptr, step, lr, beta1, beta2, adam_eps, 0.0f, 1), sac_make_owed(owed, batch, seed, workspace),
                           (hipStream_t)stream);
 }
 extern "C" int mi_sac_actor_update(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
@@ -1652,7 +1753,11 @@ static int sac_launch_logp(const float* actor, const float* observations, const 
     if (const int rc = sac_status_check("SAC log-prob pass")) return rc;
     {
         mi_prof_scope prof(MI_PROF_SAC_LOGP, s);
-        sac_actor_kernel<<<ws_kp(batch) / SR, SA_THREADS, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al, sac_owed_t{}, 0);
+        const sac_wt_t wt = {shadow_valid(actor), nullptr, nullptr};
+        if (wt.actor)
+            sac_actor_kernel<true><<<ws_kp(batch) / SR, SA_THREADS, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al, sac_owed_t{}, 0, wt);
+        else
+            sac_actor_kernel<false><<<ws_kp(batch) / SR, SA_THREADS, 0, s>>>(actor, nullptr, observations, idx, batch, eps, seed, update_index, nullptr, 0.0f, (float*)workspace, 1, al, sac_owed_t{}, 0, sac_wt_t{});
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -1718,6 +1823,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 extern "C" int mi_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1,
                        double beta2, double eps, void* stream) {
     MI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad arguments");
+    shadow_invalidate_range(params, (size_t)n);   // this launch does not keep a transposed copy in step
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     adam_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
                                                                  (float)(1.0 - beta2), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps);
@@ -1732,6 +1838,7 @@ __global__ void __launch_bounds__(256) polyak_kernel(float* __restrict__ t, cons
 
 extern "C" int mi_polyak(float* target, const float* param, int n, float tau, void* stream) {
     MI_CHECK_ARG(target && param && n > 0, "bad arguments");
+    shadow_invalidate_range(target, (size_t)n);
     polyak_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(target, param, n, tau);
     MI_LAUNCH_CHECK();
     return MI_OK;

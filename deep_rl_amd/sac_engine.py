@@ -21,6 +21,8 @@ _OWE_ALPHA = os.environ.get("MIRL_SAC_OWE_ALPHA", "1") != "0"   # 0: every alpha
 _DEFER_CRITIC = os.environ.get("MIRL_SAC_DEFER_CRITIC", "1") != "0"
 # diagnostics (tests/_rccl_world1_worker.py): walk the sharded branches even at world_size 1, so that RCCL really runs on a one-GPU box
 _FORCE_SHARDED = os.environ.get("MIRL_OFFPOLICY_SHARDED", "0") == "1"
+# MIRL_SAC_TRANSPOSED=0: no transposed layer-2 copies (the forward passes stream torch's [out][in] matrices: ~1 us per pass slower, bit-identical) — the A/B switch
+_TRANSPOSED = os.environ.get("MIRL_SAC_TRANSPOSED", "1") != "0"
 
 
 class SACEngine:
@@ -70,6 +72,15 @@ class SACEngine:
         self.max_ep = int(max_episodes_logged if max_episodes_logged is not None else (64 if Nn <= 8 else 0))
         self.episodes = torch.zeros((max(self.max_ep, 1), 4), dtype=torch.int32, device=dev)
         self.episode_stats = torch.zeros(4, dtype=torch.int32, device=dev)
+        # transposed copies of the five layer-2 matrices (include/mi_rl.h mi_sac_shadow_*): single-process runs only (the sharded routes step through mi_adam / mi_polyak,
+        # which do not maintain them).  The library keeps them in step with its own fused optimizer steps; torch-side writes are caught through the version counters of the
+        # flat vectors and of every parameter bound to them (load_state_dict, load_flat, copy_ ...) and answered with a refresh launch.
+        self._shadows = []
+        if _TRANSPOSED and self._single():
+            for flat, mods, is_actor in ((actor.flat, (actor,), 1), (self._q_flat, (qf1, qf2), 0), (self._qt_flat, (qf1_target, qf2_target), 0)):
+                sh = torch.zeros((1 if is_actor else 2) * 65536, dtype=torch.float32, device=dev)
+                N.check(N.lib().mi_sac_shadow_set(N.ptr(flat), is_actor, N.ptr(sh)), "mi_sac_shadow_set")
+                self._shadows.append([flat, sh, [flat] + [p for m in mods for p in m.parameters()], None])
         self.observation = None
         self.global_step = 0
         self.update_index = 0       # critic updates done
@@ -78,6 +89,26 @@ class SACEngine:
 
     def _s(self):
         return N.stream_ptr(self.device)
+
+    def _sync_shadows(self):
+        """Refresh a transposed copy whose parameters torch has written since the last refresh (or that has never been refreshed)."""
+        for ent in self._shadows:
+            ver = sum(t._version for t in ent[2])
+            if ver != ent[3]:
+                N.check(N.lib().mi_sac_shadow_refresh(N.ptr(ent[0]), self._s()), "mi_sac_shadow_refresh")
+                ent[3] = ver
+
+    def params_changed(self):
+        """Tell the engine that actor / critic / target parameters were written in a way torch's version counters do not see (`.data` in-place ops, foreign kernels)."""
+        for ent in self._shadows:
+            ent[3] = None
+
+    def __del__(self):
+        try:
+            for ent in getattr(self, "_shadows", []):
+                N.lib().mi_sac_shadow_set(N.ptr(ent[0]), 0, None)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _single(self):
         return self.world_size == 1 and not _FORCE_SHARDED
@@ -187,6 +218,7 @@ class SACEngine:
 
     def act(self, forced_actions=None, forced_eps=None, forced_resets=None):
         """One iteration of sac.py:138-158 for every env, one launch."""
+        self._sync_shadows()
         dev = self.device
         fa = None if forced_actions is None else forced_actions.to(dev, torch.float32).reshape(self.N).contiguous()
         fe = None if forced_eps is None else forced_eps.to(dev, torch.float32).reshape(self.N).contiguous()
@@ -234,6 +266,7 @@ class SACEngine:
     def update_critic(self, eps=None, polyak=False, sample_in_launch=False):
         """sac.py:170-185 (+ the target update of :213-217 when `polyak`).  Single process: ONE fused call — the launch that assembles the
         gradient also applies Adam and the polyak step; sharded: gradient, all-reduce, Adam (, polyak)."""
+        self._sync_shadows()
         if self._single():
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.q_optimizer
@@ -293,6 +326,7 @@ class SACEngine:
 
     def update_actor(self, eps=None):
         """sac.py:189-197 (single process: one fused call, as update_critic)."""
+        self._sync_shadows()
         if self._single():
             e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
             o = self.actor_optimizer
@@ -323,6 +357,7 @@ class SACEngine:
 
     def update_alpha(self, eps=None):
         """sac.py:199-207: fresh log-probs, alpha loss, Adam on log_alpha, alpha = exp(log_alpha) — all on the device."""
+        self._sync_shadows()
         self.flush_critic()          # the log-prob launch writes gradient slabs a deferred critic step would still read
         if eps is None and self._single() and self._stash_fresh and self._owed_fits and _OWE_ALPHA:
             # keyed draws, single process, right after a fused actor update: the step is OWED — the next row-group launch (actor or critic update) carries its
@@ -362,6 +397,8 @@ class SACEngine:
     def update_targets(self):
         """sac.py:213-217 for both target critics in one launch."""
         N.check(N.lib().mi_polyak(N.ptr(self.qt_flat), N.ptr(self.q_flat), self.q_flat.numel(), self.tau, self._s()), "mi_polyak")
+        if self._shadows:
+            self._shadows[2][3] = None   # mi_polyak does not maintain the targets' transposed copy: refreshed before the next launch
 
     def train_step(self, policy_frequency=2, target_network_frequency=1, indices=None):
         """The optimisation half of one loop iteration (sac.py:161-217) at the current global_step.  The target update uses the critic

@@ -50,7 +50,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier, mi_comm_p2p_set_colocated; mi_test_contraction).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier, mi_comm_p2p_set_colocated; mi_test_contraction; mi_sac_shadow_*).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
 #define MI_VERSION 105
 #define MI_PPO_NPARAMS 9155
@@ -491,6 +491,23 @@ int mi_sac_act_step_carry(void* handle, const float* actor, int64_t global_step,
  *                                     hipDeviceProp_t.multiProcessorCount does not see); steers performance only.  mi_sac_usable_cus() reports the figure in use.
  *   mi_sac_test_fault(mode)           TEST HOOK: bit 0 = publishing siblings skip their hand-off words, bit 1 = the owed alpha role does not publish its epoch
  *                                     (later launches then time out as they would if a producer never ran); 0 = off. */
+/* ---- transposed copies of the 256 x 256 layer-2 matrices ("shadows"; round 5).  The row-group kernels stream a layer's matrix straight from L2 into MFMA operand
+ * registers; for a FORWARD pass on torch's [out][in] layout 16 consecutive lanes then read 16 bytes from each of 16 rows a kilobyte apart, for the backward pass 64
+ * contiguous bytes — one warm pass takes 4.84 us against 3.96 (first touch: 7.0 / 5.8).  With a transposed copy W^T[in][out] the forward pass uses the backward pass's
+ * access pattern and performs the SAME multiply-adds in the same order: bit-identical results, every forward pass ~1 us shorter.  The caller owns the buffers:
+ *   mi_sac_shadow_set(params, is_actor, shadow)   registers (shadow: dev f32 [65536] for the actor's flat vector, [2][65536] for a critics' / targets' vector; invalid
+ *                                                 until refreshed) or, with shadow == NULL, drops the entry.  Keyed by the device pointer `params`.
+ *   mi_sac_shadow_refresh(params, stream)         one transpose launch; the shadow is valid from here on.
+ *   mi_sac_shadow_invalidate(params)              the caller has written the parameters some other way (NULL: every registered vector).
+ *   mi_sac_shadow_valid(params)                   1 / 0.
+ * While a vector's shadow is valid, mi_sac_act_step*, the critic / actor update and log-prob launches stream its forward passes from the shadow (all the shadows a launch
+ * needs must be valid, else it takes the plain form), and the library's FUSED optimizer steps (mi_sac_*_update*, mi_sac_critic_step, the carried step) write every
+ * layer-2 element — and its polyak-averaged target — to both copies.  Its other writers (mi_adam, mi_polyak) mark the shadow invalid.  A wrong `valid` can only
+ * come from the caller writing parameters behind the library's back without mi_sac_shadow_invalidate / _refresh; deep_rl_amd.SACEngine tracks torch's version counters. */
+int mi_sac_shadow_set(const float* params, int is_actor, float* shadow);
+int mi_sac_shadow_refresh(const float* params, void* stream);
+int mi_sac_shadow_invalidate(const float* params);
+int mi_sac_shadow_valid(const float* params);
 int mi_sac_check(void* stream, int wait);
 int mi_sac_clear_error(void* workspace, int batch, void* stream);
 int mi_sac_set_max_cus(int max_cus);

@@ -106,7 +106,8 @@ def test_every_entry_point_survives_null_and_zero_arguments(N):
     harmless = {"mi_comm_destroy", "mi_env_destroy", "mi_timer_destroy",                    # destroying nothing is fine
                 "mi_version", "mi_last_error", "mi_perm_key", "mi_ppo_workspace_bytes", "mi_dqn_workspace_bytes", "mi_sac_workspace_bytes", "mi_per_workspace_bytes",
                 "mi_env_state_bytes", "mi_ppo_get_contraction", "mi_ppo_set_contraction",   # (mode 0 = f32 is valid)
-                "mi_sac_set_max_cus", "mi_sac_usable_cus", "mi_sac_test_fault", "mi_sac_owed_alpha_fits", "mi_ppo_test_assume_sharded", "mi_prof_pause"}   # (0 = off is valid)
+                "mi_sac_set_max_cus", "mi_sac_usable_cus", "mi_sac_test_fault", "mi_sac_owed_alpha_fits", "mi_ppo_test_assume_sharded", "mi_prof_pause",   # (0 = off is valid)
+                "mi_sac_shadow_invalidate", "mi_sac_shadow_valid"}   # (NULL = every registered vector / "not registered": 0)
     # valid with all-zero arguments wherever HIP works: "is the status word clear" / "clear it, no workspace" — MI_OK on a GPU box; on a CPU-only box
     # their hipHostMalloc fails and they say so.  Either way never a positive code or a crash.
     host_dependent = {"mi_sac_check", "mi_sac_clear_error"}
