@@ -122,6 +122,8 @@ class SACEngine:
     # ---- the critics' state: reading it settles a deferred optimizer step first ----
     def flush_critic(self):
         """Run a deferred critic step now, as the launch of its own that update_critic would have made (mi_sac_critic_step)."""
+        if self._owed_critic is not None:
+            self._sync_shadows()
         st = self._owed_critic
         if st is not None:
             N.check(N.lib().mi_sac_critic_step(C.byref(st), self._s()), "mi_sac_critic_step")
@@ -169,6 +171,7 @@ class SACEngine:
 
     def flush_alpha(self):
         """Run an owed alpha step now (a launch of its own)."""
+        self._sync_shadows()
         o = self._owed_struct()
         if o is not None:
             self.flush_critic()      # (every launch but the acting one may use workspace regions a deferred critic step still reads)
@@ -255,6 +258,7 @@ class SACEngine:
 
     def critic_grad(self, eps=None):
         """sac.py:170-182 + backward -> self.q_grads [2 * MI_SAC_Q_NPARAMS], self.q_losses (all-reduced when sharded)."""
+        self._sync_shadows()
         e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
         N.check(N.lib().mi_sac_critic_grad(
             N.ptr(self.q_flat), N.ptr(self.qt_flat), N.ptr(self.actor.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards),
@@ -317,6 +321,7 @@ class SACEngine:
 
     def actor_grad(self, eps=None):
         """sac.py:189-193 + backward -> self.actor_grads, self.actor_out."""
+        self._sync_shadows()
         e = None if eps is None else eps.to(self.device, torch.float32).reshape(-1).contiguous()
         N.check(N.lib().mi_sac_actor_grad(
             N.ptr(self.actor.flat), N.ptr(self.q_flat), N.ptr(self.observations), N.ptr(self.batch_inds), self.batch_size, N.ptr(e),
