@@ -482,8 +482,74 @@ def carrier_legs(eng, world, dev, one_update, timed_updates, u0, steps):
             DD.use_comm(None)
         res[which] = entry
     res["note"] = ("in_update: HIP events around each in-stream all-reduce inside the update (includes the wait for the slowest rank = the exposed cost); back_to_back: 200 "
-                   "all-reduces of the 9,159-float gradient buffer on an idle stream, wall clock / 200, this rank; the headline window runs on MIRL_COMM (default rccl)")
+                   "all-reduces of the 9,159-float gradient buffer on an idle stream, wall clock / 200, this rank; the headline window runs on MIRL_COMM (bench.py's default at N > 1: auto = the faster carrier that passed its "
+                   "known-answer probe, see carrier_choice; the library's default: rccl)")
     return res
+
+
+def tune_carrier(eng, dev, n=15):
+    """MIRL_COMM=auto, second stage (runs on the THROWAWAY prewarm engine, before the measured engine exists): when both carriers passed the library's known-answer probe,
+    the same window of `n` real sharded updates is timed on each (MAX over ranks) and the faster one becomes the choice — the probe compares stand-alone all-reduces,
+    but on the P2P carrier PPO's sixteen gradient exchanges per update ride INSIDE the slab-sum launches.  Every step is collective; a carrier whose window leaves a
+    timed-out wait or diverged replicas behind is not eligible."""
+    import torch
+
+    import deep_rl_amd.dist as DD
+    import deep_rl_amd.engine as E
+
+    DD.native_comm(eng.pg)                      # first use: the probe (collective)
+    rep = DD.carrier_report(eng.pg)
+    if rep is None:
+        return None
+    cands = [w for w in ("p2p", "rccl") if rep.get(w, {}).get("ok")]
+    if len(cands) < 2:
+        return None
+    multi = torch.distributed.get_world_size() > 1
+    res, rounds = {w: float("inf") for w in cands}, {w: [] for w in cands}
+    dead = set()
+    for rnd in range(2):                        # alternating, best of two windows per carrier: a window's place in the sequence must not decide
+        for w in cands:
+            if w in dead:
+                continue
+            comm = DD.native_comm(eng.pg, which=w)
+            ok, ms = 1, float("inf")
+            try:
+                DD.use_comm(comm)
+                E._FORCE_NATIVE_SHARDED = True
+                for _ in range(3):
+                    eng.update()
+                torch.cuda.synchronize(); torch.distributed.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    eng.update()
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t0) / n
+                if multi:
+                    eng.check_replicas()
+                else:
+                    DD.check_native_comm(eng.pg)
+            except Exception as ex:  # noqa: BLE001
+                ok = 0
+                sys.stderr.write("bench.py: carrier %s left the tuning window with %s: %s\n" % (w, type(ex).__name__, ex))
+            finally:
+                E._FORCE_NATIVE_SHARDED = False
+                DD.use_comm(None)
+            t = torch.tensor([ms if ok else float("inf")], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            v = float(t.item())
+            if v == float("inf"):
+                dead.add(w)
+                res[w] = v
+            else:
+                rounds[w].append(round(v, 4))
+                res[w] = min(res[w], v)
+    best = min(res, key=res.get)
+    if res[best] == float("inf"):
+        return {"error": "no carrier finished its tuning window", "ms_per_update": {k: None for k in res}}
+    how = {"what": "windows of %d real sharded updates of the throwaway prewarm engine, two per carrier, alternating; wall clock, MAX over ranks, best window" % n,
+           "ms_per_update": {k: (round(v, 4) if v != float("inf") else None) for k, v in res.items()}, "windows": rounds}
+    DD.set_auto_choice(eng.pg, best, how)
+    return how
 
 
 def sharded_route_leg(eng, one_update, timed_updates, u0, steps, dev, base_ms, base_grad_us):
@@ -616,6 +682,11 @@ def main():
 
     # production: RCCL ("nccl"), one rank per GPU.  MIRL_BENCH_BACKEND=gloo MIRL_BENCH_ONE_GPU=1 lets the N > 1 code path of this script be
     # exercised on a single-GPU box (both ranks on cuda:0; tests/test_gpu_script.py) — RCCL itself refuses two ranks on one device.
+    # N > 1: unless MIRL_COMM says otherwise the carrier of the 17 per-update all-reduces is CHOSEN BY MEASUREMENT when the first engine asks for its communicator
+    # (deep_rl_amd/dist.py: _auto_choice — both carriers sum a known-answer buffer and are timed on the path's own 36.6 KB message; the ranks agree on the faster one
+    # that passed, RCCL and then the host-sequenced route being the fall-backs); the line records what was measured and chosen (collectives.carrier_choice)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("MIRL_COMM", "auto")
     rank, world, local_rank = init_from_env(os.environ.get("MIRL_BENCH_BACKEND", "nccl"))
     if os.environ.get("MIRL_BENCH_ONE_GPU", "0") == "1":
         local_rank = 0
@@ -653,6 +724,10 @@ def main():
         for _ in range(prewarm_updates):
             p_eng.update()
         torch.cuda.synchronize()
+        from deep_rl_amd import dist as _d0
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and _d0.carrier() == "auto":
+            tune_carrier(p_eng, dev)    # recorded in dist.carrier_report -> collectives.carrier_choice
+            torch.cuda.synchronize()
         del p_eng, p_agent, p_env
 
     num_updates = args.warmup + args.steps
@@ -766,6 +841,9 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 collectives["carriers"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             collectives["rccl_env"] = _dist.apply_rccl_env() or None
+        if collectives is not None:
+            collectives["carrier_choice"] = {"MIRL_COMM": _dist.carrier(), "resolved": _dist.resolved_carrier(eng.pg) if eng_native else None,
+                                             "measured": _dist.carrier_report(eng.pg)}
     finite = bool(torch.isfinite(agent.flat).all().item())
     ep = stats_host.tolist()
     if rank == 0:
@@ -785,7 +863,7 @@ def main():
             "config": {"workload": "ppo.py CartPole-v1, %d envs/GPU x %d steps per update, 4 epochs x 4 minibatches of %d rows, "
                                    "2x64-tanh actor+critic (9155 params), on-device env.step + GAE + fwd/bwd + clip + Adam" % (ENVS_PER_GPU, T, mb),
                        "envs_per_gpu": ENVS_PER_GPU, "num_steps": T, "minibatch_rows": mb, "parallelism": "env-sharded x%d, grad all-reduce" % world,
-                       "collectives": "none (single process)" if world == 1 else (("%s (mi_ppo_update_sharded: one C call per update, 17 in-stream all-reduces)" % ("P2P over hipIpc inboxes" if _dist.carrier() == "p2p" else "RCCL direct")) if eng_native else "torch.distributed (host-sequenced, 17 all-reduces per update)")},
+                       "collectives": "none (single process)" if world == 1 else (("%s (mi_ppo_update_sharded: one C call per update, 17 in-stream all-reduces)" % ("P2P over hipIpc inboxes" if _dist.resolved_carrier(eng.pg) == "p2p" else "RCCL direct")) if eng_native else "torch.distributed (host-sequenced, 17 all-reduces per update)")},
             "roofline": {"bound": "mfma", "kernel": "grad_kernel_f32", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_launch, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "launches": g_n,

@@ -122,11 +122,13 @@ _native_comms = {}
 
 
 def carrier():
-    """MIRL_COMM: "rccl" (default — libmirl's own RCCL communicator; needs an NCCL process group, one device per rank) or "p2p" (the one-shot exchange over
-    hipIpc-mapped inboxes, csrc/mi_comm.hip; any process group — the handles travel through it — and any placement, two ranks on one device included)."""
+    """MIRL_COMM: "rccl" (default — libmirl's own RCCL communicator; needs an NCCL process group, one device per rank), "p2p" (the one-shot exchange over
+    hipIpc-mapped inboxes, csrc/mi_comm.hip; any process group — the handles travel through it — and any placement, two ranks on one device included) or "auto"
+    (both are created, checked against a known answer and timed on the path's own message when the first engine asks for a communicator; the ranks agree on the
+    faster one that passed: `resolved_carrier`, `carrier_report`)."""
     c = os.environ.get("MIRL_COMM", "rccl").lower()
-    if c not in ("rccl", "p2p"):
-        raise MiError("MIRL_COMM=%r: known carriers are rccl and p2p" % c)
+    if c not in ("rccl", "p2p", "auto"):
+        raise MiError("MIRL_COMM=%r: known carriers are rccl, p2p and auto" % c)
     return c
 
 
@@ -205,6 +207,10 @@ def native_comm(group=None, which=None):
     if not (dist.is_available() and dist.is_initialized()):
         return None
     which = which or carrier()
+    if which == "auto":
+        which = _auto_choice(group)
+        if which is None:
+            return None
     if which == "rccl" and dist.get_backend(group) != "nccl":
         return None
     key = (id(group) if group is not None else 0, which)
@@ -224,6 +230,119 @@ def native_comm(group=None, which=None):
         else:
             _native_comms[key] = h
     return _native_comms[key]
+
+
+_auto = {}
+
+
+def _probe(h, group, n_words, rounds):
+    """Known-answer check + timing of ONE carrier on the path's own message (collective; every step runs on every rank, then the ranks agree).
+    -> (ok agreed over the ranks, us per all-reduce: MAX over the ranks, why not)."""
+    import time
+
+    from . import _native as N
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    world, rk = dist.get_world_size(group), dist.get_rank(group)
+    ok, why, us = 1, "", 0.0
+    try:
+        # integers: every summation order gives the same bits, so the answer is known whatever the carrier's grouping (ring, tree, rank order)
+        buf = torch.empty(n_words, dtype=torch.float32, device=dev)
+        want = float(world * (world + 1) // 2)
+        for k in range(3):
+            buf.fill_(float(rk + 1))
+            N.check(N.lib().mi_comm_allreduce_sum(h, N.ptr(buf), buf.numel(), 0, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+            torch.cuda.synchronize()
+            N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+            bad = int((buf != want).sum().item())
+            if bad:
+                raise MiError("known-answer all-reduce %d: %d of %d elements differ from %g" % (k, bad, n_words, want))
+        buf.zero_()
+        for _ in range(10):
+            N.check(N.lib().mi_comm_allreduce_sum(h, N.ptr(buf), buf.numel(), 0, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+        torch.cuda.synchronize()
+    except Exception as ex:  # noqa: BLE001  (a carrier that cannot run here is an answer, not an error)
+        ok, why = 0, "%s: %s" % (type(ex).__name__, ex)
+    if _agree(ok, group) == 0:
+        return 0, 0.0, why or "failed on another rank"
+    try:
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            N.check(N.lib().mi_comm_allreduce_sum(h, N.ptr(buf), buf.numel(), 0, N.stream_ptr(dev)), "mi_comm_allreduce_sum")
+        torch.cuda.synchronize()
+        us = 1e6 * (time.perf_counter() - t0) / rounds
+        N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+    except Exception as ex:  # noqa: BLE001
+        ok, why = 0, "%s: %s" % (type(ex).__name__, ex)
+    t = torch.tensor([us if ok else float("inf")], dtype=torch.float64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if not torch.isfinite(t).all():
+        return 0, 0.0, why or "failed on another rank"
+    return 1, float(t.item()), ""
+
+
+def _auto_choice(group):
+    """MIRL_COMM=auto: "p2p", "rccl" or None (neither carrier passed: host-sequenced torch.distributed collectives).  Decided once per process group, collectively:
+    each carrier that can be created sums a known-answer buffer of the path's largest PPO message (9,159 floats; mi_comm_check behind it) and is then timed on 100
+    back-to-back all-reduces of it; the time of a carrier is the MAX over the ranks, the choice the smaller time — the same on every rank by construction.  The
+    message is latency-bound (36.6 KB, sixteen dependent ones per update: DESIGN.md §6), which is what the probe measures."""
+    gkey = id(group) if group is not None else 0
+    if gkey in _auto:
+        return _auto[gkey]["chosen"]
+    from . import _native as N
+
+    report = {"probe": "known-answer SUM of %d floats x 3, then 100 back-to-back all-reduces of it on an idle stream; us = MAX over ranks" % (N.NPARAMS + 4)}
+    best, best_us = None, None
+    for which in ("p2p", "rccl"):
+        if which == "rccl" and dist.get_backend(group) != "nccl":
+            report[which] = {"ok": False, "why": "process group is %s (RCCL needs nccl)" % dist.get_backend(group)}
+            continue
+        if which == "p2p" and not torch.cuda.is_available():
+            report[which] = {"ok": False, "why": "no GPU in this process"}
+            continue
+        h = native_comm(group, which=which)
+        if h is None:
+            report[which] = {"ok": False, "why": "communicator could not be created (stderr has the reason)"}
+            continue
+        ok, us, why = _probe(h, group, N.NPARAMS + 4, 100)
+        report[which] = {"ok": bool(ok), "us_per_allreduce": round(us, 2)} if ok else {"ok": False, "why": why}
+        if not ok:   # a carrier that failed its probe is not kept: it may hold a timed-out wait
+            key = (gkey, which)
+            if _native_comms.get(key) is not None:
+                N.lib().mi_comm_destroy(_native_comms[key])
+            _native_comms[key] = None
+        elif best is None or us < best_us:
+            best, best_us = which, us
+    report["chosen"] = best
+    _auto[gkey] = report
+    return best
+
+
+def set_auto_choice(group, which, how):
+    """Replace the probe's choice for `group` by a measurement of the caller's (bench.py: the same short window of real sharded updates on every carrier that passed
+    the probe — the probe times stand-alone all-reduces, while on the P2P carrier PPO's gradient exchange rides inside the slab-sum launch).  Every rank must call it
+    with the same `which`; only a carrier that passed its known-answer probe can be chosen."""
+    gkey = id(group) if group is not None else 0
+    rep = _auto.get(gkey)
+    if rep is None or not rep.get(which, {}).get("ok"):
+        raise MiError("set_auto_choice(%r): not a carrier that passed the MIRL_COMM=auto probe of this process group" % (which,))
+    rep["chosen_by_probe"], rep["chosen"], rep["chosen_by"] = rep["chosen"], which, how
+
+
+def resolved_carrier(group=None):
+    """The carrier the one-call routes of `group` take: MIRL_COMM, with "auto" resolved (collective on first use) — "rccl", "p2p" or None (host-sequenced)."""
+    c = carrier()
+    if c != "auto":
+        return c
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return _auto_choice(group)
+
+
+def carrier_report(group=None):
+    """What MIRL_COMM=auto measured for `group` (None before the first communicator was asked for, or with a fixed carrier)."""
+    return _auto.get(id(group) if group is not None else 0)
 
 
 def check_native_comm(group=None):
@@ -246,6 +365,7 @@ def destroy_native_comms():
     for h in live:
         N.lib().mi_comm_destroy(h)
     _native_comms.clear()
+    _auto.clear()
 
 
 def global_adv_mean_std(sums):

@@ -20,6 +20,11 @@ def test_carrier_selection_and_rccl_env(monkeypatch):
     assert D.carrier() == "rccl"                                   # the default stays RCCL (BASELINE.json north_star names it)
     monkeypatch.setenv("MIRL_COMM", "P2P")
     assert D.carrier() == "p2p"
+    monkeypatch.setenv("MIRL_COMM", "auto")
+    assert D.carrier() == "auto"
+    assert D.resolved_carrier() is None and D.carrier_report() is None and D.native_comm() is None   # no process group: nothing to choose, single process
+    monkeypatch.setenv("MIRL_COMM", "p2p")
+    assert D.resolved_carrier() == "p2p"                            # a fixed carrier resolves to itself
     monkeypatch.setenv("MIRL_COMM", "mpi")
     with pytest.raises(MiError):
         D.carrier()
@@ -50,6 +55,46 @@ def test_native_comm_without_process_group_and_override(monkeypatch):
         D.use_comm(None)
     D.check_native_comm()                                          # nothing created: nothing to check
     D.destroy_native_comms()
+
+
+_AUTO_WORKER = r"""
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MIRL_ROOT"])
+import deep_rl_amd.dist as D
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=2)
+assert D.carrier() == "auto"
+assert D.native_comm() is None            # no GPU, gloo: neither carrier exists -> the host-sequenced torch.distributed route, agreed by both ranks
+r = D.carrier_report()
+assert r["chosen"] is None and r["p2p"]["ok"] is False and r["rccl"]["ok"] is False and "gloo" in r["rccl"]["why"], r
+assert D.resolved_carrier() is None
+assert D.native_comm() is None            # decided once
+t = torch.full((5,), float(dist.get_rank() + 1))
+D.allreduce_sum_(t)
+assert (t == 3.0).all()
+D.destroy_native_comms()
+assert D.carrier_report() is None
+dist.destroy_process_group()
+print("AUTO_WORKER_OK")
+"""
+
+
+def test_auto_carrier_on_cpu_gloo_falls_back_collectively(tmp_path):
+    """MIRL_COMM=auto at world_size 2 without a GPU: both ranks agree that no carrier of libmirl's communicator can run and keep the torch.distributed route."""
+    import socket
+
+    w = tmp_path / "w.py"
+    w.write_text(_AUTO_WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MIRL_ROOT=ROOT, MIRL_COMM="auto", RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(w)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for pr in procs:
+        out, err = pr.communicate(timeout=300)
+        assert pr.returncode == 0 and "AUTO_WORKER_OK" in out, err[-3000:]
 
 
 def test_p2p_entry_points_check_their_arguments():

@@ -176,17 +176,22 @@ def test_bench_contract_line():
         assert x["cpu_baseline"]["kind"] == "port" and x["cpu_baseline"]["value"] > 0
 
 
-def test_bench_two_ranks_code_path_on_one_gpu():
+@pytest.mark.parametrize("mirl_comm", [None, "rccl"])
+def test_bench_two_ranks_code_path_on_one_gpu(mirl_comm):
     """`python bench.py --gpus 2` as the driver types it: the parent (no GPU call, no torch import) starts the two ranks through torch.distributed.run as a
     CHILD process, relays rank 0's one JSON line and returns the child's code.  Both ranks on cuda:0 over gloo here — RCCL on
-    2..8 GPUs is the driver's run (tests/test_gpu_multigpu.py covers it when >= 2 GPUs are visible)."""
+    2..8 GPUs is the driver's run (tests/test_gpu_multigpu.py covers it when >= 2 GPUs are visible).
+    MIRL_COMM unset: bench.py's N > 1 default, auto — the carriers are probed (known answer + timing) and the HEADLINE runs the one-call route on the one that passed
+    (here P2P: RCCL cannot exist under gloo); MIRL_COMM=rccl: the library's default — under gloo the host-sequenced route."""
     import json
     import torch
 
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_BENCH_BACKEND="gloo", MIRL_BENCH_ONE_GPU="1")
-    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_BENCH_BACKEND="gloo", MIRL_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("MIRL_COMM", None)
+    if mirl_comm:
+        env["MIRL_COMM"] = mirl_comm
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
                          timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -197,8 +202,16 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert abs(d["value"] - 2 * 2 * 128 * 4096 / (2 * d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]      # whole-job aggregate over both ranks
     assert "x2" in d["config"]["parallelism"] and d["roofline"]["launches"] == 16
     c = d["collectives"]
-    assert c["per_update"] == 17 and c["world_size"] == 2 and "gloo" in c["carrier"] and c["grad_allreduce"]["bytes"] == 4 * 9159
+    assert c["per_update"] == 17 and c["world_size"] == 2 and c["grad_allreduce"]["bytes"] == 4 * 9159
     assert c["back_to_back"]["us_per_allreduce_grad"] > 0 and c["back_to_back"]["us_per_allreduce_stats"] > 0
+    ch = c["carrier_choice"]
+    if mirl_comm is None:
+        assert ch["MIRL_COMM"] == "auto" and ch["resolved"] == "p2p" and ch["measured"]["chosen"] == "p2p", ch
+        assert ch["measured"]["p2p"]["ok"] is True and ch["measured"]["p2p"]["us_per_allreduce"] > 0 and ch["measured"]["rccl"]["ok"] is False, ch
+        assert c["carrier"].startswith("P2P") and "P2P" in d["config"]["collectives"] and c["headline_exchange"]["replicas_identical"] is True
+    else:
+        assert ch["MIRL_COMM"] == "rccl" and ch["resolved"] is None and ch["measured"] is None, ch
+        assert "gloo" in c["carrier"] and "host-sequenced" in d["config"]["collectives"]
     # the per-carrier legs (round 5): RCCL cannot exist under gloo / two ranks on one device; the P2P carrier runs the ONE-CALL route with both ranks on cuda:0
     k = c["carriers"]
     assert "error" in k["rccl"] and "error" not in k["p2p"], k
@@ -233,6 +246,34 @@ def test_bench_native_rccl_diagnostics_at_world_size_1():
     k = c["carriers"]                                             # both carriers at world_size 1 (a one-rank P2P communicator needs no peer)
     for which in ("rccl", "p2p"):
         assert "error" not in k[which] and k[which]["ms_per_step"] > 0 and k[which]["replicas_identical"] is True, k
+    assert c["carrier_choice"] == {"MIRL_COMM": "rccl", "resolved": "rccl", "measured": None}
+
+
+def test_bench_auto_carrier_tunes_on_real_updates_at_world_size_1():
+    """MIRL_COMM=auto where BOTH carriers exist (a world_size-1 RCCL group; P2P needs no peer): the library's probe (known answer + stand-alone timing) passes both, then
+    bench.py times the same window of real sharded updates of the throwaway prewarm engine on each and the faster one carries the headline's engine — the branch an
+    8-GPU run of the driver takes (there with seven peers behind every exchange)."""
+    import json
+    import socket
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_FORCE_PG="1", MIRL_COMM="auto", MIRL_BENCH_CARRIER_LEGS="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--headline-only", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    ch = d["collectives"]["carrier_choice"]
+    m = ch["measured"]
+    assert ch["MIRL_COMM"] == "auto" and m["p2p"]["ok"] is True and m["rccl"]["ok"] is True and m["p2p"]["us_per_allreduce"] > 0 and m["rccl"]["us_per_allreduce"] > 0, ch
+    t = m["chosen_by"]["ms_per_update"]
+    assert t["p2p"] > 0 and t["rccl"] > 0 and m["chosen"] == min(t, key=t.get) == ch["resolved"] and m["chosen_by_probe"] in ("p2p", "rccl"), ch
+    assert ("P2P" if m["chosen"] == "p2p" else "RCCL direct") in d["collectives"]["carrier"]
 
 
 def test_bench_self_launch_propagates_failure():
