@@ -473,11 +473,27 @@ extern "C" int mi_dqn_sample(uint64_t seed, uint64_t update_index, int64_t upper
 //      end — until round 3 every 8 rows got a workgroup of their own that re-read both nets and wrote a full 43.7 KB slab (batch 4,096: 512 slabs, 27.6 MB of
 //      writes for 0.23 MB of gathers).  R = 8 while the batch gives at most TD_MAX_BLOCKS groups of 8 (one group per workgroup: the round-3 arithmetic, bit for bit);
 //      beyond that R = 16, which fills the MFMAs' 16 row columns (at R = 8 half of every B operand is zero) -----------------------------------------------------
+#ifdef TD_STAMPS   // diagnostic build: the phases of dqn_td_kernel on the wall clock (s_memrealtime, 100 MHz), wave 0 of every workgroup; tools/dqn_td_stamps.py
+__device__ unsigned long long td_mark_dbg[16][16];   // [workgroup < 16][mark]
+#define TD_MARK(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 16) { unsigned long long rt_; \
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); td_mark_dbg[blockIdx.x][k] = rt_; } \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TD_MARK_NOWAIT(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 16) { unsigned long long rt_; \
+                        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); td_mark_dbg[blockIdx.x][k] = rt_; } \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int mi_debug_dqn_td_marks(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(td_mark_dbg), sizeof(unsigned long long) * 16 * 16) == hipSuccess ? 0 : -2;
+}
+#else
+#define TD_MARK(k) do {} while (0)
+#define TD_MARK_NOWAIT(k) do {} while (0)
+#endif
 #define TD_R 8                 // rows per group of the small-batch form; also the granule of mi_dqn_workspace_bytes
 #define TD_MAX_BLOCKS 256      // workgroups (= slabs) per launch at most: one per CU of an MI355X
 #define TD_SLAB (DQ_NP + 2)   // + loss
 template <int R>
 struct __attribute__((aligned(16))) td_smem {
+    float W2s[2][DQ_H2 * DQ_H1];   // layer 2 of both nets as in memory (row-major [unit][k]), staged once per workgroup by fully coalesced loads: the MFMA fragments come from here
     float x[2][R][4];          // [0] obs, [1] next obs
     float h1[2][R][DQ_H1];     // [0] online on obs, [1] target on next obs
     float h2[2][R][DQ_H2];
@@ -503,87 +519,119 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
     __shared__ td_smem<R> sm;
     MI_INSIDE_SCOPE(MI_PROF_DQN_TD);
     const int t = threadIdx.x;
+    TD_MARK_NOWAIT(0);   // entry
+#ifdef TD_PROBE_LATENCY
+    { float dummy_ = params[t] + target_params[t]; asm volatile("" :: "v"(dummy_)); TD_MARK(12); }   // one cold load of each net, waited for: the raw first-touch latency
+#endif
     const int n_groups = (batch + R - 1) / R;
     float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
     // The batch rows of a group: thread (net nt = t / 4R, row r, component k = t & 3) < 8R derives row r's index ITSELF (the four threads of a row repeat the draw or
-    // the load: no LDS hand-over, no barrier between index and gather) and fetches its element of obs (nt = 0) or next obs (nt = 1); the k = 0 threads also fetch the
-    // row's action / the successor's reward and terminated flag.  The index of the NEXT group is requested a whole group ahead, and the very first one BEFORE the
-    // weight operands (loads return in order: a gather issued behind 43 KB of weight requests would wait for all of them).
-    const bool gth = t < 2 * R * 4;
-    const int g_nt = t / (R * 4), g_r = (t >> 2) % R, g_k = t & 3;
-    auto row_index = [&](int grp) -> long long {   // -> this thread's row's flat ring index
-        const int b = grp * R + g_r < batch ? grp * R + g_r : batch - 1;
-        if (sample_upper) {     // batch_inds = randint(upper, size=batch) (dqn.py:116) drawn here: the contract of dqn_sample_kernel, no launch of its own
-            uint32_t r4[4];
-            mi_philox(sample_seed, sample_update, (uint64_t)b, STREAM_SAMPLE, r4);
-            return (long long)((((uint64_t)r4[1] << 32) | r4[0]) % sample_upper);
-        }
-        return idx[b];
+    // the load: no LDS hand-over, no barrier between index and gather) and fetches its element of obs (nt = 0) or next obs (nt = 1) plus the row's action / the
+    // successor's reward and terminated flag.  The index of the NEXT group is requested a whole group ahead.
+    // Round 5 (-DTD_STAMPS, tools/dqn_td_stamps.py): the prologue is ONE memory latency deep.  Before, rows were in LDS 4.3 us after entry although a cold load
+    // returns in 0.4 us: every guarded load and every operation on a loaded value inside a divergent branch is a basic block that ends in s_waitcnt vmcnt(0) (loads
+    // return in order), so the weights, the gathers, the dh1 operands and the thin parameters were four latencies in a row.  Now every request of the prologue is
+    // UNCONDITIONAL (all 256 threads, clamped addresses, branch-free), nothing touches a loaded value before the last request has left, and the LDS stores (the
+    // COMMIT of a gather) come behind everything.
+    const int g_nt = (t / (R * 4)) & 1, g_r = (t >> 2) % R, g_k = t & 3;
+    const bool small_ring = (unsigned long long)slots * (unsigned long long)n_envs <= 0xffffffffull;   // uniform: every flat index fits 32 bits (any ring below 4 G transitions)
+    const uint64_t upper1 = sample_upper ? sample_upper : 1;
+    auto row_b = [&](int grp) -> int { return grp * R + g_r < batch ? grp * R + g_r : batch - 1; };
+    auto row_draw = [&](int grp) -> long long {   // batch_inds = randint(upper, size=batch) (dqn.py:116) drawn here: the contract of dqn_sample_kernel, no launch of its own
+        uint32_t r4[4];
+        mi_philox(sample_seed, sample_update, (uint64_t)row_b(grp), STREAM_SAMPLE, r4);
+        return (long long)((((uint64_t)r4[1] << 32) | r4[0]) % upper1);
     };
-    auto gather_group = [&](int grp, long long i) {
-        if (!gth) return;
-        // next-slot row of the same env: ((i / N + 1) % slots) * N + i % N.  Flat indices below 2^32 (every ring this side of 4 G transitions) take the
-        // 32-bit divider; the wrap is a compare (slot < slots always), not a second modulo.
+    struct row_req { float xv; int a; float rw; unsigned term; long long i; };
+    auto gather_request = [&](long long i) -> row_req {
+        // next-slot row of the same env: ((i / N + 1) % slots) * N + i % N; the wrap is a compare (slot < slots always), not a second modulo
         long long sl, en;
-        if ((unsigned long long)i >> 32) { sl = i / n_envs; en = i % n_envs; }
-        else { const unsigned q = (unsigned)i / (unsigned)n_envs; sl = q; en = (unsigned)i - q * (unsigned)n_envs; }
+        if (small_ring) { const unsigned qq = (unsigned)i / (unsigned)n_envs; sl = qq; en = (unsigned)i - qq * (unsigned)n_envs; }
+        else { sl = i / n_envs; en = i % n_envs; }
         sl = sl + 1 == slots ? 0 : sl + 1;
         const long long nx = sl * n_envs + en;
-        const float xv = observations[4 * (g_nt ? nx : i) + g_k];
-        if (g_k == 0) {
-            if (g_nt == 0) {
-                sm.act[g_r] = (int)actions[i];
-                if (sample_upper && grp * R + g_r < batch) idx_out[grp * R + g_r] = i;
-            } else {
-                sm.rw[g_r] = rewards[nx];
-                sm.live[g_r] = terminated[nx] ? 0.0f : 1.0f;
-            }
-        }
-        sm.x[g_nt][g_r][g_k] = xv;
+        row_req q;
+        q.i = i;
+        q.xv = observations[4 * (g_nt ? nx : i) + g_k];
+        q.a = reinterpret_cast<const int*>(actions)[2 * i];   // low dword of the int64 action
+        q.rw = rewards[nx];
+        q.term = terminated[nx];
+        return q;
     };
-    long long i_cur = (gth && (int)blockIdx.x < n_groups) ? row_index((int)blockIdx.x) : 0;
-    // MFMA roles (layer 2, dh1, dW2): wave mw, lane (mj, mlg).  None of the weight operands depends on the batch: requested once, they stay in registers for every
-    // group of the workgroup (layer 2: 24 float4 + 12 bias dwords per lane; dh1: 42 dwords, requested behind the first group's gathers)
-    const int mw = t >> 6, mj = t & 15, mlg = (t >> 4) & 3;
-    const int mnet = mw >> 1;
-    const float* mp = mnet ? target_params : params;
-    f32x4_t wA[3][8], bias2[3];
-#pragma unroll
-    for (int T3 = 0; T3 < 3; ++T3) {
-        const int T = 3 * (mw & 1) + T3, u2 = 16 * T + mj;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            // (unconditional from a clamped address, masked afterwards: a guarded load is a basic block of its own — ~90 of them in this prologue, round 4)
-            const int k = 16 * c + 4 * mlg;
-            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(mp + DQ_W2 + DQ_H1 * (u2 < DQ_H2 ? u2 : DQ_H2 - 1) + (k < DQ_H1 ? k : DQ_H1 - 4));
-            wA[T3][c] = (u2 < DQ_H2 && k < DQ_H1) ? v : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        const int o0 = 16 * T + 4 * mlg;   // 84 = 21 x 4: a lane's four units are all inside or all outside
-        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(mp + DQ_B2 + (o0 < DQ_H2 ? o0 : DQ_H2 - 4));
-        bias2[T3] = o0 < DQ_H2 ? bv : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    float wa1[2][21];   // the dh1 pass's A operands (W2 read column-wise)
-    if ((int)blockIdx.x < n_groups) gather_group((int)blockIdx.x, i_cur);
-    // the dh1 operands, behind the first group's gathers
-#pragma unroll
-    for (int s2 = 0; s2 < 21; ++s2)
-#pragma unroll
-        for (int U2 = 0; U2 < 2; ++U2) {
-            const int k = 16 * (2 * mw + U2) + mj;
-            const float v = params[DQ_W2 + DQ_H1 * (4 * s2 + mlg) + (k < DQ_H1 ? k : DQ_H1 - 1)];
-            wa1[U2][s2] = k < DQ_H1 ? v : 0.0f;
-        }
-    // thin parameters: layer 1 of the thread's (net, unit), the online head's column of thread j < 84; both heads into LDS for the forward dot products
+    // the commit is unconditional too — threads t, t + 8R, ... hold the same (net, row, component) and store the same values — because a load whose only use sits
+    // inside a branch is SUNK into that branch by the compiler (seen in the ISA: the action / reward / terminated loads had moved behind every other request)
+    auto gather_commit = [&](int grp, const row_req& q) {
+        sm.act[g_r] = q.a;
+        sm.rw[g_r] = q.rw;
+        sm.live[g_r] = q.term ? 0.0f : 1.0f;
+        sm.x[g_nt][g_r][g_k] = q.xv;
+        if (sample_upper && t < 4 * R && g_k == 0 && grp * R + g_r < batch) idx_out[grp * R + g_r] = q.i;
+    };
+    const bool first = (int)blockIdx.x < n_groups;
+    const int grp0 = first ? (int)blockIdx.x : 0;
+    // a caller's index list (teacher-forced runs, PER's sampler) is a load: first in the queue (with the keyed draw `idx` is the output list: a harmless read);
+    // the keyed draw is arithmetic and runs while the weights are on their way
+    const long long i_list = idx[row_b(grp0)];
+    TD_MARK_NOWAIT(1);   // index requested (a caller's list)
+    // Order of the requests = order of first use (loads return in order, and a CU's address unit takes ~1.2 us for the 98 KB of layer-2 operands of a workgroup):
+    // thin parameters and the rows (layer 1 needs nothing else) in FRONT of the layer-2 operands, which stream in while layer 1 runs; the dh1 operands are requested
+    // behind layer 2's matrix instructions and arrive during the thin phases that follow.
+    // thin parameters: layer 1 of the thread's (net, unit), the online head's column of thread j < 84 (both only ever read by the threads inside those ranges); both
+    // heads into LDS for the forward dot products
     const int net = t >> 7, u = t & 127;                 // threads 0..127: online net, 128..255: target net
     const float* p = net ? target_params : params;
     const int uc = u < DQ_H1 ? u : DQ_H1 - 1, tc = t < DQ_H2 ? t : DQ_H2 - 1;
-    float4 w1v = *reinterpret_cast<const float4*>(p + DQ_W1 + 4 * uc);
-    float b1v = p[DQ_B1 + uc];
-    if (u >= DQ_H1) { w1v = make_float4(0.0f, 0.0f, 0.0f, 0.0f); b1v = 0.0f; }
-    float w30 = params[DQ_W3 + tc], w31 = params[DQ_W3 + DQ_H2 + tc];
-    if (t >= DQ_H2) { w30 = 0.0f; w31 = 0.0f; }
-    for (int i = t; i < 2 * 2 * DQ_H2; i += 256) { const int n3 = i / (2 * DQ_H2), rem = i % (2 * DQ_H2); (&sm.w3[n3][0][0])[rem] = (n3 ? target_params : params)[DQ_W3 + rem]; }
-    if (t < 4) sm.b3[t >> 1][t & 1] = ((t >> 1) ? target_params : params)[DQ_B3 + (t & 1)];
+    const float4 w1v = *reinterpret_cast<const float4*>(p + DQ_W1 + 4 * uc);
+    const float b1v = p[DQ_B1 + uc];
+    const float w30 = params[DQ_W3 + tc], w31 = params[DQ_W3 + DQ_H2 + tc];
+    static_assert(2 * 2 * DQ_H2 <= 2 * 256 && 2 * 2 * DQ_H2 > 256, "two head values per thread");
+    const int h3a = t, h3b = t + 256 < 2 * 2 * DQ_H2 ? t + 256 : 2 * 2 * DQ_H2 - 1;
+    const float hv0 = (h3a / (2 * DQ_H2) ? target_params : params)[DQ_W3 + h3a % (2 * DQ_H2)];
+    const float hv1 = (h3b / (2 * DQ_H2) ? target_params : params)[DQ_W3 + h3b % (2 * DQ_H2)];
+    const float hb = ((t & 2) ? target_params : params)[DQ_B3 + (t & 1)];
+    const long long i_phx = row_draw(grp0);
+    const long long i_cur = sample_upper ? i_phx : i_list;
+    row_req q_cur = gather_request(i_cur);
+    // MFMA roles (layer 2, dh1, dW2): wave mw, lane (mj, mlg).  None of the weight operands depends on the batch: fetched once, they stay in registers for every
+    // group of the workgroup (layer 2: 24 float4 + 12 bias dwords per lane; dh1: 42 dwords).
+    // Round 5: the operands go THROUGH LDS.  Requested in fragment layout — a lane's float4 of row 16T + j: sixteen 64-byte segments 480 bytes apart per instruction —
+    // a CU's address unit needed ~165 cycles per instruction and wave (-DTD_STAMPS: 28 such loads kept a wave in the issue stage for 2.1 us, and the 42 column-wise
+    // dwords of the dh1 operands another 0.5).  Now the workgroup copies both nets' W2 (2 x 40,320 bytes) with 20 fully coalesced float4 loads per thread (1 KB
+    // contiguous per instruction) into LDS as it lies in memory, and every lane picks its fragments from there (ds_read_b128 / ds_read_b32).
+    const int mw = t >> 6, mj = t & 15, mlg = (t >> 4) & 3;
+    const int mnet = mw >> 1;
+    const float* mp = mnet ? target_params : params;
+    constexpr int W2V = DQ_H2 * DQ_H1 / 4;               // float4 per net
+    constexpr int STG = (2 * W2V + 255) / 256;           // float4 per thread (the last ones clamped: threads past the end repeat the last element)
+    static_assert(DQ_H2 * DQ_H1 % 4 == 0 && DQ_W2 % 4 == 0, "W2 is float4-aligned");
+    f32x4_t stg[STG];
+#pragma unroll
+    for (int q = 0; q < STG; ++q) {
+        const int v = t + 256 * q < 2 * W2V ? t + 256 * q : 2 * W2V - 1;
+#ifdef TD_PROBE_SAME_NET   // timing experiment: both halves from the online net (half the distinct lines)
+        stg[q] = v < W2V ? reinterpret_cast<const f32x4_t*>(params + DQ_W2)[v] : reinterpret_cast<const f32x4_t*>(params + DQ_W2)[v - W2V];
+#else
+        stg[q] = v < W2V ? reinterpret_cast<const f32x4_t*>(params + DQ_W2)[v] : reinterpret_cast<const f32x4_t*>(target_params + DQ_W2)[v - W2V];
+#endif
+    }
+    f32x4_t wA[3][8], bias2[3];
+#pragma unroll
+    for (int T3 = 0; T3 < 3; ++T3) {
+        const int o0 = 16 * (3 * (mw & 1) + T3) + 4 * mlg;   // 84 = 21 x 4: a lane's four units are all inside or all outside
+        bias2[T3] = *reinterpret_cast<const f32x4_t*>(mp + DQ_B2 + (o0 < DQ_H2 ? o0 : DQ_H2 - 4));
+    }
+    float wa1[2][21];   // the dh1 pass's A operands (W2 read column-wise): requested in the first group, behind layer 2
+    TD_MARK_NOWAIT(2);       // every prologue request issued
+    // ---- nothing above this line reads a loaded value; the commit below waits for the rows and the thin parameters only ----
+    gather_commit(grp0, q_cur);   // (a workgroup without a group commits row 0's values and never reads them: a guard here would sink the gather behind it)
+#pragma unroll
+    for (int q = 0; q < STG; ++q) {
+        const int v = t + 256 * q < 2 * W2V ? t + 256 * q : 2 * W2V - 1;
+        reinterpret_cast<f32x4_t*>(&sm.W2s[0][0])[v] = stg[q];
+    }
+    (&sm.w3[0][0][0])[h3a] = hv0;
+    (&sm.w3[0][0][0])[h3b] = hv1;           // (threads past the end repeat the last element)
+    sm.b3[(t >> 1) & 1][t & 1] = hb;        // (every thread: the same four values)
     // gradient accumulators over the workgroup's groups
     float g30 = 0.0f, g31 = 0.0f, gb2 = 0.0f;            // t < 84: dW3[0][t], dW3[1][t], db2[t];  t = 84, 85: g30 = db3[t - 84];  t = 86: g30 = loss
     float gb1 = 0.0f, gw1[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // t < 120: db1[t], dW1[t][0..3]
@@ -598,9 +646,21 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int row0 = grp * R;
         __syncthreads();                                   // this group's rows are in LDS (gather_group below: before the loop / at the end of the previous group)
+        TD_MARK_NOWAIT(3);   // rows in LDS (thread 0 gathers: its own loads have returned; loads return in order, so has every weight request in front of them)
         const int nxt_grp = grp + (int)gridDim.x;
         long long i_nxt = 0;
-        if (gth && nxt_grp < n_groups) i_nxt = row_index(nxt_grp);   // requested a whole group ahead
+        if (nxt_grp < n_groups) i_nxt = sample_upper ? row_draw(nxt_grp) : idx[row_b(nxt_grp)];   // requested a whole group ahead (uniform branch)
+        if (grp == (int)blockIdx.x) {   // (uniform) the layer-2 fragments of this lane: on their way from LDS while layer 1 runs
+#pragma unroll
+            for (int T3 = 0; T3 < 3; ++T3) {
+                const int u2 = 16 * (3 * (mw & 1) + T3) + mj;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int k = 16 * c + 4 * mlg;
+                    wA[T3][c] = *reinterpret_cast<const f32x4_t*>(&sm.W2s[mnet][DQ_H1 * (u2 < DQ_H2 ? u2 : DQ_H2 - 1) + (k < DQ_H1 ? k : DQ_H1 - 4)]);
+                }
+            }
+        }
         // ---- layer 1 ----
         if (u < DQ_H1) {
 #pragma unroll
@@ -612,6 +672,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             }
         }
         __syncthreads();
+        TD_MARK_NOWAIT(4);   // layer 1 done
         // ---- layer 2 on v_mfma_f32_16x16x4_f32, D[unit][row] = W2[unit][k] h1[k][row]: 2 nets x 6 unit tiles over the 4 waves (wave w: net w >> 1, tiles
         //      3 (w & 1) ..+2).  Lane (j, lg) supplies k = 16c + 4lg + r in k-step (c, r): A = W2[16T + j][k] (register-resident), B = h1[row j][k] (one LDS float4
         //      per c; rows >= R are zero columns).
@@ -625,6 +686,16 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
                 hB[c] = (j < R && k < DQ_H1) ? *reinterpret_cast<const f32x4_t*>(&sm.h1[mnet][j][k]) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
             }
 #pragma unroll
+            for (int T3 = 0; T3 < 3; ++T3) {   // zero padding of the operands (units >= 84, k >= 120; idempotent): selects on the loaded values, here at their first use
+                const int T = 3 * (mw & 1) + T3, u2 = 16 * T + mj, o0 = 16 * T + 4 * mlg;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int k = 16 * c + 4 * mlg;
+                    if (!(u2 < DQ_H2 && k < DQ_H1)) wA[T3][c] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                if (!(o0 < DQ_H2)) bias2[T3] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
             for (int T3 = 0; T3 < 3; ++T3) acc2[T3] = bias2[T3];
 #pragma unroll
             for (int c = 0; c < 8; ++c)
@@ -632,6 +703,15 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int T3 = 0; T3 < 3; ++T3) acc2[T3] = DQ_MFMA(wA[T3][c][r], hB[c][r], acc2[T3]);
+            if (grp == (int)blockIdx.x) {   // (uniform) the dh1 operands (the online net's W2 read column-wise), from the staged copy
+#pragma unroll
+                for (int s2 = 0; s2 < 21; ++s2)
+#pragma unroll
+                    for (int U2 = 0; U2 < 2; ++U2) {
+                        const int k = 16 * (2 * mw + U2) + mj;
+                        wa1[U2][s2] = sm.W2s[0][DQ_H1 * (4 * s2 + mlg) + (k < DQ_H1 ? k : DQ_H1 - 1)];
+                    }
+            }
 #pragma unroll
             for (int T3 = 0; T3 < 3; ++T3) {
                 const int o = 16 * (3 * (mw & 1) + T3) + 4 * lg;
@@ -640,14 +720,17 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             }
         }
         __syncthreads();
+        TD_MARK(5);          // layer 2 done (all of this thread's weight operands have arrived)
         // ---- layer 3: 2 nets x R rows x 2 actions dot products of length 84 ----
-        if (t < 2 * R * 2) {
+        if (t < 2 * R * 2) {   // (split over P = 64 / R lanes per dot + a butterfly: 0.80 -> 0.48 us of the launch, but another summation order than the oracle's chain
+            // for a gain inside the noise of the iteration: measured in round 5 and not kept)
             const int n3 = t / (R * 2), r = (t >> 1) % R, a = t & 1;
             float acc = 0.0f;
             for (int j = 0; j < DQ_H2; ++j) acc = __builtin_fmaf(sm.w3[n3][a][j], sm.h2[n3][r][j], acc);
             sm.q[n3][r][a] = acc + sm.b3[n3][a];
         }
         __syncthreads();
+        TD_MARK_NOWAIT(6);   // layer 3 done
         // ---- TD target, loss, d loss / d q (dqn.py:119-123) ----
         if (t < R) {
             const bool valid = row0 + t < batch;
@@ -662,6 +745,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             sm.dq[t][1] = a == 1 ? -2.0f * (wb * diff) * invn : 0.0f;
         }
         __syncthreads();
+        TD_MARK_NOWAIT(7);   // loss done
         // ---- backward through layer 3 (online net only): thread j < 84 ----
         if (t < DQ_H2) {
             float g0 = 0.0f, g1 = 0.0f, gb = 0.0f;
@@ -687,6 +771,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             g30 += l;
         }
         __syncthreads();
+        TD_MARK_NOWAIT(8);   // backward through layer 3 done
         // ---- dh1[k][row] = sum_j W2[j][k] dz2[j][row] on the MFMA: 8 k-tiles over the 4 waves (wave w: tiles 2w, 2w + 1), 21 k-steps over j = 4s + lg.
         //      A = W2[j][16U + kk] (register-resident), B = dz2[j][row] from LDS; D: lane (row, lg), register r <-> k = 16U + 4lg + r ----
         {
@@ -695,6 +780,10 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             float db[21];
 #pragma unroll
             for (int s2 = 0; s2 < 21; ++s2) db[s2] = j < R ? sm.dz2[4 * s2 + lg][j] : 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 21; ++s2)   // zero padding (k >= 120; idempotent)
+#pragma unroll
+                for (int U2 = 0; U2 < 2; ++U2) if (!(16 * (2 * w + U2) + j < DQ_H1)) wa1[U2][s2] = 0.0f;
 #pragma unroll
             for (int s2 = 0; s2 < 21; ++s2)
 #pragma unroll
@@ -731,6 +820,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
             }
         }
         __syncthreads();   // dz1 complete
+        TD_MARK(9);          // dh1 + dW2 done
         // ---- db1, dW1: thread k < 120 ----
         if (t < DQ_H1) {
             float gb = 0.0f, gw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -745,8 +835,9 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 #pragma unroll
             for (int c = 0; c < 4; ++c) gw1[c] += gw[c];
         }
-        if (nxt_grp < n_groups) { __syncthreads(); gather_group(nxt_grp, i_nxt); }
+        if (nxt_grp < n_groups) { const row_req q_nxt = gather_request(i_nxt); __syncthreads(); gather_commit(nxt_grp, q_nxt); }
     }
+    TD_MARK_NOWAIT(10);      // main loop done
     // ---- the workgroup's slab: every gradient element once ----
     if (t < DQ_H2) { part[DQ_W3 + t] = g30; part[DQ_W3 + DQ_H2 + t] = g31; part[DQ_B2 + t] = gb2; }
     else if (t < DQ_H2 + 2) part[DQ_B3 + (t - DQ_H2)] = g30;
@@ -767,6 +858,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
         part[DQ_B1 + t] = gb1;
         *reinterpret_cast<float4*>(part + DQ_W1 + 4 * t) = make_float4(gw1[0], gw1[1], gw1[2], gw1[3]);
     }
+    TD_MARK(11);             // slab stores acknowledged
 }
 
 // grads[p] = sum over workgroup slabs in slab order; loss = sum of the slab losses * inv_count.  With `opt.params` set the same launch applies
