@@ -145,6 +145,7 @@ struct __attribute__((aligned(16))) da4_rec {
     int fin_len; float fin_ret; unsigned ep_lo, ep_hi;
 };
 struct __attribute__((aligned(16))) da4_smem {
+    float W2s[DQ_H2 * DQ_H1];       // layer 2 as it lies in memory, staged once per launch by coalesced loads: the forward waves pick their MFMA fragments from here
     da4_rec rec[2][2][DA_ENVS];     // [step parity][action][env]
     float qp[2][3][DA_ENVS][2];     // [step parity][forward wave][env][action]: partial head sums
     int expl[4][DA_ENVS];           // [step & 3][env]: bit 0 explore, bit 1 the random action
@@ -168,61 +169,63 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     const int g = mine ? i : N - 1;
     const int la = lg & 1;                                  // dynamics wave: the action this lane group speculates on
     const bool writer = phys && mine && lg == 0;
-    // ---- forward waves: resident operands ----
+    // ---- prologue: ONE memory latency deep (round 5, the lesson of dqn_td_kernel's stamps: a guarded load is a basic block that ends in s_waitcnt vmcnt(0), and a
+    //      float4 requested in MFMA-fragment layout — sixteen 64-byte segments 480 bytes apart — costs a CU's address unit ~40 cycles per instruction and wave).
+    //      Every request is unconditional and the same in all four waves (the dynamics wave drops the operands, the forward waves the env state): the observation
+    //      first, W2 as it lies in memory through LDS (10 fully coalesced float4 per thread), the thin operands, the env state; selects and LDS stores behind the last
+    //      request.  Until then: weights (forward waves, one branch) -> wait -> env state (dynamics wave, another branch) -> observation -> wait: 2.3 us. ----
+    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
+    float b30 = params[DQ_B3], b31 = params[DQ_B3 + 1];   // every wave derives the action
+    constexpr int W2V = DQ_H2 * DQ_H1 / 4, STG = (W2V + 255) / 256;
+    dq_f32x4 stg[STG];
+#pragma unroll
+    for (int q = 0; q < STG; ++q) {
+        const int v = (int)threadIdx.x + 256 * q < W2V ? (int)threadIdx.x + 256 * q : W2V - 1;   // (threads past the end repeat the last element)
+        stg[q] = reinterpret_cast<const dq_f32x4*>(params + DQ_W2)[v];
+    }
+    // thin operands of the forward waves.  120 = 30 x 4 and 84 = 21 x 4: a lane's four consecutive units are all inside or all outside.
     float w1a[8];
     dq_f32x4 b1v[8];
     float w2a[2][8][4];
     dq_f32x4 b2v[2], w3v[2][2];
-    float b30 = params[DQ_B3], b31 = params[DQ_B3 + 1];   // every wave derives the action
-    if (!phys) {
-        // every request unconditional, from a clamped address, masked afterwards: a guarded load is a basic block of its own (42 of them, 21 with a scalar wait), this form
-        // is ~30 vector loads in flight at once.  120 = 30 x 4 and 84 = 21 x 4: a lane's four consecutive units are all inside or all outside.
+    const int wf = phys ? 0 : w;   // (the dynamics wave requests wave 0's operands and zeroes them)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int ua = 16 * t + j, u0 = 16 * t + 4 * lg;
-            const float wv = params[DQ_W1 + 4 * (ua < DQ_H1 ? ua : DQ_H1 - 1) + lg];
-            const float4 bv = *reinterpret_cast<const float4*>(params + DQ_B1 + (u0 < DQ_H1 ? u0 : DQ_H1 - 4));
-            w1a[t] = ua < DQ_H1 ? wv : 0.0f;
-            b1v[t] = u0 < DQ_H1 ? dq_f32x4{bv.x, bv.y, bv.z, bv.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
+    for (int t = 0; t < 8; ++t) {
+        const int ua = 16 * t + j, u0 = 16 * t + 4 * lg;
+        w1a[t] = params[DQ_W1 + 4 * (ua < DQ_H1 ? ua : DQ_H1 - 1) + lg];
+        b1v[t] = *reinterpret_cast<const dq_f32x4*>(params + DQ_B1 + (u0 < DQ_H1 ? u0 : DQ_H1 - 4));
+    }
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            const int row = 16 * (2 * w + T) + j, rowc = row < DQ_H2 ? row : DQ_H2 - 1;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int col = 16 * t + 4 * lg;
-                const float4 v = *reinterpret_cast<const float4*>(params + DQ_W2 + DQ_H1 * rowc + (col < DQ_H1 ? col : DQ_H1 - 4));
-                const bool in = row < DQ_H2 && col < DQ_H1;
-                w2a[T][t][0] = in ? v.x : 0.0f; w2a[T][t][1] = in ? v.y : 0.0f; w2a[T][t][2] = in ? v.z : 0.0f; w2a[T][t][3] = in ? v.w : 0.0f;
-            }
-            const int o0 = 16 * (2 * w + T) + 4 * lg, oc = o0 < DQ_H2 ? o0 : DQ_H2 - 4;
-            const float4 bb = *reinterpret_cast<const float4*>(params + DQ_B2 + oc);
-            const float4 wa = *reinterpret_cast<const float4*>(params + DQ_W3 + oc), wb = *reinterpret_cast<const float4*>(params + DQ_W3 + DQ_H2 + oc);
-            const bool in = o0 < DQ_H2;
-            b2v[T] = in ? dq_f32x4{bb.x, bb.y, bb.z, bb.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            w3v[T][0] = in ? dq_f32x4{wa.x, wa.y, wa.z, wa.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            w3v[T][1] = in ? dq_f32x4{wb.x, wb.y, wb.z, wb.w} : dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { w1a[t] = 0.0f; b1v[t] = dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            b2v[T] = dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f}; w3v[T][0] = b2v[T]; w3v[T][1] = b2v[T];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) w2a[T][t][0] = w2a[T][t][1] = w2a[T][t][2] = w2a[T][t][3] = 0.0f;
-        }
+    for (int T = 0; T < 2; ++T) {
+        const int o0 = 16 * (2 * wf + T) + 4 * lg, oc = o0 < DQ_H2 ? o0 : DQ_H2 - 4;
+        b2v[T] = *reinterpret_cast<const dq_f32x4*>(params + DQ_B2 + oc);
+        w3v[T][0] = *reinterpret_cast<const dq_f32x4*>(params + DQ_W3 + oc);
+        w3v[T][1] = *reinterpret_cast<const dq_f32x4*>(params + DQ_W3 + DQ_H2 + oc);
     }
     // ---- env state: the dynamics wave owns it (every lane group holds a copy) ----
-    double sx = 0.0, sxd = 0.0, sth = 0.0, sthd = 0.0;
-    int elapsed = 0, eplen = 0;
-    float epret = 0.0f;
-    uint64_t episode = 0, stepctr0 = 0;
-    if (phys) {
-        sx = e.x[g]; sxd = e.x_dot[g]; sth = e.theta[g]; sthd = e.theta_dot[g];
-        elapsed = e.elapsed[g]; eplen = e.ep_len[g]; epret = e.ep_ret[g]; episode = e.episode[g]; stepctr0 = e.step_ctr[g];
+    double sx = e.x[g], sxd = e.x_dot[g], sth = e.theta[g], sthd = e.theta_dot[g];
+    int elapsed = e.elapsed[g], eplen = e.ep_len[g];
+    float epret = e.ep_ret[g];
+    uint64_t episode = e.episode[g], stepctr0 = e.step_ctr[g];
+    // ---- nothing above this line reads a loaded value ----
+    const dq_f32x4 z4 = dq_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int ua = 16 * t + j, u0 = 16 * t + 4 * lg;
+        if (phys || !(ua < DQ_H1)) w1a[t] = 0.0f;
+        if (phys || !(u0 < DQ_H1)) b1v[t] = z4;
     }
-    float4 ob = reinterpret_cast<const float4*>(obs_cur)[g];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const int o0 = 16 * (2 * wf + T) + 4 * lg;
+        if (phys || !(o0 < DQ_H2)) { b2v[T] = z4; w3v[T][0] = z4; w3v[T][1] = z4; }
+    }
+    if (!phys) { sx = 0.0; sxd = 0.0; sth = 0.0; sthd = 0.0; elapsed = 0; eplen = 0; epret = 0.0f; episode = 0; stepctr0 = 0; }
+#pragma unroll
+    for (int q = 0; q < STG; ++q) {
+        const int v = (int)threadIdx.x + 256 * q < W2V ? (int)threadIdx.x + 256 * q : W2V - 1;
+        reinterpret_cast<dq_f32x4*>(sm.W2s)[v] = stg[q];
+    }
     int st_cnt = 0, st_len = 0, st_max = 0;
     auto draw = [&](int s) {   // exploration words of step s -> bit 0 explore, bit 1 random action (dqn.py:86-90)
         uint32_t r[4];
@@ -234,6 +237,17 @@ dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long lo
     if (phys && lg == 0) sm.expl[0][j] = draw(0);
     asm volatile("" : "+v"(ob.x), "+v"(ob.y), "+v"(ob.z), "+v"(ob.w), "+v"(sx), "+v"(sxd), "+v"(sth), "+v"(sthd), "+v"(elapsed), "+v"(eplen), "+v"(epret), "+v"(episode), "+v"(stepctr0), "+v"(b30), "+v"(b31));
     __syncthreads();
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {   // the layer-2 fragments of this lane (zeros in the dynamics wave and in the padding)
+        const int row = 16 * (2 * wf + T) + j, rowc = row < DQ_H2 ? row : DQ_H2 - 1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int col = 16 * t + 4 * lg;
+            const dq_f32x4 v = *reinterpret_cast<const dq_f32x4*>(&sm.W2s[DQ_H1 * rowc + (col < DQ_H1 ? col : DQ_H1 - 4)]);
+            const bool in = !phys && row < DQ_H2 && col < DQ_H1;
+            w2a[T][t][0] = in ? v[0] : 0.0f; w2a[T][t][1] = in ? v[1] : 0.0f; w2a[T][t][2] = in ? v[2] : 0.0f; w2a[T][t][3] = in ? v[3] : 0.0f;
+        }
+    }
     int a = 0;
     int ex = sm.expl[0][j];   // exploration word of the step about to run; the next step's is fetched together with the head sums behind the barrier (off the forward's chain)
 #ifdef DA_STAMPS
