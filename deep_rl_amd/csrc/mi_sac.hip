@@ -573,7 +573,7 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
     if (role >= 2) issue_thin_q(q + (role - 2) * SQ_NP, th); else
     issue_thin_actor(actor, th);
     // the batch rows: thread (r = t / 4, k = t & 3) derives row r's index itself (four threads repeat the draw: no LDS hand-over, no barrier) and requests its
-    // element; the weight stream is started AFTER these requests (loads return in order: the first pass cannot start before layer 1 has the rows anyway)
+    // element; the weight stream is started AFTER the rows are in LDS (loads return in order: the first pass cannot start before layer 1 has the rows anyway)
     float gx = 0.0f, gxn = 0.0f;
     if (t < SR * 4) {
         const int r = t >> 2, k = t & 3;
@@ -594,11 +594,16 @@ sac_critic_kernel(const float* __restrict__ q, const float* __restrict__ qt, con
         gxn = k < 3 ? observations[3 * nx + k] : 0.0f;
         if (k == 0) { sm.cur[r] = i; sm.nxt[r] = nx; }
     }
-    stream_prime<TR>(role >= 2 ? (role == 2 ? QW0 : QW1) : AW, ws);
-    float e_row = 0.0f;
-    if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
+    // Order (round 5, from the ISA): the row noise is arithmetic and runs while the gathers are on their way; the rows go to LDS BEFORE the weight stream is primed.
+    // With ~100 stream requests between the gathers and their LDS stores the wait in front of the stores could only be written as vmcnt(62) — it waited for the
+    // gathers AND the first 35 stream requests — and the noise, computed behind the stream, landed in a register the allocator had also given to a stream request:
+    // s_waitcnt vmcnt(0) in wave 0, i.e. the rows barrier waited for the whole primed stream (rows in LDS 2.0 - 2.5 us after entry).
+    // (the noise is drawn by WAVE 1: Philox + Box-Muller are ~1,000 dependent cycles, as long as wave 0's Philox + 64-bit modulo in front of the gathers)
+    if (t >= 64 && t < 64 + SR) { const int r = t - 64, b = row0 + r < batch ? row0 + r : batch - 1; sm.noise[r] = eps ? eps[b] : keyed_normal(seed, (2ull << 40) + update, (uint64_t)b); }
     if (t < SR * 4) { sm.x[t >> 2][t & 3] = gx; sm.xn[t >> 2][t & 3] = gxn; }
+    stream_prime<TR>(role >= 2 ? (role == 2 ? QW0 : QW1) : AW, ws);
     __syncthreads();
+    const float e_row = t < SR ? sm.noise[t] : 0.0f;
     SAC_MARK(0, (int)blockIdx.y & 3, 1);
     unsigned long long* xw = reinterpret_cast<unsigned long long*>(ws_ + ws_xch_off(batch)) + 6 * (size_t)row0;
     if (role >= 2) {   // critic role - 2 (quad), critic 2 fed the finished TD target (split)
@@ -710,16 +715,17 @@ sac_actor_kernel(const float* __restrict__ actor, const float* __restrict__ q, c
     issue_thin_actor(actor, th);
     float gv = 0.0f;
     if (t < SR * 3) { const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1; gv = observations[3 * idx[b] + k]; }
-    stream_prime<TR>(AW, ws);   // (after the row requests: loads return in order)
+    // (the noise: arithmetic, drawn by wave 1 while wave 0 waits for the index -> row requests)
+    if (t >= 64 && t < 64 + SR) { const int r = t - 64, b = row0 + r < batch ? row0 + r : batch - 1; sm.noise[r] = eps ? eps[b] : keyed_normal(seed, ((logp_only ? 4ull : 3ull) << 40) + update, (uint64_t)b); }
     if (t < SR * 3) {
         const int r = t / 3, k = t % 3; const int b = row0 + r < batch ? row0 + r : batch - 1;
         sm.x[r][k] = gv;
         // kept for an alpha step that rides on a LATER launch, in the slot that an alpha step owed to THIS launch does not read (sac_owed_alpha_role reads ow.slot)
         if (!logp_only && !second && row0 + r < batch) ws_[ws_stash_off(batch) + (size_t)stash_slot * 3 * (size_t)ws_kp(batch) + 3 * (size_t)b + k] = gv;
     }
-    float e_row = 0.0f;
-    if (t < SR) { const int b = row0 + t < batch ? row0 + t : batch - 1; e_row = eps ? eps[b] : keyed_normal(seed, ((logp_only ? 4ull : 3ull) << 40) + update, (uint64_t)b); }
+    stream_prime<TR>(AW, ws);   // (behind the rows' LDS stores: see sac_critic_kernel)
     __syncthreads();
+    const float e_row = t < SR ? sm.noise[t] : 0.0f;
     SAC_MARK(1, (int)blockIdx.y & 3, 1);
     layer1<3>(sm, th, sm.x, sm.b0);                              // actor h1 -> b0 (kept for the backward)
     const float wm = th.h0, wl = th.h1;                          // this unit's head weights, kept for the actor's backward
@@ -1291,14 +1297,16 @@ sac_act_kernel(mi_env e, const float* __restrict__ actor, long long global_step,
         wstream ws; thin_t th; f32x4 acc[SA_NT];
         issue_thin_actor(actor, th);
         const float* const AW = TR ? actor_t : actor + AC_W2;
-        stream_prime<TR>(AW, ws);
-        if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; sm.x[r][k] = obs_cur[3 * (size_t)g + k]; }
-        float eps = 0.0f;
+        float ov = 0.0f;   // the observation is requested first, the noise is arithmetic behind the request, the weight stream is primed behind the LDS store (see sac_critic_kernel)
+        if (threadIdx.x < SR * 3) { const int r = threadIdx.x / 3, k = threadIdx.x % 3; const int g = row0 + r < N ? row0 + r : N - 1; ov = obs_cur[3 * (size_t)g + k]; }
         if (threadIdx.x < SR) {
             const int g = row0 + threadIdx.x < N ? row0 + threadIdx.x : N - 1;
-            eps = forced_eps ? forced_eps[g] : keyed_normal(e.seed, (1ull << 40) + e.env_id_base + (uint64_t)g, (uint64_t)global_step);
+            sm.noise[threadIdx.x] = forced_eps ? forced_eps[g] : keyed_normal(e.seed, (1ull << 40) + e.env_id_base + (uint64_t)g, (uint64_t)global_step);
         }
+        if (threadIdx.x < SR * 3) sm.x[threadIdx.x / 3][threadIdx.x % 3] = ov;
+        stream_prime<TR>(AW, ws);
         __syncthreads();
+        const float eps = threadIdx.x < SR ? sm.noise[threadIdx.x] : 0.0f;
         layer1<3>(sm, th, sm.x, sm.b0);
         __syncthreads();
         actor_forward2<false, TR>(sm, actor, AW, nullptr, sm.b0, ws, acc, eps);
