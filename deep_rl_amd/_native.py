@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
-ABI_VERSION = 105   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
+ABI_VERSION = 106   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
@@ -121,6 +121,7 @@ SIGNATURES = {
     "mi_per_update_priorities_sums": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I64, _F, _VP, _VP]),
     "mi_dueling_pack": (_I, [_VP, _VP, _VP]),
     "mi_dueling_unpack_grads": (_I, [_VP, _VP, _VP]),
+    "mi_dueling_td_update": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _U64, _U64, _I64, _VP]),
     "mi_env_step_cont": (_I, [_VP] * 10),
     "mi_sac_actor_sample": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "mi_sac_q_forward": (_I, [_VP, _VP, _VP, _I, _VP, _VP]),

@@ -877,7 +877,35 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 
 // grads[p] = sum over workgroup slabs in slab order; loss = sum of the slab losses * inv_count.  With `opt.params` set the same launch applies
 // optimizer.step() (torch Adam without clipping, dqn.py:68,133) to the element it has just summed: no launch of its own in single-process runs.
-struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, rbc2, eps; };
+// Dueling layout (q_network1.parameters(), dueling_dqn.py:24-40): features as DQN | value W[84] b | advantage W[2][84] b[2] = MI_DUELING_NPARAMS
+#define DU_WV 10764
+#define DU_BV 10848
+#define DU_WA 10849
+#define DU_BA 11017
+#define DU_NP 11019
+// `du_params` set (mi_dueling_td_update): params is the plain-DQN IMAGE of a dueling net (see the dueling block below), m / v / du_params / du_grads are in the dueling
+// layout; the element that has summed a plain gradient maps it back (mi_dueling_unpack_grads' expressions), steps the dueling parameters and rewrites the image
+// (mi_dueling_pack's expressions): the thread of head element (action 0, unit j) also sums action 1's slabs and owns Wv[j], Wa[0][j], Wa[1][j]; likewise the biases.
+struct dqn_opt_t { float* params; float* m; float* v; float w1, b2, w2, step_size, rbc2, eps; float* du_params; float* du_grads; };
+__device__ __forceinline__ float dqn_opt_step(const dqn_opt_t& o, float p, float g, int at) {   // Adam on optimizer-state element `at`
+    float mi = o.m[at], vi = o.v[at];
+    const float r = mi_adam_elem(p, g, mi, vi, o.w1, o.b2, o.w2, o.step_size, o.rbc2, o.eps);
+    o.m[at] = mi; o.v[at] = vi;
+    return r;
+}
+// one head column (or the bias triple): plain gradients g0 / g1 of the two actions -> the three dueling parameters stepped, the two image elements rewritten
+__device__ __forceinline__ void dueling_head_step(const dqn_opt_t& o, float g0, float g1, int at_v, int at_a0, int at_a1, int img0, int img1) {
+    const float gv = g0 + g1;                                  // dWv = sum_a g3[a]
+    const float ga0 = g0 - (g0 + g1) / 2.0f, ga1 = g1 - (g0 + g1) / 2.0f;   // dWa[k] = g3[k] - mean_a g3[a]
+    o.du_grads[at_v] = gv; o.du_grads[at_a0] = ga0; o.du_grads[at_a1] = ga1;
+    const float wv = dqn_opt_step(o, o.du_params[at_v], gv, at_v);
+    const float wa0 = dqn_opt_step(o, o.du_params[at_a0], ga0, at_a0);
+    const float wa1 = dqn_opt_step(o, o.du_params[at_a1], ga1, at_a1);
+    o.du_params[at_v] = wv; o.du_params[at_a0] = wa0; o.du_params[at_a1] = wa1;
+    const float mean = (wa0 + wa1) / 2.0f;                     // W3eff[a] = Wv + (Wa[a] - mean_a Wa)
+    o.params[img0] = wv + (wa0 - mean);
+    o.params[img1] = wv + (wa1 - mean);
+}
 __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
                                                          float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
     MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
@@ -886,7 +914,7 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
         // the optimizer state is requested before the slabs, and the slabs 16 at a time with every load in flight at once (the kernel is one memory
         // latency deep instead of one per group of four); the sum keeps its order: accumulator b & 3 takes slab b, then (0 + 1) + (2 + 3)
         float pi = 0.0f, mi = 0.0f, vi = 0.0f;
-        if (opt.params) { pi = opt.params[p]; mi = opt.m[p]; vi = opt.v[p]; }
+        if (opt.params && (!opt.du_params || p < DQ_W3)) { pi = opt.params[p]; mi = opt.m[p]; vi = opt.v[p]; }   // (dueling: the image's feature layers are copies of the parameters)
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         int b = 0;
         for (; b + 16 <= n_slabs; b += 16) {
@@ -899,7 +927,21 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
         for (; b < n_slabs; ++b) acc[b & 3] += workspace[(size_t)b * TD_SLAB + p];
         const float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         grads[p] = g;
-        if (opt.params) {   // the formula of clip_adam_kernel at coef = 1 (max_norm = inf), bit for bit (mi_adam_elem)
+        if (opt.du_params) {
+            if (p < DQ_W3) {                                   // feature layers: the same index in both layouts; the image holds a copy
+                opt.du_grads[p] = g;
+                const float w = mi_adam_elem(pi, g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
+                opt.du_params[p] = w; opt.params[p] = w;
+                opt.m[p] = mi; opt.v[p] = vi;
+            } else if (p < DQ_W3 + DQ_H2 || p == DQ_B3) {      // action 0's element: sums action 1's slabs too (same order) and steps the column
+                const int p1 = p < DQ_B3 ? p + DQ_H2 : p + 1;
+                float a1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int b1 = 0; b1 < n_slabs; ++b1) a1[b1 & 3] += workspace[(size_t)b1 * TD_SLAB + p1];
+                const float g1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+                if (p < DQ_B3) { const int j = p - DQ_W3; dueling_head_step(opt, g, g1, DU_WV + j, DU_WA + j, DU_WA + DQ_H2 + j, p, p1); }
+                else dueling_head_step(opt, g, g1, DU_BV, DU_BA, DU_BA + 1, p, p1);
+            }
+        } else if (opt.params) {   // the formula of clip_adam_kernel at coef = 1 (max_norm = inf), bit for bit (mi_adam_elem)
             opt.params[p] = mi_adam_elem(pi, g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
             opt.m[p] = mi; opt.v[p] = vi;
         }
@@ -1048,7 +1090,7 @@ extern "C" int mi_dqn_td_update(float* params, const float* target_params, const
     dqn_opt_t o;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     o.params = params; o.m = exp_avg; o.v = exp_avg_sq; o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2);
-    o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps;
+    o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps; o.du_params = nullptr; o.du_grads = nullptr;
     return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / batch, workspace, grads, loss,
                        weights, td_abs, o, sample_seed, sample_update, sample_upper, stream);
 }
@@ -1057,12 +1099,7 @@ extern "C" int mi_dqn_td_update(float* params, const float* target_params, const
 // values + (advantages - mean(advantages)) is LINEAR in the 84 features, so a dueling net equals a plain 4->120->84->2 net whose
 // head is W3eff[a] = Wv + (Wa[a] - mean_a Wa), b3eff[a] = bv + (ba[a] - mean_a ba): the acting and TD kernels run unchanged on the
 // packed parameters, and the chain rule maps the plain head's gradient back: dWv = sum_a g3[a], dWa[k] = g3[k] - mean_a g3[a].
-// Dueling layout (q_network1.parameters()): features as DQN | value W[84] b | advantage W[2][84] b[2] = MI_DUELING_NPARAMS.
-#define DU_WV 10764
-#define DU_BV 10848
-#define DU_WA 10849
-#define DU_BA 11017
-#define DU_NP 11019
+// Dueling layout (q_network1.parameters()): features as DQN | value W[84] b | advantage W[2][84] b[2] = MI_DUELING_NPARAMS (DU_* above dqn_opt_t).
 __global__ void __launch_bounds__(256) dueling_pack_kernel(const float* __restrict__ d, float* __restrict__ q) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < DQ_W3) q[i] = d[i];                                   // feature layers
@@ -1103,6 +1140,31 @@ extern "C" int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_gr
     dueling_unpack_kernel<<<(DU_NP + 255) / 256, 256, 0, (hipStream_t)stream>>>(dqn_grads, dueling_grads);
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+
+// dueling_dqn.py:109-129 as ONE call (single process, no clipping): TD gradient on the plain-DQN images + slab sum, and — in the slab-sum launch, batches below
+// DR_MIN_SLABS row groups; behind it as three launches otherwise — the gradient mapped back, Adam on the dueling parameters, the image rewritten.  Bit-identical to
+// mi_dqn_td_grad(images) + mi_dueling_unpack_grads + mi_clip_adam(max_norm = +inf) on the dueling vector + mi_dueling_pack.
+extern "C" int mi_dueling_td_update(float* params_img, const float* target_img, const float* observations, const int64_t* actions, const float* rewards,
+                                    const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, void* workspace, float* grads, float* loss,
+                                    float* dueling_params, float* dueling_grads, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
+                                    double eps, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* stream) {
+    MI_CHECK_ARG(params_img && dueling_params && dueling_grads && exp_avg && exp_avg_sq && step >= 1, "NULL pointer / bad step");
+    const int groups8 = (batch + TD_R - 1) / TD_R;
+    if (groups8 >= DR_MIN_SLABS) {   // the many-slab sum keeps its own shape: epilogue as launches of its own (still no Python between them)
+        int rc = dqn_td_impl(params_img, target_img, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / batch, workspace, grads, loss,
+                             nullptr, nullptr, dqn_no_opt(), sample_seed, sample_update, sample_upper, stream);
+        if (rc) return rc;
+        if ((rc = mi_dueling_unpack_grads(grads, dueling_grads, stream))) return rc;
+        if ((rc = mi_clip_adam(dueling_params, dueling_grads, exp_avg, exp_avg_sq, DU_NP, step, lr, beta1, beta2, eps, INFINITY, nullptr, stream))) return rc;
+        return mi_dueling_pack(dueling_params, params_img, stream);
+    }
+    dqn_opt_t o;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    o.params = params_img; o.m = exp_avg; o.v = exp_avg_sq; o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2);
+    o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps; o.du_params = dueling_params; o.du_grads = dueling_grads;
+    return dqn_td_impl(params_img, target_img, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / batch, workspace, grads, loss,
+                       nullptr, nullptr, o, sample_seed, sample_update, sample_upper, stream);
 }
 
 // ---- Prioritized replay (reference deep_rl/per.py) as epilogues on the DQN path ---------------------------------

@@ -216,10 +216,30 @@ class DuelingDQNEngine(DQNEngine):
             self.loss.copy_(self._dgradbuf[N.DUELING_NPARAMS:N.DUELING_NPARAMS + 1])
 
     def train_step(self, indices=None):
-        self.sample(indices)
-        self.td_grad()
-        self.optimizer.step(self.dueling_grads)
-        self.q.repack()
+        """One optimisation step (dueling_dqn.py:109-129).  Single process without gradient clipping: ONE call, two launches — the TD launch draws the batch itself and the
+        launch that sums the gradient slabs maps the gradient back, steps the dueling parameters and rewrites the plain-DQN image (mi_dueling_td_update, bit-identical to
+        td_grad() + optimizer.step() + repack())."""
+        g = self.optimizer.param_groups[0]
+        if self.world_size == 1 and not _FORCE_SHARDED and g["max_grad_norm"] == float("inf") and type(self).td_grad is DuelingDQNEngine.td_grad:
+            o = self.optimizer
+            upper = 0
+            if indices is None and type(self).sample is DQNEngine.sample:
+                upper = min(self.global_step, self.slots) * self.N
+                if upper == 0:
+                    raise N.MiError("train_step: the replay ring is empty (global_step == 0); act() before training")
+            else:
+                self.sample(indices)
+            N.check(N.lib().mi_dueling_td_update(
+                N.ptr(self.q.eff), N.ptr(self.target.eff), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
+                N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(self.workspace), N.ptr(self.grads), N.ptr(self.loss),
+                N.ptr(self.q.flat), N.ptr(self.dueling_grads), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1],
+                g["eps"], self.env._seed, self.update_index, upper, self._s()), "mi_dueling_td_update")
+            o.step_count += 1   # committed only once the call has accepted the step
+        else:
+            self.sample(indices)
+            self.td_grad()
+            self.optimizer.step(self.dueling_grads)
+            self.q.repack()
         self.update_index += 1
         self._maybe_check_replicas()
 

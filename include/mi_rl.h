@@ -50,9 +50,9 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier, mi_comm_p2p_set_colocated; mi_test_contraction; mi_sac_shadow_*).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier, mi_comm_p2p_set_colocated; mi_test_contraction; mi_sac_shadow_*; 106: mi_dueling_td_update).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
-#define MI_VERSION 105
+#define MI_VERSION 106
 #define MI_PPO_NPARAMS 9155
 #define MI_PPO_ACTOR_NPARAMS 4610
 #define MI_OBS_DIM 4
@@ -336,6 +336,15 @@ int mi_dqn_td_update_sharded(float* params, const float* target_params, const fl
 #define MI_DUELING_NPARAMS 11019
 int mi_dueling_pack(const float* dueling_params, float* dqn_params, void* stream);
 int mi_dueling_unpack_grads(const float* dqn_grads, float* dueling_grads, void* stream);
+/* One optimisation step of dueling_dqn.py (:109-129) as ONE call (single process, no gradient clipping): the TD launch on the plain-DQN images `params_img` /
+ * `target_img` (mi_dueling_pack's output), and in the launch that sums the gradient slabs the gradient mapped back to the dueling layout (-> dueling_grads), Adam on
+ * `dueling_params` (exp_avg / exp_avg_sq: dev f32 [MI_DUELING_NPARAMS]) and `params_img` rewritten — bit-identical to mi_dqn_td_grad(images) + mi_dueling_unpack_grads +
+ * mi_clip_adam(max_norm = +inf) + mi_dueling_pack.  grads: dev f32 [MI_DQN_NPARAMS] (the plain gradient).  sample_upper as in mi_dqn_td_update.  Batches of 512 rows
+ * and more keep the many-slab sum and run the three epilogue launches behind it, inside this call. */
+int mi_dueling_td_update(float* params_img, const float* target_img, const float* observations, const int64_t* actions, const float* rewards,
+                         const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, void* workspace, float* grads, float* loss,
+                         float* dueling_params, float* dueling_grads, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
+                         double eps, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* stream);
 
 /* ---- Prioritized replay (reference deep_rl/per.py, run on CartPole-v1) as epilogues on the DQN calls.
  * priorities: dev f32 [slots, N] beside the replay ring; max_priority: dev f32 [1] (per.py:84, initial 1e-2); owner: dev i32 [slots*N],

@@ -149,3 +149,35 @@ def test_script_reference_shape_n1():
     assert '"learning_starts": 600' in out.stdout and '"global_step": 6000' in out.stdout
     assert "NETS DuelingQNetwork 11019 11019 541" in out.stdout     # updates at steps 600, 610, ..., 6000
     assert np.isfinite(float(out.stdout.split("LOSS")[1].split()[0]))
+
+
+@pytest.mark.parametrize("batch", [128, 96, 1000])
+def test_one_call_update_is_bitwise_the_launch_sequence(dev, batch):
+    """mi_dueling_td_update (round 5: TD launch + ONE launch that sums the slabs, maps the gradient back, steps the dueling parameters and rewrites the plain-DQN image;
+    batch 1000: the many-slab sum + three epilogue launches inside the call) against td_grad() + optimizer.step() + repack() — parameters, image, both moments, both
+    gradients, loss and the drawn indices bit for bit over 12 chained steps with target syncs in between (dueling_dqn.py:109-137)."""
+    import deep_rl_amd.dqn_engine as E
+
+    def run(fused):
+        E._FORCE_SHARDED = not fused          # the launch sequence: sample, TD + slab sum, unpack, clip + Adam, pack
+        try:
+            eng = _engine(dev, 64, slots=32, batch_size=batch, learning_starts=0, total_timesteps=10_000)
+            eng.reset()
+            out = []
+            for k in range(12):
+                eng.act(10)
+                eng.train_step()
+                if k % 5 == 4:
+                    eng.sync_target()
+                o = eng.optimizer
+                out.append([t.clone() for t in (eng.q.flat, eng.q.eff, o.exp_avg, o.exp_avg_sq, eng.grads, eng.dueling_grads, eng.loss, eng.batch_inds)])
+            assert o.step_count == 12
+            return out
+        finally:
+            E._FORCE_SHARDED = False
+
+    a, b = run(True), run(False)
+    for k, (x, y) in enumerate(zip(a, b)):
+        for name, u, v in zip(("params", "image", "exp_avg", "exp_avg_sq", "plain grads", "dueling grads", "loss", "indices"), x, y):
+            assert torch.equal(u, v), (k, name, (u.float() - v.float()).abs().max().item())
+    assert torch.isfinite(a[-1][0]).all() and not torch.equal(a[-1][0], a[0][0])
