@@ -534,9 +534,6 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
     MI_INSIDE_SCOPE(MI_PROF_DQN_TD);
     const int t = threadIdx.x;
     TD_MARK_NOWAIT(0);   // entry
-#ifdef TD_PROBE_LATENCY
-    { float dummy_ = params[t] + target_params[t]; asm volatile("" :: "v"(dummy_)); TD_MARK(12); }   // one cold load of each net, waited for: the raw first-touch latency
-#endif
     const int n_groups = (batch + R - 1) / R;
     float* part = workspace + (size_t)blockIdx.x * TD_SLAB;
     // The batch rows of a group: thread (net nt = t / 4R, row r, component k = t & 3) < 8R derives row r's index ITSELF (the four threads of a row repeat the draw or
@@ -622,11 +619,7 @@ dqn_td_kernel(const float* __restrict__ params, const float* __restrict__ target
 #pragma unroll
     for (int q = 0; q < STG; ++q) {
         const int v = t + 256 * q < 2 * W2V ? t + 256 * q : 2 * W2V - 1;
-#ifdef TD_PROBE_SAME_NET   // timing experiment: both halves from the online net (half the distinct lines)
-        stg[q] = v < W2V ? reinterpret_cast<const f32x4_t*>(params + DQ_W2)[v] : reinterpret_cast<const f32x4_t*>(params + DQ_W2)[v - W2V];
-#else
         stg[q] = v < W2V ? reinterpret_cast<const f32x4_t*>(params + DQ_W2)[v] : reinterpret_cast<const f32x4_t*>(target_params + DQ_W2)[v - W2V];
-#endif
     }
     f32x4_t wA[3][8], bias2[3];
 #pragma unroll

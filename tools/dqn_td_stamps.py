@@ -15,7 +15,7 @@ eng = D.DQNEngine(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=256, batc
 eng.reset()
 f = N.lib().mi_debug_dqn_td_marks; f.argtypes = [C.c_void_p]; f.restype = C.c_int
 names = ["entry", "index derived", "prologue requests issued", "rows in LDS (first barrier)", "layer 1", "layer 2 (MFMA; weight operands landed)", "layer 3 (84-long dots)",
-         "TD target + loss", "backward through layer 3", "dh1 + dW2 (MFMA)", "db1 + dW1 = main loop done", "slab stored", "(probe build) one cold load of each net returned"]
+         "TD target + loss", "backward through layer 3", "dh1 + dW2 (MFMA)", "db1 + dW1 = main loop done", "slab stored"]
 acc = []
 for it in range(300):
     eng.act(10); eng.train_step()
@@ -23,7 +23,7 @@ for it in range(300):
         torch.cuda.synchronize()
         mk = (C.c_ulonglong * 256)()
         assert f(mk) == 0
-        acc.append(np.array(mk, dtype=np.float64).reshape(16, 16)[:, :13] / 100.0)
+        acc.append(np.array(mk, dtype=np.float64).reshape(16, 16)[:, :12] / 100.0)
 m = np.stack(acc)                                  # [sample][workgroup][mark] in us
 rel = m - m[:, :, :1].min(axis=1, keepdims=True)   # since the first workgroup's entry
 print("dqn_td_kernel, batch %d: us since the first workgroup's entry (mean over %d launches; workgroup mean / slowest workgroup), step = mean since the previous mark" % (batch, len(acc)))
