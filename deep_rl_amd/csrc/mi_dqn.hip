@@ -1247,6 +1247,48 @@ __global__ void __launch_bounds__(256) per_sums1_kernel(const double* __restrict
     }
 }
 
+// Sixteen steps of a prefix-sum walk (the sampler's contract: while the remainder x is >= the next value, subtract it and advance — sequential, in index order, in
+// double) for the lanes whose bit is set in `alive`; x, the advance count and `alive` come back updated.  The step is predicated on EXEC instead of selected: v_cmpx
+// narrows EXEC to the lanes that go on, the subtraction and the count then simply do not happen in the others — 3 vector instructions per step against the ~14 the
+// compiler makes of `go = go & (x >= v); x = go ? x - v : x; m += go` (compare to a scalar mask, mask arithmetic, two selects for the double, a select and an add for the
+// count, and scalar-register spills): -DPER_STAMPS measured 73 cycles per step for that form, the whole walk being one wave's instruction issue.  The same subtractions
+// of the same values in the same order.  EXEC is restored before the block ends.
+__device__ __forceinline__ void per_walk16(double& x, int& cnt, unsigned long long& alive, const double (&v)[16]) {
+    unsigned long long save;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[al]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v0]\n\tv_add_f64 %[x], %[x], -%[v0]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v1]\n\tv_add_f64 %[x], %[x], -%[v1]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v2]\n\tv_add_f64 %[x], %[x], -%[v2]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v3]\n\tv_add_f64 %[x], %[x], -%[v3]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v4]\n\tv_add_f64 %[x], %[x], -%[v4]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v5]\n\tv_add_f64 %[x], %[x], -%[v5]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v6]\n\tv_add_f64 %[x], %[x], -%[v6]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v7]\n\tv_add_f64 %[x], %[x], -%[v7]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v8]\n\tv_add_f64 %[x], %[x], -%[v8]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v9]\n\tv_add_f64 %[x], %[x], -%[v9]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v10]\n\tv_add_f64 %[x], %[x], -%[v10]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v11]\n\tv_add_f64 %[x], %[x], -%[v11]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v12]\n\tv_add_f64 %[x], %[x], -%[v12]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v13]\n\tv_add_f64 %[x], %[x], -%[v13]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v14]\n\tv_add_f64 %[x], %[x], -%[v14]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "v_cmpx_ge_f64_e32 vcc, %[x], %[v15]\n\tv_add_f64 %[x], %[x], -%[v15]\n\tv_add_u32_e32 %[c], 1, %[c]\n\t"
+        "s_mov_b64 %[al], exec\n\ts_mov_b64 exec, %[sv]"
+        : [x] "+v"(x), [c] "+v"(cnt), [al] "+s"(alive), [sv] "=&s"(save)
+        : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]), [v8] "v"(v[8]), [v9] "v"(v[9]), [v10] "v"(v[10]), [v11] "v"(v[11]), [v12] "v"(v[12]), [v13] "v"(v[13]), [v14] "v"(v[14]), [v15] "v"(v[15])
+        : "vcc");
+}
+#ifdef PER_STAMPS   // diagnostic build: the phases of per_sample_kernel on the wall clock (s_memrealtime, 100 MHz), thread 0; tools/per_sample_stamps.py
+__device__ unsigned long long per_mark_dbg[16];
+#define PER_MARK(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) { unsigned long long rt_; \
+                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); per_mark_dbg[k] = rt_; } \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int mi_debug_per_sample_marks(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(per_mark_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+#else
+#define PER_MARK(k) do {} while (0)
+#endif
 // indices (sample != 0) by the prefix-sum descent, then the importance weights of per.py:131,145-146, normalised by their maximum
 __global__ void __launch_bounds__(256)
 per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio, long long n, const double* __restrict__ s0, const double* __restrict__ a0,
@@ -1255,7 +1297,14 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
     __shared__ float wmax[16];
     __shared__ double l1s[PER_MAX_L1];                      // the level-1 sums: walked by every draw
     __shared__ double tot[2];
+    // wave-private transposition buffer: the 64 values a draw walks at level 0 (and then its 64 priorities) are 512 (256) contiguous bytes, but a lane per draw
+    // fetching them itself makes every load instruction touch 64 different lines (~64 cycles of the CU's address unit each, 64 instructions: -DPER_STAMPS showed the
+    // "round trip" at 3.5 us).  The wave fetches draw d's values with ONE coalesced instruction (chunk start from lane d by v_readlane), parks them in row d, and every
+    // lane then reads its own row (row stride 65: conflict-free for floats, two-way for doubles).
+    __shared__ double stg[4][PER_CHUNK][PER_CHUNK + 1];
+    const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
     const long long n0 = per_n0(n), n1 = per_n0(n0);
+    PER_MARK(0);
     if (a0) {   // incremental form: level 1 is kept current in memory (a0 here = the level-1 sums of p^alpha); only the totals remain (per_sums1_kernel's order)
         __shared__ double a1s[PER_MAX_L1];
         for (long long m = threadIdx.x; m < n1; m += blockDim.x) { l1s[m] = s1[m]; a1s[m] = a0[m]; }
@@ -1272,6 +1321,7 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
         if (threadIdx.x == 0) { tot[0] = totals[0]; tot[1] = totals[1]; }
     }
     __syncthreads();
+    PER_MARK(1);   // level 1 staged, totals taken
     const double total = tot[0];
     const float total_alpha = (float)tot[1];
     float mx = 0.0f;
@@ -1282,6 +1332,7 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
             mi_philox(seed, update, (uint64_t)b, STREAM_PER, r);
             const double u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
             double x = u * total;
+            PER_MARK(2);   // keyed draw
             // the three walks subtract in index order (the contract); each level's 64 values are requested together, so a draw costs
             // three memory round trips instead of up to 384 dependent ones.  32-bit indices (capacity <= 4M entries), no guarded reads and
             // no short-circuit conditions: every guard of this loop nest used to be a branch or a 64-bit scalar compare held in SGPRs
@@ -1294,39 +1345,101 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
 #pragma unroll
                 for (int j = 0; j < PER_CHUNK; ++j) v[j] = l1s[gq + j < PER_MAX_L1 ? gq + j : PER_MAX_L1 - 1];
                 const int left = n1_i - gq;                            // a step may advance only while a next level-1 entry exists
+                // (round 5, -DPER_STAMPS: a step cost 78 cycles as compare(x) -> mask -> select(x) -> next compare, one dependent chain through the vector unit, the
+                // scalar mask and back.  While a draw is alive x IS the unconditional remainder r, so the compare reads r: the only long chain left is r's 64
+                // subtractions; the mask, the count and the frozen x are short side chains.  The same subtractions of the same values in the same order.)
+                if (left >= PER_CHUNK) {                               // (uniform) a full group: 64 steps, 63 when its last value is the last of the level
+                    if (left == PER_CHUNK) v[PER_CHUNK - 1] = __builtin_inf();
+                    unsigned long long al = __ballot(go);
 #pragma unroll
-                for (int jj = 0; jj < PER_CHUNK; ++jj) { go = go & (jj + 1 < left) & (x >= v[jj]); x = go ? x - v[jj] : x; m += go ? 1 : 0; }
+                    for (int q4 = 0; q4 < PER_CHUNK / 16; ++q4) {
+                        const double (&vq)[16] = *reinterpret_cast<const double (*)[16]>(&v[16 * q4]);
+                        per_walk16(x, m, al, vq);
+                    }
+                    go = (al >> (threadIdx.x & 63)) & 1ull;
+                } else {
+                    double rr = x;
+#pragma unroll
+                    for (int jj = 0; jj < PER_CHUNK; ++jj) { go = go & (jj + 1 < left) & (rr >= v[jj]); rr = rr - v[jj]; x = go ? rr : x; m += go ? 1 : 0; }
+                }
                 if (!__any(go)) break;                                 // wave-uniform exit: every draw of the wave has stopped
             }
+            PER_MARK(3);   // level-1 walk (up to 256 steps)
             int k = m * PER_CHUNK;
             {
                 const int cnt = k + PER_CHUNK < n0_i ? PER_CHUNK : n0_i - k;
                 double v[PER_CHUNK];
+                const bool coop = blockDim.x <= 256 && __ballot(true) == ~0ull && __all(cnt == PER_CHUNK);   // (wave-uniform) a full wave of draws on whole chunks
+                if (coop) {
+                    double (*row)[PER_CHUNK + 1] = stg[wv];
 #pragma unroll
-                for (int j = 0; j < PER_CHUNK; ++j) v[j] = s0[k + j < n0_i ? k + j : n0_i - 1];
-                go = true;
+                    for (int d = 0; d < PER_CHUNK; ++d) row[d][lane] = s0[__builtin_amdgcn_readlane(k, d) + lane];
 #pragma unroll
-                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) { go = go & (jj + 1 < cnt) & (x >= v[jj]); x = go ? x - v[jj] : x; k += go ? 1 : 0; }
+                    for (int j = 0; j < PER_CHUNK; ++j) v[j] = row[lane][j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PER_CHUNK; ++j) v[j] = s0[k + j < n0_i ? k + j : n0_i - 1];
+                }
+                if (__all(cnt == PER_CHUNK)) {                         // (wave-uniform) whole chunks: the walk may pass 63 of the 64 values
+                    v[PER_CHUNK - 1] = __builtin_inf();
+                    unsigned long long al = __ballot(true);
+#pragma unroll
+                    for (int q4 = 0; q4 < PER_CHUNK / 16; ++q4) {
+                        const double (&vq)[16] = *reinterpret_cast<const double (*)[16]>(&v[16 * q4]);
+                        per_walk16(x, k, al, vq);
+                    }
+                } else {
+                    go = true;
+                    double rr = x;
+#pragma unroll
+                    for (int jj = 0; jj < PER_CHUNK - 1; ++jj) { go = go & (jj + 1 < cnt) & (rr >= v[jj]); rr = rr - v[jj]; x = go ? rr : x; k += go ? 1 : 0; }
+                }
             }
+            PER_MARK(4);   // level-0 sums: round trip + walk
             int ii = k * PER_CHUNK;
             {
                 const int cnt = ii + PER_CHUNK < n_i ? PER_CHUNK : n_i - ii;
                 float v[PER_CHUNK];
+                const bool coop = blockDim.x <= 256 && __ballot(true) == ~0ull && __all(cnt == PER_CHUNK);
+                if (coop) {
+                    float (*row)[PER_CHUNK + 1] = reinterpret_cast<float (*)[PER_CHUNK + 1]>(&stg[wv][0][0]);
 #pragma unroll
-                for (int j = 0; j < PER_CHUNK; ++j) v[j] = prio[ii + j < n_i ? ii + j : n_i - 1];
-                go = true;
+                    for (int d = 0; d < PER_CHUNK; ++d) row[d][lane] = prio[__builtin_amdgcn_readlane(ii, d) + lane];
 #pragma unroll
-                for (int jj = 0; jj < PER_CHUNK - 1; ++jj) { const double vd = (double)v[jj]; go = go & (jj + 1 < cnt) & (x >= vd); x = go ? x - vd : x; ii += go ? 1 : 0; }
+                    for (int j = 0; j < PER_CHUNK; ++j) v[j] = row[lane][j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PER_CHUNK; ++j) v[j] = prio[ii + j < n_i ? ii + j : n_i - 1];
+                }
+                if (__all(cnt == PER_CHUNK)) {
+                    unsigned long long al = __ballot(true);
+#pragma unroll
+                    for (int q4 = 0; q4 < PER_CHUNK / 16; ++q4) {
+                        double vq[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) vq[j] = (double)v[16 * q4 + j];
+                        if (q4 == PER_CHUNK / 16 - 1) vq[15] = __builtin_inf();
+                        per_walk16(x, ii, al, vq);
+                    }
+                } else {
+                    go = true;
+                    double rr = x;
+#pragma unroll
+                    for (int jj = 0; jj < PER_CHUNK - 1; ++jj) { const double vd = (double)v[jj]; go = go & (jj + 1 < cnt) & (rr >= vd); rr = rr - vd; x = go ? rr : x; ii += go ? 1 : 0; }
+                }
             }
             i = ii;
+            PER_MARK(5);   // priorities: round trip + walk
             while (i > 0 && prio[i] == 0.0f) --i;
             idx[b] = i;
+            PER_MARK(6);   // zero-skip
         } else i = idx[b];
         const float prob = per_pow(prio[i], alpha) / total_alpha;
         const float w = powf(count * prob, -beta);
         weights[b] = w;
         mx = fmaxf(mx, w);
     }
+    PER_MARK(7);       // weights
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
@@ -1334,6 +1447,7 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
     mx = wmax[0];
     for (int k = 1; k < (int)(blockDim.x >> 6); ++k) mx = fmaxf(mx, wmax[k]);
     for (int b = threadIdx.x; b < batch; b += blockDim.x) weights[b] = weights[b] / mx;
+    PER_MARK(8);       // normalised
 }
 
 // priorities[idx[b]] = |td_b| with the LAST occurrence of a duplicated index winning (per.py:141 on the host is sequential), and
