@@ -13,7 +13,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
 
 
 @pytest.mark.parametrize("src,defs", [
-    ("mi_dqn.hip", ["-DTD_STAMPS", "-DDA_STAMPS"]),
+    ("mi_dqn.hip", ["-DTD_STAMPS", "-DDA_STAMPS", "-DPER_STAMPS"]),
     ("mi_sac.hip", ["-DSAC_MARKS"]),
     ("mi_sac.hip", ["-DSAC_STAMPS"]),
     ("mi_update.hip", ["-DGRAD_STAMPS"]),
