@@ -96,8 +96,9 @@ def run_all():
 
 st = run_all()
 native = bool(st["dqn_native"][0]) and bool(st["sac_native"][0])
-p2p = DD.carrier() == "p2p"    # MIRL_COMM=p2p: the one-call routes on the peer-to-peer carrier, whatever the process group
-assert native == (backend == "nccl" or p2p), "backend %s, carrier %s: one-call routes %s" % (backend, DD.carrier(), native)
+carrier_name = DD.resolved_carrier()   # (MIRL_COMM=auto: what the probe chose; taken before destroy_native_comms forgets it)
+p2p = carrier_name == "p2p"    # MIRL_COMM=p2p: the one-call routes on the peer-to-peer carrier, whatever the process group
+assert native == (backend == "nccl" or p2p), "backend %s, carrier %s: one-call routes %s" % (backend, DD.resolved_carrier(), native)
 if native:
     DD.check_native_comm()
 if native:   # host-sequenced route over torch.distributed all-reduces (RCCL, or gloo under the P2P carrier): bit-identical at world_size 2
@@ -112,4 +113,4 @@ torch.distributed.barrier()
 DD.destroy_native_comms()
 torch.distributed.destroy_process_group()
 if rank == 0:
-    print("OFFPOLICY_WORKER_OK backend=%s native=%d carrier=%s" % (backend, int(native), DD.carrier()))
+    print("OFFPOLICY_WORKER_OK backend=%s native=%d carrier=%s" % (backend, int(native), carrier_name))

@@ -64,8 +64,9 @@ def state(eng):
 
 eng, params0 = run_rank()
 native = DD.native_comm(eng.pg) is not None
-p2p = DD.carrier() == "p2p"    # MIRL_COMM=p2p: the one-call route on the peer-to-peer carrier, whatever the process group (gloo with both ranks on cuda:0 included)
-assert native == (backend == "nccl" or p2p), "backend %s, carrier %s: one-call route %s" % (backend, DD.carrier(), native)
+carrier_name = DD.resolved_carrier()   # (MIRL_COMM=auto: what the probe chose; taken before destroy_native_comms forgets it)
+p2p = carrier_name == "p2p"    # MIRL_COMM=p2p: the one-call route on the peer-to-peer carrier, whatever the process group (gloo with both ranks on cuda:0 included)
+assert native == (backend == "nccl" or p2p), "backend %s, carrier %s: one-call route %s" % (backend, DD.resolved_carrier(), native)
 if native:
     ws, rk, ver, cnt = N.C.c_int(), N.C.c_int(), N.C.c_int(), N.C.c_int()
     N.check(N.lib().mi_comm_info(DD.native_comm(eng.pg), N.C.byref(ws), N.C.byref(rk), N.C.byref(ver), N.C.byref(cnt)), "mi_comm_info")
@@ -87,4 +88,4 @@ torch.distributed.barrier()
 DD.destroy_native_comms()
 torch.distributed.destroy_process_group()
 if rank == 0:
-    print("SHARDED_WORKER_OK backend=%s native=%d carrier=%s" % (backend, int(native), DD.carrier()))
+    print("SHARDED_WORKER_OK backend=%s native=%d carrier=%s" % (backend, int(native), carrier_name))

@@ -111,11 +111,11 @@ def test_ppo_update_on_synthetic_ranks_equals_plain_update(world):
         assert torch.isfinite(out[0][0]).all()
 
 
-def _launch(worker, env_extra, timeout=600, nproc=2):
+def _launch(worker, env_extra, timeout=600, nproc=2, comm="p2p"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", MIRL_COMM="p2p", **env_extra)
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", MIRL_COMM=comm, **env_extra)
     # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP)
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
                            os.path.join(ROOT, "tests", worker)], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
@@ -128,13 +128,13 @@ def test_two_ranks_one_gpu_p2p_collective():
     assert "P2P_WORKER_OK" in out.stdout, out.stdout[-2000:]
 
 
-def _ppo(backend):
+def _ppo(backend, comm="p2p"):
     import tempfile
 
     import test_gpu_multigpu as M
 
     with tempfile.TemporaryDirectory() as tmp:
-        out = _launch("_sharded_update_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL="64"))
+        out = _launch("_sharded_update_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL="64"), comm=comm)
         assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
         assert "SHARDED_WORKER_OK backend=%s native=1 carrier=p2p" % backend in out.stdout, out.stdout[-2000:]
         r0, r1 = dict(np.load(os.path.join(tmp, "rank0.npz"))), dict(np.load(os.path.join(tmp, "rank1.npz")))
@@ -149,13 +149,13 @@ def _ppo(backend):
         assert np.allclose(rk["adv_sums"], rk["seq_adv_sums"], rtol=1e-12, atol=0.0)
 
 
-def _offpolicy(backend):
+def _offpolicy(backend, comm="p2p"):
     import tempfile
 
     import test_gpu_multigpu as M
 
     with tempfile.TemporaryDirectory() as tmp:
-        out = _launch("_offpolicy_sharded_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp), timeout=900)
+        out = _launch("_offpolicy_sharded_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp), timeout=900, comm=comm)
         assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
         assert "OFFPOLICY_WORKER_OK backend=%s native=1 carrier=p2p" % backend in out.stdout, out.stdout[-2000:]
         r0, r1 = dict(np.load(os.path.join(tmp, "off_rank0.npz"))), dict(np.load(os.path.join(tmp, "off_rank1.npz")))
@@ -176,6 +176,14 @@ def test_two_ranks_one_gpu_p2p_ppo():
 def test_two_ranks_one_gpu_p2p_offpolicy():
     _need_gpu()
     _offpolicy("gloo")
+
+
+def test_two_ranks_one_gpu_auto_carrier_ppo_and_offpolicy():
+    """MIRL_COMM=auto between two real processes (gloo, both on cuda:0): the probe finds RCCL impossible and the P2P carrier sound (known answer), every engine's one-call
+    route then runs on it — the same equalities as with MIRL_COMM=p2p."""
+    _need_gpu()
+    _ppo("gloo", comm="auto")
+    _offpolicy("gloo", comm="auto")
 
 
 def test_two_gpus_p2p_ppo():
