@@ -114,12 +114,25 @@ __global__ void __launch_bounds__(256) perm_stats_kernel(uint32_t n, uint32_t a,
     int32_t* __restrict__ out = ep.out[blockIdx.y];
     double* __restrict__ sums = sums_all + (size_t)3 * n_mb * blockIdx.y;
     double s = 0.0, q = 0.0;
+    if (base + PS_PER_BLOCK <= n) {   // (uniform) a whole block: its 16 gathers per thread in flight together — one memory latency instead of four (same sums in the same order)
+        float av[PS_PER_BLOCK / 256];
+#pragma unroll
+        for (int u = 0; u < PS_PER_BLOCK / 256; ++u) {
+            const uint32_t i = base + threadIdx.x + 256 * u;
+            const uint32_t p = mi_feistel(i, n, a, b, k0, k1);
+            out[i] = (int32_t)p;
+            av[u] = adv[p];
+        }
+#pragma unroll
+        for (int u = 0; u < PS_PER_BLOCK / 256; ++u) { const double v = (double)av[u]; s += v; q += v * v; }
+    } else {
 #pragma unroll 4
     for (uint32_t i = base + threadIdx.x; i < base + PS_PER_BLOCK && i < n; i += 256) {
         const uint32_t p = mi_feistel(i, n, a, b, k0, k1);
         out[i] = (int32_t)p;
         const double v = (double)adv[p];
         s += v; q += v * v;
+    }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
