@@ -929,7 +929,15 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
             } else if (p < DQ_W3 + DQ_H2 || p == DQ_B3) {      // action 0's element: sums action 1's slabs too (same order) and steps the column
                 const int p1 = p < DQ_B3 ? p + DQ_H2 : p + 1;
                 float a1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                for (int b1 = 0; b1 < n_slabs; ++b1) a1[b1 & 3] += workspace[(size_t)b1 * TD_SLAB + p1];
+                int b1 = 0;
+                for (; b1 + 16 <= n_slabs; b1 += 16) {             // (the same 16-at-a-time form as above: every load in flight at once)
+                    float y[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) y[k] = workspace[(size_t)(b1 + k) * TD_SLAB + p1];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) a1[k & 3] += y[k];
+                }
+                for (; b1 < n_slabs; ++b1) a1[b1 & 3] += workspace[(size_t)b1 * TD_SLAB + p1];
                 const float g1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
                 if (p < DQ_B3) { const int j = p - DQ_W3; dueling_head_step(opt, g, g1, DU_WV + j, DU_WA + j, DU_WA + DQ_H2 + j, p, p1); }
                 else dueling_head_step(opt, g, g1, DU_BV, DU_BA, DU_BA + 1, p, p1);
