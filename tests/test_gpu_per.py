@@ -252,3 +252,32 @@ def test_script_reference_shape_n1():
     assert '"alpha": 0.6' in out.stdout and '"beta_0": 0.4' in out.stdout and '"global_step": 6000' in out.stdout
     assert "PRIO (6001,) 6000 True 541" in out.stdout     # per.py:79: no env axis at one env
     assert np.isfinite(float(out.stdout.split("LOSS")[1].split()[0]))
+
+
+def test_sampler_random_shapes_bit_exact(dev, R):
+    """The sampler's fast paths (round 5: EXEC-predicated 16-step walks on full groups / whole chunks, coalesced wave loads of the per-draw chunks when a wave is full of
+    draws) and their fall-backs meet at every boundary: ring sizes that leave a partial last level-1 group, exactly 64 level-1 entries, a partial last chunk, batches of
+    1 / 63 / 65 / 128 / 300 draws (partially active waves, several passes of the draw loop) — indices bit-exact against the oracle in every case."""
+    rng = np.random.default_rng(2025)
+    shapes = [(1, 64 * 64 * 3 + 100, 1.0), (1, 64 * 64, 1.0), (1, 64 * 64 + 1, 1.0), (3, 700, 0.77), (17, 1000, 0.3), (64, 512, 1.0), (5, 13109, 0.9), (2, 2, 1.0)]
+    for k, (n_envs, slots, frac) in enumerate(shapes):
+        for batch in (1, 63, 65, 128, 300):
+            eng = _engine(dev, n_envs, slots, seed=3 + k, batch_size=batch, total_timesteps=10 * slots)
+            cap = slots * n_envs
+            stored_steps = max(int(slots * frac), 1)
+            prio = rng.gamma(0.5, 1.0, cap).astype(np.float32)
+            prio[rng.random(cap) < 0.2] = 0.0
+            prio[stored_steps * n_envs:] = 0.0
+            if not (prio[:stored_steps * n_envs] > 0).any():
+                prio[0] = 1.0
+            eng.priorities.copy_(torch.from_numpy(prio.reshape(slots, n_envs)))
+            eng.refresh_sums()
+            eng.global_step = stored_steps
+            eng.update_index = 100 + batch
+            eng.sample()
+            n = stored_steps * n_envs
+            s0, s1, total, total_alpha = R.per_sums(prio, n, ALPHA)
+            want = R.per_sample(3 + k, 100 + batch, prio, n, s0, s1, total, batch)
+            got = eng.batch_inds.cpu().numpy()
+            assert np.array_equal(got, want), (n_envs, slots, frac, batch, np.flatnonzero(got != want)[:5])
+            assert (prio[got] > 0).all()
