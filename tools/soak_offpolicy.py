@@ -3,7 +3,7 @@
 them once or twice): dqn.py (4096 envs, 256-slot ring, batch 128, 10 env steps per update) or sac.py on Pendulum-v1 (2048 envs, 512-slot ring, batch 256, one update per
 step) for ENV_STEPS env steps (default 1e9), production RNG, the loops of deep_rl_amd/dqn.py / sac.py.  Prints a progress line every ~5 % and a JSON summary: ring wraps,
 updates, finiteness of every parameter / moment tensor, loss, episodic returns at the end.
-    python tools/soak_offpolicy.py dqn|sac [env_steps]"""
+    python tools/soak_offpolicy.py dqn|dueling|per|sac [env_steps]     (dueling / per: dueling_dqn.py / per.py on the same ring and loop as dqn)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,12 +13,14 @@ kind = sys.argv[1]
 target = float(sys.argv[2]) if len(sys.argv) > 2 else 1e9
 dev = torch.device("cuda", 0)
 t0 = time.time()
-if kind == "dqn":
+if kind in ("dqn", "dueling", "per"):
     N_ENVS, SLOTS = 4096, 256
     steps = int(target // N_ENVS) // 10 * 10
     env = D.make("CartPole-v1", num_envs=N_ENVS, device=dev, seed=1); torch.manual_seed(1)
-    q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
-    eng = D.DQNEngine(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=SLOTS, batch_size=128, learning_starts=1000, total_timesteps=steps, max_episodes_logged=0)
+    Net = D.DuelingQNetwork if kind == "dueling" else D.QNetwork
+    Eng = {"dqn": D.DQNEngine, "dueling": D.DuelingDQNEngine, "per": D.PERDQNEngine}[kind]
+    q = Net(env); t = Net(env); t.load_state_dict(q.state_dict())
+    eng = Eng(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=SLOTS, batch_size=128, learning_starts=1000, total_timesteps=steps, max_episodes_logged=0)
     eng.reset()
     gs, mark = 0, max(steps // 20, 10)
     while gs < steps:
@@ -33,7 +35,9 @@ if kind == "dqn":
     torch.cuda.synchronize()
     st = eng.episode_stats.tolist()
     tensors = {"q": eng.q.flat, "target": eng.target.flat, "exp_avg": eng.optimizer.exp_avg, "exp_avg_sq": eng.optimizer.exp_avg_sq, "observations": eng.observations, "rewards": eng.rewards}
-    out = {"script": "dqn.py", "envs": N_ENVS, "ring_slots": SLOTS, "ring_transitions": N_ENVS * SLOTS, "batch": 128, "time_steps": gs, "env_steps": gs * N_ENVS, "ring_wraps": round(gs / SLOTS, 1),
+    if kind == "per":
+        tensors["priorities"] = eng.priorities; tensors["weights"] = eng.weights
+    out = {"script": {"dqn": "dqn.py", "dueling": "dueling_dqn.py", "per": "per.py"}[kind], "envs": N_ENVS, "ring_slots": SLOTS, "ring_transitions": N_ENVS * SLOTS, "batch": 128, "time_steps": gs, "env_steps": gs * N_ENVS, "ring_wraps": round(gs / SLOTS, 1),
            "updates": eng.update_index, "final_loss": float(eng.loss), "mean_return_last_launch": round(st[1] / max(st[0], 1), 2), "episodes_last_launch": st[0], "longest_last_launch": st[2]}
 else:
     N_ENVS, SLOTS = 2048, 512
