@@ -327,6 +327,19 @@ def kernel_device_durations(window_ms):
         return {"error": "profiles/latest_kernel_durations.json: %s" % ex}
 
 
+def collectives_label(world, is_p2p, native, carriers, policy):
+    """config.collectives: which carrier the HEADLINE windows ran on, and — when that is not the RCCL configuration BASELINE.json names — why not."""
+    if world == 1:
+        return "none (single process)"
+    why_not_rccl = carriers.get("rccl", (None, {}))[1].get("why")
+    if native and not is_p2p:
+        return "RCCL direct (mi_ppo_update_sharded: one C call per update, 17 in-stream ncclAllReduce over xGMI); the P2P carrier is reported beside it (value_p2p)"
+    tail = ("RCCL could not carry this run: %s" % why_not_rccl) if why_not_rccl else ("policy: %s" % policy)
+    if native:
+        return "P2P over hipIpc inboxes (mi_ppo_update_sharded: one C call per update, the gradient exchange inside the slab-sum launch) — NOT the RCCL configuration; " + tail
+    return "torch.distributed (host-sequenced, 17 all-reduces per update) — NOT the RCCL configuration; " + tail
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` with N > 1: start the N ranks as a child process and relay rank 0's line.  The parent makes no GPU call
     and never replaces itself (a process that has initialised HIP must not exec; this one has not even imported torch)."""
@@ -682,11 +695,11 @@ def main():
 
     # production: RCCL ("nccl"), one rank per GPU.  MIRL_BENCH_BACKEND=gloo MIRL_BENCH_ONE_GPU=1 lets the N > 1 code path of this script be
     # exercised on a single-GPU box (both ranks on cuda:0; tests/test_gpu_script.py) — RCCL itself refuses two ranks on one device.
-    # N > 1: unless MIRL_COMM says otherwise the carrier of the 17 per-update all-reduces is CHOSEN BY MEASUREMENT when the first engine asks for its communicator
-    # (deep_rl_amd/dist.py: _auto_choice — both carriers sum a known-answer buffer and are timed on the path's own 36.6 KB message; the ranks agree on the faster one
-    # that passed, RCCL and then the host-sequenced route being the fall-backs); the line records what was measured and chosen (collectives.carrier_choice)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        os.environ.setdefault("MIRL_COMM", "auto")
+    # N > 1, HEADLINE POLICY: `value` / `ms_per_step` / `config.collectives` are measured on RCCL — BASELINE.json configs[4] and north_star say
+    # "RCCL grad all-reduce over xGMI" — whenever an RCCL communicator can be created and passes its known-answer probe; libmirl's P2P carrier is measured BESIDE it
+    # (value_p2p, ms_per_step_p2p, timed_windows_p2p, replicas_identical_p2p, best_carrier / value_best_carrier: its own three windows), never instead of it.  Only when
+    # RCCL cannot carry the run (a gloo group on a one-GPU box, a failed probe) does `value` fall to the carrier that ran, and config.collectives says so with the
+    # reason.  MIRL_COMM=p2p / auto set by the CALLER overrides the policy (and the line says which carrier it measured).
     rank, world, local_rank = init_from_env(os.environ.get("MIRL_BENCH_BACKEND", "nccl"))
     if os.environ.get("MIRL_BENCH_ONE_GPU", "0") == "1":
         local_rank = 0
@@ -714,6 +727,31 @@ def main():
     # first 40 launches, 188 us afterwards, whatever the build), which is longer than W = 5 warm-up updates (7 ms) and put the first timed window of a short run 1.2 - 1.8 %
     # above the windows behind it (timed_windows, profiles/r04_grad_ab.txt).  A THROWAWAY engine of the same shape runs PREWARM_UPDATES updates first; the engine that is
     # measured is built afterwards and starts from its own fresh state (same seed, same parameters, same W warm-up and K timed updates as without the ramp).
+    from deep_rl_amd import dist as DD
+    import deep_rl_amd.engine as E
+    carriers, headline_carrier, policy = {}, None, None
+    # (world == 1 with a process group: MIRL_FORCE_PG=1, the one-GPU diagnostic that makes a single process join a world_size-1 RCCL group — the same policy, and the
+    # engine is told to take the one-call sharded route although it is alone, so that the branch a multi-GPU run takes is the one measured: tests/test_gpu_script.py)
+    policy_on = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
+    if policy_on:
+        forced = os.environ.get("MIRL_COMM", "").lower() or None
+        for w in ("rccl", "p2p"):
+            try:
+                carriers[w] = DD.probed_comm(None, w)
+            except Exception as ex:  # noqa: BLE001  (every step in there is agreed over the ranks; an exception here is local set-up)
+                carriers[w] = (None, {"ok": False, "why": "%s: %s" % (type(ex).__name__, ex)})
+        if forced in ("rccl", "p2p"):
+            headline_carrier, policy = (forced if carriers[forced][0] is not None else None), "MIRL_COMM=%s set by the caller" % forced
+        elif forced == "auto":
+            headline_carrier, policy = "auto", "MIRL_COMM=auto set by the caller: the faster carrier that passed its probe (collectives.carrier_choice)"
+        else:
+            headline_carrier = "rccl" if carriers["rccl"][0] is not None else ("p2p" if carriers["p2p"][0] is not None else None)
+            policy = "RCCL when it can be created and passes its probe (the configuration BASELINE.json names), else P2P, else host-sequenced torch.distributed"
+        if headline_carrier in ("rccl", "p2p"):
+            DD.use_comm(carriers[headline_carrier][0])   # every engine of this process takes its one-call route on this communicator from here on
+        if world == 1:
+            E._FORCE_NATIVE_SHARDED = True
+
     prewarm_updates = 0 if args.no_prewarm else PREWARM_UPDATES
     if prewarm_updates:
         p_env = D.make("CartPole-v1", num_envs=ENVS_PER_GPU, device=dev, seed=12345, env_id_base=rank * ENVS_PER_GPU)
@@ -724,10 +762,10 @@ def main():
         for _ in range(prewarm_updates):
             p_eng.update()
         torch.cuda.synchronize()
-        from deep_rl_amd import dist as _d0
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and _d0.carrier() == "auto":
+        if headline_carrier == "auto":
             tune_carrier(p_eng, dev)    # recorded in dist.carrier_report -> collectives.carrier_choice
             torch.cuda.synchronize()
+            headline_carrier = DD.resolved_carrier(None)
         del p_eng, p_agent, p_env
 
     num_updates = args.warmup + args.steps
@@ -793,6 +831,30 @@ def main():
         except Exception as ex:  # noqa: BLE001
             headline_exchange = {"replicas_identical": False, "error": "%s: %s" % (type(ex).__name__, ex)}
 
+    # BESIDE the headline, never instead of it: the same three windows on libmirl's P2P carrier (rank-ordered sum over hipIpc-mapped inboxes, the gradient exchange
+    # inside the slab-sum launch), the engine simply going on learning; then back to the headline's carrier for everything behind
+    p2p_beside = None
+    if policy_on and headline_carrier == "rccl" and carriers.get("p2p", (None,))[0] is not None and os.environ.get("MIRL_BENCH_P2P_BESIDE", "1") != "0":
+        p2p_beside = {}
+        try:
+            DD.use_comm(carriers["p2p"][0])
+            for _ in range(2):
+                one_update(num_updates - 1)
+            p2p_beside["windows"] = [timed_updates(num_updates, args.steps)[0] for _ in range(1 if args.single_window else 3)]
+            try:
+                eng.check_replicas()                                                    # (a no-op for a single process ...)
+                N.check(N.lib().mi_comm_check(carriers["p2p"][0]), "mi_comm_check")     # ... so the carrier's own status word is asked too
+                p2p_beside["replicas_identical"] = True
+            except Exception as ex:  # noqa: BLE001
+                p2p_beside["replicas_identical"] = False
+                p2p_beside["error"] = "%s: %s" % (type(ex).__name__, ex)
+        except Exception as ex:  # noqa: BLE001  (a failing carrier costs its own keys only; its optimizer steps are withheld on the device: mi_comm_poll)
+            p2p_beside["error"] = "%s: %s" % (type(ex).__name__, ex)
+        finally:
+            DD.use_comm(carriers["rccl"][0])
+    if policy_on and world == 1:
+        E._FORCE_NATIVE_SHARDED = False   # the legs below set the route themselves
+
     # the round-1..3 methodology beside it: one more window with a pair of HIP events around EVERY gradient launch of EVERY update
     dt_all = None
     if not args.single_window:
@@ -842,8 +904,15 @@ def main():
                 collectives["carriers"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             collectives["rccl_env"] = _dist.apply_rccl_env() or None
         if collectives is not None:
-            collectives["carrier_choice"] = {"MIRL_COMM": _dist.carrier(), "resolved": _dist.resolved_carrier(eng.pg) if eng_native else None,
-                                             "measured": _dist.carrier_report(eng.pg)}
+            which_ran = (("p2p" if N.lib().mi_comm_carrier(comm) == 1 else "rccl") if eng_native else None)
+            collectives["carrier_choice"] = {"MIRL_COMM": os.environ.get("MIRL_COMM"), "policy": policy, "headline_carrier": which_ran,
+                                             "probes": {w: c[1] for w, c in carriers.items()}, "measured": _dist.carrier_report(eng.pg)}
+            # whatever carried the headline: the top-level RCCL facts come from the RCCL communicator whenever one exists ("did RCCL see N ranks?")
+            if carriers.get("rccl", (None,))[0] is not None:
+                import ctypes as _C
+                ws_, rk_, ver_, cnt_ = _C.c_int(), _C.c_int(), _C.c_int(), _C.c_int()
+                if N.lib().mi_comm_info(carriers["rccl"][0], _C.byref(ws_), _C.byref(rk_), _C.byref(ver_), _C.byref(cnt_)) == 0:
+                    collectives["rccl_version"], collectives["rccl_comm_count"] = ver_.value, cnt_.value
     finite = bool(torch.isfinite(agent.flat).all().item())
     ep = stats_host.tolist()
     if rank == 0:
@@ -863,7 +932,7 @@ def main():
             "config": {"workload": "ppo.py CartPole-v1, %d envs/GPU x %d steps per update, 4 epochs x 4 minibatches of %d rows, "
                                    "2x64-tanh actor+critic (9155 params), on-device env.step + GAE + fwd/bwd + clip + Adam" % (ENVS_PER_GPU, T, mb),
                        "envs_per_gpu": ENVS_PER_GPU, "num_steps": T, "minibatch_rows": mb, "parallelism": "env-sharded x%d, grad all-reduce" % world,
-                       "collectives": "none (single process)" if world == 1 else (("%s (mi_ppo_update_sharded: one C call per update, 17 in-stream all-reduces)" % ("P2P over hipIpc inboxes" if _dist.resolved_carrier(eng.pg) == "p2p" else "RCCL direct")) if eng_native else "torch.distributed (host-sequenced, 17 all-reduces per update)")},
+                       "collectives": collectives_label(world, eng_native and N.lib().mi_comm_carrier(comm) == 1, eng_native, carriers, policy)},
             "roofline": {"bound": "mfma", "kernel": "grad_kernel_f32", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_launch, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2), "launches": g_n,
@@ -892,6 +961,18 @@ def main():
                                 "min": round(wms[0], 4), "median": round(wms[len(wms) // 2], 4), "max": round(wms[-1], 4),
                                 "note": "window 1 is `value` / `ms_per_step`; the others repeat it back to back (same barriers), learning continuing (episodes get longer: "
                                         "fewer resets per rollout)"}
+        if p2p_beside is not None:
+            if p2p_beside.get("windows"):
+                pw = [1e3 * w / args.steps for w in p2p_beside["windows"]]
+                out["value_p2p"] = round(env_steps / p2p_beside["windows"][0], 1)
+                out["ms_per_step_p2p"] = round(pw[0], 4)
+                out["timed_windows_p2p"] = {"count": len(pw), "steps_each": args.steps, "ms_per_step": [round(x, 4) for x in pw],
+                                            "note": "the same K updates on libmirl's P2P carrier, right behind the headline's windows (learning continuing); window 1 is value_p2p"}
+                out["replicas_identical_p2p"] = p2p_beside.get("replicas_identical")
+                best = "p2p" if p2p_beside.get("replicas_identical") and p2p_beside["windows"][0] < dt else "rccl"
+                out["best_carrier"], out["value_best_carrier"] = best, (out["value_p2p"] if best == "p2p" else round(steps_per_s, 1))
+            if "error" in p2p_beside:
+                out["p2p_error"] = p2p_beside["error"]
         if sharded is not None:
             out["sharded_route"] = sharded
         if collectives is not None:

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRL_SO", os.path.join(_HERE, "libmirl.so"))  # MIRL_SO: A/B builds of the same ABI
 
-ABI_VERSION = 106   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
+ABI_VERSION = 107   # == MI_VERSION of the include/mi_rl.h these signatures and struct layouts were written against
 NPARAMS = 9155
 DQN_NPARAMS = 10934
 ACTOR_NPARAMS = 4610
@@ -93,6 +93,9 @@ SIGNATURES = {
     "mi_comm_check": (_I, [_VP]),
     "mi_comm_carrier": (_I, [_VP]),
     "mi_comm_p2p_set_colocated": (_I, [_VP, _I]),
+    "mi_comm_p2p_set_fused": (_I, [_VP, _I]),
+    "mi_comm_poll": (_I, [_VP]),
+    "mi_comm_test_set_seq": (_I, [_VP, _U32]),
     "mi_dqn_forward": (_I, [_VP, _VP, _I, _VP, _VP]),
     "mi_dqn_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP]),
     "mi_dqn_act_steps2": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP, _VP]),

@@ -61,12 +61,21 @@ static int rccl_bind() {
     } while (0)
 
 // ---- the P2P carrier's inbox (device memory of its owner, mapped into every peer with hipIpcOpenMemHandle) ------------------------------------------------------
-//   [status u32, padded to P2P_HDR_BYTES] [lines u64 [2 parities][world][cap / 4]]
+//   [status u32 | barrier lines u64 [2 parities][8 ranks] at byte 64, padded to P2P_HDR_BYTES] [lines u64 [2 parities][world][cap / 4]]
 // A LINE is one 8-byte word {payload word (low), sequence number (high)}, stored and loaded as ONE 8-byte access: the payload carries its own "arrived" flag, so an
 // all-reduce needs no fence, no separate flag and no second round trip (the LL protocol idea).  Line i of slot (parity, r) = 32-bit word i of rank r's message.
+// SEQUENCE NUMBERS AND PARITY.  The parity is a bit of its own that flips with every all-reduce (never derived from the sequence number); the sequence number counts
+// 1 .. P2P_SEQ_LAST inside an EPOCH.  Messages have different lengths, so a slot keeps lines of OLDER all-reduces behind the end of a shorter one — harmless while
+// sequence numbers never repeat, i.e. inside an epoch.  When the number would pass P2P_SEQ_LAST, every rank (they count the same calls) changes the epoch in-stream:
+//   (1) clear the lines of the own inbox — the last all-reduce of the old epoch has completed here, so every store a peer aimed at this inbox in that epoch has landed;
+//   (2) a barrier through the header's barrier lines (fixed length: one line per rank, its own counter, never cleared): a rank passes it only after EVERY rank has
+//       cleared, so no store of the new epoch can meet a clear;  (3) go on with sequence number 1.
+// (Round 5 derived the parity from the number and wrapped 0xFFFFFFFF -> 1: two consecutive all-reduces on one parity, and stale lines with a "right" number.)
 #define P2P_MAX_GROUPS 64
 #define P2P_THREADS 256
 #define P2P_HDR_BYTES 256
+#define P2P_BAR_OFF 64
+#define P2P_SEQ_LAST 0xFFFFFFF0u
 enum { CARRIER_RCCL = 0, CARRIER_P2P = 1 };
 
 struct mi_comm {
@@ -78,12 +87,16 @@ struct mi_comm {
     char* peer[P2P_MAX_WORLD];     // every rank's inbox as mapped here (peer[rank] == inbox; synthetic: all == inbox)
     bool opened[P2P_MAX_WORLD];    // mapped with hipIpcOpenMemHandle (to be closed)
     size_t cap;                    // bytes per slot
-    uint32_t seq;                  // sequence number of the last enqueued all-reduce (host side; every rank counts the same calls)
+    uint32_t seq;                  // sequence number of the last enqueued all-reduce inside the current epoch (host side; every rank counts the same calls)
+    uint32_t parity;               // parity of the last enqueued all-reduce: flips with every one, whatever the sequence number does
+    uint32_t bseq;                 // epoch changes so far (= the barrier lines' own sequence number)
+    uint32_t* mirror;              // host-pinned, device-mapped copy of the status word (mi_comm_poll: no sync)
     int synthetic;                 // one process plays `world` ranks into its own inbox (slot 0 = its share, the others zeros): timing only
     int mem_kind;                  // 0 uncached, 1 fine-grained, 2 plain device memory
     unsigned long long budget;     // wait budget in 100 MHz ticks
     int connected;
-    int colocated;                 // ranks of this communicator that share this rank's DEVICE (1 = one rank per GPU, the production placement)
+    int colocated;                 // the LARGEST number of ranks of this communicator sharing one device (1 = one rank per GPU, the production placement)
+    int fused_set;                 // mi_comm_p2p_set_fused: -1 / 0 (unset) / 1
 };
 
 extern "C" int mi_comm_unique_id(void* id128) {
@@ -119,8 +132,10 @@ extern "C" int mi_comm_create(const void* id128, int world_size, int rank, void*
 // own elements, which depend on no wait — no deadlock whatever the residency (two ranks time-sharing one device included).  Two parities: rank A reaches all-reduce
 // k + 2 only after B has stored k + 1, i.e. after B's launch k — the reader of parity k & 1 — is over (launches of one stream run in order; all collectives of a
 // communicator must be enqueued on streams ordered with each other, in the same order on every rank).
-// The wait is bounded (budget: MIRL_P2P_TIMEOUT_MS, default 10 s): a peer that never arrives sets the status word, the elements concerned keep the LOCAL share, later
-// launches give up after 64 polls, and mi_comm_check reports MI_ESTATE.
+// The wait is bounded (budget: MIRL_P2P_TIMEOUT_MS, default 30 s): a peer that never arrives sets the status word (and its host-pinned mirror), the elements concerned
+// keep the LOCAL share, later launches give up after 64 polls — and nothing is lost but the update: every optimizer step behind the exchange reads the status word with
+// its state and is withheld (mi_comm_gate), every later mi_*_sharded / mi_comm_allreduce_sum call returns MI_ESTATE at its entry (mi_comm_poll, no sync),
+// mi_comm_check (synchronising) says which ranks were missing.
 template <typename T, int WORLD>
 __global__ void __launch_bounds__(P2P_THREADS) p2p_allreduce_kernel(p2p_args_t a, T* __restrict__ buf, size_t n) {
     constexpr int W = ll_elem<T>::W;
@@ -159,12 +174,59 @@ static void p2p_launch(int world, unsigned groups, hipStream_t s, const p2p_args
     }
 }
 
+// ---- epoch change (see the inbox comment): clear the own lines, then a barrier over the header's barrier lines ----
+__global__ void __launch_bounds__(256) p2p_clear_kernel(uint64_t* __restrict__ lines, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(lines + i), "v"((uint64_t)0) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+struct p2p_bar_t { uint64_t* dst[P2P_MAX_WORLD]; const uint64_t* src[P2P_MAX_WORLD]; char* mine; uint32_t* mirror; unsigned long long budget; uint32_t seq; int world; };
+__global__ void __launch_bounds__(64) p2p_barrier_kernel(p2p_bar_t b) {
+    const int r = threadIdx.x;
+    if (r >= b.world) return;
+    ll_store_nowait(b.dst[r], 0u, b.seq);
+    unsigned long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+        uint64_t v = ll_load_nowait(b.src[r]);
+        ll_wait_loads(); ll_pin(v);
+        if ((uint32_t)(v >> 32) == b.seq) return;
+        if (spins == 0) t0 = p2p_clock();
+        if ((spins & 63) == 63 && (p2p_clock() - t0 > b.budget || __hip_atomic_load(p2p_status(b.mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            const uint32_t missing = 1u | (1u << (8 + r));
+            __hip_atomic_fetch_or(p2p_status(b.mine), missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b.mirror) __hip_atomic_fetch_or(b.mirror, missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+static int p2p_new_epoch(mi_comm* c, hipStream_t s) {
+    const size_t n_lines = 2 * (size_t)c->world * 2 * c->cap / 8;
+    p2p_clear_kernel<<<64, 256, 0, s>>>(reinterpret_cast<uint64_t*>(c->inbox + P2P_HDR_BYTES), n_lines);
+    MI_LAUNCH_CHECK();
+    p2p_bar_t b;
+    memset(&b, 0, sizeof(b));
+    if (++c->bseq == 0) c->bseq = 1;   // (2^32 epochs of 2^32 all-reduces each: fixed-length lines, rewritten at every use of their parity — a repeat is harmless)
+    const int bp = c->bseq & 1;
+    auto line = [&](char* box, int r) { return reinterpret_cast<uint64_t*>(box + P2P_BAR_OFF) + (size_t)bp * P2P_MAX_WORLD + r; };
+    for (int d = 0; d < c->world; ++d) {
+        const int p = (c->rank + d) % c->world;
+        b.dst[d] = line(c->peer[p], c->synthetic ? p : c->rank);
+        b.src[d] = line(c->inbox, d);
+    }
+    b.mine = c->inbox; b.mirror = c->mirror; b.budget = c->budget; b.seq = c->bseq; b.world = c->world;
+    p2p_barrier_kernel<<<1, 64, 0, s>>>(b);
+    MI_LAUNCH_CHECK();
+    c->seq = 0;
+    return MI_OK;
+}
+
 static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm** out) {
     mi_comm* c = (mi_comm*)calloc(1, sizeof(mi_comm));
     if (!c) { mi_set_error("mi_comm_p2p: out of host memory"); return MI_ENOMEM; }
     c->carrier = CARRIER_P2P; c->world = world; c->rank = rank; c->synthetic = synthetic; c->colocated = 1;
     c->cap = (max_bytes + 255) & ~(size_t)255;
-    unsigned long long ms = 10000;
+    unsigned long long ms = 30000;   // a stall this long on one rank (a checkpoint write, a debugger) fails the run LOUDLY (fail-safe below) instead of being waited out
     if (const char* e = getenv("MIRL_P2P_TIMEOUT_MS")) { const long long v = atoll(e); if (v > 0) ms = (unsigned long long)v; }
     c->budget = ms * 100000ull;   // s_memrealtime: 100 MHz
     hipError_t e = hipGetDevice(&c->device);
@@ -191,6 +253,14 @@ static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm
         mi_set_error("mi_comm_p2p: clearing the inbox failed"); (void)hipFree(box); free(c); return MI_EHIP;
     }
     c->inbox = (char*)box;
+    {   // the status word's host-visible mirror: written (system scope) by the wait that runs out, read by the host without a sync
+        uint32_t* h = nullptr;
+        if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            mi_set_error("mi_comm_p2p: cannot allocate the pinned status mirror"); (void)hipGetLastError(); (void)hipFree(box); free(c); return MI_ENOMEM;
+        }
+        h[0] = 0u;
+        c->mirror = h;
+    }
     c->peer[rank] = c->inbox;
     if (synthetic) { for (int r = 0; r < world; ++r) c->peer[r] = c->inbox; c->connected = 1; }
     *out = c;
@@ -245,14 +315,16 @@ extern "C" int mi_comm_p2p_synthetic(int world_size, size_t max_bytes, void** ou
     return MI_OK;
 }
 
-int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world_out) {
+int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world_out, hipStream_t s) {
     mi_comm* c = (mi_comm*)comm;
     if (!c || c->carrier != CARRIER_P2P) { mi_set_error("mi_comm: not a P2P communicator"); return MI_EINVAL; }
     if (!c->connected) { mi_set_error("mi_comm (p2p): all-reduce before mi_comm_p2p_connect"); return MI_ESTATE; }
     if (n_words * 4 > c->cap) { mi_set_error("mi_comm (p2p): a %zu-byte message does not fit the %zu-byte slots (max_bytes of mi_comm_p2p_alloc)", n_words * 4, c->cap); return MI_EINVAL; }
-    if (++c->seq == 0) c->seq = 1;   // 0 is the cleared inbox
+    if (c->seq >= P2P_SEQ_LAST) { const int rc = p2p_new_epoch(c, s); if (rc) return rc; }
+    ++c->seq;            // 1 .. P2P_SEQ_LAST inside an epoch; 0 is the cleared inbox
+    c->parity ^= 1u;     // its own bit: consecutive all-reduces never share a slot set, whatever the sequence number does
     memset(a, 0, sizeof(*a));
-    const int parity = c->seq & 1, world = c->world;
+    const int parity = (int)c->parity, world = c->world;
     auto slot = [&](char* box, int r) { return reinterpret_cast<uint64_t*>(box + P2P_HDR_BYTES + ((size_t)parity * world + r) * 2 * c->cap); };
     for (int d = 0; d < world; ++d) {
         const int p = (c->rank + d) % world;
@@ -260,12 +332,41 @@ int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world_out) 
         if (c->synthetic && p != 0) a->zeros |= 1u << d;
         a->src[d] = slot(c->inbox, d);
     }
-    a->mine = c->inbox; a->budget = c->budget; a->seq = c->seq;
+    a->mine = c->inbox; a->mirror = c->mirror; a->budget = c->budget; a->seq = c->seq;
     if (world_out) *world_out = world;
     return MI_OK;
 }
 
 bool mi_comm_is_p2p(void* comm) { return comm && ((mi_comm*)comm)->carrier == CARRIER_P2P; }
+const uint32_t* mi_comm_gate(void* comm) { return mi_comm_is_p2p(comm) ? reinterpret_cast<const uint32_t*>(((mi_comm*)comm)->inbox) : nullptr; }
+
+static void p2p_describe_failure(mi_comm* c, uint32_t st, const char* tail) {
+    char who[64]; int k = 0;
+    who[0] = 0;
+    for (int r = 0; r < c->world; ++r) if (st & (1u << (8 + r))) k += snprintf(who + k, sizeof(who) - k, " %d", r);
+    mi_set_error("mi_comm (p2p), rank %d: a wait ran out (MIRL_P2P_TIMEOUT_MS); ranks that never arrived:%s — %s", c->rank, k ? who : " ?", tail);
+}
+// no synchronisation: a plain host load of the pinned mirror the timed-out wait wrote (system scope) — what every mi_*_sharded call does first
+int mi_comm_poll_impl(void* comm) {
+    if (!mi_comm_is_p2p(comm)) return MI_OK;
+    mi_comm* c = (mi_comm*)comm;
+    const uint32_t st = c->mirror ? __atomic_load_n(c->mirror, __ATOMIC_RELAXED) : 0u;
+    if (!st) return MI_OK;
+    p2p_describe_failure(c, st, "every optimizer step behind that exchange was WITHHELD (parameters, moments and targets are those in front of it); elements of that and "
+                                "every later all-reduce hold the LOCAL share; the communicator is dead (destroy it)");
+    return MI_ESTATE;
+}
+extern "C" int mi_comm_poll(void* comm) {
+    MI_CHECK_ARG(comm != nullptr, "comm is NULL");
+    return mi_comm_poll_impl(comm);
+}
+// TEST HOOK: the sequence number of the last all-reduce inside the epoch (every rank must set the same value, between all-reduces) — presets it just below the epoch
+// change so that a test crosses it in a few exchanges (tests/test_gpu_p2p.py)
+extern "C" int mi_comm_test_set_seq(void* comm, uint32_t seq) {
+    MI_CHECK_ARG(mi_comm_is_p2p(comm), "not a P2P communicator");
+    ((mi_comm*)comm)->seq = seq;
+    return MI_OK;
+}
 
 // May a kernel of 145 x 1,024 threads (grad_reduce_kernel) spin-wait for its peers' exchange?  One rank per device: always.  Ranks SHARING a device (test placements):
 // every waiting rank holds 145 workgroups' worth of wave slots and registers while it spins, and a peer's gradient launch needs whole CUs (512 VGPRs per SIMD lane): two
@@ -273,8 +374,19 @@ bool mi_comm_is_p2p(void* comm) { return comm && ((mi_comm*)comm)->carrier == CA
 // x 4096 envs on one MI355X.  More than two colocated ranks therefore take the stand-alone all-reduce launch (18 small workgroups per rank).  MIRL_P2P_FUSED=0 / 1 overrides.
 bool mi_comm_p2p_fused_ok(void* comm) {
     if (!mi_comm_is_p2p(comm)) return false;
+    const mi_comm* c = (const mi_comm*)comm;
+    if (c->fused_set) return c->fused_set > 0;     // agreed over the ranks by the caller (mi_comm_p2p_set_fused)
     if (const char* e = getenv("MIRL_P2P_FUSED")) return atoi(e) != 0;
-    return ((mi_comm*)comm)->colocated <= 2;
+    return c->colocated <= 2;
+}
+// The ranks of a communicator MUST take the same form of PPO's gradient exchange: the in-launch one publishes line p in SLAB order, the stand-alone one in PARAMETER
+// order, both under the same sequence number — a mix sums permuted elements silently.  deep_rl_amd.dist agrees on one value over the process group
+// (MAX of the per-device rank counts, the MIRL_P2P_FUSED settings compared) and fixes it here: -1 = stand-alone launch, 1 = in-launch, 0 = back to the rule above.
+extern "C" int mi_comm_p2p_set_fused(void* comm, int mode) {
+    MI_CHECK_ARG(mi_comm_is_p2p(comm), "not a P2P communicator");
+    MI_CHECK_ARG(mode >= -1 && mode <= 1, "mode must be -1 (stand-alone), 0 (by colocation) or 1 (in-launch)");
+    ((mi_comm*)comm)->fused_set = mode;
+    return MI_OK;
 }
 
 extern "C" int mi_comm_p2p_set_colocated(void* comm, int ranks_on_this_device) {
@@ -287,7 +399,7 @@ extern "C" int mi_comm_p2p_set_colocated(void* comm, int ranks_on_this_device) {
 static int p2p_allreduce(mi_comm* c, void* buf, size_t n, int dtype, hipStream_t s) {
     p2p_args_t a;
     int world = 1;
-    int rc = mi_comm_p2p_next(c, n * (dtype ? 2 : 1), &a, &world);
+    int rc = mi_comm_p2p_next(c, n * (dtype ? 2 : 1), &a, &world, s);
     if (rc) return rc;
     // two elements per thread while that gives <= P2P_MAX_GROUPS workgroups (PPO's 9,159 floats: 18 workgroups), more beyond (SAC's 134,660: 9 per thread)
     size_t groups = (n + 2 * P2P_THREADS - 1) / (2 * P2P_THREADS);
@@ -306,10 +418,7 @@ extern "C" int mi_comm_check(void* comm) {
     uint32_t st = 0;
     MI_HIP(hipMemcpy(&st, c->inbox, 4, hipMemcpyDeviceToHost));
     if (st) {
-        char who[64]; int k = 0;
-        for (int r = 0; r < c->world; ++r) if (st & (1u << (8 + r))) k += snprintf(who + k, sizeof(who) - k, " %d", r);
-        mi_set_error("mi_comm (p2p), rank %d: a wait ran out (MIRL_P2P_TIMEOUT_MS); ranks that never arrived:%s — elements of that and every later all-reduce hold "
-                     "the LOCAL share", c->rank, k ? who : " ?");
+        p2p_describe_failure(c, st, "elements of that and every later all-reduce hold the LOCAL share, and every optimizer step behind it was withheld");
         return MI_ESTATE;
     }
     return MI_OK;
@@ -324,6 +433,7 @@ extern "C" int mi_comm_destroy(void* comm) {
         (void)hipDeviceSynchronize();
         for (int r = 0; r < c->world; ++r) if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
         if (c->inbox) (void)hipFree(c->inbox);
+        if (c->mirror) (void)hipHostFree(c->mirror);
     } else if (g_rccl.so && c->comm) {
         (void)g_rccl.CommDestroy(c->comm);
     }
@@ -356,5 +466,6 @@ int mi_comm_allreduce_impl(void* comm, void* buf, size_t n, int dtype, hipStream
 
 extern "C" int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stream) {
     MI_CHECK_ARG(comm && buf && n > 0 && (dtype == 0 || dtype == 1), "bad arguments");
+    if (const int rc = mi_comm_poll_impl(comm)) return rc;
     return mi_comm_allreduce_impl(comm, buf, n, dtype, (hipStream_t)stream);
 }

@@ -121,6 +121,7 @@ struct p2p_args_t {          // everything resolved on the host: the kernel does
     uint64_t* dst[P2P_MAX_WORLD];         // d-th target: slot (parity, this rank) of rank (rank + d) % world's inbox — the own inbox first, then rank + 1 ...: the links are used side by side
     const uint64_t* src[P2P_MAX_WORLD];   // slot (parity, r) of the OWN inbox, r in rank order
     char* mine;                           // own inbox (status word)
+    uint32_t* mirror;                     // host-pinned, device-mapped copy of the status word: the host reads it at the entry of every call WITHOUT a sync (mi_comm_poll)
     unsigned long long budget;
     uint32_t seq;
     uint32_t zeros;                       // bit d: target d receives zeros (synthetic communicator: the ranks this process plays besides its own)
@@ -171,6 +172,7 @@ __device__ __forceinline__ bool ll_gather(const p2p_args_t& x, size_t line, uint
 #pragma unroll
                 for (int k = 0; k < W; ++k) if ((uint32_t)(v[r][k] >> 32) != x.seq) missing |= 1u << (8 + r);
             __hip_atomic_fetch_or(p2p_status(x.mine), missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x.mirror) __hip_atomic_fetch_or(x.mirror, missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -190,9 +192,19 @@ template <> struct ll_elem<double> {
 };
 
 // Fills `a` for the NEXT all-reduce of `n_words` 32-bit words on a P2P communicator (advances its sequence number: the caller MUST launch exactly one kernel that
-// publishes and consumes those lines on every rank); MI_EINVAL when the message does not fit, MI_ESTATE when the communicator is not connected.
-int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world);
+// publishes and consumes those lines on every rank, on stream `s`); MI_EINVAL when the message does not fit, MI_ESTATE when the communicator is not connected or an
+// earlier wait on it ran out.  When the 32-bit sequence number is about to wrap, the call first enqueues the epoch change on `s` (inbox cleared, barrier: mi_comm.hip).
+int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world, hipStream_t s);
 bool mi_comm_is_p2p(void* comm);
+// The FAIL-SAFE of the P2P carrier.  A wait that runs out sets the inbox's status word (device) and its host-pinned mirror; from then on
+//   * every optimizer step that would consume an exchanged gradient is WITHHELD: its launch reads the word behind `mi_comm_gate` with its state and leaves parameters,
+//     moments and targets as they are (the pattern of mi_sac.hip's fault word) — a stalled peer costs the update, never the parameters;
+//   * every mi_*_sharded call and mi_comm_allreduce_sum returns MI_ESTATE at its entry (mi_comm_poll_impl: a plain host load of the mirror, no synchronisation).
+const uint32_t* mi_comm_gate(void* comm);   // device pointer of the status word (nullptr: RCCL / no communicator — nothing to gate on)
+int mi_comm_poll_impl(void* comm);          // MI_OK / MI_ESTATE, no synchronisation (NULL comm: MI_OK)
+int mi_clip_adam_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1, double beta2, double eps,
+                       float max_norm, float* grad_norm, void* comm, void* stream);   // mi_update.hip: mi_clip_adam, withheld when comm's status word is set
+__device__ __forceinline__ bool mi_gate_closed(const uint32_t* gate) { return gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
 bool mi_comm_p2p_fused_ok(void* comm);   // grad_reduce_kernel may carry the exchange (false when more than two ranks share this device: see mi_comm.hip)
 
 // ---- RNG contract (include/mi_rl.h) ----------------------------------------------------------------

@@ -1068,7 +1068,10 @@ extern "C" int mi_dqn_td_update_sharded(float* params, const float* target_param
                                         double beta2, double eps, float max_norm, float* grad_norm, void* comm, void* stream) {
     MI_CHECK_ARG(gradbuf && exp_avg && exp_avg_sq && step >= 1, "NULL optimizer state / bad step");
     int world = 1;
-    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    if (comm) {
+        if (const int rc = mi_comm_poll_impl(comm)) return rc;   // an earlier wait of the P2P carrier ran out: MI_ESTATE before anything is enqueued
+        if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
+    }
     int rc = dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / ((double)batch * world), workspace,
                          gradbuf, gradbuf + DQ_NP, weights, td_abs, dqn_no_opt(), 0, 0, 0, stream);
     if (rc) return rc;
@@ -1077,7 +1080,7 @@ extern "C" int mi_dqn_td_update_sharded(float* params, const float* target_param
         rc = mi_comm_allreduce_impl(comm, gradbuf, (size_t)DQ_NP + 2, 0, (hipStream_t)stream);
         if (rc) return rc;
     }
-    return mi_clip_adam(params, gradbuf, exp_avg, exp_avg_sq, DQ_NP, step, lr, beta1, beta2, eps, max_norm, grad_norm, stream);
+    return mi_clip_adam_gated(params, gradbuf, exp_avg, exp_avg_sq, DQ_NP, step, lr, beta1, beta2, eps, max_norm, grad_norm, comm, stream);   // withheld after a timed-out exchange
 }
 
 // single-process fusion: TD gradient (optionally importance-weighted, weights / td_abs nullable together) + optimizer.step() in two launches

@@ -1208,8 +1208,12 @@ extern "C" int mi_sac_shadow_invalidate(const float* params) {   // NULL: every 
     for (int k = 0; k < g_nshadow; ++k) if (!params || g_shadow[k].base == params) g_shadow[k].valid = false;
     return MI_OK;
 }
-static void shadow_invalidate_range(const float* p, size_t n) {   // a library writer that does not maintain shadows touched [p, p + n)
-    for (int k = 0; k < g_nshadow; ++k) if (g_shadow[k].base >= p && g_shadow[k].base < p + n) g_shadow[k].valid = false;
+static void shadow_invalidate_range(const float* p, size_t n) {   // a library writer that does not maintain shadows touched [p, p + n): any OVERLAP with a registered vector
+    for (int k = 0; k < g_nshadow; ++k) {
+        const float* base = g_shadow[k].base;
+        const size_t len = g_shadow[k].is_actor ? (size_t)AC_NP : (size_t)2 * SQ_NP;
+        if (base < p + n && base + len > p) g_shadow[k].valid = false;
+    }
 }
 // t[m][k][u] = W_m[u][k]: 32 x 32 tiles through LDS, both sides coalesced
 __global__ void __launch_bounds__(256) sac_transpose_kernel(const float* __restrict__ params, int is_actor, float* __restrict__ t) {
@@ -1676,6 +1680,13 @@ extern "C" int mi_sac_actor_update(float* actor, const float* q, const float* ob
                                     adam_eps, nullptr, stream);
 }
 
+static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1, double beta2, double eps,
+                       const uint32_t* gate, void* stream);
+static int polyak_launch(float* target, const float* param, int n, float tau, const uint32_t* gate, void* stream);
+static int alpha_adam_launch(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, float* alpha,
+                             float* out, const uint32_t* gate, void* stream);
+// FAIL-SAFE (mi_common.h): a timed-out wait of the P2P carrier withholds the optimizer steps behind the exchange (adam / polyak / alpha read the carrier's status word
+// with their state), and the next call returns MI_ESTATE at its entry.
 // ---- sharded runs, ONE C call per update (the pattern of mi_ppo_update_sharded): the *_grad launches with the share scaled by 1 / (world * batch), an in-stream RCCL
 // SUM all-reduce of the caller's {gradient, 2 scalars} buffer, then mi_adam (and mi_polyak) — exactly the launches of the host-sequenced route (sac_engine.py: *_grad,
 // torch.distributed.all_reduce, Adam.step, update_targets), so the two agree bit for bit; no Python between launches.
@@ -1686,7 +1697,10 @@ extern "C" int mi_sac_critic_update_sharded(float* q, float* q_target, const flo
                                             void* comm, void* stream) {
     MI_CHECK_ARG(qbuf && exp_avg && exp_avg_sq && step >= 1, "NULL optimizer state / bad step");
     int world = 1;
-    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    if (comm) {
+        if (const int rc = mi_comm_poll_impl(comm)) return rc;
+        if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
+    }
     int rc = mi_sac_critic_grad(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
                                 1.0 / ((double)batch * world), workspace, qbuf, qbuf + 2 * SQ_NP, stream);
     if (rc) return rc;
@@ -1695,16 +1709,19 @@ extern "C" int mi_sac_critic_update_sharded(float* q, float* q_target, const flo
         rc = mi_comm_allreduce_impl(comm, qbuf, (size_t)2 * SQ_NP + 2, 0, (hipStream_t)stream);
         if (rc) return rc;
     }
-    rc = mi_adam(q, qbuf, exp_avg, exp_avg_sq, 2 * SQ_NP, step, lr, beta1, beta2, adam_eps, stream);
+    rc = adam_launch(q, qbuf, exp_avg, exp_avg_sq, 2 * SQ_NP, step, lr, beta1, beta2, adam_eps, mi_comm_gate(comm), stream);
     if (rc || tau < 0.0f) return rc;
-    return mi_polyak(q_target, q, 2 * SQ_NP, tau, stream);
+    return polyak_launch(q_target, q, 2 * SQ_NP, tau, mi_comm_gate(comm), stream);
 }
 extern "C" int mi_sac_actor_update_sharded(float* actor, const float* q, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                                            uint64_t update_index, const float* alpha, void* workspace, float* abuf /* grads [ACTOR_NP] + out [2] */, float* exp_avg,
                                            float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double adam_eps, void* comm, void* stream) {
     MI_CHECK_ARG(abuf && exp_avg && exp_avg_sq && step >= 1, "NULL optimizer state / bad step");
     int world = 1;
-    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    if (comm) {
+        if (const int rc = mi_comm_poll_impl(comm)) return rc;
+        if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
+    }
     int rc = mi_sac_actor_grad(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / ((double)batch * world), workspace, abuf, abuf + AC_NP, stream);
     if (rc) return rc;
     if (comm) {
@@ -1712,14 +1729,17 @@ extern "C" int mi_sac_actor_update_sharded(float* actor, const float* q, const f
         rc = mi_comm_allreduce_impl(comm, abuf, (size_t)AC_NP + 2, 0, (hipStream_t)stream);
         if (rc) return rc;
     }
-    return mi_adam(actor, abuf, exp_avg, exp_avg_sq, AC_NP, step, lr, beta1, beta2, adam_eps, stream);
+    return adam_launch(actor, abuf, exp_avg, exp_avg_sq, AC_NP, step, lr, beta1, beta2, adam_eps, mi_comm_gate(comm), stream);
 }
 extern "C" int mi_sac_alpha_step_sharded(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
                                          uint64_t update_index, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr,
                                          float* alpha, float* out, float* mean_logp /* dev f32 [1] scratch */, void* workspace, void* comm, void* stream) {
     MI_CHECK_ARG(mean_logp != nullptr, "mean_logp scratch is NULL");
     int world = 1;
-    if (comm) { const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr); if (rc) return rc; }
+    if (comm) {
+        if (const int rc = mi_comm_poll_impl(comm)) return rc;
+        if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
+    }
     int rc = mi_sac_mean_logp(actor, observations, idx, batch, eps, seed, update_index, 1.0 / ((double)batch * world), mean_logp, workspace, stream);
     if (rc) return rc;
     if (comm) {
@@ -1727,13 +1747,15 @@ extern "C" int mi_sac_alpha_step_sharded(const float* actor, const float* observ
         rc = mi_comm_allreduce_impl(comm, mean_logp, 1, 0, (hipStream_t)stream);
         if (rc) return rc;
     }
-    return mi_sac_alpha_adam(mean_logp, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, stream);
+    return alpha_adam_launch(mean_logp, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, mi_comm_gate(comm), stream);
 }
 
 // ================================================ alpha, Adam, polyak ============================================================
 // one wave.  mean_in: nullable device scalar holding the (already all-reduced) mean log-prob; NULL = sum this rank's slabs (lane-strided, then the fixed DPP tree)
 __global__ void __launch_bounds__(64)
-sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const float* __restrict__ mean_in, float* __restrict__ mean_out, sac_alpha_t al) {
+sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const float* __restrict__ mean_in, float* __restrict__ mean_out, sac_alpha_t al,
+                 const uint32_t* __restrict__ gate) {
+    if (mi_gate_closed(gate)) return;   // mean_in came out of a timed-out exchange: the alpha step is withheld
     float mean_lp;
     if (mean_in) mean_lp = mean_in[0];
     else {
@@ -1805,51 +1827,60 @@ extern "C" int mi_sac_mean_logp(const float* actor, const float* observations, c
     const int rc = sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace, sac_alpha_t{}, (hipStream_t)stream);
     if (rc) return rc;
     sac_alpha_t al{}; al.inv_count = (float)inv_count;
-    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, mean_logp, al);
+    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, mean_logp, al, nullptr);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
 
-extern "C" int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
-                                 double lr, float* alpha, float* out, void* stream) {
+static int alpha_adam_launch(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, float* alpha,
+                             float* out, const uint32_t* gate, void* stream) {
     MI_CHECK_ARG(mean_logp && log_alpha && exp_avg && exp_avg_sq && alpha && step >= 1, "bad arguments");
     sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>(nullptr, 0, 0, mean_logp, nullptr,
-                                                       sac_make_alpha(target_entropy, 0.0f, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr));
+                                                       sac_make_alpha(target_entropy, 0.0f, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr), gate);
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+extern "C" int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step,
+                                 double lr, float* alpha, float* out, void* stream) {
+    return alpha_adam_launch(mean_logp, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr, stream);
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
-                                                    float w1, float b2, float w2, float step_size, float rbc2, float eps) {
+                                                    float w1, float b2, float w2, float step_size, float rbc2, float eps, const uint32_t* __restrict__ gate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || sac_faulted()) return;   // (mi_adam / mi_polyak are the SAC engines' unfused steps: they honour the device's fault word like the fused ones)
+    if (i >= n || sac_faulted() || mi_gate_closed(gate)) return;   // gate: the P2P exchange that produced g timed out (mi_common.h) - the step is withheld   // (mi_adam / mi_polyak are the SAC engines' unfused steps: they honour the device's fault word like the fused ones)
     float mi = m[i], vi = v[i];
     p[i] = mi_adam_elem(p[i], g[i], mi, vi, w1, b2, w2, step_size, rbc2, eps);
     m[i] = mi; v[i] = vi;
 }
 
-extern "C" int mi_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1,
-                       double beta2, double eps, void* stream) {
+static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1,
+                       double beta2, double eps, const uint32_t* gate, void* stream) {
     MI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad arguments");
     shadow_invalidate_range(params, (size_t)n);   // this launch does not keep a transposed copy in step
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     adam_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
-                                                                 (float)(1.0 - beta2), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps);
+                                                                 (float)(1.0 - beta2), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps, gate);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
-
-__global__ void __launch_bounds__(256) polyak_kernel(float* __restrict__ t, const float* __restrict__ p, int n, float tau) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && !sac_faulted()) t[i] = tau * p[i] + (1.0f - tau) * t[i];
+extern "C" int mi_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1,
+                       double beta2, double eps, void* stream) {
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, nullptr, stream);
 }
 
-extern "C" int mi_polyak(float* target, const float* param, int n, float tau, void* stream) {
+__global__ void __launch_bounds__(256) polyak_kernel(float* __restrict__ t, const float* __restrict__ p, int n, float tau, const uint32_t* __restrict__ gate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && !sac_faulted() && !mi_gate_closed(gate)) t[i] = tau * p[i] + (1.0f - tau) * t[i];
+}
+
+static int polyak_launch(float* target, const float* param, int n, float tau, const uint32_t* gate, void* stream) {
     MI_CHECK_ARG(target && param && n > 0, "bad arguments");
     shadow_invalidate_range(target, (size_t)n);
-    polyak_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(target, param, n, tau);
+    polyak_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(target, param, n, tau, gate);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
+extern "C" int mi_polyak(float* target, const float* param, int n, float tau, void* stream) { return polyak_launch(target, param, n, tau, nullptr, stream); }
 
 MI_INSIDE_EXPORT(sac)

@@ -432,6 +432,7 @@ struct grad_pending_t {
     float* p_out; float* m_out; float* v_out;             // ... after it (never the *_in buffers)
     float* grad_norm;                                     // nullable: pre-clip total norm of `grads`
     const double* norm_parts;                             // nullable: the block sums of squares grad_reduce_kernel wrote for `grads` (single rank only: see block_grad_norm)
+    const uint32_t* gate;                                 // nullable: status word of the P2P carrier that exchanged `grads` (mi_comm_gate) — non-zero: the step is WITHHELD, out = in
     float w1, b2, w2, step_size, rbc2, eps, max_norm;
 };
 
@@ -662,7 +663,7 @@ static int ppo_grad_launch(const float* params, const grad_pending_t& pend, cons
         int world = 0;
         if (p2p) {
             if (loss_terms != grads + NPARAMS) { mi_set_error("ppo_grad_launch: the P2P exchange needs loss_terms == grads + MI_PPO_NPARAMS"); return MI_EINVAL; }
-            int rc = mi_comm_p2p_next(p2p, (size_t)NPARAMS + 4, &x, &world);
+            int rc = mi_comm_p2p_next(p2p, (size_t)NPARAMS + 4, &x, &world, s);
             if (rc) return rc;
         }
         const float* ws = (const float*)workspace;
@@ -704,9 +705,10 @@ extern "C" int mi_ppo_minibatch_grad(const float* params, const float* observati
 __global__ void __launch_bounds__(512) clip_adam_kernel(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out,
                                                          const float* __restrict__ grads, int n, float w1, float b2,
                                                          float w2, float step_size, float rbc2, float eps, float max_norm,
-                                                         float* __restrict__ grad_norm, const double* __restrict__ norm_parts) {
+                                                         float* __restrict__ grad_norm, const double* __restrict__ norm_parts, const uint32_t* __restrict__ gate) {
     __shared__ double ws[4], sparts[256];
     MI_INSIDE_SCOPE(MI_PROF_CLIP_ADAM);
+    const bool hold = mi_gate_closed(gate);   // the exchange that produced `grads` timed out: keep the state (out of place: copy it through)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // 256 threads, or 512 for a PPO parameter vector (block_grad_norm's 8-wave branch when there are no block sums)
     const bool live = i < n;
     float pm = live ? m_in[i] : 0.0f, pv = live ? v_in[i] : 0.0f;
@@ -716,7 +718,8 @@ __global__ void __launch_bounds__(512) clip_adam_kernel(const float* p_in, const
     coef = coef > 1.0f ? 1.0f : coef;
     if (grad_norm && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm = total;
     if (live) {
-        const float np = mi_adam_elem(pp, pg * coef, pm, pv, w1, b2, w2, step_size, rbc2, eps);
+        float np = pp;
+        if (!hold) np = mi_adam_elem(pp, pg * coef, pm, pv, w1, b2, w2, step_size, rbc2, eps);
         m_out[i] = pm; v_out[i] = pv;
         p_out[i] = np;
     }
@@ -732,13 +735,20 @@ static adam_consts_t adam_consts(int64_t step, double lr, double beta1, double b
 }
 
 static int clip_adam_launch(const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out, const float* grads, int n,
-                            const adam_consts_t& k, float max_norm, float* grad_norm, const double* norm_parts, hipStream_t s) {
+                            const adam_consts_t& k, float max_norm, float* grad_norm, const double* norm_parts, hipStream_t s, const uint32_t* gate = nullptr) {
     mi_prof_scope prof(MI_PROF_CLIP_ADAM, s);
     const int threads = n == NPARAMS ? 512 : 256;   // same tree for any block size; 8 waves take the cheap branch on a PPO vector without block sums (sharded runs, mi_clip_adam)
     clip_adam_kernel<<<(n + threads - 1) / threads, threads, 0, s>>>(p_in, m_in, v_in, p_out, m_out, v_out, grads, n, k.w1, k.b2, k.w2, k.step_size, k.rbc2, k.eps, max_norm,
-                                                                    grad_norm, norm_parts);
+                                                                    grad_norm, norm_parts, gate);
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+
+// mi_clip_adam behind an exchange on `comm` (mi_dqn_td_update_sharded): the step is withheld when that carrier's status word is set
+int mi_clip_adam_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1, double beta2, double eps,
+                       float max_norm, float* grad_norm, void* comm, void* stream) {
+    return clip_adam_launch(params, exp_avg, exp_avg_sq, params, exp_avg, exp_avg_sq, grads, n, adam_consts(step, lr, beta1, beta2, eps), max_norm, grad_norm,
+                            nullptr, (hipStream_t)stream, mi_comm_gate(comm));
 }
 
 extern "C" int mi_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr,
@@ -864,7 +874,9 @@ extern "C" int mi_ppo_update(void* handle, const mi_ppo_buffers_t* b, const mi_p
 extern "C" int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* b, const mi_ppo_hparams_t* hp, void* comm, void* stream) {
     int world = 1;
     if (comm) {
-        int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr);
+        int rc = mi_comm_poll_impl(comm);   // an earlier wait of the P2P carrier ran out: MI_ESTATE before anything is enqueued
+        if (rc) return rc;
+        rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr);
         if (rc) return rc;
         MI_CHECK_ARG(b && b->loss_terms == b->grads + NPARAMS, "sharded update: loss_terms must be grads + MI_PPO_NPARAMS (one buffer, one all-reduce)");
     }
@@ -935,6 +947,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
                 pend.grad_norm = b->grad_norm; pend.w1 = c.w1; pend.b2 = c.b2; pend.w2 = c.w2; pend.step_size = c.step_size; pend.rbc2 = c.rbc2; pend.eps = c.eps;
                 pend.max_norm = hp->max_grad_norm;
                 pend.norm_parts = sharded_norm ? nullptr : ws_norm_parts(b->workspace);   // sharded: the all-reduce changed the gradient after the block sums were taken
+                pend.gate = mi_comm_gate(comm);
                 cur = out;   // what this launch trains on and what the next owed step starts from
             }
             rc = ppo_grad_launch(owed ? nullptr : cur.p, pend, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
@@ -951,7 +964,7 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
         }
     }
     return clip_adam_launch(cur.p, cur.m, cur.v, caller.p, caller.m, caller.v, b->grads, NPARAMS, adam_consts(step, hp->lr, hp->beta1, hp->beta2, hp->eps),
-                            hp->max_grad_norm, b->grad_norm, sharded_norm ? nullptr : ws_norm_parts(b->workspace), s);
+                            hp->max_grad_norm, b->grad_norm, sharded_norm ? nullptr : ws_norm_parts(b->workspace), s, mi_comm_gate(comm));
 }
 
 // =====================================================================================================

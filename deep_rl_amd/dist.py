@@ -16,12 +16,17 @@ MIRL_FORCE_COLLECTIVES=1 makes `allreduce_sum_` issue its collective even at wor
 """
 import os
 
-import ctypes as C
+# This pool's driver only supports dmabuf IPC: without this, RCCL's set-up and hipIpcGetMemHandle (the P2P carrier's inboxes, CUDA-tensor sharing) fail with
+# "invalid argument".  Set here — at import, before anything of this process can have initialised HIP (importing torch does not) — so that bench.py started directly as a
+# rank by torch.distributed.run and the drop-in scripts' documented 8-GPU command get it too, not only the launchers that remembered to export it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch
-import torch.distributed as dist
+import ctypes as C  # noqa: E402
 
-from ._native import MiError
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from ._native import MiError  # noqa: E402
 
 _FORCE_PG = os.environ.get("MIRL_FORCE_PG", "0") == "1"
 _FORCE_COLLECTIVES = os.environ.get("MIRL_FORCE_COLLECTIVES", "0") == "1"
@@ -175,12 +180,31 @@ def _create_p2p(group):
     except Exception:  # noqa: BLE001  (no uuid on this torch: the index — right on one node, where CUDA_VISIBLE_DEVICES-style remapping is the launcher's business)
         where = (socket.gethostname(), str(dev))
     boxes = [None] * world
-    dist.all_gather_object(boxes, (bytes(mine.raw), ok, where), group=group)
+    dist.all_gather_object(boxes, (bytes(mine.raw), ok, where, os.environ.get("MIRL_P2P_FUSED")), group=group)
     if ok and all(b[1] for b in boxes):
         if N.lib().mi_comm_p2p_connect(h, b"".join(b[0] for b in boxes)) != 0:
             ok, err = 0, N.lib().mi_last_error().decode()
-        else:   # ranks sharing this rank's device (test placements): > 2 of them take the stand-alone all-reduce launch (csrc/mi_comm.hip: mi_comm_p2p_fused_ok)
-            N.check(N.lib().mi_comm_p2p_set_colocated(h, sum(1 for b in boxes if b[2] == where)), "mi_comm_p2p_set_colocated")
+        else:
+            # Which form PPO's gradient exchange takes (inside the slab sum / a launch of its own) must be ONE decision for the whole communicator: the two forms publish
+            # the gradient's lines in different orders under the same sequence number, and a mix sums permuted elements without any wait failing.  Every
+            # rank derives it from the SAME gathered list: the LARGEST number of ranks on one device (test placements: > 2 take the stand-alone launch, csrc/mi_comm.hip
+            # mi_comm_p2p_fused_ok) and the MIRL_P2P_FUSED settings, which must agree.
+            per_device = {}
+            for b in boxes:
+                per_device[b[2]] = per_device.get(b[2], 0) + 1
+            settings = {b[3] for b in boxes}
+            if len(settings) > 1:
+                ok, err = 0, "MIRL_P2P_FUSED differs across the ranks (%s): the ranks of a communicator must take the same form of the exchange" % sorted(map(str, settings))
+            else:
+                N.check(N.lib().mi_comm_p2p_set_colocated(h, max(per_device.values())), "mi_comm_p2p_set_colocated")
+                forced = settings.pop()
+                if forced is not None:
+                    try:
+                        mode = 1 if int(forced) != 0 else -1
+                    except ValueError:
+                        ok, err, mode = 0, "MIRL_P2P_FUSED=%r is not an integer" % forced, 0
+                    if ok:
+                        N.check(N.lib().mi_comm_p2p_set_fused(h, mode), "mi_comm_p2p_set_fused")
     elif ok:
         ok, err = 0, "a peer could not allocate its inbox"
     return h, ok, err
@@ -319,6 +343,33 @@ def _auto_choice(group):
     return best
 
 
+def probed_comm(group, which, rounds=50):
+    """libmirl's communicator of carrier `which` ("rccl" / "p2p") for `group`, created AND checked: the known-answer all-reduce of the path's own message (9,159 floats,
+    three times, mi_comm_check behind it) and a short timing — the same probe MIRL_COMM=auto runs — whatever MIRL_COMM says.  Collective.  -> (handle | None, report);
+    a carrier that cannot be created or fails its probe on ANY rank is destroyed on every rank (it may hold a timed-out wait) and reported with the reason.
+    bench.py's N > 1 policy stands on this: the headline runs on RCCL (the configuration BASELINE.json names), the P2P carrier beside it."""
+    from . import _native as N
+
+    gkey = id(group) if group is not None else 0
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, {"ok": False, "why": "no process group"}
+    if which == "rccl" and dist.get_backend(group) != "nccl":
+        return None, {"ok": False, "why": "process group is %s (RCCL needs nccl: one device per rank)" % dist.get_backend(group)}
+    if which == "p2p" and not torch.cuda.is_available():
+        return None, {"ok": False, "why": "no GPU in this process"}
+    h = native_comm(group, which=which)
+    if h is None:
+        return None, {"ok": False, "why": "communicator could not be created (stderr has the reason)"}
+    ok, us, why = _probe(h, group, N.NPARAMS + 4, rounds)
+    if not ok:
+        key = (gkey, which)
+        if _native_comms.get(key) is not None:
+            N.lib().mi_comm_destroy(_native_comms[key])
+        _native_comms[key] = None
+        return None, {"ok": False, "why": why}
+    return h, {"ok": True, "us_per_allreduce": round(us, 2), "probe": "known-answer SUM of %d floats x 3, then %d back-to-back all-reduces; us = MAX over ranks" % (N.NPARAMS + 4, rounds)}
+
+
 def set_auto_choice(group, which, how):
     """Replace the probe's choice for `group` by a measurement of the caller's (bench.py: the same short window of real sharded updates on every carrier that passed
     the probe — the probe times stand-alone all-reduces, while on the P2P carrier PPO's gradient exchange rides inside the slab-sum launch).  Every rank must call it
@@ -352,6 +403,19 @@ def check_native_comm(group=None):
     for (g, _), h in _native_comms.items():
         if h is not None and g == (id(group) if group is not None else 0):
             N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+
+
+def poll_native_comm(group=None):
+    """The same question WITHOUT a synchronisation (mi_comm_poll: the host-pinned mirror of the carrier's status word, written by the wait that ran out): raises
+    MiError once a wait of the P2P carrier has timed out on this rank.  Every mi_*_sharded call asks it at its entry anyway; loops that want to stop at the update
+    that failed rather than at the next call poll it after their per-update host touch."""
+    from . import _native as N
+
+    if _override is not None:
+        N.check(N.lib().mi_comm_poll(_override), "mi_comm_poll")
+    for (g, _), h in _native_comms.items():
+        if h is not None and g == (id(group) if group is not None else 0):
+            N.check(N.lib().mi_comm_poll(h), "mi_comm_poll")
 
 
 def destroy_native_comms():

@@ -132,6 +132,8 @@ class PPOEngine:
     def drain_episodes(self):
         """Host sync.  -> (count, [(env, t, return, length), ...] sorted by (t, env)) of the last rollout."""
         n = int(self.episode_stats[0].item())
+        if self.world_size > 1:
+            D.poll_native_comm(self.pg)   # behind the sync above: a wait of the P2P carrier that ran out during the last update raises HERE, not one call later
         k = min(n, self.max_ep)
         if k == 0:
             return n, []
@@ -145,6 +147,8 @@ class PPOEngine:
         (read it after the next sync point; CartPole return == length).  Same single-stream contract as `episode_stats`.  The direct route below lets the device
         kernel write into `pinned.data_ptr()`: that holds for tensors torch itself pinned (`.pin_memory()` / hipHostMalloc: mapped at the same address on the device);
         memory pinned some other way (hipHostRegister of a foreign allocation) need not be — pass `direct=False` for such tensors."""
+        if self.world_size > 1:
+            D.poll_native_comm(self.pg)   # no sync: raises once a wait of the P2P carrier has run out (the optimizer steps behind it were withheld on the device)
         ok = direct and self._lazy_stats and self._stats_any and pinned.is_pinned() and pinned.dtype == torch.int32 and pinned.numel() >= 4 and pinned.is_contiguous()
         if ok:
             # the sum of the per-workgroup statistics is written straight into the pinned host tensor (device-visible at the same address): no copy behind it

@@ -79,7 +79,11 @@ class SACEngine:
         if _TRANSPOSED and self._single():
             for flat, mods, is_actor in ((actor.flat, (actor,), 1), (self._q_flat, (qf1, qf2), 0), (self._qt_flat, (qf1_target, qf2_target), 0)):
                 sh = torch.zeros((1 if is_actor else 2) * 65536, dtype=torch.float32, device=dev)
-                N.check(N.lib().mi_sac_shadow_set(N.ptr(flat), is_actor, N.ptr(sh)), "mi_sac_shadow_set")
+                if N.lib().mi_sac_shadow_set(N.ptr(flat), is_actor, N.ptr(sh)) != 0:
+                    # the library's registry is full (engines that were not collected yet): a missing shadow only means the old access pattern, so this engine runs
+                    # without any — all three or none, the update launches pick per vector
+                    self.close()
+                    break
                 self._shadows.append([flat, sh, [flat] + [p for m in mods for p in m.parameters()], None])
         self.observation = None
         self.global_step = 0
@@ -103,10 +107,16 @@ class SACEngine:
         for ent in self._shadows:
             ent[3] = None
 
+    def close(self):
+        """Unregister this engine's transposed copies from the library (idempotent; the engine keeps working on the plain access pattern).  Call it when an engine is
+        dropped in a loop that builds many: `__del__` does the same, but only when the object is collected."""
+        for ent in getattr(self, "_shadows", []):
+            N.lib().mi_sac_shadow_set(N.ptr(ent[0]), 0, None)
+        self._shadows = []
+
     def __del__(self):
         try:
-            for ent in getattr(self, "_shadows", []):
-                N.lib().mi_sac_shadow_set(N.ptr(ent[0]), 0, None)
+            self.close()
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 

@@ -50,9 +50,9 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout, a workspace size or a signature changes (101: mi_ppo_buffers_t gained episode_stats_next and the SAC
  * workspace grew in round 2; round 3 adds mi_sac_check / the workspace status words and mi_comm_info's comm_count; 102, round 4: mi_explained_var_parts,
- * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier, mi_comm_p2p_set_colocated; mi_test_contraction; mi_sac_shadow_*; 106: mi_dueling_td_update).  Bindings must compare mi_version()
+ * mi_ppo_test_assume_sharded; 103: mi_sac_critic_update_deferred / mi_sac_critic_step / mi_sac_act_step_carry; 104: mi_env_episode_stats, episode statistics kept per workgroup; 105, round 5: the P2P carrier of mi_comm — mi_comm_p2p_alloc / _connect / _synthetic, mi_comm_check, mi_comm_carrier, mi_comm_p2p_set_colocated; mi_test_contraction; mi_sac_shadow_*; 106: mi_dueling_td_update; 107, round 6: mi_comm_poll / the P2P carrier's fail-safe, mi_comm_p2p_set_fused, mi_comm_test_set_seq, mi_per_td_update).  Bindings must compare mi_version()
  * with the MI_VERSION they were written against and refuse to run on a mismatch (deep_rl_amd/_native.py does). */
-#define MI_VERSION 106
+#define MI_VERSION 107
 #define MI_PPO_NPARAMS 9155
 #define MI_PPO_ACTOR_NPARAMS 4610
 #define MI_OBS_DIM 4
@@ -237,33 +237,48 @@ int mi_comm_destroy(void* comm);
  * (ncclCommCount; -1 if the entry point is missing).  Any out pointer may be NULL. */
 int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version, int* comm_count);
 int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stream);
-/* The second carrier behind the same handle: a ONE-SHOT peer-to-peer all-reduce over hipIpc-mapped inboxes (round 5).  Every rank owns an inbox
- * [2 parities][world][max_bytes] (+ one flag word per parity, rank and workgroup) in uncached device memory, mapped into every peer.  One all-reduce = ONE launch:
- * store the local share into slot (parity, rank) of every rank's inbox, publish the sequence number, wait (bounded: MIRL_P2P_TIMEOUT_MS, default 10,000) for the
- * world's sequence numbers in the own inbox, sum the world's slots IN RANK ORDER -> bitwise the same result on every rank by construction, for any world size
- * (a ring's grouping depends on the rank); at world 2 also bitwise RCCL's / gloo's a + b.  Works with two ranks on ONE device (RCCL refuses that), which is how
- * a one-GPU box runs the one-call *_sharded routes at world_size 2 (tests/test_gpu_p2p.py).  world_size <= 8 (one node).
+/* The second carrier behind the same handle: a ONE-SHOT peer-to-peer all-reduce over hipIpc-mapped inboxes (round 5; csrc/mi_comm.hip).  Every rank owns an inbox in
+ * uncached device memory, mapped into every peer: 256 header bytes (status word, barrier lines) + [2 parities][world] slots of 2 * max_bytes each — a slot holds the
+ * message as 8-byte LINES {payload word, sequence number of the all-reduce}, so the footprint is 256 + 2 * world * 2 * max_bytes bytes per rank.  One all-reduce = ONE
+ * launch: every 32-bit word of the local share is stored, TOGETHER with the sequence number, as one line into slot (parity, rank) of every rank's inbox; the launch then
+ * polls (bounded: MIRL_P2P_TIMEOUT_MS, default 30,000) the world's lines of its own elements in its own inbox until each carries the sequence number — the payload is
+ * its own "arrived" flag: no fence, no flag word, no second round trip — and sums them IN RANK ORDER -> bitwise the same result on every rank by construction, for any
+ * world size (a ring's grouping depends on the rank); at world 2 also bitwise RCCL's / gloo's a + b.  The parity flips with every all-reduce (a bit of its own); when
+ * the 32-bit sequence number is used up, the ranks change the epoch in-stream (own lines cleared, a barrier through the header, numbers restart at 1).  Works with two
+ * ranks on ONE device (RCCL refuses that), which is how a one-GPU box runs the one-call *_sharded routes at world_size 2 (tests/test_gpu_p2p.py).  world_size <= 8.
+ * FAIL-SAFE.  A wait that runs out (a peer that stalls beyond the budget) sets the inbox's status word and its host-pinned mirror.  From then on every optimizer step
+ * that would consume an exchanged gradient — PPO's owed clip + Adam and its last step, DQN's / PER's clip + Adam, SAC's Adam / polyak / alpha steps on the *_sharded
+ * routes — reads that word with its state and is WITHHELD (parameters, moments and targets stay as they were in front of the failed exchange), and every later
+ * mi_*_sharded / mi_comm_allreduce_sum call returns MI_ESTATE at its entry (a plain host load of the mirror: no synchronisation).  The communicator is dead after
+ * that (destroy it); what is lost is the update, never the parameters.
  *   mi_comm_p2p_alloc    allocates this rank's inbox on the CURRENT device for messages of <= max_bytes and writes its 64-byte hipIpcMemHandle_t; the caller ships the
  *                        handles of all ranks to all ranks (torch.distributed all_gather / file / MPI) ...
  *   mi_comm_p2p_connect  ... and hands them over in rank order (world_size * 64 bytes): maps the peers' inboxes.  The handle then works wherever an RCCL one does
  *                        (mi_comm_allreduce_sum, mi_*_sharded).  All collectives of one communicator must be enqueued on streams ordered with each other, by every rank
  *                        in the same order.  Put a barrier in front of mi_comm_destroy: a peer may still be storing into this rank's inbox.
- *   mi_comm_p2p_synthetic  ONE process plays world_size ranks into its own inbox (slot 0 = its share, the others zeros: results unchanged): the stores, flags,
- *                        waits and the world-slot sum of a world_size-rank exchange minus the links — for timing on a one-GPU box (bench.py `sharded_route`).
+ *   mi_comm_p2p_synthetic  ONE process plays world_size ranks into its own inbox (slot 0 = its share, the others zeros: results unchanged): the stores, polls and the
+ *                        world-slot sum of a world_size-rank exchange minus the links — for timing on a one-GPU box (bench.py `sharded_route`).
  *                        mi_comm_info reports world_size 1 (the sharded calls scale their shares by 1 / world_size: it IS one rank) and comm_count = the ranks played.
- *   mi_comm_check        host-synchronising.  MI_OK, or MI_ESTATE when a wait ran out: that all-reduce and every later one on the communicator left the LOCAL share in
- *                        its buffer (a launch never spins beyond its budget, later launches return at once).  Always MI_OK for RCCL.
+ *   mi_comm_check        host-synchronising.  MI_OK, or MI_ESTATE when a wait ran out (mi_last_error names the ranks that never arrived).  Always MI_OK for RCCL.
+ *   mi_comm_poll         the same answer WITHOUT synchronising (the mirror): what the *_sharded calls test at their entry; callers may poll it per update.
  *   mi_comm_carrier      0 = RCCL, 1 = P2P. */
 #define MI_COMM_IPC_BYTES 64
 int mi_comm_p2p_alloc(int world_size, int rank, size_t max_bytes, void** comm, void* ipc_handle64);
 int mi_comm_p2p_connect(void* comm, const void* ipc_handles);
 int mi_comm_p2p_synthetic(int world_size, size_t max_bytes, void** comm);
 int mi_comm_check(void* comm);
+int mi_comm_poll(void* comm);
 int mi_comm_carrier(void* comm);
-/* How many ranks of the communicator share THIS rank's device (default 1 = one rank per GPU).  With more than two, mi_ppo_update_sharded takes a stand-alone launch per
- * all-reduce instead of the exchange inside the slab sum: three or more ranks spin-waiting in 145 x 1,024-thread workgroups fill the chip, and the rank they wait for cannot be
- * scheduled (test placements only; MIRL_P2P_FUSED=0 / 1 overrides).  deep_rl_amd.dist derives the count from the ranks' (host, device uuid). */
-int mi_comm_p2p_set_colocated(void* comm, int ranks_on_this_device);
+/* The LARGEST number of ranks of the communicator that share one device (default 1 = one rank per GPU) — the SAME value on every rank.  With more than two,
+ * mi_ppo_update_sharded takes a stand-alone launch per all-reduce instead of the exchange inside the slab sum: three or more ranks spin-waiting in 145 x 1,024-thread
+ * workgroups fill the chip, and the rank they wait for cannot be scheduled (test placements only).  The two forms publish the gradient's lines in different orders (slab
+ * order / parameter order) under one sequence number, so ALL ranks must take the same one: deep_rl_amd.dist derives the count from the gathered (host, device uuid) of every
+ * rank and, when MIRL_P2P_FUSED is set, checks that every rank has the same setting and fixes it with mi_comm_p2p_set_fused (-1 stand-alone, 1 in-launch, 0 = by count). */
+int mi_comm_p2p_set_colocated(void* comm, int max_ranks_on_one_device);
+int mi_comm_p2p_set_fused(void* comm, int mode);
+/* TEST HOOK: presets the P2P carrier's sequence number (the last all-reduce's number inside the epoch; the same value on every rank, between all-reduces) so that a test
+ * crosses the epoch change — at 0xFFFFFFF0 — within a few exchanges. */
+int mi_comm_test_set_seq(void* comm, uint32_t seq);
 int mi_ppo_update_sharded(void* handle, const mi_ppo_buffers_t* buf, const mi_ppo_hparams_t* hp, void* comm, void* stream);
 /* TEST HOOK (process-wide; 0 = off): mi_ppo_update / mi_ppo_update_sharded behave as at world_size > 1 in everything but the collective — the owed optimizer steps
  * recompute the clip coefficient from the (all-reduced) gradient itself instead of reading the slab sum's block sums, the one branch a single-GPU run never takes.

@@ -57,6 +57,25 @@ for dtype, sizes in ((torch.float32, (1, 3, 9159, 10936, 134660, 1024, 4097)), (
 torch.cuda.synchronize()
 dist.barrier()
 
+# ---- epoch change: both ranks preset the sequence number 3 below the last one of the epoch and run 8 mixed exchanges across it (twice: the second epoch change finds
+#      the barrier lines of the first) ----
+SEQ_LAST = 0xFFFFFFF0
+for rep in range(2):
+    N.check(L.mi_comm_test_set_seq(comm, SEQ_LAST - 3), "mi_comm_test_set_seq")
+    for k, (dtype, n) in enumerate([(torch.float32, 134660), (torch.float32, 9159), (torch.float64, 48), (torch.float32, 9159), (torch.float32, 134660), (torch.float64, 48),
+                                    (torch.float32, 9159), (torch.float32, 1)]):
+        mine = (torch.randn(n, generator=gen, dtype=dtype) * 3).to(dev)
+        want = mine.clone()
+        dist.all_reduce(want)
+        got = mine.clone()
+        N.check(L.mi_comm_allreduce_sum(comm, got.data_ptr(), n, 0 if dtype == torch.float32 else 1, s), "mi_comm_allreduce_sum")
+        torch.cuda.synchronize()
+        N.check(L.mi_comm_check(comm), "mi_comm_check")
+        N.check(L.mi_comm_poll(comm), "mi_comm_poll")
+        assert torch.equal(got, want), ("epoch change", rep, k, dtype, n, (got - want).abs().max().item())
+torch.cuda.synchronize()
+dist.barrier()
+
 # a message larger than the slots is refused up front
 big = torch.zeros((1 << 20) // 4 + 64, dtype=torch.float32, device=dev)
 assert L.mi_comm_allreduce_sum(comm, big.data_ptr(), big.numel(), 0, s) == -1 and b"does not fit" in L.mi_last_error()
@@ -73,12 +92,86 @@ if rank == 0:
     N.check(L.mi_comm_allreduce_sum(h, x.data_ptr(), 100, 0, s), "mi_comm_allreduce_sum")
     torch.cuda.synchronize()
     assert L.mi_comm_check(h) == -4 and b"never arrived: 1" in L.mi_last_error(), L.mi_last_error()
+    assert L.mi_comm_poll(h) == -4 and b"WITHHELD" in L.mi_last_error(), L.mi_last_error()   # the same answer without a sync (host-pinned mirror)
     assert torch.equal(x, torch.arange(100, dtype=torch.float32, device=dev) + 1)      # the local share, untouched
-    N.check(L.mi_comm_allreduce_sum(h, x.data_ptr(), 100, 0, s), "mi_comm_allreduce_sum")   # later launches return at once
-    torch.cuda.synchronize()
-    assert L.mi_comm_check(h) == -4
+    assert L.mi_comm_allreduce_sum(h, x.data_ptr(), 100, 0, s) == -4                    # later calls are refused at their entry
 else:
-    assert L.mi_comm_check(h) == 0
+    assert L.mi_comm_check(h) == 0 and L.mi_comm_poll(h) == 0
+dist.barrier()
+L.mi_comm_destroy(h)
+
+
+# ---- the fail-safe through the engines: rank 0 runs an update on a communicator whose peer never calls ----
+def lonely_comm(nbytes):
+    hh, me = C.c_void_p(), (C.c_char * 64)()
+    N.check(L.mi_comm_p2p_alloc(2, rank, nbytes, C.byref(hh), me), "mi_comm_p2p_alloc")
+    bx = [None, None]
+    dist.all_gather_object(bx, bytes(me.raw))
+    N.check(L.mi_comm_p2p_connect(hh, b"".join(bx)), "mi_comm_p2p_connect")
+    return hh
+
+
+import deep_rl_amd as D  # noqa: E402
+import deep_rl_amd.engine as E  # noqa: E402
+
+assert "MIRL_CHECK_REPLICAS" not in os.environ
+h = lonely_comm(1 << 16)
+if rank == 0:
+    env = D.make("CartPole-v1", num_envs=64, device=dev, seed=5)
+    torch.manual_seed(5)
+    agent = D.ActorCritic(env)
+    opt = D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
+    eng = D.PPOEngine(env, agent, opt, num_steps=128)
+    eng.reset()
+    before = [t.clone() for t in (agent.flat, opt.exp_avg, opt.exp_avg_sq)]
+    DD.use_comm(h)
+    try:
+        eng.update()                       # every exchange of it times out (300 ms the first, 64 polls the others): all 16 optimizer steps are withheld
+        torch.cuda.synchronize()
+        for a, b in zip(before, (agent.flat, opt.exp_avg, opt.exp_avg_sq)):
+            assert torch.equal(a, b), "a timed-out exchange cost the optimizer state"
+        assert not torch.equal(eng.observations[1], eng.observations[0])   # (the rollout itself ran)
+        try:
+            eng.update()
+            raise AssertionError("the update behind a timed-out exchange did not raise")
+        except N.MiError as ex:
+            assert "never arrived: 1" in str(ex) and "WITHHELD" in str(ex), str(ex)
+        try:
+            pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
+            eng.episode_summary_async(pinned)
+            raise AssertionError("episode_summary_async did not poll the carrier")
+        except N.MiError:
+            pass
+        for a, b in zip(before, (agent.flat, opt.exp_avg, opt.exp_avg_sq)):
+            assert torch.equal(a, b)
+    finally:
+        DD.use_comm(None)
+dist.barrier()
+L.mi_comm_destroy(h)
+
+h = lonely_comm(1 << 16)
+if rank == 0:
+    env = D.make("CartPole-v1", num_envs=64, device=dev, seed=6)
+    torch.manual_seed(6)
+    q = D.QNetwork(env); tq = D.QNetwork(env); tq.load_state_dict(q.state_dict())
+    opt = D.ClipAdam(q, lr=2.5e-4, eps=1e-8)
+    eng = D.DQNEngine(env, q, tq, opt, slots=64, batch_size=128, learning_starts=10, total_timesteps=1000, max_episodes_logged=0)
+    eng.reset()
+    eng.act(20)
+    before = [t.clone() for t in (q.flat, opt.exp_avg, opt.exp_avg_sq)]
+    DD.use_comm(h)
+    try:
+        eng.train_step()
+        torch.cuda.synchronize()
+        for a, b in zip(before, (q.flat, opt.exp_avg, opt.exp_avg_sq)):
+            assert torch.equal(a, b), "DQN: a timed-out exchange cost the optimizer state"
+        try:
+            eng.train_step()
+            raise AssertionError("DQN: the step behind a timed-out exchange did not raise")
+        except N.MiError as ex:
+            assert "never arrived: 1" in str(ex), str(ex)
+    finally:
+        DD.use_comm(None)
 dist.barrier()
 L.mi_comm_destroy(h)
 

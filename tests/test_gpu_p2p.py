@@ -67,6 +67,82 @@ def test_synthetic_world_allreduce_is_identity(world):
         L.mi_comm_destroy(h)
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
+def test_synthetic_world_epoch_change(world):
+    """The 32-bit sequence number runs out (round 5 wrapped 0xFFFFFFFF -> 1, two consecutive all-reduces on one parity, stale lines with a "right"
+    number).  Preset it 3 below the epoch's last number and run exchanges of MIXED sizes across the change: a long message first, so that lines of the old epoch sit
+    behind the end of the short ones that follow; the same numbers come round again after the change (1, 2, ...) and must not be mistaken for arrivals — the inbox is
+    cleared under a barrier.  x + 0 + ... + 0 in rank order == x, bit for bit; both the stand-alone launch and grad_reduce_kernel's in-launch exchange cross it."""
+    torch = _need_gpu()
+    from deep_rl_amd import _native as N
+
+    dev = torch.device("cuda", 0)
+    L, s = N.lib(), N.stream_ptr(dev)
+    h = C.c_void_p()
+    N.check(L.mi_comm_p2p_synthetic(world, 1 << 20, C.byref(h)), "mi_comm_p2p_synthetic")
+    try:
+        gen = torch.Generator(device="cpu").manual_seed(7 * world)
+        # seed the slots of BOTH parities with sequence numbers 1 .. 6 on long messages: what a fresh epoch will count through again
+        for _ in range(6):
+            y = torch.ones(262144, dtype=torch.float32, device=dev)
+            N.check(L.mi_comm_allreduce_sum(h, y.data_ptr(), y.numel(), 0, s), "mi_comm_allreduce_sum")
+        for rep in range(2):
+            N.check(L.mi_comm_test_set_seq(h, 0xFFFFFFF0 - 3), "mi_comm_test_set_seq")
+            for dtype, n in ((torch.float32, 262144), (torch.float32, 9159), (torch.float64, 48), (torch.float32, 9159), (torch.float32, 134660), (torch.float64, 48),
+                             (torch.float32, 262144), (torch.float32, 3)):
+                x = (torch.randn(n, generator=gen, dtype=dtype) * 10).to(dev)
+                x[x == 0] = 1.0
+                y = x.clone()
+                N.check(L.mi_comm_allreduce_sum(h, y.data_ptr(), n, 0 if dtype == torch.float32 else 1, s), "mi_comm_allreduce_sum")
+                torch.cuda.synchronize()
+                assert torch.equal(x, y), (world, rep, dtype, n)
+            N.check(L.mi_comm_check(h), "mi_comm_check")
+            N.check(L.mi_comm_poll(h), "mi_comm_poll")
+    finally:
+        L.mi_comm_destroy(h)
+
+
+def test_ppo_update_on_synthetic_ranks_crosses_the_epoch_change():
+    """mi_ppo_update_sharded's in-launch exchange (grad_reduce_kernel draws its sequence numbers through mi_comm_p2p_next like the stand-alone launch) across the epoch
+    change: 2 updates x 17 exchanges with the number preset 20 below the last one == mi_ppo_update, exactly."""
+    torch = _need_gpu()
+    import deep_rl_amd as D
+    import deep_rl_amd.dist as DD
+    import deep_rl_amd.engine as E
+    from deep_rl_amd import _native as N
+
+    dev = torch.device("cuda", 0)
+    out = []
+    for synthetic in (False, True):
+        h = C.c_void_p()
+        if synthetic:
+            N.check(N.lib().mi_comm_p2p_synthetic(4, 1 << 16, C.byref(h)), "mi_comm_p2p_synthetic")
+            N.check(N.lib().mi_comm_test_set_seq(h, 0xFFFFFFF0 - 20), "mi_comm_test_set_seq")
+            DD.use_comm(h)
+            E._FORCE_NATIVE_SHARDED = True
+        try:
+            env = D.make("CartPole-v1", num_envs=64, device=dev, seed=22)
+            torch.manual_seed(22)
+            agent = D.ActorCritic(env)
+            opt = D.ClipAdam(agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
+            eng = D.PPOEngine(env, agent, opt, num_steps=128)
+            eng.reset()
+            for _ in range(2):
+                eng.update()
+            torch.cuda.synchronize()
+            if synthetic:
+                N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+            out.append([t.clone() for t in (agent.flat, opt.exp_avg, opt.exp_avg_sq, eng.grads, eng.loss_terms, opt.grad_norm)])
+        finally:
+            E._FORCE_NATIVE_SHARDED = False
+            DD.use_comm(None)
+            if h.value:
+                torch.cuda.synchronize()
+                N.lib().mi_comm_destroy(h)
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_ppo_update_on_synthetic_ranks_equals_plain_update(world):
     """mi_ppo_update_sharded on the P2P carrier with `world` synthetic ranks (slot 0 = this process's share, the others zeros) against mi_ppo_update: grad_reduce_kernel's
