@@ -329,7 +329,7 @@ def kernel_device_durations(window_ms):
 
 def collectives_label(world, is_p2p, native, carriers, policy):
     """config.collectives: which carrier the HEADLINE windows ran on, and — when that is not the RCCL configuration BASELINE.json names — why not."""
-    if world == 1:
+    if world == 1 and not carriers:
         return "none (single process)"
     why_not_rccl = carriers.get("rccl", (None, {}))[1].get("why")
     if native and not is_p2p:

@@ -61,7 +61,9 @@ static int rccl_bind() {
     } while (0)
 
 // ---- the P2P carrier's inbox (device memory of its owner, mapped into every peer with hipIpcOpenMemHandle) ------------------------------------------------------
-//   [status u32 | barrier lines u64 [2 parities][8 ranks] at byte 64, padded to P2P_HDR_BYTES] [lines u64 [2 parities][world][cap / 4]]
+//   [barrier lines u64 [2 parities][8 ranks] at byte 64, padded to P2P_HDR_BYTES] [lines u64 [2 parities][world][cap / 4]]
+// (the status word — bit 0: a wait ran out, bit 8 + r: rank r never arrived — is NOT in the inbox: only this rank's own launches read it, so it lives in plain, cacheable
+// device memory; in the uncached inbox its load cost every gated gradient launch 0.15 us)
 // A LINE is one 8-byte word {payload word (low), sequence number (high)}, stored and loaded as ONE 8-byte access: the payload carries its own "arrived" flag, so an
 // all-reduce needs no fence, no separate flag and no second round trip (the LL protocol idea).  Line i of slot (parity, r) = 32-bit word i of rank r's message.
 // SEQUENCE NUMBERS AND PARITY.  The parity is a bit of its own that flips with every all-reduce (never derived from the sequence number); the sequence number counts
@@ -91,6 +93,7 @@ struct mi_comm {
     uint32_t parity;               // parity of the last enqueued all-reduce: flips with every one, whatever the sequence number does
     uint32_t bseq;                 // epoch changes so far (= the barrier lines' own sequence number)
     uint32_t* mirror;              // host-pinned, device-mapped copy of the status word (mi_comm_poll: no sync)
+    char* status;                  // the status word: 64 bytes of PLAIN device memory (read by the waits of this rank's launches and by every gated optimizer step)
     int synthetic;                 // one process plays `world` ranks into its own inbox (slot 0 = its share, the others zeros): timing only
     int mem_kind;                  // 0 uncached, 1 fine-grained, 2 plain device memory
     unsigned long long budget;     // wait budget in 100 MHz ticks
@@ -214,7 +217,7 @@ static int p2p_new_epoch(mi_comm* c, hipStream_t s) {
         b.dst[d] = line(c->peer[p], c->synthetic ? p : c->rank);
         b.src[d] = line(c->inbox, d);
     }
-    b.mine = c->inbox; b.mirror = c->mirror; b.budget = c->budget; b.seq = c->bseq; b.world = c->world;
+    b.mine = c->status; b.mirror = c->mirror; b.budget = c->budget; b.seq = c->bseq; b.world = c->world;
     p2p_barrier_kernel<<<1, 64, 0, s>>>(b);
     MI_LAUNCH_CHECK();
     c->seq = 0;
@@ -253,10 +256,13 @@ static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm
         mi_set_error("mi_comm_p2p: clearing the inbox failed"); (void)hipFree(box); free(c); return MI_EHIP;
     }
     c->inbox = (char*)box;
+    if (hipMalloc((void**)&c->status, 64) != hipSuccess || hipMemset(c->status, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        mi_set_error("mi_comm_p2p: cannot allocate the status word"); (void)hipGetLastError(); (void)hipFree(box); free(c); return MI_ENOMEM;
+    }
     {   // the status word's host-visible mirror: written (system scope) by the wait that runs out, read by the host without a sync
         uint32_t* h = nullptr;
         if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
-            mi_set_error("mi_comm_p2p: cannot allocate the pinned status mirror"); (void)hipGetLastError(); (void)hipFree(box); free(c); return MI_ENOMEM;
+            mi_set_error("mi_comm_p2p: cannot allocate the pinned status mirror"); (void)hipGetLastError(); (void)hipFree(c->status); (void)hipFree(box); free(c); return MI_ENOMEM;
         }
         h[0] = 0u;
         c->mirror = h;
@@ -277,7 +283,7 @@ extern "C" int mi_comm_p2p_alloc(int world_size, int rank, size_t max_bytes, voi
     if (rc) return rc;
     hipIpcMemHandle_t h;
     hipError_t e = hipIpcGetMemHandle(&h, c->inbox);
-    if (e != hipSuccess) { mi_set_error("mi_comm_p2p_alloc: hipIpcGetMemHandle failed: %s", hipGetErrorString(e)); (void)hipFree(c->inbox); free(c); return MI_EHIP; }
+    if (e != hipSuccess) { mi_set_error("mi_comm_p2p_alloc: hipIpcGetMemHandle failed: %s", hipGetErrorString(e)); (void)hipFree(c->inbox); (void)hipFree(c->status); (void)hipHostFree(c->mirror); free(c); return MI_EHIP; }
     memcpy(ipc_handle64, &h, sizeof(h));
     *out = c;
     return MI_OK;
@@ -332,13 +338,13 @@ int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world_out, 
         if (c->synthetic && p != 0) a->zeros |= 1u << d;
         a->src[d] = slot(c->inbox, d);
     }
-    a->mine = c->inbox; a->mirror = c->mirror; a->budget = c->budget; a->seq = c->seq;
+    a->mine = c->status; a->mirror = c->mirror; a->budget = c->budget; a->seq = c->seq;
     if (world_out) *world_out = world;
     return MI_OK;
 }
 
 bool mi_comm_is_p2p(void* comm) { return comm && ((mi_comm*)comm)->carrier == CARRIER_P2P; }
-const uint32_t* mi_comm_gate(void* comm) { return mi_comm_is_p2p(comm) ? reinterpret_cast<const uint32_t*>(((mi_comm*)comm)->inbox) : nullptr; }
+const uint32_t* mi_comm_gate(void* comm) { return mi_comm_is_p2p(comm) ? reinterpret_cast<const uint32_t*>(((mi_comm*)comm)->status) : nullptr; }
 
 static void p2p_describe_failure(mi_comm* c, uint32_t st, const char* tail) {
     char who[64]; int k = 0;
@@ -416,7 +422,7 @@ extern "C" int mi_comm_check(void* comm) {
     mi_comm* c = (mi_comm*)comm;
     if (c->carrier != CARRIER_P2P) return MI_OK;
     uint32_t st = 0;
-    MI_HIP(hipMemcpy(&st, c->inbox, 4, hipMemcpyDeviceToHost));
+    MI_HIP(hipMemcpy(&st, c->status, 4, hipMemcpyDeviceToHost));
     if (st) {
         p2p_describe_failure(c, st, "elements of that and every later all-reduce hold the LOCAL share, and every optimizer step behind it was withheld");
         return MI_ESTATE;
@@ -433,6 +439,7 @@ extern "C" int mi_comm_destroy(void* comm) {
         (void)hipDeviceSynchronize();
         for (int r = 0; r < c->world; ++r) if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
         if (c->inbox) (void)hipFree(c->inbox);
+        if (c->status) (void)hipFree(c->status);
         if (c->mirror) (void)hipHostFree(c->mirror);
     } else if (g_rccl.so && c->comm) {
         (void)g_rccl.CommDestroy(c->comm);

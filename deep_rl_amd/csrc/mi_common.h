@@ -120,7 +120,7 @@ int mi_comm_allreduce_impl(void* comm, void* buf, size_t n, int dtype /* 0 f32, 
 struct p2p_args_t {          // everything resolved on the host: the kernel does no address arithmetic beyond "+ element"
     uint64_t* dst[P2P_MAX_WORLD];         // d-th target: slot (parity, this rank) of rank (rank + d) % world's inbox — the own inbox first, then rank + 1 ...: the links are used side by side
     const uint64_t* src[P2P_MAX_WORLD];   // slot (parity, r) of the OWN inbox, r in rank order
-    char* mine;                           // own inbox (status word)
+    char* mine;                           // this rank's status word (plain device memory of its own: only local launches read it — peers never do — so its loads hit L2 like any other)
     uint32_t* mirror;                     // host-pinned, device-mapped copy of the status word: the host reads it at the entry of every call WITHOUT a sync (mi_comm_poll)
     unsigned long long budget;
     uint32_t seq;
@@ -204,7 +204,11 @@ const uint32_t* mi_comm_gate(void* comm);   // device pointer of the status word
 int mi_comm_poll_impl(void* comm);          // MI_OK / MI_ESTATE, no synchronisation (NULL comm: MI_OK)
 int mi_clip_adam_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int64_t step, double lr, double beta1, double beta2, double eps,
                        float max_norm, float* grad_norm, void* comm, void* stream);   // mi_update.hip: mi_clip_adam, withheld when comm's status word is set
+#ifdef MI_NO_GATE   // A/B build only (tools/ab_headline.sh): what the fail-safe's loads and branches cost the launches that carry them
+__device__ __forceinline__ bool mi_gate_closed(const uint32_t*) { return false; }
+#else
 __device__ __forceinline__ bool mi_gate_closed(const uint32_t* gate) { return gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
+#endif
 bool mi_comm_p2p_fused_ok(void* comm);   // grad_reduce_kernel may carry the exchange (false when more than two ranks share this device: see mi_comm.hip)
 
 // ---- RNG contract (include/mi_rl.h) ----------------------------------------------------------------
