@@ -122,6 +122,9 @@ SIGNATURES = {
     "mi_per_mark_sums": (_I, [_VP, _I, _I64, _I64, _I, _VP, _F, _VP, _VP]),
     "mi_per_sample_current": (_I, [_U64, _U64, _VP, _I64, _I64, _D, _F, _F, _I, _I, _VP, _VP, _VP, _VP]),
     "mi_per_update_priorities_sums": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I64, _F, _VP, _VP]),
+    "mi_per_act_steps": (_I, [_VP, _VP, _I, _I64, _I64, _I64, _D, _D, _D, _I64] + [_VP] * 9 + [_I, _VP, _VP, _VP, _F, _VP, _VP, _I, _VP]),
+    "mi_per_td_update": (_I, [_VP] * 7 + [_I, _I, _I64, _F] + [_VP] * 7 + [_I64, _D, _D, _D, _D, _U64, _U64, _VP, _I64, _D, _F, _F, _I, _VP, _VP, _VP, _VP]),
+    "mi_per_settle_sums": (_I, [_VP, _VP, _I, _I64, _F, _VP, _VP]),
     "mi_dueling_pack": (_I, [_VP, _VP, _VP]),
     "mi_dueling_unpack_grads": (_I, [_VP, _VP, _VP]),
     "mi_dueling_td_update": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _U64, _U64, _I64, _VP]),

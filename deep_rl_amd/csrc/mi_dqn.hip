@@ -83,6 +83,216 @@ extern "C" int mi_dqn_forward(const float* params, const float* obs, int n, floa
 #define DQN_MAX_STEPS_PER_CALL 64
 struct dqn_eps_tab { float v[DQN_MAX_STEPS_PER_CALL]; };  // epsilon(global_step + k), passed by value
 
+// =====================================================================================================================================
+// Prioritized replay (reference per.py): the pieces of its bookkeeping that RIDE on launches of the DQN path (round 6; the kernels they came from and the
+// sampler's contract are in the "Prioritized replay" block further down).  One optimisation step used to be six launches sequenced from Python — act, marks,
+// sampler, TD, slab sum + Adam, scatter + sums: 67.6 us per iteration, 29.5 us of it bookkeeping in three launches of their own.  Now
+//   acting launch   + MARK workgroups: priorities[new rows] = max_priority (per.py:105), the write head, the touched level-1 groups' sums — max_priority only changes
+//                     at an update (per.py:145), i.e. at a kernel boundary in front of this launch;
+//                   + one OWED-SUMS workgroup: the chunk sums of the entries the LAST update re-prioritised (their scatter ran in that update's slab-sum launch);
+//                     nothing reads a sum before the next sampler, which sits behind this launch's boundary;
+//   sampler launch  unchanged (per_sample_kernel);
+//   TD launch       unchanged (dqn_td_kernel);
+//   slab sum + Adam + one SCATTER workgroup: "last duplicate wins" (atomicMax owner scheme), priorities[batch_inds] = |td|, max_priority (per.py:144-145) — |td| is final
+//                     at the TD kernel's boundary and the slab sum does not read priorities.
+// Every role executes the expression sequence of the stand-alone kernel it replaces (recompute, never adjust): indices, weights, priorities, sums and parameters are
+// bit-identical to the six-launch sequence (tests/test_gpu_per.py).
+#define PER_CHUNK 64
+#define STREAM_PER 7u
+struct per_ws_t { double* s0; double* a0; double* s1; double* a1; double* totals; };   // a0 / a1: the same sums of p^alpha; totals = {sum p, sum p^alpha}
+struct per_mark_t { long long a[2], b[2]; int nb0; };   // the touched flat ranges [a, b) (the second one after the ring wrap) and piece 0's workgroup count
+// p^alpha of a priority (per.py:131): 2^(alpha log2 p) on the hardware log2 / exp2 (3 instructions instead of ~150 for powf; relative
+// error ~1e-6, it only enters the importance weights, which are compared to 2e-5).  p = 0 -> 0 for EVERY alpha, explicitly: never-written entries and
+// the ring's write head must contribute +0 to the incremental sums, and alpha = 0 (uniform PER, legitimate in per.py) would otherwise give 0 * -inf = NaN.
+// (torch's 0 ** 0 = 1 would add the count of never-written entries to sum p^alpha at alpha = 0; the weights of per.py:145-146 are normalised by their
+// maximum and every sampled entry has p > 0, so they are exactly 1 either way.  the CPU oracle makes the same choice.)
+__device__ __forceinline__ float per_pow(float p, float alpha) { return p == 0.0f ? 0.0f : __builtin_amdgcn_exp2f(alpha * __builtin_amdgcn_logf(p)); }
+__host__ __device__ inline int64_t per_n0(int64_t n) { return (n + PER_CHUNK - 1) / PER_CHUNK; }
+
+struct per_ride_t {            // what the acting launch carries for PER (all zero: nothing)
+    float* prio; const float* max_prio; double *s0, *a0, *s1, *a1;
+    per_mark_t mk; long long capacity, slots, gs; float alpha; int N, n_steps;
+    int n_mark;                // MARK workgroups = level-1 groups the acting call's rows reach
+    const int64_t* owed_idx; int owed_batch;   // OWED-SUMS workgroups (PER_OWED_WGS of them, behind the mark workgroups): the last update's batch indices; nullptr: nothing owed
+};
+struct per_scatter_t { float* prio; const int64_t* idx; const float* td_abs; int batch; int32_t* owner; float* max_prio; };   // the slab-sum launch's SCATTER workgroup
+
+__host__ __device__ inline bool per_group_marked(const per_mark_t& mk, long long grp) {   // is level-1 group `grp` one a MARK workgroup of this launch rebuilds?
+    constexpr long long G = (long long)PER_CHUNK * PER_CHUNK;
+    for (int p = 0; p < 2; ++p) if (mk.b[p] > mk.a[p] && grp >= mk.a[p] / G && grp <= (mk.b[p] - 1) / G) return true;
+    return false;
+}
+
+struct per_mark_smem { float pv[PER_CHUNK][PER_CHUNK + 1], pa[PER_CHUNK][PER_CHUNK + 1]; double cs[PER_CHUNK], ca[PER_CHUNK]; };
+// MARK role, NT threads (a multiple of 128 dividing 4,096): one workgroup per level-1 group (64 chunks = 4,096 entries) that the touched rows reach — writes the marks,
+// recomputes the group's 64 chunk sums and, owning the whole group, its level-1 sums (per_sums0_kernel's / per_sums1_kernel's loops, in their order).  The thread's
+// 4,096 / NT priorities are requested TOGETHER, unconditionally (a `for (e = tid; e < 4096; e += blockDim.x)` loop with its load inside is one memory round trip per
+// iteration: the first riding form of this role took 24 us for sixteen of them).
+template <int NT>
+__device__ __forceinline__ void per_mark_role(per_mark_smem& sm, int wg, const per_ride_t& r) {
+    constexpr int IT = PER_CHUNK * PER_CHUNK / NT;
+    const per_mark_t& mk = r.mk;
+    const int piece = wg < mk.nb0 ? 0 : 1;
+    const long long m = mk.a[piece] / (PER_CHUNK * PER_CHUNK) + (wg - (piece ? mk.nb0 : 0));   // this workgroup's level-1 group
+    const long long base = m * PER_CHUNK * PER_CHUNK, head = r.gs % r.slots;
+    const long long row0 = base / r.N;                 // 64-bit divisions once per workgroup; per entry only 32-bit arithmetic
+    const int off0 = (int)(base - row0 * r.N);
+    const float mp = r.max_prio[0];
+    float pr[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const long long i = base + it * NT + (int)threadIdx.x;
+        pr[it] = r.prio[i < r.capacity ? i : base];   // (base < capacity: the group exists)
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int e = it * NT + (int)threadIdx.x;
+        const long long i = base + e;
+        float p = 0.0f;
+        if (i < r.capacity) {
+            long long st = row0 + (unsigned)(off0 + e) / (unsigned)r.N - head;   // time steps after the first one written by the acting call
+            st = st < 0 ? st + r.slots : st;
+            if (st < r.n_steps) { p = mp; r.prio[i] = p; }                   // per.py:105
+            else if (st == r.n_steps) { p = 0.0f; r.prio[i] = p; }           // the ring's write head: never sampled
+            else p = pr[it];
+        }
+        sm.pv[e >> 6][e & 63] = p; sm.pa[e >> 6][e & 63] = per_pow(p, r.alpha);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * PER_CHUNK) {               // threads 0..63: chunk sums of p, 64..127: of p^alpha — per_sums0_kernel's loop
+        const int q = threadIdx.x & 63;
+        const float (*src)[PER_CHUNK + 1] = threadIdx.x < PER_CHUNK ? sm.pv : sm.pa;
+        double sum = 0.0;
+        for (int j = 0; j < PER_CHUNK; ++j) sum += (double)src[q][j];
+        const long long k = m * PER_CHUNK + q;
+        if (threadIdx.x < PER_CHUNK) { sm.cs[q] = sum; if (k * PER_CHUNK < r.capacity) r.s0[k] = sum; }
+        else { sm.ca[q] = sum; if (k * PER_CHUNK < r.capacity) r.a0[k] = sum; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64) {     // the group's level-1 sums (per_sums1_kernel's order; chunks beyond the ring are +0.0)
+        const double* src = threadIdx.x == 0 ? sm.cs : sm.ca;
+        double sum = 0.0;
+        for (int j = 0; j < PER_CHUNK; ++j) sum += src[j];
+        (threadIdx.x == 0 ? r.s1 : r.a1)[m] = sum;
+    }
+}
+
+// OWED-SUMS role, NT threads, ROWS batch rows per pass through an LDS block of 2 * ROWS * 65 doubles: the level-0 sums of every chunk the last update's scatter touched,
+// then the level-1 sums of their groups — per_scatter_sums_kernel's phases, its loops in their order.  Workgroup `part` of `nparts` takes the batch rows whose LEVEL-1
+// GROUP is congruent to it (a group's chunk sums and its level-1 sum then have one writer, and phase 2 reads what phase 1 of the SAME workgroup wrote); with nparts > 1
+// the rows are first compacted into `list` (LDS, >= batch ints; the order is whatever the LDS counter gives — every row's result depends on its own chunk only).
+// `mk` (nullable): level-1 groups that MARK workgroups of the SAME launch rebuild from the (final) priorities are left to them — same values, one writer.
+// (First riding form, one workgroup walking the batch 32 rows at a time with its loads inside runtime-strided loops: ~38 us, longer than the acting loop it was to hide
+// behind — the PER iteration went from 69 to 86 us.  Now: eight workgroups, one pass each at the reference's batch, every pass two memory round trips deep — the rows'
+// base indices first, then the thread's ROWS * 64 / NT values together.)
+template <int NT, int ROWS>
+__device__ __forceinline__ void per_owed_sums_role(unsigned char* raw, int* list, int part, int nparts, const float* __restrict__ prio, const int64_t* __restrict__ idx,
+                                                   int batch, long long capacity, float alpha, double* __restrict__ s0, double* __restrict__ a0, double* __restrict__ s1,
+                                                   double* __restrict__ a1, const per_mark_t* mk) {
+    constexpr int IT = ROWS * PER_CHUNK / NT;
+    static_assert(ROWS * PER_CHUNK % NT == 0 && 2 * ROWS <= NT, "thread map of the owed-sums role");
+    __shared__ long long cb[ROWS];   // per row of the pass: the first flat index of its chunk (phase 1) / the first level-0 index of its group (phase 2); -1: no row
+    __shared__ int cnt;
+    float (*spv)[PER_CHUNK + 1] = reinterpret_cast<float (*)[PER_CHUNK + 1]>(raw);
+    float (*spa)[PER_CHUNK + 1] = spv + ROWS;
+    double (*ts)[PER_CHUNK + 1] = reinterpret_cast<double (*)[PER_CHUNK + 1]>(raw);
+    double (*ta)[PER_CHUNK + 1] = ts + ROWS;
+    constexpr long long G = (long long)PER_CHUNK * PER_CHUNK;
+    auto live = [&](int b) { return b < batch && !(mk && per_group_marked(*mk, idx[b] / G)); };
+    int n = batch;
+    if (list) {   // compact this workgroup's rows
+        if (threadIdx.x == 0) cnt = 0;
+        __syncthreads();
+        for (int b = threadIdx.x; b < batch; b += NT)
+            if ((int)((idx[b] / G) % nparts) == part && live(b)) list[atomicAdd(&cnt, 1)] = b;
+        __syncthreads();
+        n = cnt;
+    }
+    auto row = [&](int k) { return list ? (k < n ? list[k] : -1) : (live(k) ? k : -1); };   // batch row of position k, -1: none
+    for (int b0 = 0; b0 < n; b0 += ROWS) {
+        __syncthreads();
+        if (threadIdx.x < ROWS) { const int b = row(b0 + (int)threadIdx.x); cb[threadIdx.x] = b >= 0 ? (idx[b] / PER_CHUNK) * PER_CHUNK : -1; }
+        __syncthreads();
+        float pr[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = it * NT + (int)threadIdx.x;
+            const long long i = cb[e >> 6] + (e & 63);
+            pr[it] = prio[cb[e >> 6] >= 0 && i < capacity ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = it * NT + (int)threadIdx.x, q = e >> 6, j = e & 63;
+            const float p = cb[q] >= 0 && cb[q] + j < capacity ? pr[it] : 0.0f;
+            spv[q][j] = p; spa[q][j] = per_pow(p, alpha);
+        }
+        __syncthreads();
+        if (threadIdx.x < ROWS && cb[threadIdx.x] >= 0) {
+            double sum = 0.0, sa = 0.0;
+            for (int j = 0; j < PER_CHUNK; ++j) { sum += (double)spv[threadIdx.x][j]; sa += (double)spa[threadIdx.x][j]; }
+            const long long k = cb[threadIdx.x] / PER_CHUNK;
+            s0[k] = sum; a0[k] = sa;   // (a chunk hit by several batch rows is recomputed by several threads: same inputs, same value)
+        }
+    }
+    const long long n0c = per_n0(capacity);
+    for (int b0 = 0; b0 < n; b0 += ROWS) {
+        __syncthreads();   // (first pass: also orders this workgroup's level-0 stores before the loads below)
+        if (threadIdx.x < ROWS) { const int b = row(b0 + (int)threadIdx.x); cb[threadIdx.x] = b >= 0 ? (idx[b] / G) * PER_CHUNK : -1; }
+        __syncthreads();
+        double vs[IT], va[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = it * NT + (int)threadIdx.x;
+            const long long k = cb[e >> 6] + (e & 63);
+            const bool in = cb[e >> 6] >= 0 && k < n0c;
+            vs[it] = s0[in ? k : 0]; va[it] = a0[in ? k : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = it * NT + (int)threadIdx.x, q = e >> 6, j = e & 63;
+            const bool in = cb[q] >= 0 && cb[q] + j < n0c;
+            ts[q][j] = in ? vs[it] : 0.0; ta[q][j] = in ? va[it] : 0.0;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * ROWS) {
+            const int q = threadIdx.x % ROWS;
+            if (cb[q] >= 0) {
+                const double (*src)[PER_CHUNK + 1] = (int)threadIdx.x < ROWS ? ts : ta;
+                double sum = 0.0;
+                for (int j = 0; j < PER_CHUNK; ++j) sum += src[q][j];
+                ((int)threadIdx.x < ROWS ? s1 : a1)[cb[q] / PER_CHUNK] = sum;
+            }
+        }
+    }
+}
+
+// SCATTER role (ONE workgroup): priorities[idx[b]] = |td_b| with the LAST occurrence of a duplicated index winning (per.py:144 on the host is sequential), and
+// max_priority = max(max_priority, surviving |td|) — every entry is <= the running max_priority at all times, so this equals max(torch.max(priorities), max_priority)
+// (per.py:145) without a pass over the buffer.  owner: int32 per ring entry, all -1 between calls.  (per_scatter_kernel's body; wmax: >= blockDim.x / 64 floats of LDS.)
+__device__ __forceinline__ void per_scatter_role(float* wmax, const per_scatter_t& sc) {
+    const int nt = (int)blockDim.x;
+    for (int b = threadIdx.x; b < sc.batch; b += nt) atomicMax(&sc.owner[sc.idx[b]], b);
+    __syncthreads();
+    float mx = 0.0f;
+    for (int b = threadIdx.x; b < sc.batch; b += nt)
+        if (sc.owner[sc.idx[b]] == b) { sc.prio[sc.idx[b]] = sc.td_abs[b]; mx = fmaxf(mx, sc.td_abs[b]); }
+    __syncthreads();
+    for (int b = threadIdx.x; b < sc.batch; b += nt) sc.owner[sc.idx[b]] = -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = sc.max_prio[0];
+        for (int k = 0; k < (nt >> 6); ++k) m = fmaxf(m, wmax[k]);
+        sc.max_prio[0] = m;
+    }
+}
+#define PER_RIDE_ROWS 32      // batch rows per pass of an owed-sums workgroup inside the acting launch: 2 x 32 x 65 doubles = 33 KB of the acting kernel's 46 KB LDS block
+#define PER_OWED_WGS 8        // owed-sums workgroups of the acting launch (level-1 group % 8): ~16 rows each at the reference's batch of 128
+#define PER_OWED_LIST 2048    // ... and their row lists (8 KB of the same block): larger batches settle their sums in a launch of their own
+
+
 // ---- acting: n_steps iterations of {epsilon-greedy, env.step + auto-reset, ring store} in one launch (the online net is frozen
 // between two updates).  A workgroup owns 16 envs: THREE forward waves run the Q-network on v_mfma_f32_16x16x4_f32 in the [unit][env] orientation
 // with EVERY weight resident in registers as an A operand for the whole launch (forward wave w owns output tiles 2w, 2w+1 of layer 2):
@@ -150,15 +360,35 @@ struct __attribute__((aligned(16))) da4_smem {
     float qp[2][3][DA_ENVS][2];     // [step parity][forward wave][env][action]: partial head sums
     int expl[4][DA_ENVS];           // [step & 3][env]: bit 0 explore, bit 1 the random action
 };
-template <bool FORCED, bool EPLOG>
-__global__ void __launch_bounds__(256)
+// (PER: at least 2 waves per SIMD, i.e. <= 256 registers.  A kernel's register allocation holds for ALL its workgroups: at the 268 registers the acting code takes
+// when left alone, PER's riding workgroups could not share a SIMD with an acting wave — they ran BEHIND the acting workgroups, a 4.4 us tail on a 21.5 us launch.)
+template <bool FORCED, bool EPLOG, bool PER>
+__global__ void __launch_bounds__(256, PER ? 2 : 1)
 dqn_act4_kernel(mi_env e, const float* __restrict__ params, int n_steps, long long global_step, long long slots, long long learning_starts,
                 dqn_eps_tab eps, float* __restrict__ obs_cur, float* __restrict__ observations,
                 int64_t* __restrict__ actions, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
                 const int64_t* __restrict__ forced_actions, const double* __restrict__ forced_resets, mi_episode_t* __restrict__ episodes,
-                int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next, int32_t* __restrict__ stats_part) {
+                int32_t* __restrict__ episode_stats, int max_ep, int32_t* __restrict__ zero_next, int32_t* __restrict__ stats_part, int n_act, per_ride_t ride) {
     __shared__ da4_smem sm;
     MI_INSIDE_SCOPE(MI_PROF_DQN_ACT);
+    if constexpr (PER) {
+        // workgroups behind the acting ones: PER's bookkeeping (see per_ride_t).  Acting reads the online net and the env and writes the replay ring; the roles read and
+        // write priorities and their sums only: no dependency inside the launch — whoever needs the sums (the sampler) sits behind the kernel boundary.
+        if ((int)blockIdx.x >= n_act) {
+            constexpr size_t IMG = 2 * PER_RIDE_ROWS * (PER_CHUNK + 1) * sizeof(double);
+            static_assert(sizeof(da4_smem) >= sizeof(per_mark_smem) && sizeof(da4_smem) >= IMG + PER_OWED_LIST * sizeof(int) && alignof(da4_smem) >= 8,
+                          "PER's riding roles reuse the acting kernel's LDS block");
+            const int wg = (int)blockIdx.x - n_act;
+            if (wg < ride.n_mark) per_mark_role<256>(*reinterpret_cast<per_mark_smem*>(&sm), wg, ride);
+            else per_owed_sums_role<256, PER_RIDE_ROWS>(reinterpret_cast<unsigned char*>(&sm), reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(&sm) + IMG), wg - ride.n_mark,
+                                                        PER_OWED_WGS, ride.prio, ride.owed_idx, ride.owed_batch, ride.capacity, ride.alpha, ride.s0, ride.a0, ride.s1, ride.a1,
+                                                        &ride.mk);
+            return;
+        }
+        // the riders share CUs (and SIMDs) with acting workgroups, whose step is one wave's instruction issue: the acting waves take the issue port first (priority 3
+        // against the riders' default 0) — the riders have the whole launch to finish in (round 6: 25.9 -> see docs/LEDGER.md)
+        __builtin_amdgcn_s_setprio(3);
+    }
     if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) zero_next[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, lg = lane >> 4;
     const bool phys = w == 3;
@@ -409,7 +639,8 @@ __global__ void dqn_zero_stats_kernel(int32_t* p) { if (threadIdx.x < 4) p[threa
 static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts,
                         double start_e, double end_e, double exploration_fraction, int64_t total_timesteps, float* obs_cur,
                         float* observations, int64_t* actions, float* rewards, uint8_t* terminated, const int64_t* forced_actions,
-                        const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, int32_t* zero_next, bool zero_now, void* stream) {
+                        const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, int32_t* zero_next, bool zero_now, void* stream,
+                        const per_ride_t* ride = nullptr) {
     MI_CHECK_ARG(handle && params && obs_cur && observations && actions && rewards && terminated, "NULL pointer");
     MI_CHECK_ARG(n_steps > 0 && n_steps <= DQN_MAX_STEPS_PER_CALL, "n_steps must be in [1, 64]");
     MI_CHECK_ARG(slots >= 2 && global_step >= 0, "slots must be >= 2 and global_step >= 0");
@@ -431,12 +662,20 @@ static int dqn_act_impl(void* handle, const float* params, int n_steps, int64_t 
     }
     {
     mi_prof_scope prof(MI_PROF_DQN_ACT, s);
-    const dim3 grid((e->n + DA_ENVS - 1) / DA_ENVS), block(256);
-#define DA_LAUNCH(F, L) dqn_act4_kernel<F, L><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
+    const int n_extra = ride ? ride->n_mark + (ride->owed_idx ? PER_OWED_WGS : 0) : 0;   // PER's riding workgroups behind the acting ones
+    const dim3 grid(n_wg + n_extra), block(256);
+    per_ride_t rd;
+    if (ride) rd = *ride; else memset(&rd, 0, sizeof(rd));
+#define DA_LAUNCH(F, L, P) dqn_act4_kernel<F, L, P><<<grid, block, 0, s>>>(*e, params, n_steps, (long long)global_step, (long long)slots, (long long)learning_starts, tab, \
                                                                   obs_cur, observations, actions, rewards, terminated, forced_actions, forced_resets, episodes, \
-                                                                  part ? nullptr : episode_stats, max_ep, zero_next, part ? e->stats_part : nullptr)
-    if (forced) { if (eplog) DA_LAUNCH(true, true); else DA_LAUNCH(true, false); }
-    else { if (eplog) DA_LAUNCH(false, true); else DA_LAUNCH(false, false); }
+                                                                  part ? nullptr : episode_stats, max_ep, zero_next, part ? e->stats_part : nullptr, n_wg, rd)
+    if (n_extra) {
+        if (forced) { if (eplog) DA_LAUNCH(true, true, true); else DA_LAUNCH(true, false, true); }
+        else { if (eplog) DA_LAUNCH(false, true, true); else DA_LAUNCH(false, false, true); }
+    } else {
+        if (forced) { if (eplog) DA_LAUNCH(true, true, false); else DA_LAUNCH(true, false, false); }
+        else { if (eplog) DA_LAUNCH(false, true, false); else DA_LAUNCH(false, false, false); }
+    }
 #undef DA_LAUNCH
     MI_LAUNCH_CHECK();
     }
@@ -899,9 +1138,15 @@ __device__ __forceinline__ void dueling_head_step(const dqn_opt_t& o, float g0, 
     o.params[img0] = wv + (wa0 - mean);
     o.params[img1] = wv + (wa1 - mean);
 }
+// PER: one more workgroup behind the summing ones carries per.py:144-145 (per_scatter_role) — |td| and the indices are final at the TD kernel's boundary, and nothing here
+// reads priorities.
+template <bool PER>
 __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
-                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
+                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt, per_scatter_t sc) {
     MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
+    if constexpr (PER) {
+        if (blockIdx.x == gridDim.x - 1) { __shared__ float wmax[4]; per_scatter_role(wmax, sc); return; }
+    }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < DQ_NP) {
         // the optimizer state is requested before the slabs, and the slabs 16 at a time with every load in flight at once (the kernel is one memory
@@ -959,9 +1204,13 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
 #define DR_PARAMS 64
 #define DR_GROUPS 16
 #define DR_MIN_SLABS 64   // from this many slabs on
+template <bool PER>
 __global__ void __launch_bounds__(DR_PARAMS * DR_GROUPS) dqn_reduce2_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
-                                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt) {
+                                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt, per_scatter_t sc) {
     MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
+    if constexpr (PER) {
+        if (blockIdx.x == gridDim.x - 1) { __shared__ float wmax[DR_GROUPS]; per_scatter_role(wmax, sc); return; }
+    }
     const int pl = threadIdx.x & (DR_PARAMS - 1), sg = threadIdx.x >> 6;
     const int pblocks = (DQ_NP + DR_PARAMS - 1) / DR_PARAMS;
     if ((int)blockIdx.x < pblocks) {
@@ -1019,7 +1268,7 @@ static dqn_opt_t dqn_no_opt() { dqn_opt_t o; memset(&o, 0, sizeof(o)); return o;
 static int dqn_td_impl(const float* params, const float* target_params, const float* observations, const int64_t* actions,
                        const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
                        float gamma, double inv_count, void* workspace, float* grads, float* loss, const float* weights, float* td_abs, const dqn_opt_t& opt,
-                       uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* stream) {
+                       uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* stream, const per_scatter_t* scatter = nullptr) {
     MI_CHECK_ARG(params && target_params && observations && actions && rewards && terminated && idx && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
@@ -1043,10 +1292,16 @@ static int dqn_td_impl(const float* params, const float* target_params, const fl
     MI_LAUNCH_CHECK();
     {
         mi_prof_scope prof(MI_PROF_DQN_REDUCE, s);
-        if (blocks >= DR_MIN_SLABS)
-            dqn_reduce2_kernel<<<(DQ_NP + DR_PARAMS - 1) / DR_PARAMS + 1, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
-        else
-            dqn_reduce_kernel<<<(DQ_NP + 1 + 255) / 256, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt);
+        const int g2 = (DQ_NP + DR_PARAMS - 1) / DR_PARAMS + 1, g1 = (DQ_NP + 1 + 255) / 256;
+        if (scatter) {   // PER's one-call update: one more workgroup carries the priority scatter + max_priority
+            if (blocks >= DR_MIN_SLABS) dqn_reduce2_kernel<true><<<g2 + 1, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, *scatter);
+            else dqn_reduce_kernel<true><<<g1 + 1, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, *scatter);
+        } else {
+            per_scatter_t none;
+            memset(&none, 0, sizeof(none));
+            if (blocks >= DR_MIN_SLABS) dqn_reduce2_kernel<false><<<g2, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, none);
+            else dqn_reduce_kernel<false><<<g1, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, none);
+        }
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -1175,16 +1430,13 @@ extern "C" int mi_dueling_td_update(float* params_img, const float* target_img, 
 // priorities: f32 ring [slots][N] beside the replay ring.  per.py samples with torch.multinomial(priorities) — an O(buffer) scan on
 // the host generator; here: a keyed three-level prefix-sum descent with a FIXED evaluation order (the contract the oracle implements
 // bit for bit): s0 = sums of 64-entry chunks, s1 = sums of 64 s0's, total — all sequential, in double (-ffp-contract=off: no FMA).
-#define PER_CHUNK 64
-#define STREAM_PER 7u
-struct per_ws_t { double* s0; double* a0; double* s1; double* a1; double* totals; };   // a0 / a1: the same sums of p^alpha; totals = {sum p, sum p^alpha}
+// (PER_CHUNK, STREAM_PER, per_ws_t, per_pow, per_n0, per_mark_t: defined in front of the acting kernel, which carries PER's riding roles)
 // p^alpha of a priority (per.py:131): 2^(alpha log2 p) on the hardware log2 / exp2 (3 instructions instead of ~150 for powf; relative
 // error ~1e-6, it only enters the importance weights, which are compared to 2e-5).  p = 0 -> 0 for EVERY alpha, explicitly: never-written entries and
 // the ring's write head must contribute +0 to the incremental sums, and alpha = 0 (uniform PER, legitimate in per.py) would otherwise give 0 * -inf = NaN.
 // (torch's 0 ** 0 = 1 would add the count of never-written entries to sum p^alpha at alpha = 0; the weights of per.py:145-146 are normalised by their
 // maximum and every sampled entry has p > 0, so they are exactly 1 either way.  the CPU oracle makes the same choice.)
-__device__ __forceinline__ float per_pow(float p, float alpha) { return p == 0.0f ? 0.0f : __builtin_amdgcn_exp2f(alpha * __builtin_amdgcn_logf(p)); }
-__host__ __device__ inline int64_t per_n0(int64_t n) { return (n + PER_CHUNK - 1) / PER_CHUNK; }
+// (per_pow / per_n0: see the top of the file)
 static per_ws_t per_ws(void* workspace, int64_t capacity) {
     per_ws_t w;
     const int64_t c0 = per_n0(capacity), c1 = per_n0(c0);
@@ -1461,28 +1713,11 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
     PER_MARK(8);       // normalised
 }
 
-// priorities[idx[b]] = |td_b| with the LAST occurrence of a duplicated index winning (per.py:141 on the host is sequential), and
-// max_priority = max(max_priority, surviving |td|) — every entry is <= the running max_priority at all times, so this equals
-// max(torch.max(priorities), max_priority) (per.py:142) without a pass over the buffer.  owner: int32 per ring entry, all -1 between calls.
+// per_scatter_role as a launch of its own (mi_per_update_priorities)
 __global__ void __launch_bounds__(1024) per_scatter_kernel(float* __restrict__ prio, const int64_t* __restrict__ idx, const float* __restrict__ td_abs, int batch,
                                                            int32_t* __restrict__ owner, float* __restrict__ max_prio) {
     __shared__ float wmax[16];
-    for (int b = threadIdx.x; b < batch; b += 1024) atomicMax(&owner[idx[b]], b);
-    __syncthreads();
-    float mx = 0.0f;
-    for (int b = threadIdx.x; b < batch; b += 1024)
-        if (owner[idx[b]] == b) { prio[idx[b]] = td_abs[b]; mx = fmaxf(mx, td_abs[b]); }
-    __syncthreads();
-    for (int b = threadIdx.x; b < batch; b += 1024) owner[idx[b]] = -1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = max_prio[0];
-        for (int k = 0; k < 16; ++k) m = fmaxf(m, wmax[k]);
-        max_prio[0] = m;
-    }
+    per_scatter_role(wmax, per_scatter_t{prio, idx, td_abs, batch, owner, max_prio});
 }
 
 extern "C" int mi_per_mark(float* priorities, int n_envs, int64_t slots, int64_t global_step, int n_steps, const float* max_priority, void* stream) {
@@ -1502,119 +1737,25 @@ extern "C" int mi_per_mark(float* priorities, int n_envs, int64_t slots, int64_t
 // Invariant used: an entry that was never written holds 0 (the priorities ring starts zero-filled) and contributes +0.0 to its chunk, so
 // chunk sums over whole chunks equal the contract's sums over prio[:n_valid].
 #define PS_ROWS 128   // batch rows whose chunks per_scatter_sums_kernel recomputes per pass (2 x 33 KB of LDS)
-struct per_mark_t { long long a[2], b[2]; int nb0; };   // the touched flat ranges [a, b) (the second one after the ring wrap) and piece 0's workgroup count
-// One workgroup of 1024 threads per LEVEL-1 GROUP (64 chunks = 4,096 entries) that the touched rows reach: it writes the marks, recomputes the
-// group's 64 chunk sums and — owning the whole group — the group's level-1 sums too, so the sampler never re-reads level 0.
-__global__ void __launch_bounds__(1024) per_mark_sums_kernel(float* __restrict__ prio, int N, long long slots, long long gs, int n_steps, const float* __restrict__ max_prio,
-                                                             per_mark_t mk, long long capacity, float alpha, double* __restrict__ s0, double* __restrict__ a0,
-                                                             double* __restrict__ s1, double* __restrict__ a1) {
-    __shared__ float pv[PER_CHUNK][PER_CHUNK + 1], pa[PER_CHUNK][PER_CHUNK + 1];
-    __shared__ double cs[PER_CHUNK], ca[PER_CHUNK];
-    const int piece = (int)blockIdx.x < mk.nb0 ? 0 : 1;
-    const long long m = mk.a[piece] / (PER_CHUNK * PER_CHUNK) + ((int)blockIdx.x - (piece ? mk.nb0 : 0));   // this workgroup's level-1 group
-    const long long base = m * PER_CHUNK * PER_CHUNK, head = gs % slots;
-    const long long row0 = base / N;                 // 64-bit divisions once per workgroup; per entry only 32-bit arithmetic
-    const int off0 = (int)(base - row0 * N);
-    const float mp = max_prio[0];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int e = it * 1024 + threadIdx.x;
-        const long long i = base + e;
-        float p = 0.0f;
-        if (i < capacity) {
-            long long st = row0 + (unsigned)(off0 + e) / (unsigned)N - head;   // time steps after the first one written by the acting call
-            st = st < 0 ? st + slots : st;
-            if (st < n_steps) { p = mp; prio[i] = p; }                   // per.py:106
-            else if (st == n_steps) { p = 0.0f; prio[i] = p; }           // the ring's write head: never sampled
-            else p = prio[i];
-        }
-        pv[e >> 6][e & 63] = p; pa[e >> 6][e & 63] = per_pow(p, alpha);
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * PER_CHUNK) {               // threads 0..63: chunk sums of p, 64..127: of p^alpha — per_sums0_kernel's loop
-        const int r = threadIdx.x & 63;
-        const float (*src)[PER_CHUNK + 1] = threadIdx.x < PER_CHUNK ? pv : pa;
-        double sum = 0.0;
-        for (int j = 0; j < PER_CHUNK; ++j) sum += (double)src[r][j];
-        const long long k = m * PER_CHUNK + r;
-        if (threadIdx.x < PER_CHUNK) { cs[r] = sum; if (k * PER_CHUNK < capacity) s0[k] = sum; }
-        else { ca[r] = sum; if (k * PER_CHUNK < capacity) a0[k] = sum; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 || threadIdx.x == 64) {     // the group's level-1 sums (per_sums1_kernel's order; chunks beyond the ring are +0.0)
-        const double* src = threadIdx.x == 0 ? cs : ca;
-        double sum = 0.0;
-        for (int j = 0; j < PER_CHUNK; ++j) sum += src[j];
-        (threadIdx.x == 0 ? s1 : a1)[m] = sum;
-    }
+// per_mark_role as a launch of its own (mi_per_mark_sums): one workgroup of 1024 threads per LEVEL-1 GROUP (64 chunks = 4,096 entries) that the touched rows reach
+__global__ void __launch_bounds__(1024) per_mark_sums_kernel(per_ride_t r) {
+    __shared__ per_mark_smem sm;
+    per_mark_role<1024>(sm, (int)blockIdx.x, r);
 }
 
-// per_scatter_kernel + the chunk sums of every chunk it touched
-__global__ void __launch_bounds__(1024) per_scatter_sums_kernel(float* __restrict__ prio, const int64_t* __restrict__ idx, const float* __restrict__ td_abs, int batch,
-                                                                int32_t* __restrict__ owner, float* __restrict__ max_prio, long long capacity, float alpha,
-                                                                double* __restrict__ s0, double* __restrict__ a0, double* __restrict__ s1, double* __restrict__ a1) {
+// per_scatter_role + per_owed_sums_role as ONE launch of one workgroup (mi_per_update_priorities_sums): the scatter and the sums of every chunk it touched
+__global__ void __launch_bounds__(1024) per_scatter_sums_kernel(per_scatter_t sc, long long capacity, float alpha, double* __restrict__ s0, double* __restrict__ a0,
+                                                                double* __restrict__ s1, double* __restrict__ a1) {
     __shared__ float wmax[16];
     __shared__ __attribute__((aligned(16))) unsigned char raw[2 * PS_ROWS * (PER_CHUNK + 1) * sizeof(double)];   // phase 1: two float images; phase 2: two double images
-    float (*spv)[PER_CHUNK + 1] = reinterpret_cast<float (*)[PER_CHUNK + 1]>(raw);
-    float (*spa)[PER_CHUNK + 1] = spv + PS_ROWS;
-    double (*ts)[PER_CHUNK + 1] = reinterpret_cast<double (*)[PER_CHUNK + 1]>(raw);
-    double (*ta)[PER_CHUNK + 1] = ts + PS_ROWS;
-    for (int b = threadIdx.x; b < batch; b += 1024) atomicMax(&owner[idx[b]], b);
-    __syncthreads();
-    float mx = 0.0f;
-    for (int b = threadIdx.x; b < batch; b += 1024)
-        if (owner[idx[b]] == b) { prio[idx[b]] = td_abs[b]; mx = fmaxf(mx, td_abs[b]); }
-    __syncthreads();
-    for (int b = threadIdx.x; b < batch; b += 1024) owner[idx[b]] = -1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();   // (also: every priority store of this workgroup is visible to its own later loads)
-    if (threadIdx.x == 0) {
-        float m = max_prio[0];
-        for (int k = 0; k < 16; ++k) m = fmaxf(m, wmax[k]);
-        max_prio[0] = m;
-    }
-    // the touched chunks, PS_ROWS batch rows at a time: all threads fill the [row][64] images (p and p^alpha, coalesced 256-byte reads), then
-    // one thread per row takes the two sums in index order from LDS — per_sums0_kernel's loop
-    for (int b0 = 0; b0 < batch; b0 += PS_ROWS) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < PS_ROWS * PER_CHUNK; e += 1024) {
-            const int r = e >> 6, j = e & 63;
-            float p = 0.0f;
-            if (b0 + r < batch) { const long long i = (idx[b0 + r] / PER_CHUNK) * PER_CHUNK + j; p = i < capacity ? prio[i] : 0.0f; }
-            spv[r][j] = p; spa[r][j] = per_pow(p, alpha);
-        }
-        __syncthreads();
-        if (threadIdx.x < PS_ROWS && b0 + (int)threadIdx.x < batch) {
-            double sum = 0.0, sa = 0.0;
-            for (int j = 0; j < PER_CHUNK; ++j) { sum += (double)spv[threadIdx.x][j]; sa += (double)spa[threadIdx.x][j]; }
-            const long long k = idx[b0 + threadIdx.x] / PER_CHUNK;
-            s0[k] = sum; a0[k] = sa;   // (a chunk hit by several batch rows is recomputed by several threads: same inputs, same value)
-        }
-    }
-    // phase 2: the level-1 sums of every group one of those chunks belongs to, from the (now current) level-0 sums: coalesced 512-byte reads
-    // into [row][64] images, then one thread per row and array adds in index order (per_sums1_kernel's sums)
-    const long long n0c = per_n0(capacity);
-    for (int b0 = 0; b0 < batch; b0 += PS_ROWS) {
-        __syncthreads();   // (first pass: also orders this workgroup's level-0 stores before the loads below)
-        for (int e = threadIdx.x; e < PS_ROWS * PER_CHUNK; e += 1024) {
-            const int r = e >> 6, j = e & 63;
-            double vs = 0.0, va = 0.0;
-            if (b0 + r < batch) { const long long k = (idx[b0 + r] / (PER_CHUNK * PER_CHUNK)) * PER_CHUNK + j; if (k < n0c) { vs = s0[k]; va = a0[k]; } }
-            ts[r][j] = vs; ta[r][j] = va;
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * PS_ROWS) {
-            const int r = threadIdx.x % PS_ROWS;
-            if (b0 + r < batch) {
-                const double (*src)[PER_CHUNK + 1] = threadIdx.x < PS_ROWS ? ts : ta;
-                double sum = 0.0;
-                for (int j = 0; j < PER_CHUNK; ++j) sum += src[r][j];
-                (threadIdx.x < PS_ROWS ? s1 : a1)[idx[b0 + r] / (PER_CHUNK * PER_CHUNK)] = sum;
-            }
-        }
-    }
+    per_scatter_role(wmax, sc);   // (its barriers make every priority store of this workgroup visible to the loads below)
+    per_owed_sums_role<1024, PS_ROWS>(raw, nullptr, 0, 1, sc.prio, sc.idx, sc.batch, capacity, alpha, s0, a0, s1, a1, nullptr);
+}
+// per_owed_sums_role alone (mi_per_settle_sums: the sums a one-call update left owed, when no acting launch came to carry them)
+__global__ void __launch_bounds__(1024) per_owed_sums_kernel(const float* __restrict__ prio, const int64_t* __restrict__ idx, int batch, long long capacity, float alpha,
+                                                             double* __restrict__ s0, double* __restrict__ a0, double* __restrict__ s1, double* __restrict__ a1) {
+    __shared__ __attribute__((aligned(16))) unsigned char raw[2 * PS_ROWS * (PER_CHUNK + 1) * sizeof(double)];
+    per_owed_sums_role<1024, PS_ROWS>(raw, nullptr, 0, 1, prio, idx, batch, capacity, alpha, s0, a0, s1, a1, nullptr);
 }
 
 static int per_launch_sums(const float* priorities, int64_t n_valid, float alpha, const per_ws_t& w, hipStream_t s) {
@@ -1652,27 +1793,36 @@ extern "C" int mi_per_sums_refresh(const float* priorities, int64_t capacity, fl
     return MI_OK;
 }
 
+// the acting call's marks as a per_ride_t; false: the touched rows (nearly) cover the ring — mark, then one full pass (the caller's business)
+static bool per_make_ride(per_ride_t* r, float* priorities, int n_envs, int64_t slots, int64_t global_step, int n_steps, const float* max_priority, float alpha,
+                          void* workspace) {
+    const int64_t capacity = slots * n_envs, touched = (int64_t)(n_steps + 1) * n_envs;
+    if (touched + 2 * (int64_t)PER_CHUNK * PER_CHUNK > capacity) return false;
+    const per_ws_t w = per_ws(workspace, capacity);
+    memset(r, 0, sizeof(*r));
+    const int64_t lo = (global_step % slots) * n_envs, hi = lo + touched;
+    r->mk.a[0] = lo; r->mk.b[0] = hi < capacity ? hi : capacity;
+    r->mk.a[1] = 0; r->mk.b[1] = hi > capacity ? hi - capacity : 0;
+    constexpr int64_t G = (int64_t)PER_CHUNK * PER_CHUNK;   // entries per level-1 group = per workgroup
+    auto nblocks = [](int64_t a, int64_t b) -> int { return b <= a ? 0 : (int)((b - 1) / G - a / G + 1); };
+    r->mk.nb0 = nblocks(r->mk.a[0], r->mk.b[0]);
+    r->n_mark = r->mk.nb0 + nblocks(r->mk.a[1], r->mk.b[1]);
+    r->prio = priorities; r->max_prio = max_priority; r->s0 = w.s0; r->a0 = w.a0; r->s1 = w.s1; r->a1 = w.a1;
+    r->capacity = capacity; r->slots = slots; r->gs = global_step; r->alpha = alpha; r->N = n_envs; r->n_steps = n_steps;
+    return true;
+}
+
 extern "C" int mi_per_mark_sums(float* priorities, int n_envs, int64_t slots, int64_t global_step, int n_steps, const float* max_priority, float alpha, void* workspace,
                                 void* stream) {
     MI_CHECK_ARG(priorities && max_priority && workspace && n_envs > 0 && slots >= 2 && n_steps > 0 && n_steps < slots && global_step >= 0, "bad arguments");
-    const int64_t capacity = slots * n_envs, touched = (int64_t)(n_steps + 1) * n_envs;
-    const per_ws_t w = per_ws(workspace, capacity);
-    if (touched + 2 * (int64_t)PER_CHUNK * PER_CHUNK > capacity) {   // the touched rows (nearly) cover the ring: mark, then one full pass
+    per_ride_t r;
+    if (!per_make_ride(&r, priorities, n_envs, slots, global_step, n_steps, max_priority, alpha, workspace)) {   // the touched rows (nearly) cover the ring: mark, then one full pass
         int rc = mi_per_mark(priorities, n_envs, slots, global_step, n_steps, max_priority, stream);
         if (rc) return rc;
-        return mi_per_sums_refresh(priorities, capacity, alpha, workspace, stream);
+        return mi_per_sums_refresh(priorities, slots * n_envs, alpha, workspace, stream);
     }
-    per_mark_t mk;
-    const int64_t lo = (global_step % slots) * n_envs, hi = lo + touched;
-    mk.a[0] = lo; mk.b[0] = hi < capacity ? hi : capacity;
-    mk.a[1] = 0; mk.b[1] = hi > capacity ? hi - capacity : 0;
-    constexpr int64_t G = (int64_t)PER_CHUNK * PER_CHUNK;   // entries per level-1 group = per workgroup
-    auto nblocks = [](int64_t a, int64_t b) -> int { return b <= a ? 0 : (int)((b - 1) / G - a / G + 1); };
-    mk.nb0 = nblocks(mk.a[0], mk.b[0]);
-    const int nb1 = nblocks(mk.a[1], mk.b[1]);
     mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);
-    per_mark_sums_kernel<<<mk.nb0 + nb1, 1024, 0, (hipStream_t)stream>>>(priorities, n_envs, (long long)slots, (long long)global_step, n_steps, max_priority, mk,
-                                                                        (long long)capacity, alpha, w.s0, w.a0, w.s1, w.a1);
+    per_mark_sums_kernel<<<r.n_mark, 1024, 0, (hipStream_t)stream>>>(r);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -1694,7 +1844,8 @@ extern "C" int mi_per_update_priorities_sums(float* priorities, const int64_t* i
     MI_CHECK_ARG(priorities && idx && td_abs && owner && max_priority && workspace && batch > 0 && capacity > 0, "bad arguments");
     const per_ws_t w = per_ws(workspace, capacity);
     mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);
-    per_scatter_sums_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(priorities, idx, td_abs, batch, owner, max_priority, (long long)capacity, alpha, w.s0, w.a0, w.s1, w.a1);
+    per_scatter_sums_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(per_scatter_t{priorities, idx, td_abs, batch, owner, max_priority}, (long long)capacity, alpha, w.s0, w.a0, w.s1,
+                                                                 w.a1);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -1712,6 +1863,68 @@ extern "C" int mi_per_update_priorities(float* priorities, const int64_t* idx, c
     per_scatter_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(priorities, idx, td_abs, batch, owner, max_priority);
     MI_LAUNCH_CHECK();
     return MI_OK;
+}
+
+
+// ---- PER, one call per piece of the loop (round 6; the roles are at the top of the file) ----
+// mi_dqn_act_steps2 / mi_dqn_act_steps (zero_next NULL) + mi_per_mark_sums in ONE launch, which also carries the chunk sums the last mi_per_td_update left owed
+// (owed_idx = that update's batch indices, NULL: nothing owed).
+extern "C" int mi_per_act_steps(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts, double start_e, double end_e,
+                                double exploration_fraction, int64_t total_timesteps, float* obs_cur, float* observations, int64_t* actions, float* rewards,
+                                uint8_t* terminated, const int64_t* forced_actions, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep,
+                                int32_t* zero_next, float* priorities, const float* max_priority, float alpha, void* per_workspace, const int64_t* owed_idx, int owed_batch,
+                                void* stream) {
+    MI_CHECK_ARG(handle && priorities && max_priority && per_workspace, "NULL pointer");
+    MI_CHECK_ARG(n_steps > 0 && n_steps < slots && global_step >= 0 && slots >= 2, "n_steps must be in [1, slots)");
+    MI_CHECK_ARG(!owed_idx || owed_batch > 0, "owed_batch must be positive when sums are owed");
+    MI_CHECK_ARG(!zero_next || zero_next != episode_stats, "zero_next must be a second statistics buffer");
+    const int n_envs = ((mi_env*)handle)->n;
+    per_ride_t r;
+    const bool inc = per_make_ride(&r, priorities, n_envs, slots, global_step, n_steps, max_priority, alpha, per_workspace);
+    if (owed_idx && (!inc || owed_batch > PER_OWED_LIST)) {   // nothing to ride on (or a batch beyond the riding workgroups' row lists): the owed sums first, as a launch of their own
+        const int rc0 = inc ? mi_per_settle_sums(priorities, owed_idx, owed_batch, slots * n_envs, alpha, per_workspace, stream) : MI_OK;   // (!inc: the full pass below settles them)
+        if (rc0) return rc0;
+        owed_idx = nullptr;
+    }
+    if (inc) { r.owed_idx = owed_idx; r.owed_batch = owed_idx ? owed_batch : 0; }
+    int rc = dqn_act_impl(handle, params, n_steps, global_step, slots, learning_starts, start_e, end_e, exploration_fraction, total_timesteps, obs_cur, observations,
+                          actions, rewards, terminated, forced_actions, forced_resets, episodes, episode_stats, max_ep, zero_next, zero_next == nullptr, stream, inc ? &r : nullptr);
+    if (rc || inc) return rc;
+    // the touched rows (nearly) cover the ring: mark, then one full pass over the priorities (which settles whatever was owed)
+    rc = mi_per_mark(priorities, n_envs, slots, global_step, n_steps, max_priority, stream);
+    if (rc) return rc;
+    return mi_per_sums_refresh(priorities, slots * n_envs, alpha, per_workspace, stream);
+}
+
+// the chunk sums a mi_per_td_update left owed, as a launch of their own (when the next call is not an acting call: a second update, a checkpoint, a test reading the sums)
+extern "C" int mi_per_settle_sums(const float* priorities, const int64_t* idx, int batch, int64_t capacity, float alpha, void* per_workspace, void* stream) {
+    MI_CHECK_ARG(priorities && idx && per_workspace && batch > 0 && capacity > 0, "bad arguments");
+    const per_ws_t w = per_ws(per_workspace, capacity);
+    mi_prof_scope prof(MI_PROF_PER, (hipStream_t)stream);
+    per_owed_sums_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(priorities, idx, batch, (long long)capacity, alpha, w.s0, w.a0, w.s1, w.a1);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+}
+
+// ONE optimisation step of per.py:126-153 in one call, three launches: the sampler (mi_per_sample_current), the weighted TD launch, and the slab sum + Adam launch with
+// the priority scatter + max_priority on an extra workgroup (mi_dqn_td_update with weights + the first half of mi_per_update_priorities_sums).  The chunk sums of the
+// scattered entries stay OWED: the caller hands `idx` to the next mi_per_act_steps (which carries them) or calls mi_per_settle_sums before anything reads the sums.
+extern "C" int mi_per_td_update(float* params, const float* target_params, const float* observations, const int64_t* actions, const float* rewards,
+                                const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, float* weights, float* td_abs, void* workspace,
+                                float* grads, float* loss, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps, uint64_t seed,
+                                uint64_t update_index, float* priorities, int64_t n_valid, double count, float alpha, float beta, int sample, void* per_workspace,
+                                int32_t* owner, float* max_priority, void* stream) {
+    MI_CHECK_ARG(params && exp_avg && exp_avg_sq && step >= 1 && weights && td_abs && idx && grads, "bad optimizer state / NULL pointer");
+    MI_CHECK_ARG(priorities && per_workspace && owner && max_priority && n_valid > 0 && n_valid <= slots * n_envs && batch > 0, "bad PER arguments");
+    int rc = mi_per_sample_current(seed, update_index, priorities, n_valid, slots * n_envs, count, alpha, beta, batch, sample, per_workspace, idx, weights, stream);
+    if (rc) return rc;
+    dqn_opt_t o;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    o.params = params; o.m = exp_avg; o.v = exp_avg_sq; o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2);
+    o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps; o.du_params = nullptr; o.du_grads = nullptr;
+    const per_scatter_t sc = {priorities, idx, td_abs, batch, owner, max_priority};
+    return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / batch, workspace, grads, loss,
+                       weights, td_abs, o, 0, 0, 0, stream, &sc);
 }
 
 MI_INSIDE_EXPORT(dqn)

@@ -13,6 +13,9 @@ from . import dist as D
 
 # diagnostics (tests/_rccl_world1_worker.py): walk the sharded branch even at world_size 1, so that RCCL really runs on a one-GPU box
 _FORCE_SHARDED = os.environ.get("MIRL_OFFPOLICY_SHARDED", "0") == "1"
+# MIRL_PER_ONE_CALL=0: PERDQNEngine walks the round-5 launch sequence (act, marks, sampler, TD, slab sum + Adam, scatter + sums: six launches) instead of the one-call
+# pieces mi_per_act_steps / mi_per_td_update (four launches, bit-identical) — the A/B and the reference of tests/test_gpu_per.py
+_PER_ONE_CALL = os.environ.get("MIRL_PER_ONE_CALL", "1") != "0"
 
 
 class DQNEngine:
@@ -264,16 +267,50 @@ class PERDQNEngine(DQNEngine):
         self._owner = torch.full((S * Nn,), -1, dtype=torch.int32, device=dev)
         # the sampler's chunk sums, kept current by mark / update_priorities (zero-filled = current for the zero-filled ring)
         self._per_ws = torch.zeros(N.lib().mi_per_workspace_bytes(S * Nn), dtype=torch.uint8, device=dev)
+        self._sums_owed = False   # mi_per_td_update has scattered priorities whose chunk sums are still to be rebuilt (they ride on the next acting launch)
 
     def refresh_sums(self):
         """Rebuild the sampler's chunk sums from `priorities` (after anything but act / train_step wrote them: checkpoint load, tests)."""
         N.check(N.lib().mi_per_sums_refresh(N.ptr(self.priorities), self.slots * self.N, self.alpha, N.ptr(self._per_ws), self._s()), "mi_per_sums_refresh")
+        self._sums_owed = False
+
+    def settle(self):
+        """The chunk sums the last one-call update left owed (mi_per_td_update scatters the priorities in its slab-sum launch; the sums of the touched chunks normally
+        ride on the NEXT acting launch).  Called by everything that reads the sums without an acting call in between; a no-op otherwise."""
+        if self._sums_owed:
+            N.check(N.lib().mi_per_settle_sums(N.ptr(self.priorities), N.ptr(self.batch_inds), self.batch_size, self.slots * self.N, self.alpha, N.ptr(self._per_ws), self._s()),
+                    "mi_per_settle_sums")
+            self._sums_owed = False
 
     def act(self, n_steps, forced_actions=None, forced_resets=None):
+        """n_steps iterations of per.py:92-121 for every env.  ONE launch: the acting workgroups, the workgroups that give the new rows the running max_priority
+        (per.py:105) and rebuild the touched sums, and the workgroup that rebuilds the sums the last update left owed (mi_per_act_steps)."""
         gs = self.global_step
-        super().act(n_steps, forced_actions, forced_resets)
-        N.check(N.lib().mi_per_mark_sums(N.ptr(self.priorities), self.N, self.slots, gs, int(n_steps), N.ptr(self.max_priority), self.alpha, N.ptr(self._per_ws),
-                                         self._s()), "mi_per_mark_sums")   # :106
+        if not _PER_ONE_CALL:
+            self.settle()
+            super().act(n_steps, forced_actions, forced_resets)
+            N.check(N.lib().mi_per_mark_sums(N.ptr(self.priorities), self.N, self.slots, gs, int(n_steps), N.ptr(self.max_priority), self.alpha, N.ptr(self._per_ws),
+                                             self._s()), "mi_per_mark_sums")   # :105
+            return
+        dev = self.device
+        fa = None if forced_actions is None else forced_actions.to(dev, torch.int64).contiguous()
+        fr = None if forced_resets is None else forced_resets.to(dev, torch.float64).contiguous()
+        owed = N.ptr(self.batch_inds) if self._sums_owed else None
+        if self._lazy_stats:
+            self._stats_ready, self._stats_any = False, True
+            stats, nxt, eps = None, None, None
+        else:
+            stats, nxt, eps = self._stats2[self._stats_i], self._stats2[self._stats_i ^ 1], self.episodes
+            self._stats_buf = stats
+        N.check(N.lib().mi_per_act_steps(
+            self.env.handle, N.ptr(self.q.flat), int(n_steps), gs, self.slots, self.learning_starts, self.start_e, self.end_e, self.exploration_fraction,
+            self.total_timesteps, N.ptr(self.observation), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated), N.ptr(fa), N.ptr(fr),
+            N.ptr(eps), N.ptr(stats), 0 if self._lazy_stats else self.max_ep, N.ptr(nxt), N.ptr(self.priorities), N.ptr(self.max_priority), self.alpha, N.ptr(self._per_ws),
+            owed, self.batch_size, self._s()), "mi_per_act_steps")
+        if not self._lazy_stats:
+            self._stats_i ^= 1
+        self._sums_owed = False
+        self.global_step += int(n_steps)
 
     def beta(self):
         """per.py:126: beta starts at beta_0 and increases linearly to 1."""
@@ -281,12 +318,40 @@ class PERDQNEngine(DQNEngine):
 
     def sample(self, indices=None):
         """batch_inds ~ priorities (per.py:128) and the importance weights (:131,145-146); `indices` keeps the caller's batch."""
+        self.settle()
         stored = min(self.global_step, self.slots) * self.N
         if indices is not None:
             self.batch_inds.copy_(torch.as_tensor(indices, dtype=torch.int64).reshape(-1).to(self.device))
         N.check(N.lib().mi_per_sample_current(self.env._seed, self.update_index, N.ptr(self.priorities), stored, self.slots * self.N, float(stored), self.alpha,
                                               self.beta(), self.batch_size, 0 if indices is not None else 1, N.ptr(self._per_ws), N.ptr(self.batch_inds),
                                               N.ptr(self.weights), self._s()), "mi_per_sample_current")
+
+    def train_step(self, indices=None):
+        """One optimisation step (per.py:126-153).  Single process without gradient clipping: ONE call, three launches — the sampler, the weighted TD launch, and the
+        slab sum + Adam launch whose last workgroup scatters the new priorities and updates max_priority (mi_per_td_update; bit-identical to sample() + td_grad() +
+        optimizer.step() and to the round-5 sequence).  The sums of the scattered chunks ride on the next acting launch (`settle()` otherwise)."""
+        g = self.optimizer.param_groups[0]
+        one_call = (_PER_ONE_CALL and self.world_size == 1 and not _FORCE_SHARDED and g["max_grad_norm"] == float("inf")
+                    and type(self).td_grad is PERDQNEngine.td_grad and type(self).sample is PERDQNEngine.sample)
+        if not one_call:
+            return super().train_step(indices)
+        self.settle()   # (two updates in a row: the first one's scatter must be in the sums the second one draws from)
+        stored = min(self.global_step, self.slots) * self.N
+        if stored == 0:
+            raise N.MiError("train_step: the replay ring is empty (global_step == 0); act() before training")
+        if indices is not None:
+            self.batch_inds.copy_(torch.as_tensor(indices, dtype=torch.int64).reshape(-1).to(self.device))
+        o = self.optimizer
+        N.check(N.lib().mi_per_td_update(
+            N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
+            N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(self.weights), N.ptr(self.td_abs), N.ptr(self.workspace), N.ptr(self.grads),
+            N.ptr(self.loss), N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self.env._seed,
+            self.update_index, N.ptr(self.priorities), stored, float(stored), self.alpha, self.beta(), 0 if indices is not None else 1, N.ptr(self._per_ws),
+            N.ptr(self._owner), N.ptr(self.max_priority), self._s()), "mi_per_td_update")
+        o.step_count += 1   # committed only once the call has accepted the step
+        self._sums_owed = True
+        self.update_index += 1
+        self._maybe_check_replicas()
 
     def td_grad(self):
         """weighted loss + gradient (per.py:133-147), |td| per row; then priorities[batch_inds] = |td| and max_priority (:141-142)."""

@@ -395,6 +395,26 @@ int mi_per_sample_current(uint64_t seed, uint64_t update_index, const float* pri
                           float beta, int batch, int sample, void* workspace, int64_t* idx, float* weights, void* stream);
 int mi_per_update_priorities_sums(float* priorities, const int64_t* idx, const float* td_abs, int batch, int32_t* owner, float* max_priority, int64_t capacity,
                                   float alpha, void* workspace, void* stream);
+/* The ONE-CALL form of the PER loop (round 6; per.py:84-153): the bookkeeping rides on launches that exist anyway, 4 launches per iteration instead of 6, with indices,
+ * weights, priorities, sums and parameters bit-identical to the calls above.
+ *   mi_per_act_steps   = mi_dqn_act_steps (zero_next NULL) / mi_dqn_act_steps2 + mi_per_mark_sums in ONE launch: workgroups behind the acting ones write the new rows'
+ *                        priorities (= max_priority, per.py:105 — it only changes at an update) and rebuild the touched groups' sums; one more workgroup rebuilds the chunk
+ *                        sums the last mi_per_td_update left OWED (owed_idx = that update's idx buffer, owed_batch its batch; NULL: nothing owed).
+ *   mi_per_td_update   one optimisation step (per.py:126-153) = mi_per_sample_current + the weighted TD launch + the slab sum + Adam launch of mi_dqn_td_update, whose
+ *                        last workgroup scatters priorities[idx] = |td| (last duplicate wins) and updates max_priority (per.py:144-145).  The scattered entries' chunk
+ *                        sums are NOT rebuilt by this call: they are OWED — hand idx to the next mi_per_act_steps, or call mi_per_settle_sums before anything else reads
+ *                        the sums (a second update, mi_per_sample_current, a checkpoint).  sample = 0 keeps the caller's idx.  count = transitions stored (per.py:148).
+ *   mi_per_settle_sums the owed sums as a launch of their own. */
+int mi_per_act_steps(void* handle, const float* params, int n_steps, int64_t global_step, int64_t slots, int64_t learning_starts, double start_e, double end_e,
+                     double exploration_fraction, int64_t total_timesteps, float* obs_cur, float* observations, int64_t* actions, float* rewards, uint8_t* terminated,
+                     const int64_t* forced_actions, const double* forced_resets, mi_episode_t* episodes, int32_t* episode_stats, int max_ep, int32_t* zero_next,
+                     float* priorities, const float* max_priority, float alpha, void* per_workspace, const int64_t* owed_idx, int owed_batch, void* stream);
+int mi_per_td_update(float* params, const float* target_params, const float* observations, const int64_t* actions, const float* rewards, const uint8_t* terminated,
+                     int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, float* weights, float* td_abs, void* workspace, float* grads, float* loss,
+                     float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps, uint64_t seed, uint64_t update_index,
+                     float* priorities, int64_t n_valid, double count, float alpha, float beta, int sample, void* per_workspace, int32_t* owner, float* max_priority,
+                     void* stream);
+int mi_per_settle_sums(const float* priorities, const int64_t* idx, int batch, int64_t capacity, float alpha, void* per_workspace, void* stream);
 
 /* =====================================================================================================================
  * SAC (reference deep_rl/sac.py re-targeted to Pendulum-v1; SURVEY.md §8a s1-s8, BASELINE config 4).

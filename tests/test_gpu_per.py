@@ -109,6 +109,7 @@ def test_alpha_zero_is_uniform_per_not_nan(dev, R):
     eng2.reset()
     for it in range(8):
         eng2.act(10); eng2.train_step()
+    eng2.settle()   # (round 6: the one-call update leaves the scattered chunks' sums to the next acting launch)
     inc = eng2._per_ws.clone()
     eng2.refresh_sums()
     n0 = (37 * 64 + 63) // 64; n1 = (n0 + 63) // 64
@@ -165,6 +166,7 @@ def test_incremental_sums_equal_full_pass_and_oracle(dev, R, n_envs, slots):
         eng.act(10)
         eng.train_step()
         if it % 7 == 3 or it == slots // 10 + 11:
+            eng.settle()                            # (round 6: the one-call update leaves the scattered chunks' sums to the next acting launch; nothing has carried them yet)
             inc = eng._per_ws.clone()
             eng.refresh_sums()
             assert torch.equal(inc.view(torch.float64)[:2 * n0 + 2 * n1], eng._per_ws.view(torch.float64)[:2 * n0 + 2 * n1]), it   # level-0 and level-1 sums of p and p^alpha
@@ -281,3 +283,50 @@ def test_sampler_random_shapes_bit_exact(dev, R):
             got = eng.batch_inds.cpu().numpy()
             assert np.array_equal(got, want), (n_envs, slots, frac, batch, np.flatnonzero(got != want)[:5])
             assert (prio[got] > 0).all()
+
+
+@pytest.mark.parametrize("n_envs,slots,batch", [(64, 150, 128), (4096, 32, 128), (512, 64, 1000)])
+def test_one_call_pieces_are_bitwise_the_launch_sequence(dev, n_envs, slots, batch):
+    """Round 6: one PER iteration = mi_per_act_steps (the acting launch also marks the new rows and rebuilds their sums, and carries the sums the last
+    update left owed) + mi_per_td_update (sampler, weighted TD launch, slab sum + Adam with the priority scatter + max_priority on its last workgroup) — four launches —
+    against the round-5 sequence of six (act, mi_per_mark_sums, mi_per_sample_current, TD, slab sum + Adam, mi_per_update_priorities_sums; MIRL_PER_ONE_CALL=0).  Over
+    chained iterations on a ring that fills and WRAPS (so scattered entries fall into groups the next acting call re-marks: the one-writer rule of per_owed_sums_role),
+    with two updates behind one acting call now and then (the settle path) and target syncs: drawn indices, weights, |td|, priorities, max_priority, every level-0 /
+    level-1 sum, parameters, both moments, gradient and loss bit for bit (per.py:92-153).  batch 1000: the many-slab sum launch carries the scatter."""
+    import deep_rl_amd.dqn_engine as E
+
+    cap = slots * n_envs
+    n0 = (cap + 63) // 64
+    n1 = (n0 + 63) // 64
+    iters = 2 * slots // 10 + 7
+
+    def run(one_call):
+        E._PER_ONE_CALL = one_call
+        try:
+            eng = _engine(dev, n_envs, slots, seed=9, batch_size=batch, learning_starts=0, total_timesteps=100 * slots)
+            eng.reset()
+            out = []
+            for k in range(iters):
+                eng.act(10)
+                eng.train_step()
+                if k % 4 == 1:
+                    eng.train_step()            # a second update without an acting call in between: the first one's owed sums are settled by a launch of their own
+                if k % 5 == 4:
+                    eng.sync_target()
+                o = eng.optimizer
+                row = [t.clone() for t in (eng.batch_inds, eng.weights, eng.td_abs, eng.priorities, eng.max_priority, eng.q.flat, o.exp_avg, o.exp_avg_sq, eng.grads, eng.loss)]
+                if k % 3 == 0 or k == iters - 1:
+                    eng.settle()
+                    row.append(eng._per_ws.view(torch.float64)[:2 * n0 + 2 * n1].clone())
+                out.append(row)
+            return out
+        finally:
+            E._PER_ONE_CALL = True
+
+    a, b = run(True), run(False)
+    names = ("indices", "weights", "|td|", "priorities", "max_priority", "params", "exp_avg", "exp_avg_sq", "grads", "loss", "sums")
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert len(x) == len(y)
+        for name, u, v in zip(names, x, y):
+            assert torch.equal(u, v), (k, name, (u.double() - v.double()).abs().max().item())
+    assert torch.isfinite(a[-1][5]).all() and not torch.equal(a[-1][5], a[0][5]) and a[-1][4].item() > 1e-2
