@@ -107,6 +107,94 @@ DQN_MACS_FWD = 4 * 120 + 120 * 84 + 84 * 2          # 10,728 per Q-network forwa
 SAC_MACS_NET = 4 * 256 + 256 * 256 + 256            # 66,816: critic (3+1 -> 256 -> 256 -> 1); the actor (3 -> 256 -> 256 -> 2 heads) has the same count
 
 
+# ---- chain floors of the latency-bound configs (derivations: DESIGN.md sections 8 / 9) --------------------------------------------------------
+# These loops are chains of DEPENDENT launches on a few workgroups: a fraction of the MFMA peak says nothing a builder can act on.  The floor they are measured
+# against instead = (matrix cycles on the longest wave's dependent chain, per SIMD, at the clock the chip sustains under the PPO gradient launch: 2.07 GHz)
+#                 + (kernel boundaries on the chain x 1.3 us: tools/ubench/boundary_gap.hip) + (dependent global-memory round trips on the chain x 0.45 us, a cold load).
+# A v_mfma_f32_16x16x4_f32 holds a SIMD's matrix pipe for 32 cycles (2,048 FLOP at 64 FLOP / clk / SIMD).
+SUSTAINED_GHZ = 2.07
+BOUNDARY_US = 1.3
+ROUND_TRIP_US = 0.45
+MFMA16_CYCLES = 32
+
+
+def chain_floor(name, mfma_terms, boundaries, round_trips, extra_cycles=None):
+    """-> {chain_floor_us, terms}: mfma_terms = [(what, MFMAs on the chain)], extra_cycles = [(what, cycles)] for dependent non-matrix chains (PER's prefix walks)."""
+    cyc = sum(n for _, n in mfma_terms) * MFMA16_CYCLES + sum(c for _, c in (extra_cycles or []))
+    us = cyc / (SUSTAINED_GHZ * 1e3) + boundaries * BOUNDARY_US + round_trips * ROUND_TRIP_US
+    return {"chain_floor_us": round(us, 2),
+            "chain_floor_terms": {"matrix_chain": {k: "%d MFMA x %d cycles" % (n, MFMA16_CYCLES) for k, n in mfma_terms},
+                                  "other_dependent_chains_cycles": dict(extra_cycles or []), "chain_cycles": cyc, "clock_GHz": SUSTAINED_GHZ,
+                                  "kernel_boundaries": "%d x %.1f us" % (boundaries, BOUNDARY_US), "memory_round_trips": "%d x %.2f us" % (round_trips, ROUND_TRIP_US),
+                                  "what": name}}
+
+
+# dqn.py iteration at batch 128 (DESIGN 8): acting = 10 dependent steps x 72 MFMAs on a forward wave (8 layer-1 + 64 layer-2); TD = one 8-row group per workgroup:
+# 96 (layer 2, three unit tiles per wave) + 42 (dh1) + 24 (dW2) MFMAs on a wave; the slab sum has no matrix work.  3 launches; round trips: acting prologue, TD index ->
+# rows, slab sum's loads, Adam state.
+def dqn_chain_floor(batch):
+    groups = 1 if batch <= 8 * 256 else -(-((batch + 15) // 16) // 256)   # row groups per workgroup (R = 8 up to 2,048 rows, then 16-row groups dealt to 256 workgroups)
+    td = (96 + 42 + (24 if batch <= 8 * 256 else 48)) * groups
+    return chain_floor("act (10 dependent steps) -> TD -> slab sum + Adam", [("act: 10 steps x (8 + 64)", 720), ("td: layer 2 + dh1 + dW2, %d group(s)" % groups, td)], 3, 4)
+
+
+# per.py adds the sampler launch in front of the TD launch: a draw walks <= 256 + 63 + 63 prefix sums (3 instructions of ~8 issue cycles each per step; on average half
+# of the level-1 walk: ~190 steps) behind a 256-step f64 total and three dependent fetches
+def per_chain_floor(batch):
+    f = dqn_chain_floor(batch)
+    g = chain_floor("act -> sampler (prefix-sum descent) -> TD -> slab sum + Adam + scatter", [("act: 10 steps x (8 + 64)", 720), ("td", 162)], 4, 7,
+                    [("sampler: 256-step f64 total", 256 * 8), ("sampler: ~190 walk steps x 3 instructions", 190 * 24)])
+    return g if batch <= 2048 else f
+
+
+# sac.py iteration at batch 256 (DESIGN 9): a 256 x 256 pass over a 16-row group = 1,024 MFMAs on 4 waves = 256 per wave.  On the chain: acting 1 (actor layer 2;
+# 8 waves, two tiles each: 128 MFMAs per wave but two waves per SIMD -> the same 8,192 cycles per SIMD), critic launch 2 (actor' forward, target forward; the critics'
+# own forward and unit-weight backward run inside the wait), actor launch 4 (actor forward, critic forward, critic backward, actor backward), the actor's dW2 GEMM
+# launch (256 x 256 x batch MACs over sac_dw2_blocks workgroups: ~1/4 pass per SIMD at batch 256).  4 launches with the critics' step carried by the acting launch.
+def sac_chain_floor(batch):
+    rg_per_wg = max(1, -(-((batch + 15) // 16) // 256))
+    passes = 7 * rg_per_wg
+    return chain_floor("act (+ carried critic step) -> critic -> actor -> actor's dW2 + Adam", [("%d dependent 256 x 256 passes x 256 MFMAs per wave" % passes, 256 * passes),
+                                                                                                ("dW2 GEMM, per SIMD", 64 * rg_per_wg)], 4, 6)
+
+
+def with_floor(out, floor):
+    out.update(floor)
+    out["frac_of_chain_floor"] = round(floor["chain_floor_us"] / (1e3 * out["ms_per_step"]), 4)
+    return out
+
+
+def sharded_synthetic(run_iters, set_forced, world=8):
+    """The one-call sharded route of an off-policy engine on the P2P carrier with `world` SYNTHETIC ranks (mi_comm_p2p_synthetic: ONE process stores, polls and sums what
+    a `world`-rank exchange does, minus the links — the arithmetic stays the single rank's): what the exchange and the launches only a sharded run takes (the optimizer
+    steps are launches of their own there) cost per iteration, and the weak-scaling efficiency that implies before a byte crosses xGMI.  run_iters(n) -> seconds."""
+    import ctypes as C
+
+    import torch
+
+    import deep_rl_amd.dist as DD
+    from deep_rl_amd import _native as N
+
+    h = C.c_void_p()
+    try:
+        N.check(N.lib().mi_comm_p2p_synthetic(world, 1 << 20, C.byref(h)), "mi_comm_p2p_synthetic")
+        DD.use_comm(h)
+        set_forced(True)
+        run_iters(30)
+        n = 200
+        dt, enq = run_iters(n)
+        N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+        return {"world": world, "ms_per_step": round(1e3 * dt / n, 5), "host_enqueue_ms_per_step": round(1e3 * enq / n, 5)}
+    except Exception as ex:  # noqa: BLE001
+        return {"world": world, "error": "%s: %s" % (type(ex).__name__, ex)}
+    finally:
+        set_forced(False)
+        DD.use_comm(None)
+        if h.value:
+            torch.cuda.synchronize()
+            N.lib().mi_comm_destroy(h)
+
+
 def pmc_traffic(key):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/latest_pmc.json, written by tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of the same workloads) -> (bytes | None, source text | None).  Static: not measured in this run."""
@@ -121,7 +209,7 @@ def pmc_traffic(key):
         return None, None
 
 
-def bench_dqn(dev, iters=300, cpu_seconds=3.0, batch=128):
+def bench_dqn(dev, iters=300, cpu_seconds=3.0, batch=128, variant="dqn"):
     """dqn.py CartPole-v1, 4096 envs, 256-slot ring (1,048,576 transitions on HBM), batch 128, train every 10 steps (dqn.py:84-137).
     One step = one loop iteration: 10 env steps of every env (one launch) + sample + TD update (+ target sync every 500 steps).
     batch != 128: the SCALED-batch line SURVEY.md §8d asks for beside the reference's batch (labelled as such by the caller)."""
@@ -133,10 +221,12 @@ def bench_dqn(dev, iters=300, cpu_seconds=3.0, batch=128):
     envs, slots = 4096, 256
     env = D.make("CartPole-v1", num_envs=envs, device=dev, seed=1)
     torch.manual_seed(1)
-    q = D.QNetwork(env); t = D.QNetwork(env); t.load_state_dict(q.state_dict())
+    Net = D.DuelingQNetwork if variant == "dueling" else D.QNetwork
+    Eng = {"dqn": D.DQNEngine, "dueling": D.DuelingDQNEngine, "per": D.PERDQNEngine}[variant]
+    q = Net(env); t = Net(env); t.load_state_dict(q.state_dict())
     params0 = q.flat.cpu().numpy().copy()
-    eng = D.DQNEngine(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=slots, batch_size=batch, learning_starts=100, total_timesteps=10 * (iters + 160),
-                      max_episodes_logged=0)
+    eng = Eng(env, q, t, D.ClipAdam(q, lr=2.5e-4, eps=1e-8), slots=slots, batch_size=batch, learning_starts=100, total_timesteps=10 * (iters + 600),
+              max_episodes_logged=0)
     eng.reset()
 
     def it():
@@ -151,6 +241,13 @@ def bench_dqn(dev, iters=300, cpu_seconds=3.0, batch=128):
         it()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if variant != "dqn":   # dueling_dqn.py / per.py on the same ring and loop: the iteration time against its chain floor, nothing else
+        script = {"dueling": "dueling_dqn.py", "per": "per.py"}[variant]
+        out = {"workload": "%s CartPole-v1, %d envs, %d-slot ring, batch %d, train every 10 steps" % (script, envs, slots, batch), "value": round(iters * 10 * envs / dt, 1),
+               "unit": "env-steps/s", "updates_per_s": round(iters / dt, 1), "ms_per_step": round(1e3 * dt / iters, 5), "dtype": "f32", "loss": float(eng.loss.item()),
+               "step": "10 env steps of every env + 1 update" + (" (one call per piece: mi_per_act_steps + mi_per_td_update, 4 launches)" if variant == "per" else
+                                                                 " (mi_dueling_td_update: 2 launches)")}
+        return with_floor(out, per_chain_floor(batch) if variant == "per" else dqn_chain_floor(batch))
     # kernel durations from a separate, shorter pass: the event pairs around every launch would otherwise sit inside the timed loop
     N.prof_begin(4 * 100 + 8, tags=["dqn_act", "dqn_td", "dqn_reduce"])
     for _ in range(100):
@@ -176,6 +273,28 @@ def bench_dqn(dev, iters=300, cpu_seconds=3.0, batch=128):
                            "note": ("the reference's batch of 128 rows is 16 workgroups on a 256-CU chip: the launch is a fixed ~12 us latency, not a throughput" if batch == 128 else
                                     "%d rows = %d workgroups of 8 rows" % (batch, batch // 8))},
            "loss": float(eng.loss.item())}
+    if batch == 128:   # (the scaled batch is a throughput, not a chain: its MFMA fraction is the informative figure)
+        with_floor(out, dqn_chain_floor(batch))
+        out["roofline"]["note"] += "; a fraction of the MFMA peak is uninformative for a dependent launch chain: see chain_floor_us / frac_of_chain_floor"
+    if batch == 128:   # what the sharded form of this loop costs on one GPU (the exchange + clip / Adam as a launch of its own), 8 synthetic ranks on the P2P carrier
+        import deep_rl_amd.dqn_engine as DE
+
+        def run_iters(n):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                it()
+            enq = time.perf_counter() - t1   # (host time to enqueue the loop: when it is the whole of dt the sharded loop is host-bound, not GPU-bound)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1, enq
+
+        sh = sharded_synthetic(run_iters, lambda on: setattr(DE, "_FORCE_SHARDED", on))
+        if "ms_per_step" in sh:
+            sh["efficiency_model"] = round(out["ms_per_step"] / sh["ms_per_step"], 3)
+            sh["note"] = ("mi_dqn_td_update_sharded on the P2P carrier, ONE process playing 8 ranks (every store, poll and rank-ordered add of an 8-rank exchange of the "
+                          "10,936-float gradient buffer, minus the links): TD + slab sum, the all-reduce launch, clip + Adam as a launch of its own; efficiency_model = "
+                          "single-rank iteration / this (weak scaling; real xGMI adds one link latency, ~1 - 2 us, per iteration)")
+        out["sharded_synthetic"] = sh
     out["cpu_baseline"] = cpu_baseline_dqn(params0, envs, slots, batch, cpu_seconds)
     return out
 
@@ -266,6 +385,30 @@ def bench_sac(dev, iters=400, cpu_seconds=3.0, batch=256):
                         "traffic": cr_traffic, "traffic_source": cr_src, "flops_per_launch": critic_flops, "avg_launch_us": round(us["sac_critic"], 2),
                         "note": shape_note},
            "alpha": float(eng.alpha), "q_losses": [round(float(x), 5) for x in eng.q_losses.tolist()]}
+    if batch == 256:
+        with_floor(out, sac_chain_floor(batch))
+        out["roofline"]["note"] += "; a fraction of the MFMA peak is uninformative for a dependent launch chain: see chain_floor_us / frac_of_chain_floor"
+    if batch == 256:
+        import deep_rl_amd.sac_engine as SE
+
+        def run_iters(n):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                it()
+            enq = time.perf_counter() - t1
+            eng.flush()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1, enq
+
+        eng.flush()
+        sh = sharded_synthetic(run_iters, lambda on: setattr(SE, "_FORCE_SHARDED", on))
+        if "ms_per_step" in sh:
+            sh["efficiency_model"] = round(out["ms_per_step"] / sh["ms_per_step"], 3)
+            sh["note"] = ("mi_sac_{critic,actor}_update_sharded + mi_sac_alpha_step_sharded on the P2P carrier, ONE process playing 8 ranks: three all-reduces per iteration "
+                          "(134,660 / 67,332 floats and one scalar: up to 539 KB), Adam / polyak / alpha steps as launches of their own, no deferred or owed steps; "
+                          "efficiency_model = single-rank iteration / this (weak scaling; real xGMI adds three link latencies per iteration)")
+        out["sharded_synthetic"] = sh
     out["cpu_baseline"] = cpu_baseline_sac(a0, q0, envs, slots, batch, cpu_seconds)
     return out
 
@@ -1008,6 +1151,8 @@ def main():
             cs = 0.0 if args.no_cpu_baseline else 3.0
             del eng, env, agent, opt
             out["config3_dqn"] = bench_dqn(dev, cpu_seconds=cs)
+            out["config3_dueling"] = bench_dqn(dev, iters=200, variant="dueling")
+            out["config3_per"] = bench_dqn(dev, iters=200, variant="per")
             out["config4_sac"] = bench_sac(dev, cpu_seconds=cs)
             # "(also a scaled batch, stated)" — NOT the reference's batch: the same loops with batch 4,096, where the update kernels are throughputs, not fixed latencies
             out["config3_dqn_scaled"] = dict(bench_dqn(dev, iters=150, cpu_seconds=min(cs, 2.0), batch=4096), scaled="batch 4096 instead of the reference's 128 (dqn.py:46)")

@@ -119,8 +119,13 @@ __global__ void __launch_bounds__(256) perm_stats_kernel(uint32_t n, uint32_t a,
 #pragma unroll
         for (int u = 0; u < PS_PER_BLOCK / 256; ++u) {
             const uint32_t i = base + threadIdx.x + 256 * u;
+#ifdef PS_PERM_FROM_MEMORY   // timing-only build (round 6): what the launch would cost if the permutations were generated elsewhere and only read here
+            uint32_t p = (uint32_t)out[i];                              // (a slot that still holds 0 — the first update — is computed and stored once)
+            if (p == 0u && i != 0u) { p = mi_feistel(i, n, a, b, k0, k1); out[i] = (int32_t)p; }
+#else
             const uint32_t p = mi_feistel(i, n, a, b, k0, k1);
             out[i] = (int32_t)p;
+#endif
             av[u] = adv[p];
         }
 #pragma unroll
