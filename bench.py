@@ -195,6 +195,19 @@ def sharded_synthetic(run_iters, set_forced, world=8):
             N.lib().mi_comm_destroy(h)
 
 
+def same_binary(profiled_id):
+    """'source id X = this run's library' / '... DIFFERS from this run's library (Y)': whether a static figure quoted from profiles/ describes the binary being timed
+    (mi_source_id: sha256 of the kernel sources the library was built from)."""
+    try:
+        from deep_rl_amd import _native as N
+        mine = N.lib().mi_source_id().decode()
+    except Exception:  # noqa: BLE001
+        mine = "unknown"
+    if not profiled_id:
+        return "source id of the profiled build not recorded; this run's library: %s" % mine
+    return ("source id %s = this run's library" % profiled_id) if profiled_id == mine else ("source id %s DIFFERS from this run's library (%s)" % (profiled_id, mine))
+
+
 def pmc_traffic(key):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/latest_pmc.json, written by tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of the same workloads) -> (bytes | None, source text | None).  Static: not measured in this run."""
@@ -204,7 +217,8 @@ def pmc_traffic(key):
         e = j.get(key)
         if not e or e.get("hbm_bytes_per_launch") is None:
             return None, None
-        return e["hbm_bytes_per_launch"], "profiles/latest_pmc.json[%s] (static: separate rocprofv3 --pmc passes, build %s; not measured in this run)" % (key, j.get("build", "?"))
+        return e["hbm_bytes_per_launch"], "profiles/latest_pmc.json[%s] (static: separate rocprofv3 --pmc passes, build %s, %s; not measured in this run)" % (
+            key, j.get("build", "?"), same_binary(j.get("source_id")))
     except Exception:
         return None, None
 
@@ -464,8 +478,8 @@ def kernel_device_durations(window_ms):
         d = json.load(open(os.path.join(ROOT, "profiles", "latest_kernel_durations.json")))
         return {"kernels": {n: v["ms_per_update"] for n, v in d["ppo_update"].items()}, "sum_ms": d["sum_ms"], "span_ms_profiled": d["span_ms"], "launch_gaps_ms": d["launch_gaps_ms"],
                 "launches_per_update": d.get("launches_per_update"), "this_run_window_ms": round(window_ms, 4),
-                "source": "%s, build %s, %s updates averaged — static: device durations, span and gaps of the SAME profiled run (they add up; HIP-event brackets cannot)"
-                          % (d.get("source", "?"), d.get("build", "?"), d.get("updates_averaged", "?"))}
+                "source": "%s, build %s (%s), %s updates averaged — static: device durations, span and gaps of the SAME profiled run (they add up; HIP-event brackets cannot)"
+                          % (d.get("source", "?"), d.get("build", "?"), same_binary(d.get("source_id")), d.get("updates_averaged", "?"))}
     except Exception as ex:  # noqa: BLE001
         return {"error": "profiles/latest_kernel_durations.json: %s" % ex}
 
@@ -1096,6 +1110,8 @@ def main():
                                     "repeat windows; compare BENCH_r01..r03 with this key, BENCH_r04.. with `value`"},
             "last_rollout": {"episodes": ep[0], "mean_return": round(ep[1] / max(ep[0], 1), 2), "max_return": ep[2]},
             "params_finite": finite,
+            "build": {"source_id": N.lib().mi_source_id().decode(), "abi": N.ABI_VERSION,
+                      "what": "sha256 (12 hex digits) of the kernel sources libmirl.so was built from (csrc/Makefile); the static figures quoted from profiles/ carry theirs"},
             "prewarm": {"updates": prewarm_updates, "what": "throwaway engine of the same shape, run and discarded BEFORE the engine that is measured is built (clock ramp of a fresh "
                                                              "process: ~80 ms); the W warm-up and K timed updates are the measured engine's first W + K updates; --no-prewarm turns it off"},
         }

@@ -59,6 +59,7 @@ _VP, _I, _U64, _F, _D, _I64, _SZ, _U32 = C.c_void_p, C.c_int, C.c_uint64, C.c_fl
 SIGNATURES = {
     "mi_version": (_I, []),
     "mi_last_error": (C.c_char_p, []),
+    "mi_source_id": (C.c_char_p, []),
     "mi_env_create": (_I, [_I, _I, _U64, _U64, C.POINTER(_VP)]),
     "mi_env_destroy": (_I, [_VP]),
     "mi_env_reset": (_I, [_VP, _VP, _VP, _VP]),

@@ -14,6 +14,10 @@ void mi_set_error(const char* fmt, ...) {
 }
 extern "C" const char* mi_last_error(void) { return g_err; }
 extern "C" int mi_version(void) { return MI_VERSION; }
+#ifndef MI_SOURCE_ID
+#define MI_SOURCE_ID "unknown"
+#endif
+extern "C" const char* mi_source_id(void) { return MI_SOURCE_ID; }   // sha256 (12 hex digits) of the sources this library was built from (csrc/Makefile: ALLSRC)
 
 // ---- kernels (one lane per env; all accesses coalesced over the env axis) -------------------------------
 __global__ void __launch_bounds__(256) env_reset_kernel(mi_env e, float* __restrict__ obs, const double* __restrict__ forced) {

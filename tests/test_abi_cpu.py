@@ -104,7 +104,7 @@ def test_every_entry_point_survives_null_and_zero_arguments(N):
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0][7:])
     assert set(res) == set(N.SIGNATURES)
     harmless = {"mi_comm_destroy", "mi_env_destroy", "mi_timer_destroy",                    # destroying nothing is fine
-                "mi_version", "mi_last_error", "mi_perm_key", "mi_ppo_workspace_bytes", "mi_dqn_workspace_bytes", "mi_sac_workspace_bytes", "mi_per_workspace_bytes",
+                "mi_version", "mi_last_error", "mi_source_id", "mi_perm_key", "mi_ppo_workspace_bytes", "mi_dqn_workspace_bytes", "mi_sac_workspace_bytes", "mi_per_workspace_bytes",
                 "mi_env_state_bytes", "mi_ppo_get_contraction", "mi_ppo_set_contraction",   # (mode 0 = f32 is valid)
                 "mi_sac_set_max_cus", "mi_sac_usable_cus", "mi_sac_test_fault", "mi_sac_owed_alpha_fits", "mi_ppo_test_assume_sharded", "mi_prof_pause",   # (0 = off is valid)
                 "mi_sac_shadow_invalidate", "mi_sac_shadow_valid"}   # (NULL = every registered vector / "not registered": 0)

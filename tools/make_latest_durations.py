@@ -8,7 +8,7 @@ sum}, clip + Adam).  Over the steady-state updates of the trace (the first 10 an
 launches), the update's span (rollout start -> next rollout start) and launch_gaps = span - sum, all from the SAME profiled run, so that they add up — which HIP-event
 brackets cannot give (each pair costs the loop ~3 us).  bench.py quotes this file as `kernel_device_ms_per_update` beside its own live window (profiling itself slows the
 loop a little: compare span_ms with the bench line's ms_per_step)."""
-import csv, json, sys, collections
+import csv, json, os, sys, collections
 
 tag, path = sys.argv[1], sys.argv[2]
 names = ("rollout_q4_kernel", "perm_stats_kernel", "grad_kernel_f32", "grad_kernel_bx", "grad_reduce_kernel", "clip_adam_kernel")
@@ -19,6 +19,16 @@ def short(n):
         if k in n.split("(")[0]:
             return k
     return None
+
+
+def source_id():
+    """mi_source_id() of the library that was profiled (this script runs right behind the profiled command, on the same box, with the same libmirl.so)."""
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from deep_rl_amd import _native as N
+        return N.lib().mi_source_id().decode()
+    except Exception as ex:  # noqa: BLE001
+        return "unknown (%s)" % type(ex).__name__
 
 
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(path))), key=lambda x: x[0])
@@ -43,5 +53,5 @@ for k in names:
         res[k] = {"ms_per_update": round(sum(v) / n, 5), "launches_per_update": cnt, "avg_launch_us": round(1e3 * sum(v) / n / cnt, 3)}
 span = sum(u[0] for u in updates) / max(n, 1) / 1e6
 total = sum(v["ms_per_update"] for v in res.values())
-print(json.dumps({"build": tag, "source": "profiles/%s_kernel_durations.json (rocprofv3 --kernel-trace of `bench.py --headline-only`)" % tag, "updates_averaged": n, "ppo_update": res,
+print(json.dumps({"build": tag, "source_id": source_id(), "source": "profiles/%s_kernel_durations.json (rocprofv3 --kernel-trace of `bench.py --headline-only`)" % tag, "updates_averaged": n, "ppo_update": res,
                   "span_ms": round(span, 5), "sum_ms": round(total, 5), "launch_gaps_ms": round(span - total, 5), "launches_per_update": 35}, indent=1, sort_keys=True))

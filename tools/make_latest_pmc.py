@@ -30,7 +30,17 @@ def entry(summary, kernel, src):
     return e
 
 
-out = {"build": tag}
+def source_id():
+    """mi_source_id() of the library that was profiled (this script runs right behind the profiled commands, on the same box, with the same libmirl.so)."""
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from deep_rl_amd import _native as N
+        return N.lib().mi_source_id().decode()
+    except Exception as ex:  # noqa: BLE001
+        return "unknown (%s)" % type(ex).__name__
+
+
+out = {"build": tag, "source_id": source_id()}
 ppo = load("pmc_summary.json")
 e = entry(ppo, "grad_kernel_f32", "profiles/%s_pmc_summary.json" % tag)
 if e:
