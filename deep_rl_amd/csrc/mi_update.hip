@@ -437,7 +437,7 @@ struct grad_pending_t {
     float* p_out; float* m_out; float* v_out;             // ... after it (never the *_in buffers)
     float* grad_norm;                                     // nullable: pre-clip total norm of `grads`
     const double* norm_parts;                             // nullable: the block sums of squares grad_reduce_kernel wrote for `grads` (single rank only: see block_grad_norm)
-    const uint32_t* gate;                                 // nullable: status word of the P2P carrier that exchanged `grads` (mi_comm_gate) — non-zero: the step is WITHHELD, out = in
+    const uint32_t* gate;                                 // status word of the P2P carrier that exchanged `grads` (mi_comm_gate) — non-zero: the step is WITHHELD, out = in; never null when grads is set (ppo_gate)
     float w1, b2, w2, step_size, rbc2, eps, max_norm;
 };
 
@@ -626,6 +626,16 @@ extern "C" int mi_ppo_set_contraction(int mode) {
 }
 extern "C" int mi_ppo_get_contraction(void) { return g_contraction; }
 
+// the gate of an owed step: the carrier's status word, or (no P2P carrier) a device word that is always zero — the prologue's load of it is unconditional
+__device__ uint32_t mi_always_zero_word = 0u;
+static const uint32_t* ppo_gate(void* comm) {
+    if (const uint32_t* g = mi_comm_gate(comm)) return g;
+    static const uint32_t* zero[64] = {nullptr};   // per device (the symbol has one instance per device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!zero[dev]) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(mi_always_zero_word)) == hipSuccess) zero[dev] = (const uint32_t*)p; }
+    return zero[dev];
+}
 static grad_pending_t no_pending() { grad_pending_t z; memset(&z, 0, sizeof(z)); return z; }
 
 // TEST HOOK (include/mi_rl.h): mi_ppo_update / mi_ppo_update_sharded behave as at world_size > 1 in everything but the collective — the owed optimizer steps
@@ -952,7 +962,8 @@ static int ppo_update_impl(void* handle, const mi_ppo_buffers_t* b, const mi_ppo
                 pend.grad_norm = b->grad_norm; pend.w1 = c.w1; pend.b2 = c.b2; pend.w2 = c.w2; pend.step_size = c.step_size; pend.rbc2 = c.rbc2; pend.eps = c.eps;
                 pend.max_norm = hp->max_grad_norm;
                 pend.norm_parts = sharded_norm ? nullptr : ws_norm_parts(b->workspace);   // sharded: the all-reduce changed the gradient after the block sums were taken
-                pend.gate = mi_comm_gate(comm);
+                pend.gate = ppo_gate(comm);
+                if (!pend.gate) { mi_set_error("mi_ppo_update: cannot resolve the always-zero gate word"); return MI_EHIP; }
                 cur = out;   // what this launch trains on and what the next owed step starts from
             }
             rc = ppo_grad_launch(owed ? nullptr : cur.p, pend, b->observations, b->actions, b->log_probs, b->advantages, b->returns, b->values,
