@@ -493,7 +493,8 @@ def collectives_label(world, is_p2p, native, carriers, policy):
         return "RCCL direct (mi_ppo_update_sharded: one C call per update, 17 in-stream ncclAllReduce over xGMI); the P2P carrier is reported beside it (value_p2p)"
     tail = ("RCCL could not carry this run: %s" % why_not_rccl) if why_not_rccl else ("policy: %s" % policy)
     if native:
-        return "P2P over hipIpc inboxes (mi_ppo_update_sharded: one C call per update, the gradient exchange inside the slab-sum launch) — NOT the RCCL configuration; " + tail
+        return ("P2P over hipIpc inboxes (mi_ppo_update_sharded: one C call per update, the gradient exchange inside the slab-sum launch — a launch of its own when more "
+                "than two ranks share a device) — NOT the RCCL configuration; " + tail)
     return "torch.distributed (host-sequenced, 17 all-reduces per update) — NOT the RCCL configuration; " + tail
 
 
