@@ -306,8 +306,9 @@ def bench_dqn(dev, iters=300, cpu_seconds=3.0, batch=128, variant="dqn"):
         if "ms_per_step" in sh:
             sh["efficiency_model"] = round(out["ms_per_step"] / sh["ms_per_step"], 3)
             sh["note"] = ("mi_dqn_td_update_sharded on the P2P carrier, ONE process playing 8 ranks (every store, poll and rank-ordered add of an 8-rank exchange of the "
-                          "10,936-float gradient buffer, minus the links): TD + slab sum, the all-reduce launch, clip + Adam as a launch of its own; efficiency_model = "
-                          "single-rank iteration / this (weak scaling; real xGMI adds one link latency, ~1 - 2 us, per iteration)")
+                          "10,935-float {gradient, loss} message, minus the links): the TD launch draws its batch itself and the slab-sum launch carries the exchange AND "
+                          "Adam (round 6: two launches, as in a single process; until then five: 68 us, efficiency 0.55); efficiency_model = single-rank iteration / this "
+                          "(weak scaling; real xGMI adds one link latency, ~1 - 2 us, per iteration)")
         out["sharded_synthetic"] = sh
     out["cpu_baseline"] = cpu_baseline_dqn(params0, envs, slots, batch, cpu_seconds)
     return out

@@ -110,7 +110,7 @@ SIGNATURES = {
     "mi_env_export_state": (_I, [_VP, _VP, _VP]),
     "mi_env_import_state": (_I, [_VP, _VP, _VP]),
     "mi_dqn_td_update": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _U64, _U64, _I64, _VP]),
-    "mi_dqn_td_update_sharded": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _F, _VP, _VP, _VP]),
+    "mi_dqn_td_update_sharded": (_I, [_VP] * 7 + [_I, _I, _I64, _F, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _F, _VP, _U64, _U64, _I64, _VP, _VP]),
     "mi_sac_critic_update_sharded": (_I, [_VP] * 8 + [_I, _I, _I64, _VP, _U64, _U64, _VP, _F, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _F, _VP, _VP]),
     "mi_sac_actor_update_sharded": (_I, [_VP] * 4 + [_I, _VP, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _I64, _D, _D, _D, _D, _VP, _VP]),
     "mi_sac_alpha_step_sharded": (_I, [_VP, _VP, _VP, _I, _VP, _U64, _U64, _F, _VP, _VP, _VP, _I64, _D, _VP, _VP, _VP, _VP, _VP, _VP]),

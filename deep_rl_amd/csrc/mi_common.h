@@ -191,6 +191,25 @@ template <> struct ll_elem<double> {
     static __device__ __forceinline__ double join(const uint64_t* v) { return __longlong_as_double((long long)(((uint64_t)(uint32_t)v[1] << 32) | (uint32_t)v[0])); }
 };
 
+// One f32 element of an all-reduce carried INSIDE a launch that has just produced it (PPO's grad_reduce_kernel, DQN's slab-sum kernels): store it as line `line` into
+// slot (parity, rank) of every rank's inbox, poll the WORLD lines of it in the own inbox, add them IN RANK ORDER.  WORLD = 0: no exchange.  A wait that runs out
+// returns the local share (the status word is set: every optimizer step behind it is withheld).
+template <int WORLD>
+__device__ __forceinline__ float p2p_exchange(const p2p_args_t& x, int line, float t) {
+    if constexpr (WORLD > 0) {
+#pragma unroll
+        for (int d = 0; d < WORLD; ++d) ll_store_nowait(x.dst[d] + line, (x.zeros >> d) & 1 ? 0u : __float_as_uint(t), x.seq);
+        uint64_t v[WORLD][1];
+        if (!ll_gather<WORLD, 1>(x, (size_t)line, v)) return t;
+        float acc = __uint_as_float((uint32_t)v[0][0]);
+#pragma unroll
+        for (int r = 1; r < WORLD; ++r) acc += __uint_as_float((uint32_t)v[r][0]);
+        return acc;
+    } else {
+        return t;
+    }
+}
+
 // Fills `a` for the NEXT all-reduce of `n_words` 32-bit words on a P2P communicator (advances its sequence number: the caller MUST launch exactly one kernel that
 // publishes and consumes those lines on every rank, on stream `s`); MI_EINVAL when the message does not fit, MI_ESTATE when the communicator is not connected or an
 // earlier wait on it ran out.  When the 32-bit sequence number is about to wrap, the call first enqueues the epoch change on `s` (inbox cleared, barrier: mi_comm.hip).

@@ -1140,9 +1140,14 @@ __device__ __forceinline__ void dueling_head_step(const dqn_opt_t& o, float g0, 
 }
 // PER: one more workgroup behind the summing ones carries per.py:144-145 (per_scatter_role) — |td| and the indices are final at the TD kernel's boundary, and nothing here
 // reads priorities.
-template <bool PER>
+// WORLD > 0 (sharded run on the P2P carrier without gradient clipping, round 6): the all-reduce of {gradient, loss} (dqn.py:131 -> :133 with the exchange in between)
+// happens HERE — the thread that has just summed element p exchanges it as line p (p2p_exchange: rank-ordered sum, the same bits on every rank) and steps it — instead of
+// in a launch of its own followed by a clip + Adam launch: the sharded iteration is the single process's two launches plus one exchange latency.  `gate`: the carrier's
+// status word (never null when WORLD > 0): a wait that ran out withholds the step.
+template <bool PER, int WORLD>
 __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
-                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt, per_scatter_t sc) {
+                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt, per_scatter_t sc, const p2p_args_t x,
+                                                         const uint32_t* __restrict__ gate) {
     MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
     if constexpr (PER) {
         if (blockIdx.x == gridDim.x - 1) { __shared__ float wmax[4]; per_scatter_role(wmax, sc); return; }
@@ -1163,7 +1168,16 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
             for (int k = 0; k < 16; ++k) acc[k & 3] += x[k];
         }
         for (; b < n_slabs; ++b) acc[b & 3] += workspace[(size_t)b * TD_SLAB + p];
-        const float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if constexpr (WORLD > 0) {
+            g = p2p_exchange<WORLD>(x, p, g);
+            grads[p] = g;
+            if (opt.params && !mi_gate_closed(gate)) {
+                opt.params[p] = mi_adam_elem(pi, g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
+                opt.m[p] = mi; opt.v[p] = vi;
+            }
+            return;
+        }
         grads[p] = g;
         if (opt.du_params) {
             if (p < DQ_W3) {                                   // feature layers: the same index in both layouts; the image holds a copy
@@ -1194,7 +1208,7 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
     } else if (p == DQ_NP && loss) {
         double l = 0.0;
         for (int b = 0; b < n_slabs; ++b) l += workspace[(size_t)b * TD_SLAB + DQ_NP];
-        loss[0] = (float)(l * inv_count);
+        loss[0] = p2p_exchange<WORLD>(x, DQ_NP, (float)(l * inv_count));   // (WORLD = 0: the value itself)
     }
 }
 
@@ -1204,9 +1218,10 @@ __global__ void __launch_bounds__(256) dqn_reduce_kernel(const float* __restrict
 #define DR_PARAMS 64
 #define DR_GROUPS 16
 #define DR_MIN_SLABS 64   // from this many slabs on
-template <bool PER>
+template <bool PER, int WORLD>
 __global__ void __launch_bounds__(DR_PARAMS * DR_GROUPS) dqn_reduce2_kernel(const float* __restrict__ workspace, int n_slabs, double inv_count,
-                                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt, per_scatter_t sc) {
+                                                                         float* __restrict__ grads, float* __restrict__ loss, dqn_opt_t opt, per_scatter_t sc,
+                                                                         const p2p_args_t x, const uint32_t* __restrict__ gate) {
     MI_INSIDE_SCOPE(MI_PROF_DQN_REDUCE);
     if constexpr (PER) {
         if (blockIdx.x == gridDim.x - 1) { __shared__ float wmax[DR_GROUPS]; per_scatter_role(wmax, sc); return; }
@@ -1237,8 +1252,9 @@ __global__ void __launch_bounds__(DR_PARAMS * DR_GROUPS) dqn_reduce2_kernel(cons
             float g = 0.0f;
 #pragma unroll
             for (int k = 0; k < DR_GROUPS; ++k) g += part[k][pl];
+            g = p2p_exchange<WORLD>(x, p, g);   // (WORLD = 0: the value itself)
             grads[p] = g;
-            if (opt.params) {
+            if (opt.params && !(WORLD > 0 && mi_gate_closed(gate))) {
                 opt.params[p] = mi_adam_elem(pi, g, mi, vi, opt.w1, opt.b2, opt.w2, opt.step_size, opt.rbc2, opt.eps);
                 opt.m[p] = mi; opt.v[p] = vi;
             }
@@ -1254,7 +1270,7 @@ __global__ void __launch_bounds__(DR_PARAMS * DR_GROUPS) dqn_reduce2_kernel(cons
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int k = 0; k < DR_GROUPS; ++k) t += wsum[k];
-            loss[0] = (float)(t * inv_count);
+            loss[0] = p2p_exchange<WORLD>(x, DQ_NP, (float)(t * inv_count));
         }
     }
 }
@@ -1268,7 +1284,7 @@ static dqn_opt_t dqn_no_opt() { dqn_opt_t o; memset(&o, 0, sizeof(o)); return o;
 static int dqn_td_impl(const float* params, const float* target_params, const float* observations, const int64_t* actions,
                        const float* rewards, const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots,
                        float gamma, double inv_count, void* workspace, float* grads, float* loss, const float* weights, float* td_abs, const dqn_opt_t& opt,
-                       uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* stream, const per_scatter_t* scatter = nullptr) {
+                       uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* stream, const per_scatter_t* scatter = nullptr, void* p2p = nullptr) {
     MI_CHECK_ARG(params && target_params && observations && actions && rewards && terminated && idx && workspace && grads, "NULL pointer");
     MI_CHECK_ARG(sample_upper >= 0, "sample_upper must be >= 0");
     MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "batch, n_envs must be positive and slots >= 2");
@@ -1293,15 +1309,37 @@ static int dqn_td_impl(const float* params, const float* target_params, const fl
     {
         mi_prof_scope prof(MI_PROF_DQN_REDUCE, s);
         const int g2 = (DQ_NP + DR_PARAMS - 1) / DR_PARAMS + 1, g1 = (DQ_NP + 1 + 255) / 256;
-        if (scatter) {   // PER's one-call update: one more workgroup carries the priority scatter + max_priority
-            if (blocks >= DR_MIN_SLABS) dqn_reduce2_kernel<true><<<g2 + 1, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, *scatter);
-            else dqn_reduce_kernel<true><<<g1 + 1, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, *scatter);
-        } else {
-            per_scatter_t none;
-            memset(&none, 0, sizeof(none));
-            if (blocks >= DR_MIN_SLABS) dqn_reduce2_kernel<false><<<g2, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, none);
-            else dqn_reduce_kernel<false><<<g1, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, none);
+        const bool many = blocks >= DR_MIN_SLABS;
+        per_scatter_t none;
+        memset(&none, 0, sizeof(none));
+        p2p_args_t x;
+        memset(&x, 0, sizeof(x));
+        int world = 0;
+        if (p2p) {   // the slab sum also all-reduces {grads, loss} over the P2P carrier (exactly one exchange per call, on every rank) and steps the parameters
+            if (scatter || opt.du_params || loss != grads + DQ_NP) { mi_set_error("dqn_td_impl: the in-launch exchange needs loss == grads + MI_DQN_NPARAMS and a plain DQN step"); return MI_EINVAL; }
+            const int rc = mi_comm_p2p_next(p2p, (size_t)DQ_NP + 1, &x, &world, s);
+            if (rc) return rc;
         }
+        const uint32_t* gate = mi_comm_gate(p2p);
+#define DR_LAUNCH(W) do { if (many) dqn_reduce2_kernel<false, W><<<g2, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, none, x, gate); \
+                          else dqn_reduce_kernel<false, W><<<g1, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, none, x, gate); } while (0)
+        if (scatter) {   // PER's one-call update: one more workgroup carries the priority scatter + max_priority
+            if (many) dqn_reduce2_kernel<true, 0><<<g2 + 1, DR_PARAMS * DR_GROUPS, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, *scatter, x, nullptr);
+            else dqn_reduce_kernel<true, 0><<<g1 + 1, 256, 0, s>>>((const float*)workspace, blocks, inv_count, grads, loss, opt, *scatter, x, nullptr);
+        } else {
+            switch (world) {
+                case 0: DR_LAUNCH(0); break;
+                case 1: DR_LAUNCH(1); break;
+                case 2: DR_LAUNCH(2); break;
+                case 3: DR_LAUNCH(3); break;
+                case 4: DR_LAUNCH(4); break;
+                case 5: DR_LAUNCH(5); break;
+                case 6: DR_LAUNCH(6); break;
+                case 7: DR_LAUNCH(7); break;
+                default: DR_LAUNCH(8); break;
+            }
+        }
+#undef DR_LAUNCH
     }
     MI_LAUNCH_CHECK();
     return MI_OK;
@@ -1314,21 +1352,35 @@ extern "C" int mi_dqn_td_grad(const float* params, const float* target_params, c
                        nullptr, nullptr, dqn_no_opt(), 0, 0, 0, stream);
 }
 
-// sharded runs, ONE C call (the pattern of mi_ppo_update_sharded): TD gradient share (scaled by 1 / (world * batch)) + slab sum, an in-stream RCCL SUM all-reduce
-// of gradbuf = {grads [MI_DQN_NPARAMS], loss, pad} and optimizer.step() (mi_clip_adam with `max_norm`) — the same launches as the host-sequenced route
-// (mi_dqn_td_grad / mi_per_td_grad, torch.distributed.all_reduce, mi_clip_adam), so the two agree bit for bit; no Python between launches.
+// sharded runs, ONE C call (the pattern of mi_ppo_update_sharded): TD gradient share (scaled by 1 / (world * batch)) + slab sum, an in-stream SUM all-reduce
+// of gradbuf = {grads [MI_DQN_NPARAMS], loss, pad} and optimizer.step() (mi_clip_adam with `max_norm`) — the same arithmetic as the host-sequenced route
+// (mi_dqn_td_grad / mi_per_td_grad, torch.distributed.all_reduce, mi_clip_adam), so the two agree bit for bit; no Python between launches.  sample_upper > 0: the TD launch
+// draws the batch itself (dqn.py:116, the keyed uniform draw of mi_dqn_sample) and writes it to idx.
 extern "C" int mi_dqn_td_update_sharded(float* params, const float* target_params, const float* observations, const int64_t* actions, const float* rewards,
-                                        const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, const float* weights,
+                                        const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, const float* weights,
                                         float* td_abs, void* workspace, float* gradbuf, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1,
-                                        double beta2, double eps, float max_norm, float* grad_norm, void* comm, void* stream) {
+                                        double beta2, double eps, float max_norm, float* grad_norm, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper,
+                                        void* comm, void* stream) {
     MI_CHECK_ARG(gradbuf && exp_avg && exp_avg_sq && step >= 1, "NULL optimizer state / bad step");
+    MI_CHECK_ARG(!(sample_upper > 0 && weights), "in-kernel uniform sampling and importance weights exclude each other");
     int world = 1;
     if (comm) {
         if (const int rc = mi_comm_poll_impl(comm)) return rc;   // an earlier wait of the P2P carrier ran out: MI_ESTATE before anything is enqueued
         if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
     }
-    int rc = dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, 1.0 / ((double)batch * world), workspace,
-                         gradbuf, gradbuf + DQ_NP, weights, td_abs, dqn_no_opt(), 0, 0, 0, stream);
+    const double inv_count = 1.0 / ((double)batch * world);
+    // P2P carrier, no gradient clipping (dqn.py / per.py have none): the slab-sum launch exchanges each element it has summed and steps it — the single process's two
+    // launches plus one exchange latency (the fused form needs no norm; with a finite max_norm the clip coefficient is a grid-wide dependency: the sequence below)
+    if (comm && mi_comm_p2p_fused_ok(comm) && max_norm == __builtin_inff()) {
+        dqn_opt_t o;
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        o.params = params; o.m = exp_avg; o.v = exp_avg_sq; o.w1 = (float)(1.0 - beta1); o.b2 = (float)beta2; o.w2 = (float)(1.0 - beta2);
+        o.step_size = (float)(lr / bc1); o.rbc2 = (float)(1.0 / sqrt(bc2)); o.eps = (float)eps; o.du_params = nullptr; o.du_grads = nullptr;
+        return dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace, gradbuf, gradbuf + DQ_NP,
+                           weights, td_abs, o, sample_seed, sample_update, sample_upper, stream, nullptr, comm);
+    }
+    int rc = dqn_td_impl(params, target_params, observations, actions, rewards, terminated, idx, batch, n_envs, slots, gamma, inv_count, workspace,
+                         gradbuf, gradbuf + DQ_NP, weights, td_abs, dqn_no_opt(), sample_seed, sample_update, sample_upper, stream);
     if (rc) return rc;
     if (comm) {
         mi_prof_scope prof(MI_PROF_COMM_GRAD, (hipStream_t)stream);

@@ -499,22 +499,6 @@ __device__ __forceinline__ row_in gather_row(int rid, int g, const float* __rest
 // its own inbox and adds them in RANK ORDER (the same bits on every rank), so `grads`, `loss_terms` and the block sums of squares come out ALL-REDUCED and the next
 // gradient launch's owed clip + Adam takes the single-rank branch.  Only wave 0 of a 1,024-thread workgroup waits, for peers' stores that depend on no wait; 145 small
 // workgroups never fill the chip, so two ranks time-sharing one device cannot starve each other.  A peer that never arrives: bounded wait, status word, the local share.
-template <int WORLD>
-__device__ __forceinline__ float p2p_exchange(const p2p_args_t& x, int line, float t) {
-    if constexpr (WORLD > 0) {
-#pragma unroll
-        for (int d = 0; d < WORLD; ++d) ll_store_nowait(x.dst[d] + line, (x.zeros >> d) & 1 ? 0u : __float_as_uint(t), x.seq);
-        uint64_t v[WORLD][1];
-        if (!ll_gather<WORLD, 1>(x, (size_t)line, v)) return t;
-        float acc = __uint_as_float((uint32_t)v[0][0]);
-#pragma unroll
-        for (int r = 1; r < WORLD; ++r) acc += __uint_as_float((uint32_t)v[r][0]);
-        return acc;
-    } else {
-        return t;
-    }
-}
-
 #define RED_PARAMS 64
 #define RED_GROUPS 16
 template <int WORLD>

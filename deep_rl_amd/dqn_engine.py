@@ -138,15 +138,18 @@ class DQNEngine:
         g = self.optimizer.param_groups[0]
         fusable = (self.world_size == 1 and not _FORCE_SHARDED and g["max_grad_norm"] == float("inf")
                    and type(self).td_grad in (DQNEngine.td_grad, PERDQNEngine.td_grad))
-        in_kernel_sampling = fusable and indices is None and type(self).sample is DQNEngine.sample     # uniform randint drawn by the TD launch itself
+        native = not fusable and self._native_sharded()
+        # the uniform randint of dqn.py:116 is drawn by the TD launch itself wherever ONE call runs the step (single process, and the sharded one-call route: every rank
+        # draws from its own ring with the same keys, as mi_dqn_sample would)
+        in_kernel_sampling = (fusable or native) and indices is None and type(self).sample is DQNEngine.sample
         if not in_kernel_sampling:
             self.sample(indices)
+        upper = min(self.global_step, self.slots) * self.N if in_kernel_sampling else 0
+        if in_kernel_sampling and upper == 0:   # upper == 0 means "read batch_inds" to the launch: an empty ring must not train on stale indices
+            raise N.MiError("train_step: the replay ring is empty (global_step == 0); act() before training")
         if fusable:
             o = self.optimizer
             w, td = self._row_weights()
-            upper = min(self.global_step, self.slots) * self.N if in_kernel_sampling else 0
-            if in_kernel_sampling and upper == 0:   # upper == 0 means "read batch_inds" to the launch: an empty ring must not train on stale indices
-                raise N.MiError("train_step: the replay ring is empty (global_step == 0); act() before training")
             N.check(N.lib().mi_dqn_td_update(
                 N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
                 N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self.grads),
@@ -154,15 +157,16 @@ class DQNEngine:
                 self.env._seed, self.update_index, upper, self._s()), "mi_dqn_td_update")
             o.step_count += 1   # committed only once the call has accepted the step
             self._after_td()
-        elif self._native_sharded():
-            # sharded, NCCL process group: ONE C call — TD share, slab sum, in-stream RCCL all-reduce of {grads, loss}, clip + Adam (mi_dqn_td_update_sharded)
+        elif native:
+            # sharded, ONE C call — TD share (drawing its batch itself for plain DQN), slab sum, in-stream all-reduce of {grads, loss}, clip + Adam (mi_dqn_td_update_sharded);
+            # on the P2P carrier without clipping the slab-sum launch carries the exchange and the step: two launches, as in a single process
             o = self.optimizer
             w, td = self._row_weights()
             N.check(N.lib().mi_dqn_td_update_sharded(
                 N.ptr(self.q.flat), N.ptr(self.target.flat), N.ptr(self.observations), N.ptr(self.actions), N.ptr(self.rewards), N.ptr(self.terminated),
                 N.ptr(self.batch_inds), self.batch_size, self.N, self.slots, self.gamma, N.ptr(w), N.ptr(td), N.ptr(self.workspace), N.ptr(self._gradbuf),
                 N.ptr(o.exp_avg), N.ptr(o.exp_avg_sq), o.step_count + 1, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], float(g["max_grad_norm"]),
-                N.ptr(o.grad_norm), D.native_comm(self.pg), self._s()), "mi_dqn_td_update_sharded")
+                N.ptr(o.grad_norm), self.env._seed, self.update_index, upper, D.native_comm(self.pg), self._s()), "mi_dqn_td_update_sharded")
             o.step_count += 1
             self._after_td()
         else:

@@ -335,14 +335,18 @@ int mi_dqn_td_update(float* params, const float* target_params, const float* obs
                      float gamma, const float* weights, float* td_abs, void* workspace, float* grads, float* loss, float* exp_avg, float* exp_avg_sq,
                      int64_t step, double lr, double beta1, double beta2, double eps, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper,
                      void* stream);
-/* sharded runs (one process per GPU), ONE call per optimisation step (dqn.py:118-133 with the gradient exchange between backward and step): TD gradient
- * share scaled by 1 / (world * batch), slab sum, in-stream RCCL SUM all-reduce of gradbuf = dev f32 [MI_DQN_NPARAMS + 2] {grads, loss, pad}, then mi_clip_adam(max_norm,
- * grad_norm nullable).  weights / td_abs: PER row weights and |td| out (nullable together).  The same launches as mi_dqn_td_grad (mi_per_td_grad) + caller all-reduce +
- * mi_clip_adam: bit-identical.  comm NULL or world 1: no collective. */
+/* sharded runs (one process per GPU), ONE call per optimisation step (dqn.py:116-133 with the gradient exchange between backward and step): TD gradient
+ * share scaled by 1 / (world * batch), slab sum, in-stream SUM all-reduce of gradbuf = dev f32 [MI_DQN_NPARAMS + 2] {grads, loss, pad}, then mi_clip_adam(max_norm,
+ * grad_norm nullable).  weights / td_abs: PER row weights and |td| out (nullable together).  sample_upper > 0 (DQN only): the TD launch draws the batch itself (the keyed
+ * uniform draw of mi_dqn_sample(sample_seed, sample_update, sample_upper)) and writes it to idx; 0: idx is given.  The same arithmetic as mi_dqn_td_grad
+ * (mi_per_td_grad) + caller all-reduce + mi_clip_adam: bit-identical.  comm NULL or world 1: no collective.
+ * On the P2P carrier with max_norm = +inf (dqn.py / per.py clip nothing; round 6) the slab-sum launch carries the exchange AND the step — the thread that has summed
+ * gradient element p exchanges it (rank-ordered sum) and applies Adam to it: two launches per step, as in a single process, plus one exchange latency; grad_norm is
+ * not written on that route (no norm is computed).  With RCCL, or a finite max_norm (the clip coefficient is a grid-wide dependency): slab sum, all-reduce, clip + Adam. */
 int mi_dqn_td_update_sharded(float* params, const float* target_params, const float* observations, const int64_t* actions, const float* rewards,
-                             const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, const float* weights, float* td_abs,
+                             const uint8_t* terminated, int64_t* idx, int batch, int n_envs, int64_t slots, float gamma, const float* weights, float* td_abs,
                              void* workspace, float* gradbuf, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,
-                             float max_norm, float* grad_norm, void* comm, void* stream);
+                             float max_norm, float* grad_norm, uint64_t sample_seed, uint64_t sample_update, int64_t sample_upper, void* comm, void* stream);
 /* optimizer.step() (dqn.py:131-133) = mi_clip_adam(..., n = MI_DQN_NPARAMS, eps = 1e-8, max_norm = +inf);
  * target_network.load_state_dict (dqn.py:136-137) = a device-to-device copy of the flat vector by the caller. */
 
