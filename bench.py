@@ -420,9 +420,11 @@ def bench_sac(dev, iters=400, cpu_seconds=3.0, batch=256):
         sh = sharded_synthetic(run_iters, lambda on: setattr(SE, "_FORCE_SHARDED", on))
         if "ms_per_step" in sh:
             sh["efficiency_model"] = round(out["ms_per_step"] / sh["ms_per_step"], 3)
-            sh["note"] = ("mi_sac_{critic,actor}_update_sharded + mi_sac_alpha_step_sharded on the P2P carrier, ONE process playing 8 ranks: three all-reduces per iteration "
-                          "(134,660 / 67,332 floats and one scalar: up to 539 KB), Adam / polyak / alpha steps as launches of their own, no deferred or owed steps; "
-                          "efficiency_model = single-rank iteration / this (weak scaling; real xGMI adds three link latencies per iteration)")
+            sh["note"] = ("mi_sac_{critic,actor}_update_sharded + mi_sac_alpha_step_sharded on the P2P carrier, ONE process playing 8 ranks: three exchanges per iteration "
+                          "(134,660 / 67,332 floats and one scalar: up to 539 KB), each INSIDE the launch that assembles the gradient and steps it (round 6: Adam / polyak / "
+                          "alpha ride behind the exchange; until then 14 launches: 123 us, efficiency 0.60); no deferred or owed steps on this route, and its seven calls "
+                          "per iteration make the loop nearly host-bound (host_enqueue_ms_per_step); efficiency_model = single-rank iteration / this (weak scaling; real "
+                          "xGMI adds three link latencies per iteration)")
         out["sharded_synthetic"] = sh
     out["cpu_baseline"] = cpu_baseline_sac(a0, q0, envs, slots, batch, cpu_seconds)
     return out

@@ -210,6 +210,38 @@ __device__ __forceinline__ float p2p_exchange(const p2p_args_t& x, int line, flo
     }
 }
 
+// The same with the rank count as a RUN-TIME value (SAC's gradient assembly kernels: four sites, by-value kernel arguments — no room for nine instantiations of each):
+// the loops run over P2P_MAX_WORLD with the ranks beyond `world` predicated off; stores and loads are issued together exactly as above.
+__device__ __forceinline__ float p2p_exchange_rt(const p2p_args_t& x, int world, int line, float t) {
+#pragma unroll
+    for (int d = 0; d < P2P_MAX_WORLD; ++d) if (d < world) ll_store_nowait(x.dst[d] + line, (x.zeros >> d) & 1 ? 0u : __float_as_uint(t), x.seq);
+    uint64_t v[P2P_MAX_WORLD];
+    unsigned long long t0 = 0;
+    for (uint32_t spins = 0;; ++spins) {
+#pragma unroll
+        for (int r = 0; r < P2P_MAX_WORLD; ++r) v[r] = r < world ? ll_load_nowait(x.src[r] + line) : 0ull;
+        ll_wait_loads();
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < P2P_MAX_WORLD; ++r) if (r < world) { ll_pin(v[r]); all = all && (uint32_t)(v[r] >> 32) == x.seq; }
+        if (all) break;
+        if (spins == 0) t0 = p2p_clock();
+        if ((spins & 63) == 63 && (p2p_clock() - t0 > x.budget || __hip_atomic_load(p2p_status(x.mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            uint32_t missing = 1u;
+#pragma unroll
+            for (int r = 0; r < P2P_MAX_WORLD; ++r) if (r < world && (uint32_t)(v[r] >> 32) != x.seq) missing |= 1u << (8 + r);
+            __hip_atomic_fetch_or(p2p_status(x.mine), missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x.mirror) __hip_atomic_fetch_or(x.mirror, missing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return t;   // the local share; every optimizer step behind it is withheld (gate)
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    float acc = __uint_as_float((uint32_t)v[0]);
+#pragma unroll
+    for (int r = 1; r < P2P_MAX_WORLD; ++r) if (r < world) acc += __uint_as_float((uint32_t)v[r]);
+    return acc;
+}
+
 // Fills `a` for the NEXT all-reduce of `n_words` 32-bit words on a P2P communicator (advances its sequence number: the caller MUST launch exactly one kernel that
 // publishes and consumes those lines on every rank, on stream `s`); MI_EINVAL when the message does not fit, MI_ESTATE when the communicator is not connected or an
 // earlier wait on it ran out.  When the 32-bit sequence number is about to wrap, the call first enqueues the epoch change on `s` (inbox cleared, barrier: mi_comm.hip).

@@ -986,7 +986,13 @@ __global__ void __launch_bounds__(256) sac_dw2_gemm_kernel(float* __restrict__ w
 // step to every element it has just assembled and (critics) the polyak step of the target copy: optimizer.step() and the target update
 // (sac.py:185,213-217) cost no launch of their own.
 struct sac_opt_t { float* params; float* m; float* v; float* target; float w1, b2, w2, step_size, rbc2, eps, tau;
-                   float* params_t; float* target_t; int is_actor; };   // transposed layer-2 copies of params / target (nullable: not registered or not valid), kept in step by sac_apply
+                   float* params_t; float* target_t; int is_actor;     // transposed layer-2 copies of params / target (nullable: not registered or not valid), kept in step by sac_apply
+                   // sharded run on the P2P carrier (round 6; world = 0: none): every gradient element and loss scalar is exchanged — line = its index in the caller's
+                   // {gradient, 2 scalars} buffer, rank-ordered sum — by the thread that has just assembled it, and stepped behind the exchange: the all-reduce, Adam and polyak
+                   // launches of the sharded routes disappear into the assembly launch (sac.py:185-217 with the exchange between backward and step).  gate: the carrier's
+                   // status word — a wait that ran out withholds every step (mi_common.h).
+                   p2p_args_t xa; int world; const uint32_t* gate; };
+__device__ __forceinline__ float sac_xchg(const sac_opt_t& o, int line, float g) { return o.world > 0 ? p2p_exchange_rt(o.xa, o.world, line, g) : g; }
 // flat parameter index -> index into the transposed layer-2 copy ([net][k][unit]), -1 outside the layer-2 matrices
 __device__ __forceinline__ int sac_t_index(int is_actor, int i) {
     const int net = is_actor ? 0 : (i >= SQ_NP ? 1 : 0);
@@ -1002,7 +1008,7 @@ __device__ __forceinline__ sac_state_t sac_state_load(const sac_opt_t& o, int i)
     return s;
 }
 __device__ __forceinline__ void sac_apply(const sac_opt_t& o, int i, float g, sac_state_t s) {
-    if (s.fault) return;                                       // see sac_timeout: {params, exp_avg, exp_avg_sq, target} stay as they were
+    if (s.fault || mi_gate_closed(o.gate)) return;             // see sac_timeout / the P2P carrier's fail-safe: {params, exp_avg, exp_avg_sq, target} stay as they were
     const float p = mi_adam_elem(s.p, g, s.m, s.v, o.w1, o.b2, o.w2, o.step_size, o.rbc2, o.eps);
     o.m[i] = s.m; o.v[i] = s.v;
     o.params[i] = p;
@@ -1056,11 +1062,12 @@ __device__ __forceinline__ void sac_thin_reduce(int blk, float (&part)[4][RED_SM
         if (live) part[grp][threadIdx.x & 63] = acc;
         __syncthreads();
         if (live && grp == 0 && off >= 0) {
-            const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+            float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
             if (dst >= 0) {
+                v = sac_xchg(opt, dst, v);
                 grads[dst] = v;
                 if (opt.params) sac_apply(opt, dst, v, st);
-            } else if (out2) out2[e - per * nets] = (float)((double)v * inv_count);
+            } else if (out2) out2[e - per * nets] = sac_xchg(opt, (is_actor ? AC_NP : 2 * SQ_NP) + (e - per * nets), (float)((double)v * inv_count));
         }
     }
 }
@@ -1088,7 +1095,7 @@ __global__ void __launch_bounds__(256) sac_grad_reduce_kernel(const float* __res
             acc += a1; acc += a2; acc += a3;
         } else for (int y = 1; y < n_split; ++y) acc += *reinterpret_cast<const f32x4*>(part0 + (size_t)y * 3 * SA_H * SA_H);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { grads[d0 + c] = acc[c]; if (opt.params) sac_apply(opt, d0 + c, acc[c], st[c]); }
+        for (int c = 0; c < 4; ++c) { const float gx = sac_xchg(opt, d0 + c, acc[c]); grads[d0 + c] = gx; if (opt.params) sac_apply(opt, d0 + c, gx, st[c]); }
     }
 }
 
@@ -1167,7 +1174,8 @@ __device__ __forceinline__ void sac_dw2_adam_role(sac_dw2_smem& sm, const int bi
         for (int q = 0; q < 2; ++q) sm.tile[2 * (4 * g + r0 + q) + a][2 * j + b] = sum[q];
     }
     __syncthreads();
-    const float2 gv = *reinterpret_cast<const float2*>(&sm.tile[threadIdx.x >> 4][2 * (threadIdx.x & 15)]);
+    float2 gv = *reinterpret_cast<const float2*>(&sm.tile[threadIdx.x >> 4][2 * (threadIdx.x & 15)]);
+    gv.x = sac_xchg(opt, d0, gv.x); gv.y = sac_xchg(opt, d0 + 1, gv.y);
     grads[d0] = gv.x; grads[d0 + 1] = gv.y;
     if (opt.params) { sac_apply(opt, d0, gv.x, st[0]); sac_apply(opt, d0 + 1, gv.y, st[1]); }
 }
@@ -1240,6 +1248,7 @@ extern "C" int mi_sac_shadow_valid(const float* params) { return shadow_valid(pa
 static sac_opt_t sac_no_opt() { sac_opt_t o; memset(&o, 0, sizeof(o)); return o; }
 static sac_opt_t sac_make_opt(float* params, float* m, float* v, float* target, int64_t step, double lr, double beta1, double beta2, double eps, float tau, int is_actor) {
     sac_opt_t o;
+    memset(&o, 0, sizeof(o));
     o.params_t = shadow_valid(params); o.target_t = target ? shadow_valid(target) : nullptr; o.is_actor = is_actor;
     if (target && o.target_t && !o.params_t) { (void)mi_sac_shadow_invalidate(target); o.target_t = nullptr; }   // the step would move the target without its shadow
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
@@ -1685,6 +1694,17 @@ static int adam_launch(float* params, const float* grads, float* exp_avg, float*
 static int polyak_launch(float* target, const float* param, int n, float tau, const uint32_t* gate, void* stream);
 static int alpha_adam_launch(const float* mean_logp, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, float* alpha,
                              float* out, const uint32_t* gate, void* stream);
+// P2P carrier with one (or two) ranks per device: the exchange rides INSIDE the gradient assembly launch (sac_opt_t.xa / world / gate; exactly one mi_comm_p2p_next per
+// assembling launch, on every rank) — the all-reduce, Adam and polyak launches of the sequence below disappear.  *fused = false: not that carrier (take the sequence).
+static int sac_opt_p2p(sac_opt_t* o, void* comm, size_t n_words, hipStream_t s, bool* fused) {
+    *fused = comm != nullptr && mi_comm_p2p_fused_ok(comm);
+    if (!*fused) return MI_OK;
+    int world = 0;
+    const int rc = mi_comm_p2p_next(comm, n_words, &o->xa, &world, s);
+    if (rc) return rc;
+    o->world = world; o->gate = mi_comm_gate(comm);
+    return MI_OK;
+}
 // FAIL-SAFE (mi_common.h): a timed-out wait of the P2P carrier withholds the optimizer steps behind the exchange (adam / polyak / alpha read the carrier's status word
 // with their state), and the next call returns MI_ESTATE at its entry.
 // ---- sharded runs, ONE C call per update (the pattern of mi_ppo_update_sharded): the *_grad launches with the share scaled by 1 / (world * batch), an in-stream RCCL
@@ -1700,6 +1720,17 @@ extern "C" int mi_sac_critic_update_sharded(float* q, float* q_target, const flo
     if (comm) {
         if (const int rc = mi_comm_poll_impl(comm)) return rc;
         if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
+    }
+    {   // P2P carrier: the critic launch + ONE assembly launch that exchanges, steps and polyak-averages (see sac_opt_t)
+        MI_CHECK_ARG(q && actor && observations && actions && rewards && terminated && idx && alpha && workspace, "NULL pointer");
+        MI_CHECK_ARG(batch > 0 && n_envs > 0 && slots >= 2, "bad sizes");
+        sac_opt_t o = sac_make_opt(q, exp_avg, exp_avg_sq, tau < 0.0f ? nullptr : q_target, step, lr, beta1, beta2, adam_eps, tau < 0.0f ? 0.0f : tau, 0);
+        bool fused = false;
+        // (the sequence number is drawn here, in front of the critic launch: the assembly launch behind it is the one launch that publishes and consumes those lines)
+        if (const int rc0 = sac_opt_p2p(&o, comm, (size_t)2 * SQ_NP + 2, (hipStream_t)stream, &fused)) return rc0;
+        if (fused)
+            return sac_critic_impl(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
+                                   1.0 / ((double)batch * world), workspace, qbuf, qbuf + 2 * SQ_NP, o, 0, 0, sac_owed_t{}, (hipStream_t)stream);
     }
     int rc = mi_sac_critic_grad(q, q_target, actor, observations, actions, rewards, terminated, idx, batch, n_envs, slots, eps, seed, update_index, alpha, gamma,
                                 1.0 / ((double)batch * world), workspace, qbuf, qbuf + 2 * SQ_NP, stream);
@@ -1722,6 +1753,16 @@ extern "C" int mi_sac_actor_update_sharded(float* actor, const float* q, const f
         if (const int rc = mi_comm_poll_impl(comm)) return rc;
         if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
     }
+    {
+        MI_CHECK_ARG(actor && q && observations && idx && alpha && workspace, "NULL pointer");
+        MI_CHECK_ARG(batch > 0, "bad sizes");
+        sac_opt_t o = sac_make_opt(actor, exp_avg, exp_avg_sq, nullptr, step, lr, beta1, beta2, adam_eps, 0.0f, 1);
+        bool fused = false;
+        if (const int rc0 = sac_opt_p2p(&o, comm, (size_t)AC_NP + 2, (hipStream_t)stream, &fused)) return rc0;
+        if (fused)
+            return sac_actor_impl(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / ((double)batch * world), workspace, abuf, abuf + AC_NP, o, sac_owed_t{},
+                                  (hipStream_t)stream);
+    }
     int rc = mi_sac_actor_grad(actor, q, observations, idx, batch, eps, seed, update_index, alpha, 1.0 / ((double)batch * world), workspace, abuf, abuf + AC_NP, stream);
     if (rc) return rc;
     if (comm) {
@@ -1731,31 +1772,14 @@ extern "C" int mi_sac_actor_update_sharded(float* actor, const float* q, const f
     }
     return adam_launch(actor, abuf, exp_avg, exp_avg_sq, AC_NP, step, lr, beta1, beta2, adam_eps, mi_comm_gate(comm), stream);
 }
-extern "C" int mi_sac_alpha_step_sharded(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
-                                         uint64_t update_index, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr,
-                                         float* alpha, float* out, float* mean_logp /* dev f32 [1] scratch */, void* workspace, void* comm, void* stream) {
-    MI_CHECK_ARG(mean_logp != nullptr, "mean_logp scratch is NULL");
-    int world = 1;
-    if (comm) {
-        if (const int rc = mi_comm_poll_impl(comm)) return rc;
-        if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
-    }
-    int rc = mi_sac_mean_logp(actor, observations, idx, batch, eps, seed, update_index, 1.0 / ((double)batch * world), mean_logp, workspace, stream);
-    if (rc) return rc;
-    if (comm) {
-        mi_prof_scope prof(MI_PROF_COMM_STATS, (hipStream_t)stream);
-        rc = mi_comm_allreduce_impl(comm, mean_logp, 1, 0, (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    return alpha_adam_launch(mean_logp, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, mi_comm_gate(comm), stream);
-}
-
 // ================================================ alpha, Adam, polyak ============================================================
 // one wave.  mean_in: nullable device scalar holding the (already all-reduced) mean log-prob; NULL = sum this rank's slabs (lane-strided, then the fixed DPP tree)
 __global__ void __launch_bounds__(64)
 sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const float* __restrict__ mean_in, float* __restrict__ mean_out, sac_alpha_t al,
-                 const uint32_t* __restrict__ gate) {
-    if (mi_gate_closed(gate)) return;   // mean_in came out of a timed-out exchange: the alpha step is withheld
+                 const uint32_t* __restrict__ gate, const p2p_args_t xa, int world) {
+    // world > 0 (sharded run on the P2P carrier): the mean summed from this rank's slabs is this rank's SHARE (inv_count = 1 / (world batch)); thread 0 exchanges it as line
+    // 0 (rank-ordered sum), leaves the all-reduced mean in mean_out (what the sequence's all-reduce leaves there) and steps log_alpha: slab sum, all-reduce and step in ONE launch
+    if (world == 0 && mi_gate_closed(gate)) return;   // mean_in came out of a timed-out exchange: the alpha step is withheld
     float mean_lp;
     if (mean_in) mean_lp = mean_in[0];
     else {
@@ -1765,6 +1789,12 @@ sac_alpha_kernel(const float* __restrict__ ws, int batch, int n_slabs, const flo
         mean_lp = wave_sum(s) * al.inv_count;
     }
     if (threadIdx.x != 0) return;
+    if (world > 0) {
+        mean_lp = p2p_exchange_rt(xa, world, 0, mean_lp);
+        if (mean_out) mean_out[0] = mean_lp;
+        if (!mi_gate_closed(gate)) sac_alpha_apply(al, mean_lp);
+        return;
+    }
     if (mean_out) { mean_out[0] = mean_lp; return; }
     sac_alpha_apply(al, mean_lp);
 }
@@ -1827,7 +1857,7 @@ extern "C" int mi_sac_mean_logp(const float* actor, const float* observations, c
     const int rc = sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace, sac_alpha_t{}, (hipStream_t)stream);
     if (rc) return rc;
     sac_alpha_t al{}; al.inv_count = (float)inv_count;
-    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, mean_logp, al, nullptr);
+    sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, mean_logp, al, nullptr, p2p_args_t{}, 0);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -1836,7 +1866,7 @@ static int alpha_adam_launch(const float* mean_logp, float target_entropy, float
                              float* out, const uint32_t* gate, void* stream) {
     MI_CHECK_ARG(mean_logp && log_alpha && exp_avg && exp_avg_sq && alpha && step >= 1, "bad arguments");
     sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>(nullptr, 0, 0, mean_logp, nullptr,
-                                                       sac_make_alpha(target_entropy, 0.0f, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr), gate);
+                                                       sac_make_alpha(target_entropy, 0.0f, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr), gate, p2p_args_t{}, 0);
     MI_LAUNCH_CHECK();
     return MI_OK;
 }
@@ -1844,6 +1874,40 @@ extern "C" int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, f
                                  double lr, float* alpha, float* out, void* stream) {
     return alpha_adam_launch(mean_logp, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr, stream);
 }
+
+// (the third sharded one-call route; it sits here, behind the log-prob launch and the alpha kernel it uses)
+extern "C" int mi_sac_alpha_step_sharded(const float* actor, const float* observations, const int64_t* idx, int batch, const float* eps, uint64_t seed,
+                                         uint64_t update_index, float target_entropy, float* log_alpha, float* exp_avg, float* exp_avg_sq, int64_t step, double lr,
+                                         float* alpha, float* out, float* mean_logp /* dev f32 [1] scratch */, void* workspace, void* comm, void* stream) {
+    MI_CHECK_ARG(mean_logp != nullptr, "mean_logp scratch is NULL");
+    int world = 1;
+    if (comm) {
+        if (const int rc = mi_comm_poll_impl(comm)) return rc;
+        if (const int rc = mi_comm_info(comm, &world, nullptr, nullptr, nullptr)) return rc;
+    }
+    if (comm && mi_comm_p2p_fused_ok(comm)) {   // P2P carrier: the log-prob launch + ONE one-wave launch that sums the slabs, exchanges the mean and steps log_alpha
+        MI_CHECK_ARG(actor && observations && idx && log_alpha && exp_avg && exp_avg_sq && alpha && workspace && batch > 0 && step >= 1, "bad arguments");
+        int rc0 = sac_launch_logp(actor, observations, idx, batch, eps, seed, update_index, workspace, sac_alpha_t{}, (hipStream_t)stream);
+        if (rc0) return rc0;
+        p2p_args_t xa;
+        int pw = 0;
+        rc0 = mi_comm_p2p_next(comm, 1, &xa, &pw, (hipStream_t)stream);
+        if (rc0) return rc0;
+        const sac_alpha_t al = sac_make_alpha(target_entropy, (float)(1.0 / ((double)batch * world)), log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, nullptr);
+        sac_alpha_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)workspace, batch, ws_kp(batch) / SR, nullptr, mean_logp, al, mi_comm_gate(comm), xa, pw);
+        MI_LAUNCH_CHECK();
+        return MI_OK;
+    }
+    int rc = mi_sac_mean_logp(actor, observations, idx, batch, eps, seed, update_index, 1.0 / ((double)batch * world), mean_logp, workspace, stream);
+    if (rc) return rc;
+    if (comm) {
+        mi_prof_scope prof(MI_PROF_COMM_STATS, (hipStream_t)stream);
+        rc = mi_comm_allreduce_impl(comm, mean_logp, 1, 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return alpha_adam_launch(mean_logp, target_entropy, log_alpha, exp_avg, exp_avg_sq, step, lr, alpha, out, mi_comm_gate(comm), stream);
+}
+
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
                                                     float w1, float b2, float w2, float step_size, float rbc2, float eps, const uint32_t* __restrict__ gate) {
