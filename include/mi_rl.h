@@ -573,7 +573,11 @@ int mi_sac_alpha_adam(const float* mean_logp, float target_entropy, float* log_a
 /* the three of them as ONE call each with the all-reduce in-stream on libmirl's RCCL communicator (the pattern of mi_ppo_update_sharded; sac.py:165-210 with the exchange
  * between backward and optimizer.step()): qbuf = dev f32 [2 MI_SAC_Q_NPARAMS + 2] {grads, qf1_loss, qf2_loss}; abuf = dev f32 [MI_SAC_ACTOR_NPARAMS + 2] {grads, actor_loss,
  * mean log-prob}; mean_logp = dev f32 [1] scratch.  tau < 0 skips the polyak step.  The same launches as the *_grad + caller all-reduce + mi_adam (+ mi_polyak) /
- * mi_sac_mean_logp + all-reduce + mi_sac_alpha_adam sequences: bit-identical.  comm NULL or world 1: no collective. */
+ * mi_sac_mean_logp + all-reduce + mi_sac_alpha_adam sequences: bit-identical.  comm NULL or world 1: no collective.
+ * On the P2P carrier (round 6) the exchange rides INSIDE the launch that assembles the gradient: the thread that holds a final gradient element (or loss scalar)
+ * exchanges it — line = its index in qbuf / abuf, rank-ordered sum — and applies Adam (+ polyak) behind it; the alpha step's one-wave launch sums this rank's slabs,
+ * exchanges the mean and steps log_alpha.  Same arithmetic, same bits; the all-reduce, Adam, polyak and alpha launches of the sequences disappear (14 launches -> 7 per
+ * iteration).  A wait that runs out withholds every step behind it (mi_comm_poll). */
 int mi_sac_critic_update_sharded(float* q, float* q_target, const float* actor, const float* observations, const float* actions, const float* rewards,
                                  const uint8_t* terminated, const int64_t* idx, int batch, int n_envs, int64_t slots, const float* eps, uint64_t seed, uint64_t update_index,
                                  const float* alpha, float gamma, void* workspace, float* qbuf, float* exp_avg, float* exp_avg_sq, int64_t step, double lr, double beta1,
