@@ -175,6 +175,42 @@ if rank == 0:
 dist.barrier()
 L.mi_comm_destroy(h)
 
+# SAC: the three sharded routes carry their exchange inside the gradient assembly launches (round 6): a peer that never arrives leaves critics, targets, actor, log_alpha
+# and every moment as they were, and the next call is refused
+h = lonely_comm(1 << 20)
+if rank == 0:
+    env = D.make("Pendulum-v1", num_envs=16, device=dev, seed=8)
+    torch.manual_seed(8)
+    a = D.Actor(env)
+    qs = [D.SoftQNetwork(env) for _ in range(4)]
+    qs[2].load_state_dict(qs[0].state_dict()); qs[3].load_state_dict(qs[1].state_dict())
+    sac = D.SACEngine(env, a, *qs, slots=64, batch_size=64, learning_starts=5, max_episodes_logged=0)
+    assert sac.world_size == 2
+    sac.reset()
+    for _ in range(20):
+        sac.act()
+    DD.use_comm(h)
+    try:
+        sac.sample()
+        tensors = lambda: (sac.q_flat, sac.qt_flat, sac.actor.flat, sac.log_alpha, sac.q_optimizer.exp_avg, sac.q_optimizer.exp_avg_sq, sac.actor_optimizer.exp_avg)  # noqa: E731
+        before = [t.clone() for t in tensors()]
+        sac.update_critic(polyak=True)       # its exchange times out (300 ms): Adam and polyak are withheld ...
+        torch.cuda.synchronize()
+        for x, y in zip(before, tensors()):
+            assert torch.equal(x, y), "SAC: a timed-out exchange cost the optimizer state"
+        for call in (sac.update_actor, sac.update_alpha, lambda: sac.update_critic(polyak=True)):   # ... and every later sharded call is refused at its entry
+            try:
+                call()
+                raise AssertionError("SAC: a call behind a timed-out exchange did not raise")
+            except N.MiError as ex:
+                assert "never arrived: 1" in str(ex), str(ex)
+        for x, y in zip(before, tensors()):
+            assert torch.equal(x, y)
+    finally:
+        DD.use_comm(None)
+dist.barrier()
+L.mi_comm_destroy(h)
+
 dist.barrier()
 DD.destroy_native_comms()
 dist.destroy_process_group()
