@@ -913,22 +913,12 @@ def main():
         if world == 1:
             E._FORCE_NATIVE_SHARDED = True
 
-    prewarm_updates = 0 if args.no_prewarm else PREWARM_UPDATES
-    if prewarm_updates:
-        p_env = D.make("CartPole-v1", num_envs=ENVS_PER_GPU, device=dev, seed=12345, env_id_base=rank * ENVS_PER_GPU)
-        torch.manual_seed(12345)
-        p_agent = D.ActorCritic(p_env)
-        p_eng = D.PPOEngine(p_env, p_agent, D.ClipAdam(p_agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5), num_steps=T, n_minibatch=4, update_epochs=4)
-        p_eng.reset()
-        for _ in range(prewarm_updates):
-            p_eng.update()
-        torch.cuda.synchronize()
-        if headline_carrier == "auto":
-            tune_carrier(p_eng, dev)    # recorded in dist.carrier_report -> collectives.carrier_choice
-            torch.cuda.synchronize()
-            headline_carrier = DD.resolved_carrier(None)
-        del p_eng, p_agent, p_env
-
+    # The engine that is MEASURED is built first and the throwaway engine of the clock ramp runs behind it, so that the W warm-up updates follow the ramp's last launch
+    # in the same stream without the GPU going idle in between (until round 6 the measured engine's construction — allocations, fills, a host-side orthogonal init — sat
+    # BETWEEN the ramp and the warm-up).  Neither engine touches the other's state.  Why: some runs on this pool's boxes show a first window 1 - 25 % above the two behind
+    # it (1.3702 / 1.3174 / 1.3162, 1.6657 / 1.3303 / 1.3117, the round-5 tree on the same boxes likewise).  A same-box comparison of the two orders (12 runs each,
+    # profiles/r06i_first_window_ab.txt) did NOT separate them — first / later windows <= 1.004 in 23 of 24 runs, one 1.013 in the new order: the outliers are the box's,
+    # sporadic, and `timed_windows` shows them for what they are — so this order stays for the smaller idle gap, not as a cure.
     num_updates = args.warmup + args.steps
     env = D.make("CartPole-v1", num_envs=ENVS_PER_GPU, device=dev, seed=1, env_id_base=rank * ENVS_PER_GPU)
     torch.manual_seed(1)
@@ -939,6 +929,24 @@ def main():
     eng.reset()
     stats_host = torch.zeros(4, dtype=torch.int32).pin_memory()
 
+    prewarm_updates = 0 if args.no_prewarm else PREWARM_UPDATES
+    p_keep = None
+    if prewarm_updates:
+        p_env = D.make("CartPole-v1", num_envs=ENVS_PER_GPU, device=dev, seed=12345, env_id_base=rank * ENVS_PER_GPU)
+        torch.manual_seed(12345)
+        p_agent = D.ActorCritic(p_env)
+        p_eng = D.PPOEngine(p_env, p_agent, D.ClipAdam(p_agent, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5), num_steps=T, n_minibatch=4, update_epochs=4)
+        p_eng.reset()
+        for _ in range(prewarm_updates):
+            p_eng.update()
+        if headline_carrier == "auto":
+            torch.cuda.synchronize()
+            tune_carrier(p_eng, dev)    # recorded in dist.carrier_report -> collectives.carrier_choice
+            headline_carrier = DD.resolved_carrier(None)
+            for _ in range(prewarm_updates // 2):   # (the tuning ends in synchronisations: ramp again)
+                p_eng.update()
+        p_keep = (p_eng, p_agent, p_env)   # freed behind the measurement (a hipFree in front of it would synchronise the device)
+
     def one_update(u):
         opt.param_groups[0]["lr"] = (1.0 - u / num_updates) * 2.5e-4  # ppo.py:107-108
         eng.update()
@@ -946,6 +954,9 @@ def main():
 
     def timed_updates(u0, n, prof_every=PROF_EVERY, tags=("grad",)):
         """n updates bracketed by barrier + synchronize on both sides; -> (seconds, MAX over ranks; the in-library HIP-event profile of `tags` in every prof_every-th update)"""
+        # (the profiler's events are created while the GPU is still busy with what came before: nothing but the barrier stands between the synchronisation and the window)
+        N.prof_begin((n // prof_every + 1) * 20 * len(tags) + 16, tags=list(tags))
+        N.prof_pause(True)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -954,7 +965,6 @@ def main():
         # launch of a 70 us kernel costs the loop it measures 0.098 ms per update = 7.5 % (tools/prof_overhead.py: 1.411 ms with all 320 launches of 20 updates
         # bracketed, 1.312 ms with none, the same 70.2 - 70.5 us per launch either way) - until round 4 the headline carried that.
         # (the bracketed updates sit inside the window — the 6th, 16th, ... — not right behind the synchronisation that opens it)
-        N.prof_begin((n // prof_every + 1) * 20 * len(tags) + 16, tags=list(tags))
         phase = min(prof_every // 2, n - 1)
         t0 = time.perf_counter()
         for k, u in enumerate(range(u0, u0 + n)):
@@ -981,6 +991,8 @@ def main():
     if not args.single_window:
         for _ in range(2):
             windows.append(timed_updates(num_updates, args.steps)[0])
+
+    p_keep = None   # the clock ramp's throwaway engine
 
     # a sharded headline is only worth its number if the exchange really happened: right behind the timed windows, no wait of the carrier may have run out on any rank
     # and the replicas must still be bitwise identical (one MAX all-reduce of a checksum; host-synchronising, outside the timed region)
@@ -1116,8 +1128,10 @@ def main():
             "params_finite": finite,
             "build": {"source_id": N.lib().mi_source_id().decode(), "abi": N.ABI_VERSION,
                       "what": "sha256 (12 hex digits) of the kernel sources libmirl.so was built from (csrc/Makefile); the static figures quoted from profiles/ carry theirs"},
-            "prewarm": {"updates": prewarm_updates, "what": "throwaway engine of the same shape, run and discarded BEFORE the engine that is measured is built (clock ramp of a fresh "
-                                                             "process: ~80 ms); the W warm-up and K timed updates are the measured engine's first W + K updates; --no-prewarm turns it off"},
+            "prewarm": {"updates": prewarm_updates, "what": "throwaway engine of the same shape (its own envs, parameters and storage), run right in front of the W warm-up updates "
+                                                             "of the engine that is measured (clock ramp of a fresh process: ~80 ms; the measured engine is built first so that the GPU does "
+                                                             "not idle between the ramp and the warm-up); the W warm-up and K timed updates are the measured engine's first W + K updates; "
+                                                             "--no-prewarm turns it off"},
         }
         wms = sorted(1e3 * w / args.steps for w in windows)
         out["timed_windows"] = {"count": len(wms), "steps_each": args.steps, "ms_per_step": [round(1e3 * w / args.steps, 4) for w in windows],
