@@ -76,6 +76,25 @@ for rep in range(2):
 torch.cuda.synchronize()
 dist.barrier()
 
+# ---- the form of PPO's gradient exchange is ONE decision per communicator: ranks that disagree on MIRL_P2P_FUSED get no communicator at all (the in-launch
+#      form publishes slab order, the stand-alone one parameter order, under the same sequence number: a mix would sum permuted elements with every wait satisfied) ----
+os.environ["MIRL_P2P_FUSED"] = str(rank)
+h2, ok2, err2 = DD._create_p2p(None)
+assert ok2 == 0 and "MIRL_P2P_FUSED differs across the ranks" in err2, (ok2, err2)
+dist.barrier()
+L.mi_comm_destroy(h2)
+os.environ["MIRL_P2P_FUSED"] = "0"          # the same on both ranks: created, and the stand-alone launch is fixed for it
+h2, ok2, err2 = DD._create_p2p(None)
+assert ok2 == 1, err2
+y = torch.full((9159,), float(rank + 1), device=dev)
+N.check(L.mi_comm_allreduce_sum(h2, y.data_ptr(), y.numel(), 0, s), "mi_comm_allreduce_sum")
+torch.cuda.synchronize()
+assert bool((y == 3.0).all()) and L.mi_comm_check(h2) == 0
+dist.barrier()
+L.mi_comm_destroy(h2)
+del os.environ["MIRL_P2P_FUSED"]
+dist.barrier()
+
 # a message larger than the slots is refused up front
 big = torch.zeros((1 << 20) // 4 + 64, dtype=torch.float32, device=dev)
 assert L.mi_comm_allreduce_sum(comm, big.data_ptr(), big.numel(), 0, s) == -1 and b"does not fit" in L.mi_last_error()
