@@ -29,3 +29,38 @@ def test_parent_makes_no_gpu_call_before_launching():
     head = src[:src.index("def self_launch")]
     top_level_imports = [l for l in head.splitlines() if l.startswith(("import ", "from "))]
     assert not any("torch" in l or "deep_rl_amd" in l for l in top_level_imports), top_level_imports
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_chain_floors_follow_their_definition():
+    """The floors the latency-bound configs are measured against: matrix cycles on the longest wave's dependent chain at 2.07 GHz + kernel boundaries x
+    1.3 us + dependent memory round trips x 0.45 us — the numbers DESIGN.md sections 8 / 9 derive, recomputed here from the pass counts."""
+    b = _bench()
+    f = b.dqn_chain_floor(128)
+    assert f["chain_floor_terms"]["chain_cycles"] == (10 * 72 + 96 + 42 + 24) * 32
+    assert abs(f["chain_floor_us"] - ((720 + 162) * 32 / 2070.0 + 3 * 1.3 + 4 * 0.45)) < 0.01 and 19.0 < f["chain_floor_us"] < 19.7
+    s = b.sac_chain_floor(256)
+    assert s["chain_floor_terms"]["chain_cycles"] == (7 * 256 + 64) * 32 and abs(s["chain_floor_us"] - (s["chain_floor_terms"]["chain_cycles"] / 2070.0 + 4 * 1.3 + 6 * 0.45)) < 0.01
+    p = b.per_chain_floor(128)
+    assert p["chain_floor_us"] > f["chain_floor_us"] + 1.3          # the sampler launch: one more boundary + its own dependent chains
+    out = b.with_floor({"ms_per_step": 0.0372}, f)
+    assert abs(out["frac_of_chain_floor"] - f["chain_floor_us"] / 37.2) < 1e-3 and 0 < out["frac_of_chain_floor"] < 1
+
+
+def test_collectives_label_names_the_carrier_that_ran_and_why_not_rccl():
+    """config.collectives at N > 1: RCCL when RCCL carried the headline; otherwise the carrier that ran, "NOT the RCCL configuration", and the reason."""
+    b = _bench()
+    assert b.collectives_label(1, False, False, {}, None) == "none (single process)"
+    ok = {"rccl": (object(), {"ok": True}), "p2p": (object(), {"ok": True})}
+    lab = b.collectives_label(8, False, True, ok, "policy")
+    assert lab.startswith("RCCL direct") and "value_p2p" in lab
+    no = {"rccl": (None, {"ok": False, "why": "process group is gloo (RCCL needs nccl: one device per rank)"}), "p2p": (object(), {"ok": True})}
+    lab = b.collectives_label(2, True, True, no, "policy")
+    assert lab.startswith("P2P over hipIpc inboxes") and "NOT the RCCL configuration" in lab and "process group is gloo" in lab
+    lab = b.collectives_label(2, False, False, {"rccl": (None, {"ok": False, "why": "x"}), "p2p": (None, {"ok": False, "why": "y"})}, "policy")
+    assert lab.startswith("torch.distributed") and "NOT the RCCL configuration" in lab
