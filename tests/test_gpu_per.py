@@ -285,13 +285,14 @@ def test_sampler_random_shapes_bit_exact(dev, R):
             assert (prio[got] > 0).all()
 
 
-@pytest.mark.parametrize("n_envs,slots,batch", [(64, 150, 128), (4096, 32, 128), (512, 64, 1000)])
+@pytest.mark.parametrize("n_envs,slots,batch", [(64, 150, 128), (4096, 32, 128), (512, 64, 1000), (512, 64, 2500)])
 def test_one_call_pieces_are_bitwise_the_launch_sequence(dev, n_envs, slots, batch):
     """Round 6: one PER iteration = mi_per_act_steps (the acting launch also marks the new rows and rebuilds their sums, and carries the sums the last
     update left owed) + mi_per_td_update (sampler, weighted TD launch, slab sum + Adam with the priority scatter + max_priority on its last workgroup) — four launches —
     against the round-5 sequence of six (act, mi_per_mark_sums, mi_per_sample_current, TD, slab sum + Adam, mi_per_update_priorities_sums; MIRL_PER_ONE_CALL=0).  Over
     chained iterations on a ring that fills and WRAPS (so scattered entries fall into groups the next acting call re-marks: the one-writer rule of per_owed_sums_role),
-    with two updates behind one acting call now and then (the settle path) and target syncs: drawn indices, weights, |td|, priorities, max_priority, every level-0 /
+    with two updates behind one acting call now and then (the settle path) and target syncs (batch 2500: beyond the riding workgroups' row lists — the acting call settles
+    the owed sums in a launch of their own first): drawn indices, weights, |td|, priorities, max_priority, every level-0 /
     level-1 sum, parameters, both moments, gradient and loss bit for bit (per.py:92-153).  batch 1000: the many-slab sum launch carries the scatter."""
     import deep_rl_amd.dqn_engine as E
 
