@@ -501,15 +501,37 @@ def collectives_label(world, is_p2p, native, carriers, policy):
     return "torch.distributed (host-sequenced, 17 all-reduces per update) — NOT the RCCL configuration; " + tail
 
 
+def rendezvous_port():
+    """A free TCP port on 127.0.0.1 OUTSIDE the kernel's ephemeral range (probed by a bind): a number drawn with bind(0) comes from the range every outgoing connection
+    takes its source port from, and can be gone again by the time the job's store listens on it (EADDRINUSE: seen once in the GPU suite, round 6)."""
+    import random
+    import socket
+
+    try:
+        low = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except (OSError, ValueError, IndexError):
+        low = 32768
+    lo = max(10000, low - 12000)
+    for _ in range(200):
+        port = random.randrange(lo, low) if low > lo else random.randrange(10000, 30000)
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` with N > 1: start the N ranks as a child process and relay rank 0's line.  The parent makes no GPU call
     and never replaces itself (a process that has initialised HIP must not exec; this one has not even imported torch)."""
     import socket
     import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = rendezvous_port()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the pool's driver only supports dmabuf IPC (RCCL / CUDA-tensor sharing)
     env.setdefault("OMP_NUM_THREADS", "1")              # what torch.distributed.run would set itself (with a warning)
@@ -800,10 +822,7 @@ def sharded_route_leg(eng, one_update, timed_updates, u0, steps, dev, base_ms, b
         out["p2p_synthetic"] = p2p
         made_pg = False
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+            torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % rendezvous_port(), rank=0, world_size=1, device_id=dev)
             made_pg = True
         try:
             comm = DD.native_comm(eng.pg)

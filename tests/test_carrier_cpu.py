@@ -10,6 +10,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port, run_with_port  # noqa: E402
 
 
 def test_carrier_selection_and_rccl_env(monkeypatch):
@@ -85,9 +87,7 @@ def test_auto_carrier_on_cpu_gloo_falls_back_collectively(tmp_path):
 
     w = tmp_path / "w.py"
     w.write_text(_AUTO_WORKER)
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, MIRL_ROOT=ROOT, MIRL_COMM="auto", RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")

@@ -14,6 +14,8 @@ import torch
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port, run_with_port  # noqa: E402
 T = 32
 
 
@@ -59,9 +61,7 @@ def test_two_ranks_equal_one_rank_with_all_envs():
     sys.path.insert(0, ROOT)
     from oracle import cpu_ref as R
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
@@ -144,9 +144,7 @@ def test_offpolicy_gradient_shares_sum_to_the_union_batch():
     sys.path.insert(0, ROOT)
     from oracle import cpu_ref as R
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_offpolicy, args=(r, 2, port, q)) for r in range(2)]
@@ -199,9 +197,7 @@ def _worker_guard(rank, world, port, q):
 def test_replica_guard_catches_one_flipped_mantissa_bit_within_k_updates():
     """MIRL_CHECK_REPLICAS=K (deep_rl_amd.dist.check_replicas, called by every sharded engine every K-th update): the replicas' {parameters, Adam moments} must be
     bitwise equal; one flipped mantissa bit on rank 1 after update 4 raises MiError on BOTH ranks at the next check (update 6 <= 4 + K)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_guard, args=(r, 2, port, q)) for r in range(2)]

@@ -20,17 +20,16 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port, run_with_port  # noqa: E402
 
 
 def _run(backend, nl):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, PYTHONPATH=ROOT, MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL=str(nl), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
         # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP)
-        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                              os.path.join(ROOT, "tests", "_sharded_update_worker.py")], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        out = run_with_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                           os.path.join(ROOT, "tests", "_sharded_update_worker.py")], env), capture_output=True, text=True, timeout=300, cwd=ROOT)
         assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
         assert "SHARDED_WORKER_OK backend=%s" % backend in out.stdout, out.stdout[-2000:]
         load = lambda n: dict(np.load(os.path.join(tmp, n)))  # noqa: E731
@@ -129,13 +128,10 @@ OFF_NL, OFF_STEPS, OFF_B, OFF_ROUNDS, OFF_SEED = 8, 40, 64, 3, 7   # == tests/_o
 
 
 def _run_off(backend):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, PYTHONPATH=ROOT, MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                              os.path.join(ROOT, "tests", "_offpolicy_sharded_worker.py")], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        out = run_with_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                           os.path.join(ROOT, "tests", "_offpolicy_sharded_worker.py")], env), capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
         assert "OFFPOLICY_WORKER_OK backend=%s" % backend in out.stdout, out.stdout[-2000:]
         return dict(np.load(os.path.join(tmp, "off_rank0.npz"))), dict(np.load(os.path.join(tmp, "off_rank1.npz")))

@@ -12,6 +12,8 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port, run_with_port  # noqa: E402
 T, NL = 128, 64  # envs per rank
 
 
@@ -73,9 +75,7 @@ def _worker(rank, world, port, q):
 def test_two_ranks_on_one_gpu_match_single_process():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
@@ -197,9 +197,7 @@ def test_offpolicy_engines_two_ranks_match_single_process():
     big = _mk_sac(dev, 2 * OFF_N, 0)
     bigd = _mk_dqn(dev, 2 * OFF_N, 0)
     init = {"actor": big.actor.flat.cpu().numpy().copy(), "q": big.q_flat.cpu().numpy().copy(), "dq": bigd.q.flat.cpu().numpy().copy()}
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_off, args=(r, 2, port, q, init)) for r in range(2)]

@@ -25,6 +25,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port, run_with_port  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _need_gpu():
@@ -188,13 +190,11 @@ def test_ppo_update_on_synthetic_ranks_equals_plain_update(world):
 
 
 def _launch(worker, env_extra, timeout=600, nproc=2, comm="p2p"):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", MIRL_COMM=comm, **env_extra)
-    # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP)
-    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port),
-                           os.path.join(ROOT, "tests", worker)], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    # the ranks are started as children BEFORE anything of theirs touches a GPU (never exec from a process that has initialised HIP); a run that died on EADDRINUSE is
+    # repeated on a fresh port (tests/_ports.py)
+    return run_with_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port",
+                                        str(port), os.path.join(ROOT, "tests", worker)], env), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
 
 
 def test_two_ranks_one_gpu_p2p_collective():

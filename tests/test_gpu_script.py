@@ -9,6 +9,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _ports import free_port, run_with_port  # noqa: E402
 
 
 def _run(env_over):
@@ -236,13 +238,9 @@ def test_bench_native_rccl_diagnostics_at_world_size_1():
 
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--headline-only", "--no-cpu-baseline"], env=env,
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = run_with_port(lambda port: ([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--headline-only", "--no-cpu-baseline"],
+                                      dict(os.environ, PYTHONPATH=ROOT, MIRL_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                                           HSA_ENABLE_IPC_MODE_LEGACY="0")), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1
@@ -272,15 +270,12 @@ def test_bench_started_as_ranks_by_torch_distributed_run():
 
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ, PYTHONPATH=ROOT, MIRL_BENCH_BACKEND="gloo", MIRL_BENCH_ONE_GPU="1", OMP_NUM_THREADS="1", MIRL_BENCH_CARRIER_LEGS="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MIRL_COMM", "HSA_ENABLE_IPC_MODE_LEGACY"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only"], env=env, capture_output=True, text=True,
-                         timeout=900, cwd=ROOT)
+    out = run_with_port(lambda port: ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                       os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only"], env), capture_output=True, text=True,
+                        timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -301,13 +296,9 @@ def test_bench_auto_carrier_tunes_on_real_updates_at_world_size_1():
 
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=ROOT, MIRL_FORCE_PG="1", MIRL_COMM="auto", MIRL_BENCH_CARRIER_LEGS="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
-               WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--headline-only", "--no-cpu-baseline"], env=env,
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = run_with_port(lambda port: ([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--headline-only", "--no-cpu-baseline"],
+                                      dict(os.environ, PYTHONPATH=ROOT, MIRL_FORCE_PG="1", MIRL_COMM="auto", MIRL_BENCH_CARRIER_LEGS="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                           RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][0])
     ch = d["collectives"]["carrier_choice"]
