@@ -316,3 +316,32 @@ def test_bench_self_launch_propagates_failure():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
                          timeout=300, cwd=ROOT)
     assert out.returncode != 0 and out.stdout.strip() == "", (out.returncode, out.stdout[-500:])
+
+
+def test_two_gpus_bench_headline_runs_on_rccl_with_p2p_beside_it():
+    """The first contact with a multi-GPU node: `python bench.py --gpus 2` as the driver types it, one rank per GPU over RCCL.  `value` /
+    `config.collectives` must be the RCCL configuration BASELINE.json names, the P2P carrier must stand beside it with its own windows and intact replicas, and the
+    top-level RCCL facts must come from a communicator that saw both ranks.  Skips below 2 GPUs (the one-GPU box exercises the same keys through MIRL_FORCE_PG=1)."""
+    import json
+    import torch
+
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MIRL_COMM", "MIRL_BENCH_BACKEND", "MIRL_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--headline-only"], env=env, capture_output=True,
+                         text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["collectives"]
+    ch = c["carrier_choice"]
+    assert d["n_gpus"] == 2 and ch["headline_carrier"] == "rccl" and ch["probes"]["rccl"]["ok"] is True, ch
+    assert d["config"]["collectives"].startswith("RCCL direct") and c["rccl_version"] > 0 and c["rccl_comm_count"] == 2
+    assert c["headline_exchange"]["replicas_identical"] is True
+    if ch["probes"]["p2p"]["ok"]:   # hipIpc across the two devices worked: the second carrier is measured beside the headline, never instead of it
+        assert d["value_p2p"] > 0 and d["timed_windows_p2p"]["count"] == 3 and d["replicas_identical_p2p"] is True and d["best_carrier"] in ("rccl", "p2p")
+    else:
+        assert "value_p2p" not in d and ch["probes"]["p2p"].get("why")
