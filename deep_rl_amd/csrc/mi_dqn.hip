@@ -1610,7 +1610,8 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
                   const double* __restrict__ s1, const double* __restrict__ totals, int batch, float count, float alpha, float beta, int sample,
                   int64_t* __restrict__ idx, float* __restrict__ weights) {
     __shared__ float wmax[16];
-    __shared__ double l1s[PER_MAX_L1];                      // the level-1 sums: walked by every draw
+    __shared__ double l1s[PER_MAX_L1];                      // the level-1 sums as staged
+    __shared__ double pre[PER_MAX_L1];                      // ... and their running sums: searched by every draw
     __shared__ double tot[2];
     // wave-private transposition buffer: the 64 values a draw walks at level 0 (and then its 64 priorities) are 512 (256) contiguous bytes, but a lane per draw
     // fetching them itself makes every load instruction touch 64 different lines (~64 cycles of the CU's address unit each, 64 instructions: -DPER_STAMPS showed the
@@ -1620,23 +1621,30 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
     const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
     const long long n0 = per_n0(n), n1 = per_n0(n0);
     PER_MARK(0);
-    if (a0) {   // incremental form: level 1 is kept current in memory (a0 here = the level-1 sums of p^alpha); only the totals remain (per_sums1_kernel's order)
+    // Level 1 is staged and its running sums P[j] = s1[0] + ... + s1[j] (sequential, f64: the chain the total always was — per_sums1_kernel's order) go to an array of their
+    // own (in place the loop was a load -> add -> store chain through LDS: 3.6 us instead of 2.1 for the prologue);
+    // a draw then finds its level-1 group by BINARY SEARCH over P (round 6: the contract's level-1 step, see ref_per_sample) instead of walking up to 256 dependent
+    // subtractions: 4.8 of the launch's 13 us.
+    {
         __shared__ double a1s[PER_MAX_L1];
-        for (long long m = threadIdx.x; m < n1; m += blockDim.x) { l1s[m] = s1[m]; a1s[m] = a0[m]; }
+        for (long long m = threadIdx.x; m < n1; m += blockDim.x) { l1s[m] = s1[m]; if (a0) a1s[m] = a0[m]; }
         __syncthreads();
-        if (threadIdx.x == 0 || threadIdx.x == 64) {
-            const double* src = threadIdx.x == 0 ? l1s : a1s;
+        if (threadIdx.x == 0) {
             double t = 0.0;
 #pragma unroll 16
-            for (long long m2 = 0; m2 < n1; ++m2) t += src[m2];
-            tot[threadIdx.x == 0 ? 0 : 1] = t;
+            for (long long m2 = 0; m2 < n1; ++m2) { t += l1s[m2]; pre[m2] = t; }
+            tot[0] = t;
+        } else if (threadIdx.x == 64) {   // sum of p^alpha: the incremental form keeps its level-1 sums current in memory (a0 here), the full-pass form has the total
+            double t = 0.0;
+            if (a0) {
+#pragma unroll 16
+                for (long long m2 = 0; m2 < n1; ++m2) t += a1s[m2];
+            } else t = totals[1];
+            tot[1] = t;
         }
-    } else {
-        for (long long m = threadIdx.x; m < n1; m += blockDim.x) l1s[m] = s1[m];
-        if (threadIdx.x == 0) { tot[0] = totals[0]; tot[1] = totals[1]; }
     }
     __syncthreads();
-    PER_MARK(1);   // level 1 staged, totals taken
+    PER_MARK(1);   // level 1 staged as running sums, totals taken
     const double total = tot[0];
     const float total_alpha = (float)tot[1];
     float mx = 0.0f;
@@ -1653,33 +1661,23 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
             // no short-circuit conditions: every guard of this loop nest used to be a branch or a 64-bit scalar compare held in SGPRs
             // (the kernel spilled them to VGPR lanes); now a step is compare + subtract + select on the vector unit.
             const int n_i = (int)n, n0_i = (int)n0, n1_i = (int)n1;
+            // level 1: m = the number of running sums P[j], j < n1 - 1, with x >= P[j] (P is non-decreasing: priorities are >= 0), by a fixed-depth binary search
+            // — ten dependent LDS reads at most (n1 <= 1024) — and the remainder against P[m - 1]
             int m = 0;
             bool go = true;
-            for (int gq = 0; gq < n1_i; gq += PER_CHUNK) {            // level 2 in groups of 64 register-resident values (same subtraction order)
-                double v[PER_CHUNK];
+            {
+                int lo = 0, hi = n1_i - 1;
 #pragma unroll
-                for (int j = 0; j < PER_CHUNK; ++j) v[j] = l1s[gq + j < PER_MAX_L1 ? gq + j : PER_MAX_L1 - 1];
-                const int left = n1_i - gq;                            // a step may advance only while a next level-1 entry exists
-                // (round 5, -DPER_STAMPS: a step cost 78 cycles as compare(x) -> mask -> select(x) -> next compare, one dependent chain through the vector unit, the
-                // scalar mask and back.  While a draw is alive x IS the unconditional remainder r, so the compare reads r: the only long chain left is r's 64
-                // subtractions; the mask, the count and the frozen x are short side chains.  The same subtractions of the same values in the same order.)
-                if (left >= PER_CHUNK) {                               // (uniform) a full group: 64 steps, 63 when its last value is the last of the level
-                    if (left == PER_CHUNK) v[PER_CHUNK - 1] = __builtin_inf();
-                    unsigned long long al = __ballot(go);
-#pragma unroll
-                    for (int q4 = 0; q4 < PER_CHUNK / 16; ++q4) {
-                        const double (&vq)[16] = *reinterpret_cast<const double (*)[16]>(&v[16 * q4]);
-                        per_walk16(x, m, al, vq);
-                    }
-                    go = (al >> (threadIdx.x & 63)) & 1ull;
-                } else {
-                    double rr = x;
-#pragma unroll
-                    for (int jj = 0; jj < PER_CHUNK; ++jj) { go = go & (jj + 1 < left) & (rr >= v[jj]); rr = rr - v[jj]; x = go ? rr : x; m += go ? 1 : 0; }
+                for (int it = 0; it < 10; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const bool live = lo < hi, up = live && x >= pre[mid];
+                    lo = up ? mid + 1 : lo;
+                    hi = (live && !up) ? mid : hi;
                 }
-                if (!__any(go)) break;                                 // wave-uniform exit: every draw of the wave has stopped
+                m = lo;
+                if (m > 0) x = x - pre[m - 1];
             }
-            PER_MARK(3);   // level-1 walk (up to 256 steps)
+            PER_MARK(3);   // level-1 group found
             int k = m * PER_CHUNK;
             {
                 const int cnt = k + PER_CHUNK < n0_i ? PER_CHUNK : n0_i - k;

@@ -372,8 +372,10 @@ int mi_dueling_td_update(float* params_img, const float* target_img, const float
  * priorities: dev f32 [slots, N] beside the replay ring; max_priority: dev f32 [1] (per.py:84, initial 1e-2); owner: dev i32 [slots*N],
  * all -1 between calls; workspace: mi_per_workspace_bytes(slots*N).
  * per.py:128 draws batch_inds with torch.multinomial(priorities) (O(buffer), host generator); here a keyed three-level prefix-sum descent
- * with a fixed evaluation order (64-entry chunk sums, sums of 64 of those, total; sequential, f64; u = 53-bit Philox uniform of
- * (seed, update_index, b, stream 7)) — the oracle implements the same contract bit for bit.  sample = 0 keeps the caller's idx
+ * with a fixed evaluation order (64-entry chunk sums s0, sums s1 of 64 of those, their running sums P[j] = s1[0] + ... + s1[j] with total = P[last]; all sequential, f64;
+ * u = 53-bit Philox uniform of (seed, update_index, b, stream 7), x = u * total).  Level 1: m = the number of j < n1 - 1 with x >= P[j], x -= P[m - 1] (round 6: found by
+ * binary search — until round 5 the contract walked s1 by up to n1 - 1 dependent subtractions per draw); level 0 and the priorities: walk while x >= the next value,
+ * subtracting it, inside the chosen group / chunk; entries with priority 0 at the end of the walk are skipped downwards.  The oracle implements the same contract bit for bit.  sample = 0 keeps the caller's idx
  * (parity runs) and only computes the importance weights (count * p_i^alpha / sum p^alpha)^-beta / max (per.py:131,145-146; count = the
  * reference's global_step = transitions stored).  mi_per_mark: priorities of the n_steps just written slots = max_priority (per.py:106),
  * the ring's write head = 0.  mi_per_td_grad = mi_dqn_td_grad with loss = mean(weights * td^2) and td_abs[b] = |td_b| out (per.py:139,147).
