@@ -138,12 +138,13 @@ def dqn_chain_floor(batch):
     return chain_floor("act (10 dependent steps) -> TD -> slab sum + Adam", [("act: 10 steps x (8 + 64)", 720), ("td: layer 2 + dh1 + dW2, %d group(s)" % groups, td)], 3, 4)
 
 
-# per.py adds the sampler launch in front of the TD launch: a draw walks <= 256 + 63 + 63 prefix sums (3 instructions of ~8 issue cycles each per step; on average half
-# of the level-1 walk: ~190 steps) behind a 256-step f64 total and three dependent fetches
+# per.py adds the sampler launch in front of the TD launch: behind a 256-step f64 chain (the level-1 running sums) and three dependent fetches a draw does a ten-step
+# binary search over LDS (~100 cycles per dependent read) and walks <= 63 + 63 chunk sums / priorities (3 instructions of ~8 issue cycles each per step; a wave of 64 draws
+# ends near the far end of both walks)
 def per_chain_floor(batch):
     f = dqn_chain_floor(batch)
     g = chain_floor("act -> sampler (prefix-sum descent) -> TD -> slab sum + Adam + scatter", [("act: 10 steps x (8 + 64)", 720), ("td", 162)], 4, 7,
-                    [("sampler: 256-step f64 total", 256 * 8), ("sampler: ~190 walk steps x 3 instructions", 190 * 24)])
+                    [("sampler: 256-step f64 running sums", 256 * 8), ("sampler: 10-step binary search", 10 * 100), ("sampler: ~126 walk steps x 3 instructions", 126 * 24)])
     return g if batch <= 2048 else f
 
 
