@@ -70,7 +70,8 @@ typedef struct {
 } mi_episode_t;
 
 int mi_version(void);
-/* 12 hex digits of the sha256 over the sources the library was built from (csrc/Makefile: ALLSRC, in that order) — "unknown" for a build that bypassed the Makefile.
+/* 12 hex digits of the sha256 over the CODE (comments and white space stripped: csrc/srcid.py) of the sources the library was built from (csrc/Makefile: ALLSRC, in that
+ * order) — "unknown" for a build that bypassed the Makefile.
  * Profiles record it and bench.py prints it beside the static figures it quotes from them (roofline.traffic, kernel_device_ms_per_update). */
 const char* mi_source_id(void);
 const char* mi_last_error(void); /* thread-local, valid until the next call on this thread */
