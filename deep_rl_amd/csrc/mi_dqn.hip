@@ -1610,8 +1610,8 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
                   const double* __restrict__ s1, const double* __restrict__ totals, int batch, float count, float alpha, float beta, int sample,
                   int64_t* __restrict__ idx, float* __restrict__ weights) {
     __shared__ float wmax[16];
-    __shared__ __attribute__((aligned(16))) double l1s[PER_MAX_L1];   // the level-1 sums as staged (zero-padded to a multiple of 16)
-    __shared__ __attribute__((aligned(16))) double pre[PER_MAX_L1];   // ... and their running sums: searched by every draw
+    __shared__ double l1s[PER_MAX_L1];                      // the level-1 sums as staged
+    __shared__ double pre[PER_MAX_L1];                      // ... and their running sums: searched by every draw
     __shared__ double tot[2];
     // wave-private transposition buffer: the 64 values a draw walks at level 0 (and then its 64 priorities) are 512 (256) contiguous bytes, but a lane per draw
     // fetching them itself makes every load instruction touch 64 different lines (~64 cycles of the CU's address unit each, 64 instructions: -DPER_STAMPS showed the
@@ -1626,35 +1626,22 @@ per_sample_kernel(uint64_t seed, uint64_t update, const float* __restrict__ prio
     // a draw then finds its level-1 group by BINARY SEARCH over P (round 6: the contract's level-1 step, see ref_per_sample) instead of walking up to 256 dependent
     // subtractions: 4.8 of the launch's 13 us.
     {
-        __shared__ __attribute__((aligned(16))) double a1s[PER_MAX_L1];
-        const int n1p = ((int)n1 + 15) & ~15;   // (n1 <= PER_MAX_L1 = 1024, a multiple of 16: the padding stays inside the arrays; x + 0.0 == x for the non-negative sums)
-        for (int m = threadIdx.x; m < n1p; m += blockDim.x) { l1s[m] = m < n1 ? s1[m] : 0.0; a1s[m] = (a0 && m < n1) ? a0[m] : 0.0; }
+        __shared__ double a1s[PER_MAX_L1];
+        for (long long m = threadIdx.x; m < n1; m += blockDim.x) { l1s[m] = s1[m]; if (a0) a1s[m] = a0[m]; }
         __syncthreads();
-        PER_MARK(9);   // level 1 in LDS
-        // the chains: 16 values at a time in registers, the next 16 requested from LDS before the current ones are added (as `t += l1s[m]; pre[m] = t` in a plain loop the
-        // 256 steps took 2.9 us — 25 cycles per step: LDS reads and writes share one in-order counter — against ~8 for the dependent f64 add itself)
-        if (threadIdx.x == 0 || (threadIdx.x == 64 && a0)) {
-            const bool run = threadIdx.x == 0;                     // thread 0: running sums of p into pre[]; thread 64: the sum of p^alpha
-            const double2* src = reinterpret_cast<const double2*>(run ? l1s : a1s);
-            double2 cur[8], nxt[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cur[k] = src[k];
+        if (threadIdx.x == 0) {
             double t = 0.0;
-            for (int blk = 0; blk < n1p; blk += 16) {
-                const int nb = blk + 16 < n1p ? blk + 16 : blk;    // (the last block re-reads itself: no access past the padding)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) nxt[k] = src[nb / 2 + k];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { t += cur[k].x; cur[k].x = t; t += cur[k].y; cur[k].y = t; }
-                if (run) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) reinterpret_cast<double2*>(pre)[blk / 2 + k] = cur[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
-            }
-            tot[run ? 0 : 1] = t;
-        } else if (threadIdx.x == 64) tot[1] = totals[1];          // the full-pass form has the total of p^alpha
+#pragma unroll 16
+            for (long long m2 = 0; m2 < n1; ++m2) { t += l1s[m2]; pre[m2] = t; }
+            tot[0] = t;
+        } else if (threadIdx.x == 64) {   // sum of p^alpha: the incremental form keeps its level-1 sums current in memory (a0 here), the full-pass form has the total
+            double t = 0.0;
+            if (a0) {
+#pragma unroll 16
+                for (long long m2 = 0; m2 < n1; ++m2) t += a1s[m2];
+            } else t = totals[1];
+            tot[1] = t;
+        }
     }
     __syncthreads();
     PER_MARK(1);   // level 1 staged as running sums, totals taken

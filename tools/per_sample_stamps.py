@@ -15,7 +15,7 @@ eng.reset()
 f = N.lib().mi_debug_per_sample_marks; f.argtypes = [C.c_void_p]; f.restype = C.c_int
 names = ["entry", "level 1 staged + totals", "keyed draw (Philox)", "level-1 walk (<= 256 steps)", "level-0 sums: round trip + 63 steps", "priorities: round trip + 63 steps",
          "zero-skip loop + idx store", "weights (2 pow)", "max + normalise"]
-acc, staged = [], []
+acc = []
 for it in range(400):
     eng.act(10); eng.train_step()
     if it >= 300 and it % 10 == 0:
@@ -23,10 +23,8 @@ for it in range(400):
         mk = (C.c_ulonglong * 16)()
         assert f(mk) == 0
         acc.append(np.array(mk, dtype=np.float64)[:9] / 100.0)
-        staged.append((mk[9] - mk[0]) / 100.0)
 m = np.stack(acc); rel = m - m[:, :1]
 print("per_sample_kernel, batch 128, thread 0: us since entry (mean over %d launches), step since the previous mark" % len(acc))
 prev = 0.0
 for k, nm in enumerate(names):
     v = rel[:, k].mean(); print("  %-44s %6.2f   +%.2f" % (nm, v, v - prev)); prev = v
-print("  (level 1 in LDS, before the running-sum chain: %.2f us since entry)" % (np.stack([a9 for a9 in staged]).mean()))
