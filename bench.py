@@ -679,13 +679,13 @@ def carrier_legs(eng, world, dev, one_update, timed_updates, u0, steps):
             DD.use_comm(None)
         res[which] = entry
     res["note"] = ("in_update: HIP events around each in-stream all-reduce inside the update (includes the wait for the slowest rank = the exposed cost); back_to_back: 200 "
-                   "all-reduces of the 9,159-float gradient buffer on an idle stream, wall clock / 200, this rank; the headline window runs on MIRL_COMM (bench.py's default at N > 1: auto = the faster carrier that passed its "
-                   "known-answer probe, see carrier_choice; the library's default: rccl)")
+                   "all-reduces of the 9,159-float gradient buffer on an idle stream, wall clock / 200, this rank; the headline windows run on RCCL whenever it passed its probe (carrier_choice.policy), the P2P carrier's "
+                   "own windows stand beside them (value_p2p)")
     return res
 
 
 def tune_carrier(eng, dev, n=15):
-    """MIRL_COMM=auto, second stage (runs on the THROWAWAY prewarm engine, before the measured engine exists): when both carriers passed the library's known-answer probe,
+    """MIRL_COMM=auto set by the caller, second stage (runs on the THROWAWAY prewarm engine): when both carriers passed the library's known-answer probe,
     the same window of `n` real sharded updates is timed on each (MAX over ranks) and the faster one becomes the choice — the probe compares stand-alone all-reduces,
     but on the P2P carrier PPO's sixteen gradient exchanges per update ride INSIDE the slab-sum launches.  Every step is collective; a carrier whose window leaves a
     timed-out wait or diverged replicas behind is not eligible."""
