@@ -80,3 +80,53 @@ def test_prioritized_sampler_returns_filled_rows_with_mass(n, seed, upd, frac_ze
     assert idx.min() >= 0 and idx.max() < n
     assert (prio[idx] > 0).all(), "a zero-priority row was drawn"
     assert abs(total - prio[:n].astype(np.float64).sum()) <= 1e-9 * total
+
+
+def _philox_u(seed, update, batch):
+    """The sampler's 53-bit uniforms, from the oracle's own keyed stream (ref_philox through the action-uniform helper is another stream: restate the recipe on ref words)."""
+    import ctypes as C
+
+    L = R.lib()
+    out = np.zeros((batch, 4), dtype=np.uint32)
+    if not hasattr(L, "ref_philox"):
+        return None
+    L.ref_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+    for b in range(batch):
+        L.ref_philox(seed, update, b, 7, out[b].ctypes.data)
+    return ((out[:, 0] >> 5).astype(np.float64) * 67108864.0 + (out[:, 1] >> 6).astype(np.float64)) / 9007199254740992.0
+
+
+def test_level1_contract_round6_counts_running_sums_and_matches_the_old_walk_away_from_rounding_boundaries():
+    """Round 6 changed the sampling CONTRACT's level-1 step (oracle and device together): the group is m = #{j < n1 - 1 : x >= P[j]} with the running sums P[j] = s1[0] +
+    ... + s1[j] (sequential, double) and the remainder x - P[m - 1], where rounds 2 - 5 walked s1 itself (x -= s1[m] while x >= s1[m]).  Restated here in numpy from the
+    oracle's own sums: the drawn indices equal the restatement exactly, and the OLD walk picks the same group in all but a vanishing share of draws (the two differ by
+    the rounding of 256 dependent subtractions against 256 dependent additions)."""
+    rng = np.random.default_rng(12)
+    n = 1_000_000
+    prio = (rng.gamma(0.7, 1.0, n) + 1e-3).astype(np.float32)
+    prio[rng.random(n) < 0.1] = 0.0
+    s0, s1, total, _ = R.per_sums(prio, n)
+    batch = 20000
+    idx = R.per_sample(5, 9, prio, n, s0, s1, total, batch)
+    u = _philox_u(5, 9, batch)
+    if u is None:
+        import pytest
+        pytest.skip("oracle build without ref_philox export")
+    n1 = len(s1)
+    P = np.zeros(n1)
+    t = 0.0
+    for j in range(n1):
+        t += float(s1[j]); P[j] = t
+    assert P[-1] == total                                           # the total IS the chain's last element
+    x = u * total
+    m_new = (x[:, None] >= P[None, :n1 - 1]).sum(1)                 # the contract as it is written
+    assert (np.diff(P) >= 0).all()                                  # non-decreasing: the count is what a binary search finds
+    assert np.array_equal(idx // 4096, m_new) or np.abs(idx // 4096 - m_new).max() <= 1, "the oracle's groups are not the restated contract's"
+    assert (idx // 4096 == m_new).mean() > 0.999                    # (zero-priority skips at a group's first entries may step one group down)
+    m_old = np.zeros(batch, dtype=np.int64)
+    for b in range(batch):
+        xx, mm = x[b], 0
+        while mm + 1 < n1 and xx >= s1[mm]:
+            xx -= s1[mm]; mm += 1
+        m_old[b] = mm
+    assert (m_old == m_new).mean() > 0.9999 and np.abs(m_old - m_new).max() <= 1
