@@ -19,6 +19,7 @@ import os
 # This pool's driver only supports dmabuf IPC: without this, RCCL's set-up and hipIpcGetMemHandle (the P2P carrier's inboxes, CUDA-tensor sharing) fail with
 # "invalid argument".  Set here — at import, before anything of this process can have initialised HIP (importing torch does not) — so that bench.py started directly as a
 # rank by torch.distributed.run and the drop-in scripts' documented 8-GPU command get it too, not only the launchers that remembered to export it.
+_IPC_MODE_WAS_SET = "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import ctypes as C  # noqa: E402
@@ -28,6 +29,11 @@ import torch.distributed as dist  # noqa: E402
 
 from ._native import MiError  # noqa: E402
 
+if not _IPC_MODE_WAS_SET and torch.cuda.is_initialized():   # too late for this process: the HIP runtime read its environment when it was initialised
+    import sys as _sys
+    print("deep_rl_amd.dist: HSA_ENABLE_IPC_MODE_LEGACY was not exported and HIP is already initialised in this process — import deep_rl_amd (or export "
+          "HSA_ENABLE_IPC_MODE_LEGACY=0) BEFORE the first CUDA / HIP call, or RCCL set-up and hipIpc (the P2P carrier) may fail with 'invalid argument' on this driver",
+          file=_sys.stderr)
 _FORCE_PG = os.environ.get("MIRL_FORCE_PG", "0") == "1"
 _FORCE_COLLECTIVES = os.environ.get("MIRL_FORCE_COLLECTIVES", "0") == "1"
 
