@@ -118,3 +118,17 @@ def test_every_entry_point_survives_null_and_zero_arguments(N):
             assert isinstance(r, int) and r <= 0, (name, r)
             continue
         assert isinstance(r, int) and r < 0, (name, r)
+
+
+def test_committed_profiles_describe_the_committed_kernels(N):
+    """the static figures bench.py quotes (roofline.traffic from profiles/latest_pmc.json, kernel_device_ms_per_update from
+    profiles/latest_kernel_durations.json) must come from the binary that is timed.  The library's mi_source_id() hashes the CODE of its sources (comments stripped:
+    csrc/srcid.py); both files record the id of the library they were measured on.  A kernel change without a new profiling round (tools/profile_round.sh,
+    tools/profile_headline.sh) fails here — and bench.py would print "DIFFERS from this run's library" beside the figures."""
+    import json
+
+    mine = N.lib().mi_source_id().decode()
+    assert len(mine) == 12 and mine != "unknown"
+    for name in ("latest_pmc.json", "latest_kernel_durations.json"):
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert rec.get("source_id") == mine, (name, rec.get("source_id"), mine)
