@@ -242,7 +242,7 @@ int mi_comm_destroy(void* comm);
 int mi_comm_info(void* comm, int* world_size, int* rank, int* rccl_version, int* comm_count);
 int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stream);
 /* The second carrier behind the same handle: a ONE-SHOT peer-to-peer all-reduce over hipIpc-mapped inboxes (round 5; csrc/mi_comm.hip).  Every rank owns an inbox in
- * uncached device memory, mapped into every peer: 256 header bytes (status word, barrier lines) + [2 parities][world] slots of 2 * max_bytes each — a slot holds the
+ * uncached device memory, mapped into every peer: 256 header bytes (the epoch change's barrier lines) + [2 parities][world] slots of 2 * max_bytes each — a slot holds the
  * message as 8-byte LINES {payload word, sequence number of the all-reduce}, so the footprint is 256 + 2 * world * 2 * max_bytes bytes per rank.  One all-reduce = ONE
  * launch: every 32-bit word of the local share is stored, TOGETHER with the sequence number, as one line into slot (parity, rank) of every rank's inbox; the launch then
  * polls (bounded: MIRL_P2P_TIMEOUT_MS, default 30,000) the world's lines of its own elements in its own inbox until each carries the sequence number — the payload is
@@ -250,7 +250,8 @@ int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stre
  * world size (a ring's grouping depends on the rank); at world 2 also bitwise RCCL's / gloo's a + b.  The parity flips with every all-reduce (a bit of its own); when
  * the 32-bit sequence number is used up, the ranks change the epoch in-stream (own lines cleared, a barrier through the header, numbers restart at 1).  Works with two
  * ranks on ONE device (RCCL refuses that), which is how a one-GPU box runs the one-call *_sharded routes at world_size 2 (tests/test_gpu_p2p.py).  world_size <= 8.
- * FAIL-SAFE.  A wait that runs out (a peer that stalls beyond the budget) sets the inbox's status word and its host-pinned mirror.  From then on every optimizer step
+ * FAIL-SAFE.  A wait that runs out (a peer that stalls beyond the budget) sets the rank's status word (plain device memory: only its own launches read it) and a
+ * host-pinned mirror of it.  From then on every optimizer step
  * that would consume an exchanged gradient — PPO's owed clip + Adam and its last step, DQN's / PER's clip + Adam, SAC's Adam / polyak / alpha steps on the *_sharded
  * routes — reads that word with its state and is WITHHELD (parameters, moments and targets stay as they were in front of the failed exchange), and every later
  * mi_*_sharded / mi_comm_allreduce_sum call returns MI_ESTATE at its entry (a plain host load of the mirror: no synchronisation).  The communicator is dead after
@@ -408,7 +409,7 @@ int mi_per_update_priorities_sums(float* priorities, const int64_t* idx, const f
 /* The ONE-CALL form of the PER loop (round 6; per.py:84-153): the bookkeeping rides on launches that exist anyway, 4 launches per iteration instead of 6, with indices,
  * weights, priorities, sums and parameters bit-identical to the calls above.
  *   mi_per_act_steps   = mi_dqn_act_steps (zero_next NULL) / mi_dqn_act_steps2 + mi_per_mark_sums in ONE launch: workgroups behind the acting ones write the new rows'
- *                        priorities (= max_priority, per.py:105 — it only changes at an update) and rebuild the touched groups' sums; one more workgroup rebuilds the chunk
+ *                        priorities (= max_priority, per.py:105 — it only changes at an update) and rebuild the touched groups' sums; eight more workgroups rebuild the chunk
  *                        sums the last mi_per_td_update left OWED (owed_idx = that update's idx buffer, owed_batch its batch; NULL: nothing owed).
  *   mi_per_td_update   one optimisation step (per.py:126-153) = mi_per_sample_current + the weighted TD launch + the slab sum + Adam launch of mi_dqn_td_update, whose
  *                        last workgroup scatters priorities[idx] = |td| (last duplicate wins) and updates max_priority (per.py:144-145).  The scattered entries' chunk
