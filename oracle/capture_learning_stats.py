@@ -13,7 +13,9 @@ Stored per (script, seed): every ``global_step=…, episodic_return=…`` line (
 (offsets + concatenated values) and the mean return of the last tenth of the episodes — the statistic
 ``tests/test_gpu_learning.py`` compares the drop-in scripts with.
 
-Usage:  python oracle/capture_learning_stats.py [--scripts ppo,dqn,dueling_dqn,per] [--seeds 10] [--jobs 4] [--sac-seeds 0]
+Usage:  python oracle/capture_learning_stats.py [--scripts ppo,dqn,dueling_dqn,per] [--seeds 10] [--jobs 4] [--sac-seeds 0] [--first-seed 1]
+Seeds first-seed..seeds are run; seeds the output file already holds for a script are kept (round 6 extended the sample from 10 to 50 / 30 seeds this way, and a
+re-run of seeds 1..10 reproduced the round-3 numbers exactly: the runs are deterministic).
 """
 import argparse, contextlib, io, multiprocessing as mp, os, runpy, sys, time
 import numpy as np
@@ -68,10 +70,11 @@ def main():
     ap.add_argument("--seeds", type=int, default=10)
     ap.add_argument("--sac-seeds", type=int, default=0, help="sac.py takes ~8 CPU-minutes per seed")
     ap.add_argument("--jobs", type=int, default=4)
+    ap.add_argument("--first-seed", type=int, default=1)
     ap.add_argument("--out", default=os.path.join(GOLD, "learning_stats.npz"))
     args = ap.parse_args()
-    jobs = [(s, k) for s in args.scripts.split(",") if s for k in range(1, args.seeds + 1)]
-    jobs += [("sac", k) for k in range(1, args.sac_seeds + 1)]
+    jobs = [(s, k) for s in args.scripts.split(",") if s for k in range(args.first_seed, args.seeds + 1)]
+    jobs += [("sac", k) for k in range(args.first_seed, args.sac_seeds + 1)]
     out = dict(np.load(args.out)) if os.path.exists(args.out) else {}
     with mp.get_context("spawn").Pool(args.jobs, maxtasksperchild=1) as pool:
         res = {}
@@ -79,6 +82,10 @@ def main():
             res.setdefault(script, {})[seed] = (steps, rets)
             print("%-12s seed %2d: %4d episodes, last-tenth mean %8.2f  (%.0f s)" % (script, seed, len(rets), last_tenth(rets), wall), flush=True)
     for script, by_seed in res.items():
+        if script + "_seeds" in out:                                             # keep the seeds the file already holds
+            off = out[script + "_offsets"]
+            for i, s0 in enumerate(out[script + "_seeds"].tolist()):
+                by_seed.setdefault(s0, (out[script + "_episode_global_step"][off[i]:off[i + 1]].astype(np.int64), out[script + "_episode_return"][off[i]:off[i + 1]].astype(np.float64)))
         seeds = sorted(by_seed)
         if 1 in by_seed and os.path.exists(os.path.join(GOLD, FIX[script])):  # seed 1 must be the run the trace fixture holds
             g = np.load(os.path.join(GOLD, FIX[script]))
