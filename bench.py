@@ -881,6 +881,11 @@ def main():
     # (value_p2p, ms_per_step_p2p, timed_windows_p2p, replicas_identical_p2p, best_carrier / value_best_carrier: its own three windows), never instead of it.  Only when
     # RCCL cannot carry the run (a gloo group on a one-GPU box, a failed probe) does `value` fall to the carrier that ran, and config.collectives says so with the
     # reason.  MIRL_COMM=p2p / auto set by the CALLER overrides the policy (and the line says which carrier it measured).
+    # (an N-rank run on a node with fewer than N GPUs is refused here, before any rendezvous, with the reason: ranks that time-share a device would print a scaling
+    # curve that says nothing about xGMI.  device_count() does not initialise the GPU.)
+    if os.environ.get("MIRL_BENCH_ONE_GPU", "0") != "1" and int(os.environ.get("LOCAL_RANK", "0")) >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK=%s but this node has %d GPU(s): --gpus N needs N GPUs (one rank per GPU).  To exercise the N > 1 code path on one GPU: "
+                         "MIRL_BENCH_ONE_GPU=1 MIRL_BENCH_BACKEND=gloo (a diagnostic, labelled as such in the line)" % (os.environ.get("LOCAL_RANK", "0"), torch.cuda.device_count()))
     rank, world, local_rank = init_from_env(os.environ.get("MIRL_BENCH_BACKEND", "nccl"))
     if os.environ.get("MIRL_BENCH_ONE_GPU", "0") == "1":
         local_rank = 0

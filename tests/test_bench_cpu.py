@@ -64,3 +64,18 @@ def test_collectives_label_names_the_carrier_that_ran_and_why_not_rccl():
     assert lab.startswith("P2P over hipIpc inboxes") and "NOT the RCCL configuration" in lab and "process group is gloo" in lab
     lab = b.collectives_label(2, False, False, {"rccl": (None, {"ok": False, "why": "x"}), "p2p": (None, {"ok": False, "why": "y"})}, "policy")
     assert lab.startswith("torch.distributed") and "NOT the RCCL configuration" in lab
+
+
+def test_a_rank_without_a_gpu_of_its_own_is_refused_before_any_rendezvous():
+    """bench.py started as rank 1 of 2 on a node with fewer GPUs than ranks leaves at once with the reason (no rendezvous, no hang, nothing on stdout): ranks that
+    time-share a device would print a scaling curve that says nothing about xGMI.  (One GPU shared on purpose: MIRL_BENCH_ONE_GPU=1, tests/test_gpu_script.py.)"""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a node with fewer than two GPUs")
+    env = dict(os.environ, PYTHONPATH=ROOT, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    env.pop("MIRL_BENCH_ONE_GPU", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert out.returncode != 0 and out.stdout == ""
+    assert "LOCAL_RANK=1 but this node has" in out.stderr and "MIRL_BENCH_ONE_GPU" in out.stderr
