@@ -247,7 +247,7 @@ __device__ __forceinline__ float p2p_exchange_rt(const p2p_args_t& x, int world,
 // earlier wait on it ran out.  When the 32-bit sequence number is about to wrap, the call first enqueues the epoch change on `s` (inbox cleared, barrier: mi_comm.hip).
 int mi_comm_p2p_next(void* comm, size_t n_words, p2p_args_t* a, int* world, hipStream_t s);
 bool mi_comm_is_p2p(void* comm);
-// The FAIL-SAFE of the P2P carrier.  A wait that runs out sets the inbox's status word (device) and its host-pinned mirror; from then on
+// The FAIL-SAFE of the P2P carrier.  A wait that runs out sets the rank's status word (plain device memory) and its host-pinned mirror; from then on
 //   * every optimizer step that would consume an exchanged gradient is WITHHELD: its launch reads the word behind `mi_comm_gate` with its state and leaves parameters,
 //     moments and targets as they are (the pattern of mi_sac.hip's fault word) — a stalled peer costs the update, never the parameters;
 //   * every mi_*_sharded call and mi_comm_allreduce_sum returns MI_ESTATE at its entry (mi_comm_poll_impl: a plain host load of the mirror, no synchronisation).
