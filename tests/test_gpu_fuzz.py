@@ -1,0 +1,292 @@
+"""Randomised shapes through the hot path, checked against the CPU oracle (oracle/cpu_ref.c) — what the fixed parametrisations of test_gpu_{parity,dqn,sac,per}.py
+do at hand-picked sizes, at sizes nobody picked: env counts that are no multiple of a workgroup's share, rollouts shorter and LONGER than the 128 steps the rollout
+launch keeps in LDS (the ring then wraps and the actor wave waits for the critic wave: T up to 300), minibatches / batches with ragged tails, rings that wrap at odd
+slot counts, priorities with holes.  Bars as in those files: bit-exact for env state, flags, indices and the GAE given its inputs; the fp32 tolerances written at each
+assert for everything behind a network.
+
+MIRL_FUZZ_CASES (default 4 per family: the suite stays short) and MIRL_FUZZ_SEED (default 1) choose the cases; a failing assert names the case's shape, so it can be
+replayed.  Round 6 ran 300 cases per family once (profiles/r06_fuzz.txt)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+CASES = int(os.environ.get("MIRL_FUZZ_CASES", "4"))
+SEED = int(os.environ.get("MIRL_FUZZ_SEED", "1"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import cpu_ref
+
+    cpu_ref.lib().ref_set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    return cpu_ref
+
+
+@pytest.fixture(autouse=True)
+def _fdlibm_mode(R):
+    R.set_sincos_mode("fdlibm")  # the device-matched sin/cos mode
+    yield
+    R.set_sincos_mode("libm")
+
+
+# A ReLU's DERIVATIVE jumps at 0: a pre-activation within rounding of 0 may land on either side on the device and in the oracle, and the gradient of that row then
+# differs by a whole term (seen once in ~500 random batches of > 1,000 rows; the fixed-shape tests never met one).  The gradient comparisons below therefore draw
+# their rows from those whose hidden pre-activations (computed here in float64) all stay clear of 0 — the tolerances then hold without exception.
+NEAR_ZERO = 1e-5
+
+
+def _mlp_clear_of_zero(x, W1, b1, W2, b2):
+    """rows of x whose two hidden layers' pre-activations are all farther than NEAR_ZERO from 0; also returns the second hidden layer"""
+    z1 = x.astype(np.float64) @ W1.astype(np.float64).T + b1
+    h1 = np.maximum(z1, 0.0)
+    z2 = h1 @ W2.astype(np.float64).T + b2
+    return (np.abs(z1).min(1) > NEAR_ZERO) & (np.abs(z2).min(1) > NEAR_ZERO), np.maximum(z2, 0.0)
+
+
+def _dqn_rows_clear(params, obs):
+    W1, b1 = params[:480].reshape(120, 4), params[480:600]
+    W2, b2 = params[600:10680].reshape(84, 120), params[10680:10764]
+    return _mlp_clear_of_zero(obs, W1, b1, W2, b2)[0]
+
+
+def _sacq(q_p, c, R):
+    p = q_p[c * R.SQ_NPARAMS:(c + 1) * R.SQ_NPARAMS]
+    return p[:1024].reshape(256, 4), p[1024:1280], p[1280:1280 + 65536].reshape(256, 256), p[66816:67072], p[67072:67328], p[67328]
+
+
+def _sac_q_rows_clear(q_p, x, R):
+    """rows of x = [obs, action] clear of 0 in BOTH critics; and the two Q-values"""
+    ok, qs = np.ones(len(x), bool), []
+    for c in range(2):
+        W1, b1, W2, b2, w3, b3 = _sacq(q_p, c, R)
+        o, h2 = _mlp_clear_of_zero(x, W1, b1, W2, b2)
+        ok &= o
+        qs.append(h2 @ w3.astype(np.float64) + b3)
+    return ok, qs[0], qs[1]
+
+
+def _sac_actor_rows_clear(a_p, obs):
+    W1, b1 = a_p[:768].reshape(256, 3), a_p[768:1024]
+    W2, b2 = a_p[1024:1024 + 65536].reshape(256, 256), a_p[66560:66816]
+    return _mlp_clear_of_zero(obs, W1, b1, W2, b2)[0]
+
+
+def _log(rec):
+    path = os.path.join(ROOT, "gpurun_out", "fuzz_cases.txt")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "a") as f:
+        f.write(rec + "\n")
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_ppo_rollout_gae_grad_any_shape(dev, R, case):
+    """ppo.py:110-151 + :160-189 at a random (envs, steps, minibatch): two rollouts (the second from carried-over env state, counters and RNG indices) with the device's
+    own actions replayed on the oracle, GAE bit-exact given the device's values, then one minibatch gradient of a random size on parameters that are not the
+    behaviour parameters."""
+    import test_gpu_parity as P
+
+    rng = np.random.default_rng([SEED, 1, case])
+    n = int(rng.choice([rng.integers(1, 9), rng.integers(9, 70), rng.integers(70, 260)]))
+    T = int(rng.choice([rng.integers(1, 20), rng.integers(20, 129), rng.integers(129, 301)]))
+    seed, base = int(rng.integers(1, 1000)), int(rng.integers(0, 5000))
+    mb = int(rng.integers(1, min(T * n, 6000) + 1))
+    shape = "ppo case %d: envs %d, T %d, seed %d, env_id_base %d, mb %d" % (case, n, T, seed, base, mb)
+    eng = P._engine(dev, n, seed=seed, env_id_base=base, T_=T, max_episodes_logged=T * n + 16, n_minibatch=1)   # (any T x envs: no divisibility by 4 asked of the shape)
+    params = (eng.agent.flat.cpu().numpy() + rng.normal(0, 0.15, 9155) * (np.arange(9155) >= 4480) * (np.arange(9155) < 4610)).astype(np.float32)
+    eng.agent.load_flat(params)
+    env = R.VecCartPole(n, seed=seed, env_id_base=base)
+    obs_cur = env.reset()
+    assert np.array_equal(eng.reset().cpu().numpy(), obs_cur), shape
+    st = R.Storage(T, n)
+    for upd in range(2):
+        eng.rollout_gae()
+        n_ep, eps = eng.drain_episodes()
+        acts = eng.actions[:T].cpu().numpy()
+        reps, rn = R.rollout(env, params, st, obs_cur, forced_actions=acts, max_ep=T * n + 16)
+        assert np.array_equal(eng.observations.cpu().numpy(), st.observations), (shape, upd)
+        assert np.array_equal(eng.dones.cpu().numpy(), st.dones) and np.array_equal(eng.rewards.cpu().numpy(), st.rewards), (shape, upd)
+        assert np.abs(eng.values.cpu().numpy() - st.values).max() < 3e-6, (shape, upd)
+        assert np.abs(eng.log_probs[:T].cpu().numpy() - st.log_probs[:T]).max() < 3e-6, (shape, upd)
+        assert n_ep == rn and sorted(eps) == sorted(reps), (shape, upd, n_ep, rn)
+        assert np.array_equal(eng.observation.cpu().numpy(), obs_cur), (shape, upd)
+        st.values[...] = eng.values.cpu().numpy()
+        R.gae(st)
+        assert np.array_equal(eng.advantages.cpu().numpy(), st.advantages) and np.array_equal(eng.returns.cpu().numpy(), st.returns), (shape, upd)
+    p2 = (params + rng.normal(0, 0.05, 9155)).astype(np.float32)
+    eng.agent.load_flat(p2)
+    eng.make_perm(0)
+    eng.adv_stats(mb=mb, n_mb=1)
+    eng.minibatch_grad(0, mb=mb)
+    so = P._storage_to_oracle(R, eng)
+    idx = eng.perm[:mb].cpu().numpy()
+    assert np.array_equal(np.sort(eng.perm.cpu().numpy()), np.arange(T * n)), shape
+    og, ot = R.minibatch(p2, so, idx)
+    grads = eng.grads.cpu().numpy(); terms = eng.loss_terms.cpu().numpy()
+    scale = max(np.abs(og).max(), 1e-12)
+    # (a one-row minibatch has advantage std 0 / nan in the reference's normalisation: the comparison is of finite cases only, like ppo.py can run them)
+    if np.isfinite(og).all():
+        assert np.abs(grads - og).max() <= 3e-5 * scale, (shape, np.abs(grads - og).max() / scale)
+        assert np.allclose(terms, ot, rtol=1e-4, atol=2e-5), (shape, terms, ot)
+    else:
+        assert not np.isfinite(grads).all(), shape
+    eng.minibatch_grad(0, mb=mb)
+    assert np.array_equal(eng.grads.cpu().numpy(), grads, equal_nan=True), shape
+    _log(shape + " ok")
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_dqn_act_and_td_any_shape(dev, R, case):
+    """dqn.py:86-108 + :113-133 at a random (envs, slots, steps per launch, batch): the ring after every acting launch bit-exact against the oracle with the device's
+    actions replayed, the keyed batch indices bit-exact, the TD gradient within 1e-5 of the oracle's largest element."""
+    import test_gpu_dqn as Q
+
+    rng = np.random.default_rng([SEED, 2, case])
+    n = int(rng.choice([rng.integers(1, 17), rng.integers(17, 100), rng.integers(100, 400)]))
+    S = int(rng.integers(2, 41))
+    k = int(rng.integers(1, min(S, 12) + 1))
+    calls = int(rng.integers(max(2, (S + k - 1) // k + 1), max(3, 3 * S // k + 3)))
+    ls, tt = int(rng.integers(0, 40)), int(rng.integers(50, 600))
+    batch = int(rng.choice([rng.integers(1, 130), rng.integers(130, 2049), rng.integers(2049, 4500)]))
+    seed, base = int(rng.integers(1, 1000)), int(rng.integers(0, 5000))
+    shape = "dqn case %d: envs %d, slots %d, %d calls x %d steps, learning_starts %d, total %d, batch %d, seed %d, base %d" % (case, n, S, calls, k, ls, tt, batch, seed, base)
+    eng = Q._engine(dev, n, slots=S, seed=seed, base=base, batch_size=batch, learning_starts=ls, total_timesteps=tt, max_episodes_logged=0)
+    params = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    tparams = (params + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    eng.q.load_flat(params); eng.target.load_flat(tparams)
+    env = R.VecCartPole(n, seed=seed, env_id_base=base); st = R.ReplayStorage(S, n)
+    obs_cur = env.reset(); st.observations[0] = obs_cur
+    assert np.array_equal(eng.reset().cpu().numpy(), obs_cur), shape
+    gs = 0
+    for call in range(calls):
+        eng.act(k)
+        fa = np.stack([eng.actions[(gs + s) % S].cpu().numpy() for s in range(k)])
+        R.dqn_act_steps(env, params, st, obs_cur, k, gs, learning_starts=ls, total_timesteps=tt, forced_actions=fa)
+        for name in ["observations", "actions", "rewards", "terminated"]:
+            assert np.array_equal(getattr(eng, name).cpu().numpy(), getattr(st, name)), (shape, call, name)
+        assert np.array_equal(eng.observation.cpu().numpy(), obs_cur), (shape, call)
+        gs += k
+    assert gs >= S, shape      # the ring is full: the sampler's range is the whole ring
+    eng.sample()
+    idx = eng.batch_inds.cpu().numpy()
+    assert np.array_equal(idx, R.dqn_sample(seed, 0, S * n, batch)), shape
+    clear = np.flatnonzero(_dqn_rows_clear(params, st.observations.reshape(S * n, 4)))
+    assert clear.size > 0.5 * S * n, shape
+    idx = rng.choice(clear, batch)
+    last = clear[clear // n == S - 1]
+    if last.size:
+        idx[0] = last[0]               # a successor that wraps to slot 0
+    eng.sample(idx)
+    eng.td_grad()
+    og, ol = R.dqn_td_grads(params, tparams, st, idx)
+    g = eng.grads.cpu().numpy()
+    assert np.abs(g - og).max() <= 1e-5 * np.abs(og).max(), (shape, np.abs(g - og).max() / np.abs(og).max())
+    assert abs(float(eng.loss.item()) - ol) <= 2e-5 * max(ol, 1e-6), (shape, float(eng.loss.item()), ol)
+    eng.td_grad()
+    assert np.array_equal(eng.grads.cpu().numpy(), g), shape
+    _log(shape + " ok")
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_sac_grads_any_shape(dev, R, case):
+    """sac.py:165-211 at a random (envs, slots, batch, weight scale) on a random ring: critic, actor and alpha gradients against the oracle."""
+    import test_gpu_sac as S_
+
+    rng = np.random.default_rng([SEED, 3, case])
+    n, slots = int(rng.integers(1, 40)), int(rng.integers(2, 80))
+    batch = int(rng.choice([rng.integers(1, 17), rng.integers(17, 600), rng.integers(600, 2300)]))
+    scale = float(rng.choice([1.0, 1.5, 2.0]))
+    alpha = float(rng.uniform(0.05, 1.0))
+    shape = "sac case %d: envs %d, slots %d, batch %d, scale %.1f, alpha %.3f" % (case, n, slots, batch, scale, alpha)
+    a_p, q_p = S_._rand_nets(R, rng, scale)
+    _, qt_p = S_._rand_nets(R, rng, scale)
+    st = S_._random_storage(R, rng, slots, n)
+    eng = S_._engine(dev, n, slots, actor=a_p, q=q_p, qt=qt_p, batch_size=batch)
+    S_._upload(eng, st)
+    flat_obs = st.observations.reshape(slots * n, 3)
+    x_all = np.concatenate([flat_obs, st.actions.reshape(slots * n, 1)], 1)
+    clear = np.flatnonzero(_sac_q_rows_clear(q_p, x_all, R)[0] & _sac_actor_rows_clear(a_p, flat_obs))
+    assert clear.size > 0.3 * slots * n, (shape, clear.size)
+    idx = rng.choice(clear, batch)
+    last = clear[clear // n == slots - 1]
+    if last.size:
+        idx[0] = last[0]                      # the last slot: "next" wraps around the ring
+    eps = rng.standard_normal((2, batch)).astype(np.float32)
+    for _ in range(50):                       # the actor update evaluates the critics at the actor's OWN action: redraw the noise of rows that land near a ReLU's 0 or a min(q1, q2) tie
+        a_new, _ = R.sac_actor_sample(a_p, flat_obs[idx], eps[1])
+        ok, q1, q2 = _sac_q_rows_clear(q_p, np.concatenate([flat_obs[idx], np.asarray(a_new, np.float32).reshape(-1, 1)], 1), R)
+        bad = np.flatnonzero(~ok | (np.abs(q1 - q2) < 1e-4 * np.maximum(1.0, np.abs(q1))))
+        if bad.size == 0:
+            break
+        eps[1, bad] = rng.standard_normal(bad.size).astype(np.float32)
+        idx[bad] = rng.choice(clear, bad.size)   # (and the row: a saturated tanh gives the same action whatever the noise)
+    else:
+        raise AssertionError((shape, "no clear noise found"))
+    eng.alpha.fill_(alpha)
+    a32 = float(np.float32(alpha))
+    eng.sample(idx); eng.critic_grad(torch.from_numpy(eps[0]))
+    g_ref, l_ref = R.sac_critic_grads(q_p, qt_p, a_p, st, idx, eps[0], a32)
+    g = eng.q_grads.cpu().numpy()
+    assert np.allclose(eng.q_losses.cpu().numpy(), l_ref, rtol=1e-4), (shape, eng.q_losses.cpu().numpy(), l_ref)   # (scale 2 nets: |q| of tens, a mean of their squared differences)
+    for c in range(2):
+        sl = slice(c * R.SQ_NPARAMS, (c + 1) * R.SQ_NPARAMS)
+        err = S_._rel(g[sl], g_ref[sl])
+        assert err < 3e-5, (shape, "critic", c, err)
+    eng.critic_grad(torch.from_numpy(eps[0]))
+    assert np.array_equal(eng.q_grads.cpu().numpy(), g), shape
+    eng.actor_grad(torch.from_numpy(eps[1]))
+    ga_ref, loss_ref, mlp_ref = R.sac_actor_grads(a_p, q_p, st, idx, eps[1], a32)
+    out = eng.actor_out.cpu().numpy()
+    assert abs(out[0] - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)) and abs(out[1] - mlp_ref) <= 1e-4 * max(1.0, abs(mlp_ref)), (shape, out, loss_ref, mlp_ref)   # (scale 2: saturated tanh, log(1 - a^2 + 1e-6) of rows at the clamp)
+    err = S_._rel(eng.actor_grads.cpu().numpy(), ga_ref)
+    assert err < 1e-4, (shape, "actor", err)
+    _log(shape + " ok")
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_per_sampler_any_shape(dev, R, case):
+    """per.py:126-128,145-147 at a random (envs, slots, fill, batch, alpha): chunk sums, sampled indices (bit-exact) and importance weights against the oracle on
+    priorities with holes."""
+    import test_gpu_per as E
+
+    rng = np.random.default_rng([SEED, 4, case])
+    n = int(rng.choice([rng.integers(1, 17), rng.integers(17, 300), rng.integers(300, 1500)]))
+    slots = int(rng.integers(2, max(3, min(3000, 600000 // n))))
+    stored = int(rng.integers(1, slots + 1))
+    batch = int(rng.integers(1, 2500))
+    alpha = float(rng.choice([0.0, 0.3, 0.6, 1.0]))
+    holes = float(rng.uniform(0.0, 0.6))
+    seed, upd = int(rng.integers(1, 1000)), int(rng.integers(0, 100000))
+    shape = "per case %d: envs %d, slots %d, stored %d, batch %d, alpha %.1f, holes %.2f, seed %d, update %d" % (case, n, slots, stored, batch, alpha, holes, seed, upd)
+    eng = E._engine(dev, n, slots, seed=seed, batch_size=batch, total_timesteps=10 * slots, alpha=alpha)
+    cap = slots * n
+    prio = rng.gamma(0.5, 1.0, cap).astype(np.float32)
+    prio[rng.random(cap) < holes] = 0.0
+    prio[stored * n:] = 0.0
+    if not (prio[:stored * n] > 0).any():
+        prio[0] = 1.0
+    eng.priorities.copy_(torch.from_numpy(prio.reshape(slots, n)))
+    eng.refresh_sums()
+    eng.global_step = stored
+    eng.update_index = upd
+    eng.sample()
+    m = stored * n
+    s0, s1, total, total_alpha = R.per_sums(prio, m, alpha)
+    idx = R.per_sample(seed, upd, prio, m, s0, s1, total, batch)
+    got = eng.batch_inds.cpu().numpy()
+    assert np.array_equal(got, idx) and (prio[got] > 0).all(), (shape, int((got != idx).sum()))
+    w = R.per_weights(prio, idx, alpha, np.float32(eng.beta()), total_alpha, m)
+    assert np.allclose(eng.weights.cpu().numpy(), w, rtol=3e-5) and abs(float(eng.weights.max()) - 1.0) < 1e-6, shape
+    _log(shape + " ok")
