@@ -79,9 +79,15 @@ class SACEngine:
         if _TRANSPOSED and self._single():
             for flat, mods, is_actor in ((actor.flat, (actor,), 1), (self._q_flat, (qf1, qf2), 0), (self._qt_flat, (qf1_target, qf2_target), 0)):
                 sh = torch.zeros((1 if is_actor else 2) * 65536, dtype=torch.float32, device=dev)
-                if N.lib().mi_sac_shadow_set(N.ptr(flat), is_actor, N.ptr(sh)) != 0:
-                    # the library's registry is full (engines that were not collected yet): a missing shadow only means the old access pattern, so this engine runs
-                    # without any — all three or none, the update launches pick per vector
+                rc = N.lib().mi_sac_shadow_set(N.ptr(flat), is_actor, N.ptr(sh))
+                if rc != 0:     # the registry is full: engines that were dropped but not collected yet still hold its slots (their __del__ frees them) — collect, try once more
+                    import gc
+
+                    gc.collect()
+                    rc = N.lib().mi_sac_shadow_set(N.ptr(flat), is_actor, N.ptr(sh))
+                if rc != 0:
+                    # still full (live engines): a missing shadow only means the old access pattern, so this engine runs without any — all three or none, the update
+                    # launches pick per vector
                     self.close()
                     break
                 self._shadows.append([flat, sh, [flat] + [p for m in mods for p in m.parameters()], None])

@@ -5,7 +5,7 @@ slot counts, priorities with holes.  Bars as in those files: bit-exact for env s
 assert for everything behind a network.
 
 MIRL_FUZZ_CASES (default 4 per family: the suite stays short) and MIRL_FUZZ_SEED (default 1) choose the cases; a failing assert names the case's shape, so it can be
-replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 12,000 cases, one real finding — a one-row minibatch — fixed)."""
+replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 15,000 cases, one real finding — a one-row minibatch — fixed)."""
 import os
 import sys
 
@@ -292,4 +292,66 @@ def test_per_sampler_any_shape(dev, R, case):
     assert np.array_equal(got, idx) and (prio[got] > 0).all(), (shape, int((got != idx).sum()))
     w = R.per_weights(prio, idx, alpha, np.float32(eng.beta()), total_alpha, m)
     assert np.allclose(eng.weights.cpu().numpy(), w, rtol=3e-5) and abs(float(eng.weights.max()) - 1.0) < 1e-6, shape
+    _log(shape + " ok")
+
+
+FORMS = ("ppo", "per", "dueling", "sac_owed_alpha", "sac_deferred_critic", "sac_shadows")
+
+
+@pytest.mark.parametrize("case", range(max(CASES, len(FORMS))))
+def test_one_call_forms_equal_their_launch_sequences_any_shape(dev, case, monkeypatch):
+    """The fused / owed / deferred / riding forms of the update paths against the explicit launch sequences they replace, BIT FOR BIT, at random shapes (the fixed-shape
+    tests these bodies come from: test_gpu_fullsize.py:136, test_gpu_per.py:289, test_gpu_dueling.py:155, test_gpu_sac.py:564,600, test_gpu_sac_shadow.py:62).  No oracle
+    and no tolerance here: the two forms run the same arithmetic in the same order by construction, so any shape at which they differ is a bug of one of them."""
+    rng = np.random.default_rng([SEED, 5, case])
+    form = FORMS[case % len(FORMS)]
+    if form == "ppo":
+        import deep_rl_amd.engine as E
+        import test_gpu_parity as P
+
+        n = int(rng.choice([rng.integers(1, 9), rng.integers(9, 70), rng.integers(70, 400)]))
+        T = int(rng.choice([rng.integers(1, 20), rng.integers(20, 129), rng.integers(129, 260)]))
+        T += (-T * n) % 4 if n % 4 else 0          # ppo.py:95-96: the batch splits into 4 minibatches
+        while (T * n) % 4:
+            T += 1
+        seed = int(rng.integers(1, 1000))
+        shape = "forms case %d: ppo update, envs %d, T %d, seed %d" % (case, n, T, seed)
+        outs = []
+        for forced in (False, True):
+            monkeypatch.setattr(E, "_FORCE_SHARDED_SEQUENCE", forced)
+            eng = P._engine(dev, n, seed=seed, T_=T, max_episodes_logged=0)
+            eng.reset()
+            for u in range(2):
+                eng.optimizer.param_groups[0]["lr"] = (1.0 - u / 4) * 2.5e-4
+                eng.update()
+            o = eng.optimizer
+            outs.append([t.clone() for t in (eng.agent.flat, o.exp_avg, o.exp_avg_sq, o.grad_norm, eng.loss_terms, eng.grads, eng.observations, eng.advantages)])
+            assert o.step_count == 32, shape
+        for k, (a, b) in enumerate(zip(*outs)):      # (a one-row minibatch — 4 rows in all — is NaN in both forms, as in ppo.py: NaN compares equal to NaN here)
+            assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), (shape, k)
+    elif form == "per":
+        import test_gpu_per as E_
+
+        n, slots, batch = int(rng.choice([rng.integers(1, 17), rng.integers(17, 700)])), int(rng.integers(12, 90)), int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000)]))
+        shape = "forms case %d: per pieces, envs %d, slots %d, batch %d" % (case, n, slots, batch)
+        E_.test_one_call_pieces_are_bitwise_the_launch_sequence(dev, n, slots, batch)
+    elif form == "dueling":
+        import test_gpu_dueling as U
+
+        batch = int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000)]))
+        shape = "forms case %d: dueling update, batch %d" % (case, batch)
+        U.test_one_call_update_is_bitwise_the_launch_sequence(dev, batch)
+    else:
+        import test_gpu_sac as S_
+        import test_gpu_sac_shadow as W
+
+        # (the alpha step is owed to the next launch while that launch leaves half of the device's CUs free — mi_sac_owed_alpha_fits: batches up to ~1,000 —; beyond it is a launch of its own in both forms)
+        batch = int(rng.choice([rng.integers(1, 64), rng.integers(64, 520), rng.integers(520, 1001 if form == "sac_owed_alpha" else 1400)]))
+        shape = "forms case %d: %s, batch %d" % (case, form, batch)
+        if form == "sac_owed_alpha":
+            S_.test_owed_alpha_step_is_bit_identical_to_a_launch_of_its_own(dev, batch, monkeypatch)
+        elif form == "sac_deferred_critic":
+            S_.test_deferred_critic_step_is_bit_identical_to_a_launch_of_its_own(dev, batch, monkeypatch)
+        else:
+            W.test_shadows_change_no_bit(dev, batch)
     _log(shape + " ok")
