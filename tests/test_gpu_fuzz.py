@@ -5,7 +5,7 @@ slot counts, priorities with holes.  Bars as in those files: bit-exact for env s
 assert for everything behind a network.
 
 MIRL_FUZZ_CASES (default 4 per family: the suite stays short) and MIRL_FUZZ_SEED (default 1) choose the cases; a failing assert names the case's shape, so it can be
-replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 15,000 cases, one real finding — a one-row minibatch — fixed)."""
+replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 18,000 cases, one real finding — a one-row minibatch — fixed)."""
 import os
 import sys
 
@@ -161,8 +161,11 @@ def test_dqn_act_and_td_any_shape(dev, R, case):
     ls, tt = int(rng.integers(0, 40)), int(rng.integers(50, 600))
     batch = int(rng.choice([rng.integers(1, 130), rng.integers(130, 2049), rng.integers(2049, 4500)]))
     seed, base = int(rng.integers(1, 1000)), int(rng.integers(0, 5000))
-    shape = "dqn case %d: envs %d, slots %d, %d calls x %d steps, learning_starts %d, total %d, batch %d, seed %d, base %d" % (case, n, S, calls, k, ls, tt, batch, seed, base)
-    eng = Q._engine(dev, n, slots=S, seed=seed, base=base, batch_size=batch, learning_starts=ls, total_timesteps=tt, max_episodes_logged=0)
+    shape = "dqn case %d: envs %d, slots %d, %d calls x %d steps, learning_starts %d, total %d, batch %d, seed %d, base %d, episode log %d" % (
+        case, n, S, calls, k, ls, tt, batch, seed, base, case & 1)
+    eplog = bool(case & 1)               # every second case keeps the per-episode log (another instantiation of the acting kernel)
+    max_ep = (calls * k * n) // 8 + n + 16
+    eng = Q._engine(dev, n, slots=S, seed=seed, base=base, batch_size=batch, learning_starts=ls, total_timesteps=tt, max_episodes_logged=max_ep if eplog else 0)
     params = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
     tparams = (params + rng.normal(0, 0.05, 10934)).astype(np.float32)
     eng.q.load_flat(params); eng.target.load_flat(tparams)
@@ -173,7 +176,12 @@ def test_dqn_act_and_td_any_shape(dev, R, case):
     for call in range(calls):
         eng.act(k)
         fa = np.stack([eng.actions[(gs + s) % S].cpu().numpy() for s in range(k)])
-        R.dqn_act_steps(env, params, st, obs_cur, k, gs, learning_starts=ls, total_timesteps=tt, forced_actions=fa)
+        if eplog:
+            n_ep, eps_ = eng.drain_episodes()
+            reps, rn = R.dqn_act_steps_log(env, params, st, obs_cur, k, gs, learning_starts=ls, total_timesteps=tt, forced_actions=fa, max_ep=max_ep)
+            assert n_ep == rn and sorted(eps_) == sorted(reps), (shape, call, n_ep, rn)
+        else:
+            R.dqn_act_steps(env, params, st, obs_cur, k, gs, learning_starts=ls, total_timesteps=tt, forced_actions=fa)
         for name in ["observations", "actions", "rewards", "terminated"]:
             assert np.array_equal(getattr(eng, name).cpu().numpy(), getattr(st, name)), (shape, call, name)
         assert np.array_equal(eng.observation.cpu().numpy(), obs_cur), (shape, call)
@@ -295,11 +303,11 @@ def test_per_sampler_any_shape(dev, R, case):
     _log(shape + " ok")
 
 
-FORMS = ("ppo", "per", "dueling", "sac_owed_alpha", "sac_deferred_critic", "sac_shadows")
+FORMS = ("ppo", "per", "dueling", "sac_owed_alpha", "sac_deferred_critic", "sac_shadows", "per_incremental")
 
 
 @pytest.mark.parametrize("case", range(max(CASES, len(FORMS))))
-def test_one_call_forms_equal_their_launch_sequences_any_shape(dev, case, monkeypatch):
+def test_one_call_forms_equal_their_launch_sequences_any_shape(dev, R, case, monkeypatch):
     """The fused / owed / deferred / riding forms of the update paths against the explicit launch sequences they replace, BIT FOR BIT, at random shapes (the fixed-shape
     tests these bodies come from: test_gpu_fullsize.py:136, test_gpu_per.py:289, test_gpu_dueling.py:155, test_gpu_sac.py:564,600, test_gpu_sac_shadow.py:62).  No oracle
     and no tolerance here: the two forms run the same arithmetic in the same order by construction, so any shape at which they differ is a bug of one of them."""
@@ -335,6 +343,12 @@ def test_one_call_forms_equal_their_launch_sequences_any_shape(dev, case, monkey
         n, slots, batch = int(rng.choice([rng.integers(1, 17), rng.integers(17, 700)])), int(rng.integers(12, 90)), int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000)]))
         shape = "forms case %d: per pieces, envs %d, slots %d, batch %d" % (case, n, slots, batch)
         E_.test_one_call_pieces_are_bitwise_the_launch_sequence(dev, n, slots, batch)
+    elif form == "per_incremental":      # production acting + training on a ring that fills and wraps: incremental chunk sums == a full pass, indices == mi_per_sample's == the oracle's
+        import test_gpu_per as E_
+
+        n, slots = int(rng.choice([rng.integers(1, 17), rng.integers(17, 700)])), int(rng.integers(12, 120))
+        shape = "forms case %d: per incremental sums, envs %d, slots %d" % (case, n, slots)
+        E_.test_incremental_sums_equal_full_pass_and_oracle(dev, R, n, slots)
     elif form == "dueling":
         import test_gpu_dueling as U
 
@@ -354,4 +368,49 @@ def test_one_call_forms_equal_their_launch_sequences_any_shape(dev, case, monkey
             S_.test_deferred_critic_step_is_bit_identical_to_a_launch_of_its_own(dev, batch, monkeypatch)
         else:
             W.test_shadows_change_no_bit(dev, batch)
+    _log(shape + " ok")
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_sac_acting_any_shape(dev, R, case):
+    """sac.py:138-158 at a random (envs, slots, warm-up length): keyed warm-up actions, then the actor with supplied normal draws; per step the device's actions against the
+    oracle's actor sample on the (bit-identical) observation, then the oracle env stepped with the DEVICE's actions: ring slot and carried-over observation bit-exact."""
+    import deep_rl_amd as D
+
+    rng = np.random.default_rng([SEED, 6, case])
+    n = int(rng.choice([rng.integers(1, 17), rng.integers(17, 100), rng.integers(100, 500)]))
+    S = int(rng.integers(4, 64))
+    ls = int(rng.integers(0, 12))
+    steps = int(rng.integers(S + 2, 2 * S + 20))
+    seed, base = int(rng.integers(1, 1000)), int(rng.integers(0, 5000))
+    shape = "sac acting case %d: envs %d, slots %d, learning_starts %d, %d steps, seed %d, base %d" % (case, n, S, ls, steps, seed, base)
+    env = D.make("Pendulum-v1", num_envs=n, device=dev, seed=seed, env_id_base=base)
+    torch.manual_seed(seed)
+    a = D.Actor(env)
+    qs = [D.SoftQNetwork(env) for _ in range(4)]
+    a_p = (a.flat.cpu().numpy() + rng.normal(0, 0.03, R.AC_NPARAMS)).astype(np.float32)
+    a.load_flat(a_p)
+    eng = D.SACEngine(env, a, *qs, slots=S, batch_size=16, learning_starts=ls, max_episodes_logged=0)
+    ref = R.VecPendulum(n, seed=seed, env_id_base=base)
+    obs = ref.reset()
+    assert np.array_equal(eng.reset().cpu().numpy(), obs), shape
+    worst = 0.0
+    for t in range(steps):
+        eps = rng.standard_normal(n).astype(np.float32)
+        eng.act(forced_eps=torch.from_numpy(eps) if t >= ls else None)
+        a_dev = eng.actions[t % S].cpu().numpy()
+        if t >= ls:
+            ra, _ = R.sac_actor_sample(a_p, obs, eps)
+            worst = max(worst, float(np.abs(a_dev - ra).max()))
+        else:
+            assert a_dev.min() >= -2.0 and a_dev.max() < 2.0, shape
+        obs, rew, done, _, _ = ref.step(a_dev)
+        s_ = (t + 1) % S
+        assert np.array_equal(eng.observations[s_].cpu().numpy(), obs) and np.array_equal(eng.rewards[s_].cpu().numpy(), rew), (shape, t)
+        assert np.array_equal(eng.observation.cpu().numpy(), obs), (shape, t)
+    # (the fixed-size test's bar is 5e-6 over 1.1 M samples, 3.1e-6 measured; 22 M random samples reach 6.7e-6: u = mean + exp(log_std) eps with log_std = -1.5 + 3.5 head
+    # (sac.py:69, no squashing), so one ulp of the head moves u by 3.5 |eps| std ulps — |eps| up to 5 and std up to e^2 in this many draws)
+    assert worst <= 1.5e-5, (shape, worst)
+    assert not eng.terminated.any(), shape
+    eng.close()
     _log(shape + " ok")
