@@ -89,6 +89,7 @@ struct mi_comm {
     char* peer[P2P_MAX_WORLD];     // every rank's inbox as mapped here (peer[rank] == inbox; synthetic: all == inbox)
     bool opened[P2P_MAX_WORLD];    // mapped with hipIpcOpenMemHandle (to be closed)
     size_t cap;                    // bytes per slot
+    size_t inbox_bytes;            // size of the inbox allocation (parked, never freed: see p2p_park)
     uint32_t seq;                  // sequence number of the last enqueued all-reduce inside the current epoch (host side; every rank counts the same calls)
     uint32_t parity;               // parity of the last enqueued all-reduce: flips with every one, whatever the sequence number does
     uint32_t bseq;                 // epoch changes so far (= the barrier lines' own sequence number)
@@ -224,6 +225,32 @@ static int p2p_new_epoch(mi_comm* c, hipStream_t s) {
     return MI_OK;
 }
 
+// INBOXES ARE NEVER RETURNED TO THE ALLOCATOR WHILE THE PROCESS LIVES (round 6, found by tests/test_gpu_synthetic_world.py).  An inbox is uncached memory, cleared with
+// hipMemset and polled with sc0 sc1 loads; after hipFree its physical pages go to the next allocation — a torch tensor, cached memory — and on this chip readers of that
+// tensor then met STALE lines of the inbox's life (zeros of the clear, in exactly the 87 KB the exchanged lines had occupied in each 2 MiB slot) in one XCD's L2 until
+// something evicted them: a DQN slab-sum launch summed zeros for parts of six gradient slabs the TD launch had just written, once, in the first update behind a
+// communicator's destruction; memory itself was right (a second read after a cache flush returned the data), and with the inboxes leaked instead of freed the effect was
+// gone.  So mi_comm_destroy parks the inbox here and p2p_new takes a parked one of the same device, kind and size (cleared again, as a new one is); a process that
+// creates one communicator per carrier — every production run — never sees the pool.  Beyond P2P_POOL entries an inbox is leaked rather than freed.
+#define P2P_POOL 64
+struct p2p_parked_t { void* p; size_t bytes; int kind, device; };
+static p2p_parked_t g_parked[P2P_POOL];
+static void* p2p_take_parked(size_t bytes, int device, int first_kind, int* kind) {
+    for (int i = 0; i < P2P_POOL; ++i)
+        if (g_parked[i].p && g_parked[i].bytes == bytes && g_parked[i].device == device && g_parked[i].kind >= first_kind) {
+            void* p = g_parked[i].p;
+            *kind = g_parked[i].kind;
+            g_parked[i].p = nullptr;
+            return p;
+        }
+    return nullptr;
+}
+static void p2p_park(void* p, size_t bytes, int kind, int device) {
+    for (int i = 0; i < P2P_POOL; ++i)
+        if (!g_parked[i].p) { g_parked[i].p = p; g_parked[i].bytes = bytes; g_parked[i].kind = kind; g_parked[i].device = device; return; }
+    // pool full: the allocation stays with the process (a leak of address space is harmless; recycled pages were not)
+}
+
 static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm** out) {
     mi_comm* c = (mi_comm*)calloc(1, sizeof(mi_comm));
     if (!c) { mi_set_error("mi_comm_p2p: out of host memory"); return MI_ENOMEM; }
@@ -241,7 +268,11 @@ static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm
     int first = 0;
     if (want && !strcmp(want, "finegrained")) first = 1;
     if (want && !strcmp(want, "plain")) first = 2;
-    void* box = nullptr;
+    void* box = p2p_take_parked(bytes, c->device, first, &c->mem_kind);
+    if (box && !synthetic) {   // (a parked inbox of a synthetic communicator was never checked for export)
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, box) != hipSuccess) { (void)hipGetLastError(); p2p_park(box, bytes, c->mem_kind, c->device); box = nullptr; }
+    }
     for (int k = first; k < 3 && !box; ++k) {
         e = hipExtMallocWithFlags(&box, bytes, kinds[k]);
         if (e != hipSuccess) { box = nullptr; (void)hipGetLastError(); continue; }
@@ -252,17 +283,18 @@ static int p2p_new(int world, int rank, size_t max_bytes, int synthetic, mi_comm
         c->mem_kind = k;
     }
     if (!box) { mi_set_error("mi_comm_p2p: cannot allocate an exportable %zu-byte inbox: %s", bytes, hipGetErrorString(e)); free(c); return MI_ENOMEM; }
+    c->inbox_bytes = bytes;
     if (hipMemset(box, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        mi_set_error("mi_comm_p2p: clearing the inbox failed"); (void)hipFree(box); free(c); return MI_EHIP;
+        mi_set_error("mi_comm_p2p: clearing the inbox failed"); p2p_park(box, bytes, c->mem_kind, c->device); free(c); return MI_EHIP;
     }
     c->inbox = (char*)box;
     if (hipMalloc((void**)&c->status, 64) != hipSuccess || hipMemset(c->status, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        mi_set_error("mi_comm_p2p: cannot allocate the status word"); (void)hipGetLastError(); (void)hipFree(box); free(c); return MI_ENOMEM;
+        mi_set_error("mi_comm_p2p: cannot allocate the status word"); (void)hipGetLastError(); p2p_park(box, bytes, c->mem_kind, c->device); free(c); return MI_ENOMEM;
     }
     {   // the status word's host-visible mirror: written (system scope) by the wait that runs out, read by the host without a sync
         uint32_t* h = nullptr;
         if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
-            mi_set_error("mi_comm_p2p: cannot allocate the pinned status mirror"); (void)hipGetLastError(); (void)hipFree(c->status); (void)hipFree(box); free(c); return MI_ENOMEM;
+            mi_set_error("mi_comm_p2p: cannot allocate the pinned status mirror"); (void)hipGetLastError(); (void)hipFree(c->status); p2p_park(box, bytes, c->mem_kind, c->device); free(c); return MI_ENOMEM;
         }
         h[0] = 0u;
         c->mirror = h;
@@ -283,7 +315,7 @@ extern "C" int mi_comm_p2p_alloc(int world_size, int rank, size_t max_bytes, voi
     if (rc) return rc;
     hipIpcMemHandle_t h;
     hipError_t e = hipIpcGetMemHandle(&h, c->inbox);
-    if (e != hipSuccess) { mi_set_error("mi_comm_p2p_alloc: hipIpcGetMemHandle failed: %s", hipGetErrorString(e)); (void)hipFree(c->inbox); (void)hipFree(c->status); (void)hipHostFree(c->mirror); free(c); return MI_EHIP; }
+    if (e != hipSuccess) { mi_set_error("mi_comm_p2p_alloc: hipIpcGetMemHandle failed: %s", hipGetErrorString(e)); p2p_park(c->inbox, c->inbox_bytes, c->mem_kind, c->device); (void)hipFree(c->status); (void)hipHostFree(c->mirror); free(c); return MI_EHIP; }
     memcpy(ipc_handle64, &h, sizeof(h));
     *out = c;
     return MI_OK;
@@ -438,7 +470,7 @@ extern "C" int mi_comm_destroy(void* comm) {
     if (c->carrier == CARRIER_P2P) {   // callers put a barrier in front: a peer may still be storing into this inbox
         (void)hipDeviceSynchronize();
         for (int r = 0; r < c->world; ++r) if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
-        if (c->inbox) (void)hipFree(c->inbox);
+        if (c->inbox) p2p_park(c->inbox, c->inbox_bytes, c->mem_kind, c->device);   // never hipFree: its pages must not be recycled into cached memory (see p2p_park)
         if (c->status) (void)hipFree(c->status);
         if (c->mirror) (void)hipHostFree(c->mirror);
     } else if (g_rccl.so && c->comm) {

@@ -260,7 +260,9 @@ int mi_comm_allreduce_sum(void* comm, void* buf, size_t n, int dtype, void* stre
  *                        handles of all ranks to all ranks (torch.distributed all_gather / file / MPI) ...
  *   mi_comm_p2p_connect  ... and hands them over in rank order (world_size * 64 bytes): maps the peers' inboxes.  The handle then works wherever an RCCL one does
  *                        (mi_comm_allreduce_sum, mi_*_sharded).  All collectives of one communicator must be enqueued on streams ordered with each other, by every rank
- *                        in the same order.  Put a barrier in front of mi_comm_destroy: a peer may still be storing into this rank's inbox.
+ *                        in the same order.  Put a barrier in front of mi_comm_destroy: a peer may still be storing into this rank's inbox.  The inbox itself is
+ *                        PARKED by mi_comm_destroy, not freed, and handed to the next communicator of the same size: pages of an uncached, polled inbox that were
+ *                        recycled into cached memory returned stale lines to their next owner on this chip (csrc/mi_comm.hip, p2p_park).
  *   mi_comm_p2p_synthetic  ONE process plays world_size ranks into its own inbox (slot 0 = its share, the others zeros: results unchanged): the stores, polls and the
  *                        world-slot sum of a world_size-rank exchange minus the links — for timing on a one-GPU box (bench.py `sharded_route`).
  *                        mi_comm_info reports world_size 1 (the sharded calls scale their shares by 1 / world_size: it IS one rank) and comm_count = the ranks played.
