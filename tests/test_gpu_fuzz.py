@@ -5,7 +5,7 @@ slot counts, priorities with holes.  Bars as in those files: bit-exact for env s
 assert for everything behind a network.
 
 MIRL_FUZZ_CASES (default 4 per family: the suite stays short) and MIRL_FUZZ_SEED (default 1) choose the cases; a failing assert names the case's shape, so it can be
-replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 18,000 cases, one real finding — a one-row minibatch — fixed)."""
+replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 20,400 cases, one real finding — a one-row minibatch — fixed)."""
 import os
 import sys
 
@@ -303,7 +303,7 @@ def test_per_sampler_any_shape(dev, R, case):
     _log(shape + " ok")
 
 
-FORMS = ("ppo", "per", "dueling", "sac_owed_alpha", "sac_deferred_critic", "sac_shadows", "per_incremental")
+FORMS = ("ppo", "per", "dueling", "sac_owed_alpha", "sac_deferred_critic", "sac_shadows", "per_incremental", "ppo_synthetic_world", "shards")
 
 
 @pytest.mark.parametrize("case", range(max(CASES, len(FORMS))))
@@ -337,6 +337,80 @@ def test_one_call_forms_equal_their_launch_sequences_any_shape(dev, R, case, mon
             assert o.step_count == 32, shape
         for k, (a, b) in enumerate(zip(*outs)):      # (a one-row minibatch — 4 rows in all — is NaN in both forms, as in ppo.py: NaN compares equal to NaN here)
             assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), (shape, k)
+    elif form == "ppo_synthetic_world":      # mi_ppo_update_sharded on the P2P carrier with 1 .. 8 synthetic ranks (x + 0 + ... + 0) against mi_ppo_update, bit for bit
+        import ctypes as C
+
+        import deep_rl_amd.dist as DD
+        import deep_rl_amd.engine as E
+        import test_gpu_parity as P
+        from deep_rl_amd import _native as N
+
+        n = int(rng.choice([rng.integers(1, 9), rng.integers(9, 70), rng.integers(70, 700)]))
+        T = int(rng.choice([rng.integers(1, 20), rng.integers(20, 129), rng.integers(129, 200)]))
+        while (T * n) % 4:
+            T += 1
+        world, seed = int(rng.integers(1, 9)), int(rng.integers(1, 1000))
+        shape = "forms case %d: ppo on %d synthetic ranks, envs %d, T %d, seed %d" % (case, world, n, T, seed)
+        outs = []
+        for synthetic in (False, True):
+            h = C.c_void_p()
+            if synthetic:
+                N.check(N.lib().mi_comm_p2p_synthetic(world, 1 << 16, C.byref(h)), "mi_comm_p2p_synthetic")
+                DD.use_comm(h)
+                monkeypatch.setattr(E, "_FORCE_NATIVE_SHARDED", True)
+            try:
+                eng = P._engine(dev, n, seed=seed, T_=T, max_episodes_logged=0)
+                eng.reset()
+                for _ in range(2):
+                    eng.update()
+                torch.cuda.synchronize()
+                if synthetic:
+                    N.check(N.lib().mi_comm_check(h), "mi_comm_check")
+                o = eng.optimizer
+                outs.append([t.clone() for t in (eng.agent.flat, o.exp_avg, o.exp_avg_sq, eng.grads, eng.loss_terms, o.grad_norm, eng.advantages)])
+            finally:
+                monkeypatch.setattr(E, "_FORCE_NATIVE_SHARDED", False)
+                DD.use_comm(None)
+                if h.value:
+                    torch.cuda.synchronize()
+                    N.lib().mi_comm_destroy(h)
+        for k, (a, b) in enumerate(zip(*outs)):
+            assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), (shape, k)
+    elif form == "shards":      # env-sharding invariance of the acting / rollout launches: an engine of n envs == two engines of n1 + n2 envs with env_id_base 0 / n1 (keyed RNG)
+        import deep_rl_amd as D
+        import test_gpu_dqn as Q
+        import test_gpu_parity as P
+
+        n = int(rng.integers(2, 600))
+        n1 = int(rng.integers(1, n))
+        seed = int(rng.integers(1, 1000))
+        T = int(rng.choice([rng.integers(1, 129), rng.integers(129, 200)]))
+        shape = "forms case %d: shards, envs %d = %d + %d, T %d, seed %d" % (case, n, n1, n - n1, T, seed)
+        whole = None
+        for base, cnt in ((0, n), (0, n1), (n1, n - n1)):
+            eng = P._engine(dev, cnt, seed=seed, env_id_base=base, T_=T, max_episodes_logged=0, n_minibatch=1)
+            pr = (torch.arange(9155, device=dev, dtype=torch.float32) % 7 - 3.0) * 0.01     # the same (non-initial) parameters for every shard
+            eng.agent.load_flat(eng.agent.flat * 0 + pr)
+            eng.reset(); eng.rollout_gae(); eng.rollout_gae()
+            got = [eng.observations, eng.actions, eng.rewards, eng.dones, eng.values, eng.log_probs, eng.advantages]
+            if whole is None:
+                whole = [t.clone() for t in got]
+            else:
+                for k, (w, g) in enumerate(zip(whole, got)):
+                    assert torch.equal(w[:, base:base + cnt], g), (shape, "ppo", base, k)
+        S, steps = int(rng.integers(4, 40)), int(rng.integers(1, 12))
+        whole = None
+        for base, cnt in ((0, n), (0, n1), (n1, n - n1)):
+            eng = Q._engine(dev, cnt, slots=S, seed=seed, base=base, batch_size=8, learning_starts=int(S // 2), total_timesteps=20 * S, max_episodes_logged=0)
+            eng.reset()
+            for _ in range(2 * S // steps + 2):
+                eng.act(steps)
+            got = [eng.observations, eng.actions, eng.rewards, eng.terminated]
+            if whole is None:
+                whole = [t.clone() for t in got]
+            else:
+                for k, (w, g) in enumerate(zip(whole, got)):
+                    assert torch.equal(w[:, base:base + cnt], g), (shape, "dqn", base, k)
     elif form == "per":
         import test_gpu_per as E_
 
