@@ -204,18 +204,18 @@ def test_two_ranks_one_gpu_p2p_collective():
     assert "P2P_WORKER_OK" in out.stdout, out.stdout[-2000:]
 
 
-def _ppo(backend, comm="p2p"):
+def _ppo(backend, comm="p2p", nl=64):
     import tempfile
 
     import test_gpu_multigpu as M
 
     with tempfile.TemporaryDirectory() as tmp:
-        out = _launch("_sharded_update_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL="64"), comm=comm)
+        out = _launch("_sharded_update_worker.py", dict(MIRL_TEST_BACKEND=backend, MIRL_TEST_OUT=tmp, MIRL_TEST_NL=str(nl)), comm=comm)
         assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
         assert "SHARDED_WORKER_OK backend=%s native=1 carrier=p2p" % backend in out.stdout, out.stdout[-2000:]
         r0, r1 = dict(np.load(os.path.join(tmp, "rank0.npz"))), dict(np.load(os.path.join(tmp, "rank1.npz")))
     assert int(r0["native"][0]) == 1 and int(r1["native"][0]) == 1     # mi_ppo_update_sharded really was the route
-    M._check(r0, r1, M._single_process(r0["params0"], 64), 64)
+    M._check(r0, r1, M._single_process(r0["params0"], nl), nl)
     # ONE C call with the in-stream peer-to-peer all-reduces == host-sequenced launches with torch.distributed all-reduces in between, bit for bit (a + b on both ranks)
     for rk in (r0, r1):
         for k in ("params", "exp_avg", "exp_avg_sq", "grads", "loss_terms", "grad_norm", "observations", "advantages"):
@@ -247,6 +247,14 @@ def _offpolicy(backend, comm="p2p"):
 def test_two_ranks_one_gpu_p2p_ppo():
     _need_gpu()
     _ppo("gloo")
+
+
+@pytest.mark.parametrize("nl", [5, 301])
+def test_two_ranks_one_gpu_p2p_ppo_ragged_env_counts(nl):
+    """The same with env counts per rank that are no multiple of a rollout workgroup's four envs or of a gradient tile (round 6; the randomised single-process sweeps of
+    tests/test_gpu_fuzz.py cannot start ranks)."""
+    _need_gpu()
+    _ppo("gloo", nl=nl)
 
 
 def test_two_ranks_one_gpu_p2p_offpolicy():
