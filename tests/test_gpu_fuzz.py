@@ -5,7 +5,7 @@ slot counts, priorities with holes.  Bars as in those files: bit-exact for env s
 assert for everything behind a network.
 
 MIRL_FUZZ_CASES (default 4 per family: the suite stays short) and MIRL_FUZZ_SEED (default 1) choose the cases; a failing assert names the case's shape, so it can be
-replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 20,400 cases, one real finding — a one-row minibatch — fixed)."""
+replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 38,400 cases, one real finding — a one-row minibatch — fixed)."""
 import os
 import sys
 
@@ -84,6 +84,29 @@ def _sac_actor_rows_clear(a_p, obs):
     return _mlp_clear_of_zero(obs, W1, b1, W2, b2)[0]
 
 
+def _ppo_rows_clear(params, obs, actions, old_logp, old_values, returns, clip=0.2):
+    """rows of the storage away from the kinks of ppo.py:172-186: the ratio's clip boundaries 1 +- clip (the derivative of max(-A r, -A clamp(r)) jumps there), the value
+    clip's boundary |v - v_old| = clip and the tie of the two value losses — a row within rounding of one lands on either side on the device and in the oracle"""
+    p = params.astype(np.float64)
+    def mlp(o, out):
+        W1, b1 = p[o:o + 256].reshape(64, 4), p[o + 256:o + 320]
+        W2, b2 = p[o + 320:o + 4416].reshape(64, 64), p[o + 4416:o + 4480]
+        W3, b3 = p[o + 4480:o + 4480 + 64 * out].reshape(out, 64), p[o + 4480 + 64 * out:o + 4480 + 65 * out]
+        h = np.tanh(np.tanh(obs.astype(np.float64) @ W1.T + b1) @ W2.T + b2)
+        return h @ W3.T + b3
+    logits = mlp(0, 2)                                  # actor first (4,610 parameters), then the critic
+    v = mlp(4610, 1)[:, 0]
+    lse = np.log(np.exp(logits - logits.max(1, keepdims=True)).sum(1)) + logits.max(1)
+    logp = logits[np.arange(len(obs)), actions] - lse
+    ratio = np.exp(logp - old_logp)
+    ok = (np.abs(ratio - (1 - clip)) > 1e-4) & (np.abs(ratio - (1 + clip)) > 1e-4)
+    dv = v - old_values
+    vc = old_values + np.clip(dv, -clip, clip)
+    ok &= np.abs(np.abs(dv) - clip) > 1e-5
+    ok &= (np.abs(dv) <= clip) | (np.abs((v - returns) ** 2 - (vc - returns) ** 2) > 1e-6)
+    return ok
+
+
 def _log(rec):
     path = os.path.join(ROOT, "gpurun_out", "fuzz_cases.txt")
     os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -128,11 +151,17 @@ def test_ppo_rollout_gae_grad_any_shape(dev, R, case):
     p2 = (params + rng.normal(0, 0.05, 9155)).astype(np.float32)
     eng.agent.load_flat(p2)
     eng.make_perm(0)
+    assert np.array_equal(np.sort(eng.perm.cpu().numpy()), np.arange(T * n)), shape
+    so = P._storage_to_oracle(R, eng)
+    clear = np.flatnonzero(_ppo_rows_clear(p2, so.observations[:T].reshape(T * n, 4), so.actions[:T].reshape(T * n).astype(np.int64), so.log_probs[:T].reshape(T * n).astype(np.float64),
+                                           so.values[:T].reshape(T * n).astype(np.float64), so.returns[:T].reshape(T * n).astype(np.float64)))
+    if clear.size >= mb:      # the minibatch: the keyed permutation's first mb rows that are clear of the loss's kinks (the permutation itself was checked above)
+        perm = eng.perm.cpu().numpy()
+        keep = perm[np.isin(perm, clear)][:mb]
+        eng.perm[:mb] = torch.from_numpy(keep).to(eng.perm.device, eng.perm.dtype)
     eng.adv_stats(mb=mb, n_mb=1)
     eng.minibatch_grad(0, mb=mb)
-    so = P._storage_to_oracle(R, eng)
     idx = eng.perm[:mb].cpu().numpy()
-    assert np.array_equal(np.sort(eng.perm.cpu().numpy()), np.arange(T * n)), shape
     og, ot = R.minibatch(p2, so, idx)
     grads = eng.grads.cpu().numpy(); terms = eng.loss_terms.cpu().numpy()
     scale = max(np.abs(og).max(), 1e-12)
