@@ -5,7 +5,7 @@ slot counts, priorities with holes.  Bars as in those files: bit-exact for env s
 assert for everything behind a network.
 
 MIRL_FUZZ_CASES (default 4 per family: the suite stays short) and MIRL_FUZZ_SEED (default 1) choose the cases; a failing assert names the case's shape, so it can be
-replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 38,400 cases, one real finding — a one-row minibatch — fixed)."""
+replayed.  Round 6 ran 2 x 1,500 cases per family once (profiles/r06_fuzz.txt: 41,400 cases, one real finding — a one-row minibatch — fixed)."""
 import os
 import sys
 
@@ -516,4 +516,79 @@ def test_sac_acting_any_shape(dev, R, case):
     assert worst <= 1.5e-5, (shape, worst)
     assert not eng.terminated.any(), shape
     eng.close()
+    _log(shape + " ok")
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_per_and_dueling_td_any_shape(dev, R, case):
+    """per.py:131-147 (importance weights, weighted TD gradient, |td| -> priorities with the last duplicate winning, max_priority) and dueling_dqn.py:36-40,118-128 (the
+    dueling head's gradient mapped back from the plain-DQN image) at a random (envs, slots, batch) on a ring filled by production acting, rows clear of ReLU kinks."""
+    import test_gpu_dueling as U
+    import test_gpu_per as E_
+
+    rng = np.random.default_rng([SEED, 7, case])
+    n = int(rng.choice([rng.integers(1, 17), rng.integers(17, 300)]))
+    S = int(rng.integers(12, 60))
+    batch = int(rng.choice([rng.integers(1, 130), rng.integers(130, 2049), rng.integers(2049, 4200)]))
+    seed = int(rng.integers(1, 1000))
+    # ---- PER
+    shape = "per td case %d: envs %d, slots %d, batch %d, seed %d" % (case, n, S, batch, seed)
+    eng = E_._engine(dev, n, S, seed=seed, batch_size=batch, learning_starts=0, total_timesteps=100 * S)
+    params = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    tparams = (params + rng.normal(0, 0.05, 10934)).astype(np.float32)
+    eng.q.load_flat(params); eng.target.load_flat(tparams)
+    eng.reset()
+    for _ in range(S // 10 + 2):
+        eng.act(10)                                     # the ring is full and has wrapped; every row carries the running max_priority
+    cap = S * n
+    prio = rng.gamma(0.5, 1.0, cap).astype(np.float32)
+    prio[rng.random(cap) < 0.2] = 0.0
+    head = eng.global_step % S                          # the write head keeps priority 0 (never sampled: per.py:105 marks it at the next step)
+    prio.reshape(S, n)[head] = 0.0
+    eng.priorities.copy_(torch.from_numpy(prio.reshape(S, n)))
+    eng.refresh_sums()
+    mp0 = float(rng.uniform(0.01, 3.0))
+    eng.max_priority.fill_(mp0)
+    st = R.ReplayStorage(S, n)
+    for name in ["observations", "actions", "rewards", "terminated"]:
+        getattr(st, name)[...] = getattr(eng, name).cpu().numpy()
+    clear = np.flatnonzero(_dqn_rows_clear(params, st.observations.reshape(cap, 4)) & (prio > 0))
+    assert clear.size > 0.2 * cap, shape
+    idx = rng.choice(clear, batch)                      # duplicates included: the scatter's "last duplicate wins"
+    eng.sample(idx)
+    s0, s1, total, total_alpha = R.per_sums(prio, cap, E_.ALPHA)
+    w = R.per_weights(prio, idx, E_.ALPHA, np.float32(eng.beta()), total_alpha, cap)
+    wd = eng.weights.cpu().numpy()
+    assert np.allclose(wd, w, rtol=3e-5), shape
+    eng.td_grad()
+    og, ol, otd = R.per_td_grads(params, tparams, st, idx, wd)
+    g = eng.grads.cpu().numpy()
+    assert np.abs(g - og).max() <= 1e-5 * np.abs(og).max(), (shape, np.abs(g - og).max() / np.abs(og).max())
+    assert abs(float(eng.loss.item()) - ol) <= 3e-5 * max(ol, 1e-6), (shape, float(eng.loss.item()), ol)
+    td = eng.td_abs.cpu().numpy()
+    assert np.allclose(td, np.abs(otd), rtol=2e-5, atol=2e-5), shape
+    want = prio.copy()
+    mp = R.per_update_priorities(want, idx, td, mp0)    # the scatter itself is index work: bit-exact given the device's |td|
+    assert np.array_equal(eng.priorities.cpu().numpy().reshape(-1), want) and float(eng.max_priority) == mp, shape
+    _log(shape + " ok")
+    # ---- dueling
+    shape = "dueling td case %d: envs %d, slots %d, batch %d, seed %d" % (case, n, S, batch, seed)
+    eng = U._engine(dev, n, slots=S, seed=seed, batch_size=batch, learning_starts=0, total_timesteps=100 * S)
+    dp = (eng.q.flat.cpu().numpy() + rng.normal(0, 0.05, eng.q.flat.numel())).astype(np.float32)
+    dt = (dp + rng.normal(0, 0.05, dp.size)).astype(np.float32)
+    eng.q.load_flat(dp); eng.target.load_flat(dt)
+    eng.reset()
+    for _ in range(S // 10 + 2):
+        eng.act(10)
+    st = R.ReplayStorage(S, n)
+    for name in ["observations", "actions", "rewards", "terminated"]:
+        getattr(st, name)[...] = getattr(eng, name).cpu().numpy()
+    clear = np.flatnonzero(_dqn_rows_clear(eng.q.eff.cpu().numpy(), st.observations.reshape(cap, 4)))     # the image's feature layers are the dueling net's
+    idx = rng.choice(clear, batch)
+    eng.sample(idx)
+    eng.td_grad()
+    og, ol = R.dueling_td_grads(dp, dt, st, idx)
+    g = eng.dueling_grads.cpu().numpy()
+    assert np.abs(g - og).max() <= 1e-5 * np.abs(og).max(), (shape, np.abs(g - og).max() / np.abs(og).max())
+    assert abs(float(eng.loss.item()) - ol) <= 3e-5 * max(ol, 1e-6), (shape, float(eng.loss.item()), ol)
     _log(shape + " ok")
