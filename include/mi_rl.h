@@ -150,7 +150,8 @@ int mi_adv_stats(const float* advantages, const int32_t* idx, int mb, int n_mb, 
  * i.e. world_size * mb).  Outputs: grads dev f32 [MI_PPO_NPARAMS] = d loss / d params (this rank's
  * share, already scaled by inv_count, so a SUM all-reduce gives the global gradient);
  * loss_terms dev f32 [4] = {pg_loss, entropy, v_loss, loss} shares scaled the same way.
- * workspace: dev, at least mi_ppo_workspace_bytes() bytes. */
+ * workspace: dev, at least mi_ppo_workspace_bytes() bytes.  A count of ONE row (mb == 1 on one rank) gives NaN gradients and loss terms: the reference normalises
+ * with torch's unbiased std, NaN for one element (ppo.py:169), and so does this — a result, not an error code. */
 size_t mi_ppo_workspace_bytes(void);
 int mi_ppo_minibatch_grad(const float* params, const float* observations, const int64_t* actions,
                           const float* log_probs, const float* advantages, const float* returns, const float* values,
